@@ -1,0 +1,1625 @@
+// =============================================================================
+// ddo_oracle.hpp -- CPU restatement of xgillard/ddo's branch-and-bound-with-MDD
+// algorithm (C++17, header only, no dependencies).
+//
+// *** THIS IS TEST INFRASTRUCTURE ***
+// It is the parity oracle the HIP engine is checked against and the "port"
+// CPU baseline timed by bench.py.  Nothing under ddo_amd/ (the product) may
+// include, link or call it.  Only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py use it, and only as the checker / the baseline.
+//
+// Parity status: the reference is Rust and there is no Rust toolchain in this
+// image, so the reference itself cannot be executed here (no oracle/_ref).
+// The oracle is pinned instead against the reference's own known-answer tests:
+//   * engine KATs      ddo/src/implementation/mdd/clean.rs:1153-2398
+//   * fringe KATs      ddo/src/implementation/fringe/no_duplicate.rs:412-640
+//   * solver KATs      ddo/src/implementation/solver/parallel.rs:902-1151
+//   * example optima   ddo/examples/misp/tests.rs:71-161, knapsack/tests.rs
+// (see oracle/kat_main.cpp and tests/test_oracle_*.py).
+//
+// What is NOT reproduced: the iteration order of FxHashMap (`next_l`).  This
+// restatement iterates a layer in insertion order.  For models whose
+// StateRanking is a total order on states (MISP) every value the engine
+// produces is independent of that order; only tie-broken solution paths may
+// differ.
+//
+// All citations are relative to /root/reference/ddo/src unless they start with
+// `examples/`.
+// =============================================================================
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace ddo {
+
+using isize = int64_t;
+constexpr isize ISIZE_MIN = std::numeric_limits<isize>::min();
+constexpr isize ISIZE_MAX = std::numeric_limits<isize>::max();
+
+/// Rust's isize::saturating_add / saturating_sub (used all over clean.rs).
+inline isize sat_add(isize a, isize b) {
+    isize r;
+    if (__builtin_add_overflow(a, b, &r)) return b > 0 ? ISIZE_MAX : ISIZE_MIN;
+    return r;
+}
+inline isize sat_sub(isize a, isize b) {
+    isize r;
+    if (__builtin_sub_overflow(a, b, &r)) return b < 0 ? ISIZE_MAX : ISIZE_MIN;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// common.rs
+// ---------------------------------------------------------------------------
+/// common.rs:33
+struct Variable {
+    size_t id;
+};
+/// common.rs:58-61
+struct Decision {
+    size_t variable;
+    isize value;
+    bool operator==(const Decision& o) const { return variable == o.variable && value == o.value; }
+};
+using Solution = std::vector<Decision>;
+
+/// common.rs:75-87
+template <class S>
+struct SubProblem {
+    std::shared_ptr<const S> state;
+    isize value = 0;
+    std::vector<Decision> path;
+    isize ub = ISIZE_MAX;
+    size_t depth = 0;
+};
+
+/// common.rs:96-101 (derives Ord: value first, then explored with false < true)
+struct Threshold {
+    isize value;
+    bool explored;
+    bool operator<(const Threshold& o) const {
+        return value != o.value ? value < o.value : (!explored && o.explored);
+    }
+    bool operator==(const Threshold& o) const { return value == o.value && explored == o.explored; }
+};
+
+/// common.rs:108-111
+enum class Reason { CutoffOccurred };
+
+/// common.rs:115-121
+struct Completion {
+    bool is_exact = false;
+    std::optional<isize> best_value;
+};
+
+// ---------------------------------------------------------------------------
+// abstraction/dp.rs
+// ---------------------------------------------------------------------------
+/// `&mut dyn Iterator<Item=&State>` (dp.rs:63-64): dynamic dispatch per item.
+template <class S>
+struct StateIter {
+    virtual ~StateIter() = default;
+    virtual const S* next() = 0;
+};
+
+/// dp.rs:112-122
+struct DecisionCallback {
+    virtual ~DecisionCallback() = default;
+    virtual void apply(Decision d) = 0;
+};
+
+/// dp.rs:34-71
+template <class S>
+struct Problem {
+    using State = S;
+    virtual ~Problem() = default;
+    virtual size_t nb_variables() const = 0;
+    virtual S initial_state() const = 0;
+    virtual isize initial_value() const = 0;
+    virtual S transition(const S& state, Decision d) const = 0;
+    virtual isize transition_cost(const S& src, const S& dst, Decision d) const = 0;
+    virtual std::optional<Variable> next_variable(size_t depth, StateIter<S>& next_layer) const = 0;
+    virtual void for_each_in_domain(Variable var, const S& state, DecisionCallback& f) const = 0;
+    virtual bool is_impacted_by(Variable, const S&) const { return true; }
+};
+
+/// dp.rs:77-107
+template <class S>
+struct Relaxation {
+    virtual ~Relaxation() = default;
+    virtual S merge(StateIter<S>& states) const = 0;
+    virtual isize relax(const S& source, const S& dest, const S& merged, Decision d, isize cost) const = 0;
+    virtual isize fast_upper_bound(const S&) const { return ISIZE_MAX; }
+};
+
+// ---------------------------------------------------------------------------
+// abstraction/heuristics.rs
+// ---------------------------------------------------------------------------
+/// heuristics.rs:69-77: returns <0, 0, >0 like Ordering
+template <class S>
+struct StateRanking {
+    virtual ~StateRanking() = default;
+    virtual int compare(const S& a, const S& b) const = 0;
+};
+
+/// heuristics.rs:61-66
+template <class S>
+struct WidthHeuristic {
+    virtual ~WidthHeuristic() = default;
+    virtual size_t max_width(const SubProblem<S>& x) const = 0;
+};
+
+/// heuristics.rs:100-105
+struct Cutoff {
+    virtual ~Cutoff() = default;
+    virtual bool must_stop() const = 0;
+};
+
+/// heuristics.rs:85-93
+template <class S>
+struct SubProblemRanking {
+    virtual ~SubProblemRanking() = default;
+    virtual int compare(const SubProblem<S>& a, const SubProblem<S>& b) const = 0;
+};
+
+// ---------------------------------------------------------------------------
+// abstraction/cache.rs, abstraction/dominance.rs
+// ---------------------------------------------------------------------------
+/// cache.rs:27-56
+template <class S>
+struct Cache {
+    virtual ~Cache() = default;
+    /// cache.rs:32-39
+    virtual bool must_explore(const SubProblem<S>& sp) const {
+        auto t = get_threshold(*sp.state, sp.depth);
+        if (t) return sp.value > t->value || (sp.value == t->value && !t->explored);
+        return true;
+    }
+    virtual void initialize(const Problem<S>& pb) = 0;
+    virtual std::optional<Threshold> get_threshold(const S& state, size_t depth) const = 0;
+    virtual void update_threshold(std::shared_ptr<const S> state, size_t depth, isize value, bool explored) = 0;
+    virtual void clear_layer(size_t depth) = 0;
+    virtual void clear() = 0;
+};
+
+/// dominance.rs:100-104
+struct DominanceCheckResult {
+    bool dominated;
+    std::optional<isize> threshold;
+};
+
+/// dominance.rs:106-126
+template <class S>
+struct DominanceChecker {
+    virtual ~DominanceChecker() = default;
+    virtual void clear_layer(size_t depth) = 0;
+    virtual DominanceCheckResult is_dominated_or_insert(std::shared_ptr<const S> state, size_t depth, isize value) = 0;
+    /// <0, 0, >0
+    virtual int cmp(const S& a, isize val_a, const S& b, isize val_b) const = 0;
+};
+
+// ---------------------------------------------------------------------------
+// State hashing / equality plumbing (Rust: `T: Eq + Hash`)
+// ---------------------------------------------------------------------------
+template <class S>
+struct StateHash {
+    size_t operator()(const S& s) const { return std::hash<S>()(s); }
+};
+template <class S>
+struct PtrHash {
+    size_t operator()(const std::shared_ptr<const S>& p) const { return StateHash<S>()(*p); }
+};
+template <class S>
+struct PtrEq {
+    bool operator()(const std::shared_ptr<const S>& a, const std::shared_ptr<const S>& b) const { return *a == *b; }
+};
+
+// ---------------------------------------------------------------------------
+// implementation/cache/{empty,simple}.rs
+// ---------------------------------------------------------------------------
+/// cache/empty.rs:33-71
+template <class S>
+struct EmptyCache : Cache<S> {
+    bool must_explore(const SubProblem<S>&) const override { return true; }
+    void initialize(const Problem<S>&) override {}
+    std::optional<Threshold> get_threshold(const S&, size_t) const override { return std::nullopt; }
+    void update_threshold(std::shared_ptr<const S>, size_t, isize, bool) override {}
+    void clear_layer(size_t) override {}
+    void clear() override {}
+};
+
+/// cache/simple.rs:36-73 (DashMap per depth -> one mutex-protected map per depth)
+template <class S>
+struct SimpleCache : Cache<S> {
+    using Map = std::unordered_map<std::shared_ptr<const S>, Threshold, PtrHash<S>, PtrEq<S>>;
+    struct Layer {
+        mutable std::mutex mtx;
+        Map map;
+    };
+    std::vector<std::unique_ptr<Layer>> layers;
+
+    void initialize(const Problem<S>& pb) override {
+        for (size_t i = 0; i <= pb.nb_variables(); ++i) layers.emplace_back(new Layer());
+    }
+    std::optional<Threshold> get_threshold(const S& state, size_t depth) const override {
+        Layer& l = *layers[depth];
+        std::lock_guard<std::mutex> g(l.mtx);
+        // lookup through a non-owning aliasing pointer
+        std::shared_ptr<const S> key(std::shared_ptr<const S>(), &state);
+        auto it = l.map.find(key);
+        if (it == l.map.end()) return std::nullopt;
+        return it->second;
+    }
+    void update_threshold(std::shared_ptr<const S> state, size_t depth, isize value, bool explored) override {
+        Layer& l = *layers[depth];
+        std::lock_guard<std::mutex> g(l.mtx);
+        Threshold t{value, explored};
+        auto it = l.map.find(state);
+        if (it == l.map.end()) l.map.emplace(std::move(state), t);
+        else if (it->second < t) it->second = t;  // simple.rs:62: max(new, old)
+    }
+    void clear_layer(size_t depth) override {
+        Layer& l = *layers[depth];
+        std::lock_guard<std::mutex> g(l.mtx);
+        l.map.clear();
+    }
+    void clear() override {
+        for (auto& l : layers) {
+            std::lock_guard<std::mutex> g(l->mtx);
+            l->map.clear();
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// implementation/dominance/empty.rs
+// ---------------------------------------------------------------------------
+/// dominance/empty.rs:24-47
+template <class S>
+struct EmptyDominanceChecker : DominanceChecker<S> {
+    void clear_layer(size_t) override {}
+    DominanceCheckResult is_dominated_or_insert(std::shared_ptr<const S>, size_t, isize) override {
+        return {false, std::nullopt};
+    }
+    int cmp(const S&, isize, const S&, isize) const override { return 0; }
+};
+
+// ---------------------------------------------------------------------------
+// implementation/heuristics/{width,cutoff,subproblem_ranking}.rs
+// ---------------------------------------------------------------------------
+/// width.rs:166-171
+template <class S>
+struct FixedWidth : WidthHeuristic<S> {
+    size_t w;
+    explicit FixedWidth(size_t w) : w(w) {}
+    size_t max_width(const SubProblem<S>&) const override { return w; }
+};
+/// width.rs:397-402
+template <class S>
+struct NbUnassignedWidth : WidthHeuristic<S> {
+    size_t nb_vars;
+    explicit NbUnassignedWidth(size_t n) : nb_vars(n) {}
+    size_t max_width(const SubProblem<S>& x) const override { return nb_vars - x.path.size(); }
+};
+/// width.rs:636-642
+template <class S>
+struct Times : WidthHeuristic<S> {
+    size_t k;
+    const WidthHeuristic<S>& inner;
+    Times(size_t k, const WidthHeuristic<S>& inner) : k(k), inner(inner) {}
+    size_t max_width(const SubProblem<S>& x) const override { return std::max<size_t>(1, k * inner.max_width(x)); }
+};
+/// width.rs:875-881
+template <class S>
+struct DivBy : WidthHeuristic<S> {
+    size_t k;
+    const WidthHeuristic<S>& inner;
+    DivBy(size_t k, const WidthHeuristic<S>& inner) : k(k), inner(inner) {}
+    size_t max_width(const SubProblem<S>& x) const override { return std::max<size_t>(1, inner.max_width(x) / k); }
+};
+
+/// cutoff.rs:160-163
+struct NoCutoff : Cutoff {
+    bool must_stop() const override { return false; }
+};
+/// cutoff.rs:302-323.  The reference arms an AtomicBool from a sleeper thread;
+/// a deadline on the monotonic clock is observationally identical at the
+/// per-layer polling granularity of clean.rs:352.
+struct TimeBudget : Cutoff {
+    std::chrono::steady_clock::time_point deadline;
+    explicit TimeBudget(double seconds)
+        : deadline(std::chrono::steady_clock::now() +
+                   std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds))) {}
+    bool must_stop() const override { return std::chrono::steady_clock::now() >= deadline; }
+};
+/// Fault-injection fixture of clean.rs:1317-1321
+struct CutoffAlways : Cutoff {
+    bool must_stop() const override { return true; }
+};
+
+/// subproblem_ranking.rs:76-91
+template <class S>
+struct MaxUB : SubProblemRanking<S> {
+    const StateRanking<S>& ranking;
+    explicit MaxUB(const StateRanking<S>& r) : ranking(r) {}
+    int compare(const SubProblem<S>& l, const SubProblem<S>& r) const override {
+        if (l.ub != r.ub) return l.ub < r.ub ? -1 : 1;
+        if (l.value != r.value) return l.value < r.value ? -1 : 1;
+        return ranking.compare(*l.state, *r.state);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// abstraction/fringe.rs + implementation/fringe/{simple,no_duplicate}.rs
+// ---------------------------------------------------------------------------
+/// fringe.rs:26-45
+template <class S>
+struct Fringe {
+    virtual ~Fringe() = default;
+    virtual void push(SubProblem<S> node) = 0;
+    virtual std::optional<SubProblem<S>> pop() = 0;
+    virtual void clear() = 0;
+    virtual size_t len() const = 0;
+    bool is_empty() const { return len() == 0; }
+};
+
+/// fringe/simple.rs:35-62 (binary max-heap on the SubProblemRanking)
+template <class S>
+struct SimpleFringe : Fringe<S> {
+    const SubProblemRanking<S>& cmp;
+    std::vector<SubProblem<S>> heap;
+    explicit SimpleFringe(const SubProblemRanking<S>& c) : cmp(c) {}
+    void push(SubProblem<S> node) override {
+        heap.push_back(std::move(node));
+        std::push_heap(heap.begin(), heap.end(),
+                       [&](const SubProblem<S>& a, const SubProblem<S>& b) { return cmp.compare(a, b) < 0; });
+    }
+    std::optional<SubProblem<S>> pop() override {
+        if (heap.empty()) return std::nullopt;
+        std::pop_heap(heap.begin(), heap.end(),
+                      [&](const SubProblem<S>& a, const SubProblem<S>& b) { return cmp.compare(a, b) < 0; });
+        SubProblem<S> r = std::move(heap.back());
+        heap.pop_back();
+        return r;
+    }
+    void clear() override { heap.clear(); }
+    size_t len() const override { return heap.size(); }
+};
+
+/// fringe/no_duplicate.rs:52-324: updatable binary heap + state -> id map.
+template <class S>
+struct NoDupFringe : Fringe<S> {
+    const SubProblemRanking<S>& cmp;
+    std::unordered_map<std::shared_ptr<const S>, size_t, PtrHash<S>, PtrEq<S>> states;
+    std::vector<SubProblem<S>> nodes;
+    std::vector<size_t> pos;
+    std::vector<size_t> heap;
+    std::vector<size_t> recycle_bin;
+
+    explicit NoDupFringe(const SubProblemRanking<S>& c) : cmp(c) {}
+
+    /// no_duplicate.rs:88-140
+    void push(SubProblem<S> node) override {
+        auto it = states.find(node.state);
+        if (it != states.end()) {
+            size_t id = it->second;
+            isize old_lp = nodes[id].value, old_ub = nodes[id].ub;
+            isize new_lp = node.value, new_ub = node.ub;
+            node.ub = std::max(new_ub, old_ub);                    // :102
+            bool up = cmp.compare(node, nodes[id]) > 0;            // :104
+            if (new_lp > old_lp) nodes[id] = std::move(node);      // :110-112
+            if (new_ub > old_ub) nodes[id].ub = new_ub;            // :113-115
+            if (up) bubble_up(id);
+        } else {
+            size_t id;
+            if (recycle_bin.empty()) {
+                id = nodes.size();
+                nodes.push_back(std::move(node));
+                pos.push_back(0);
+            } else {
+                id = recycle_bin.back();
+                recycle_bin.pop_back();
+                nodes[id] = std::move(node);
+            }
+            heap.push_back(id);
+            pos[id] = heap.size() - 1;
+            states.emplace(nodes[id].state, id);
+            bubble_up(id);
+        }
+    }
+    /// no_duplicate.rs:144-164
+    std::optional<SubProblem<S>> pop() override {
+        if (heap.empty()) return std::nullopt;
+        size_t id = heap[0];
+        heap[0] = heap.back();  // swap_remove(0)
+        heap.pop_back();
+        if (!heap.empty()) {
+            pos[heap[0]] = 0;
+            bubble_down(heap[0]);
+        }
+        recycle_bin.push_back(id);
+        SubProblem<S> node = nodes[id];
+        states.erase(node.state);
+        return node;
+    }
+    void clear() override {
+        states.clear();
+        nodes.clear();
+        pos.clear();
+        heap.clear();
+        recycle_bin.clear();
+    }
+    size_t len() const override { return heap.size(); }
+
+  private:
+    int compare_at_pos(size_t x, size_t y) const { return cmp.compare(nodes[heap[x]], nodes[heap[y]]); }
+    static size_t parent(size_t p) { return p == 0 ? 0 : (p % 2 == 1 ? p / 2 : p / 2 - 1); }  // :262-270
+    /// :227-242
+    void bubble_up(size_t id) {
+        size_t me = pos[id], par = parent(me);
+        while (me != 0 && compare_at_pos(me, par) > 0) {
+            size_t p_id = heap[par];
+            pos[p_id] = me;
+            pos[id] = par;
+            heap[me] = p_id;
+            heap[par] = id;
+            me = par;
+            par = parent(me);
+        }
+    }
+    /// :279-295 (0 = "no child")
+    size_t max_child_of(size_t p) const {
+        size_t size = heap.size(), l = 2 * p + 1, r = 2 * p + 2;
+        if (l >= size) return 0;
+        if (r >= size) return l;
+        return compare_at_pos(l, r) > 0 ? l : r;
+    }
+    /// :244-259
+    void bubble_down(size_t id) {
+        size_t me = pos[id], kid = max_child_of(me);
+        while (kid > 0 && compare_at_pos(me, kid) < 0) {
+            size_t k_id = heap[kid];
+            pos[k_id] = me;
+            pos[id] = kid;
+            heap[me] = k_id;
+            heap[kid] = id;
+            me = kid;
+            kid = max_child_of(me);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// abstraction/mdd.rs
+// ---------------------------------------------------------------------------
+/// mdd.rs:41-48
+enum class CompilationType { Exact, Relaxed, Restricted };
+/// mdd.rs:24-28
+constexpr int LAST_EXACT_LAYER = 1;
+constexpr int FRONTIER = 2;
+
+/// mdd.rs:51-71
+template <class S>
+struct CompilationInput {
+    CompilationType comp_type;
+    const Problem<S>* problem;
+    const Relaxation<S>* relaxation;
+    const StateRanking<S>* ranking;
+    const Cutoff* cutoff;
+    size_t max_width;
+    const SubProblem<S>* residual;
+    isize best_lb;
+    Cache<S>* cache;
+    DominanceChecker<S>* dominance;
+};
+
+/// Counters the reference does not have: the metric
+/// "MDD nodes expanded" = iterations of the loop at clean.rs:360.
+struct MddCounters {
+    uint64_t nodes_expanded = 0;  // Σ |curr_l| after filter + squash
+    uint64_t arcs = 0;            // _branch_on calls (clean.rs:367)
+    uint64_t layers = 0;          // layers expanded
+    uint64_t compiles = 0;
+    void add(const MddCounters& o) {
+        nodes_expanded += o.nodes_expanded;
+        arcs += o.arcs;
+        layers += o.layers;
+        compiles += o.compiles;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// implementation/mdd/node_flags.rs:48-185
+// ---------------------------------------------------------------------------
+struct NodeFlags {
+    static constexpr uint8_t F_EXACT = 1, F_RELAXED = 2, F_MARKED = 4, F_CUTSET = 8, F_DELETED = 16, F_CACHE = 32,
+                             F_ABOVE_CUTSET = 64;
+    uint8_t bits;
+    static NodeFlags new_exact() { return {F_EXACT}; }
+    static NodeFlags new_relaxed() { return {F_RELAXED}; }
+    bool test(uint8_t m) const { return (bits & m) == m; }
+    void set(uint8_t f, bool v) { if (v) bits |= f; else bits &= (uint8_t)~f; }
+    bool is_exact() const { return test(F_EXACT) && !test(F_RELAXED); }
+    bool is_relaxed() const { return test(F_RELAXED); }
+    bool is_marked() const { return test(F_MARKED); }
+    bool is_cutset() const { return test(F_CUTSET); }
+    bool is_above_cutset() const { return test(F_ABOVE_CUTSET); }
+    bool is_deleted() const { return test(F_DELETED); }
+    bool is_pruned_by_cache() const { return test(F_CACHE); }
+    void set_exact(bool v) { set(F_EXACT, v); }
+    void set_relaxed(bool v) { set(F_RELAXED, v); }
+    void set_marked(bool v) { set(F_MARKED, v); }
+    void set_cutset(bool v) { set(F_CUTSET, v); }
+    void set_above_cutset(bool v) { set(F_ABOVE_CUTSET, v); }
+    void set_deleted(bool v) { set(F_DELETED, v); }
+    void set_pruned_by_cache(bool v) { set(F_CACHE, v); }
+};
+
+// ---------------------------------------------------------------------------
+// implementation/mdd/clean.rs:115-876 -- THE HOT PATH
+// ---------------------------------------------------------------------------
+template <class S, int CUTSET_TYPE = LAST_EXACT_LAYER>
+class Mdd {
+    static constexpr size_t NONE = (size_t)-1;
+    /// clean.rs:37-69
+    struct Node {
+        std::shared_ptr<const S> state;
+        isize value_top;
+        isize value_bot;
+        size_t best;     // Option<EdgeId>
+        size_t inbound;  // EdgesListId
+        isize rub;
+        std::optional<isize> theta;
+        NodeFlags flags;
+        size_t depth;
+    };
+    /// clean.rs:74-85
+    struct Edge {
+        size_t from, to;
+        Decision decision;
+        isize cost;
+    };
+    /// clean.rs:89-92 (Nil is encoded as head == NONE)
+    struct EdgesList {
+        size_t head, tail;
+    };
+    /// clean.rs:96-99
+    struct Layer {
+        size_t from, to;
+    };
+
+    std::vector<Layer> layers;
+    std::vector<Node> nodes;
+    std::vector<Edge> edges;
+    std::vector<EdgesList> edgelists;
+    std::vector<size_t> prev_l;
+    // next_l: FxHashMap<Arc<T>, NodeId>  (clean.rs:143).  Iteration order of
+    // this restatement = insertion order (next_order).
+    std::unordered_map<std::shared_ptr<const S>, size_t, PtrHash<S>, PtrEq<S>> next_l;
+    std::vector<size_t> next_order;
+    size_t curr_depth = 0;
+    std::vector<Decision> path_to_root;
+    std::optional<size_t> lel;
+    std::vector<size_t> cutset;
+    std::optional<size_t> best_node, best_exact_node;
+    bool is_exact_ = true;
+    bool has_exact_best_path_ = false;
+
+    static constexpr size_t NIL = 0;  // clean.rs:168
+
+  public:
+    MddCounters counters;        // accumulated over all compile() calls
+    MddCounters last_counters;   // the latest compile() only
+
+    /// clean.rs:237-239
+    std::optional<Completion> compile(const CompilationInput<S>& input, Reason* why = nullptr) {
+        return _compile(input, why);
+    }
+    /// clean.rs:241-243
+    bool is_exact() const { return is_exact_ || has_exact_best_path_; }
+    /// clean.rs:309-311
+    std::optional<isize> best_value() const {
+        if (best_node) return nodes[*best_node].value_top;
+        return std::nullopt;
+    }
+    /// clean.rs:313-315
+    std::optional<Solution> best_solution() const {
+        if (best_node) return _best_path(*best_node);
+        return std::nullopt;
+    }
+    /// clean.rs:317-319
+    std::optional<isize> best_exact_value() const {
+        if (best_exact_node) return nodes[*best_exact_node].value_top;
+        return std::nullopt;
+    }
+    /// clean.rs:321-323
+    std::optional<Solution> best_exact_solution() const {
+        if (best_exact_node) return _best_path(*best_exact_node);
+        return std::nullopt;
+    }
+    /// clean.rs:417-445
+    template <class F>
+    void drain_cutset(F&& func) {
+        auto bv = best_value();
+        if (bv) {
+            for (size_t id : cutset) {
+                const Node& node = nodes[id];
+                if (node.flags.is_marked()) {
+                    isize rub = sat_add(node.value_top, node.rub);
+                    isize locb = sat_add(node.value_top, node.value_bot);
+                    isize ub = std::min(std::min(rub, locb), *bv);
+                    SubProblem<S> sp;
+                    sp.state = node.state;
+                    sp.value = node.value_top;
+                    sp.path = _best_path(id);
+                    sp.ub = ub;
+                    sp.depth = node.depth;
+                    func(std::move(sp));
+                }
+            }
+            cutset.clear();
+        }
+    }
+
+    // --- introspection used by the parity tests (not part of the reference API)
+    size_t nb_layers() const { return layers.size(); }
+    size_t nb_nodes() const { return nodes.size(); }
+    size_t nb_edges() const { return edges.size(); }
+
+  private:
+    struct MapKeysIter : StateIter<S> {
+        const std::vector<Node>& nodes;
+        const std::vector<size_t>& order;
+        size_t i = 0;
+        MapKeysIter(const std::vector<Node>& n, const std::vector<size_t>& o) : nodes(n), order(o) {}
+        const S* next() override { return i < order.size() ? nodes[order[i++]].state.get() : nullptr; }
+    };
+    struct IdsIter : StateIter<S> {
+        const std::vector<Node>& nodes;
+        const size_t* b;
+        const size_t* e;
+        IdsIter(const std::vector<Node>& n, const size_t* b, const size_t* e) : nodes(n), b(b), e(e) {}
+        const S* next() override { return b < e ? nodes[*b++].state.get() : nullptr; }
+    };
+    struct BranchCb : DecisionCallback {
+        Mdd* self;
+        size_t node_id;
+        const Problem<S>* pb;
+        void apply(Decision d) override { self->_branch_on(node_id, d, *pb); }
+    };
+
+    /// clean.rs:293-307
+    void _clear() {
+        layers.clear();
+        nodes.clear();
+        edges.clear();
+        edgelists.clear();
+        prev_l.clear();
+        next_l.clear();
+        next_order.clear();
+        path_to_root.clear();
+        cutset.clear();
+        lel.reset();
+        best_node.reset();
+        best_exact_node.reset();
+        is_exact_ = true;
+        has_exact_best_path_ = false;
+    }
+
+    /// clean.rs:325-343
+    Solution _best_path(size_t id) const {
+        Solution sol = path_to_root;
+        size_t eid = nodes[id].best;
+        while (eid != NONE) {
+            const Edge& e = edges[eid];
+            sol.push_back(e.decision);
+            eid = nodes[e.from].best;
+        }
+        return sol;
+    }
+
+    /// clean.rs:199-220
+    void append_edge_to(const Edge& edge) {
+        size_t new_eid = edges.size();
+        size_t lst_id = edgelists.size();
+        edges.push_back(edge);
+        edgelists.push_back(EdgesList{new_eid, nodes[edge.to].inbound});
+
+        const Node& parent = nodes[edge.from];
+        bool parent_exact = parent.flags.is_exact();
+        isize value = sat_add(parent.value_top, edge.cost);
+
+        Node& node = nodes[edge.to];
+        bool exact = parent_exact & node.flags.is_exact();
+        node.flags.set_exact(exact);
+        node.inbound = lst_id;
+        if (value >= node.value_top) {
+            node.best = new_eid;
+            node.value_top = value;
+        }
+    }
+
+    /// foreach!(edge of id, ...) clean.rs:187-196
+    template <class F>
+    void foreach_edge_of(size_t id, F&& action) {
+        size_t list = nodes[id].inbound;
+        while (edgelists[list].head != NONE) {
+            Edge e = edges[edgelists[list].head];
+            size_t tail = edgelists[list].tail;
+            action(e);
+            list = tail;
+        }
+    }
+
+    /// clean.rs:345-381
+    std::optional<Completion> _compile(const CompilationInput<S>& input, Reason* why) {
+        _clear();
+        last_counters = MddCounters();
+        last_counters.compiles = 1;
+        _initialize(input);
+
+        std::vector<size_t> curr_l;
+        for (;;) {
+            MapKeysIter keys(nodes, next_order);
+            auto var = input.problem->next_variable(curr_depth, keys);
+            if (!var) break;
+            if (input.cutoff->must_stop()) {  // :352-354
+                if (why) *why = Reason::CutoffOccurred;
+                counters.add(last_counters);
+                return std::nullopt;
+            }
+            if (!_move_to_next_layer(input, curr_l)) break;
+
+            last_counters.layers += 1;
+            for (size_t node_id : curr_l) {  // :360-370
+                last_counters.nodes_expanded += 1;
+                std::shared_ptr<const S> state = nodes[node_id].state;
+                isize rub = input.relaxation->fast_upper_bound(*state);
+                nodes[node_id].rub = rub;
+                isize ub = sat_add(rub, nodes[node_id].value_top);
+                if (ub > input.best_lb) {
+                    BranchCb cb;
+                    cb.self = this;
+                    cb.node_id = node_id;
+                    cb.pb = input.problem;
+                    input.problem->for_each_in_domain(*var, *state, cb);
+                }
+            }
+            curr_depth += 1;
+        }
+
+        _finalize(input);
+        counters.add(last_counters);
+        Completion c;
+        c.is_exact = is_exact();
+        c.best_value = best_value();
+        return c;
+    }
+
+    /// clean.rs:383-405
+    void _initialize(const CompilationInput<S>& input) {
+        path_to_root = input.residual->path;
+        edgelists.push_back(EdgesList{NONE, NONE});  // Nil
+        Node root;
+        root.state = input.residual->state;
+        root.value_top = input.residual->value;
+        root.value_bot = ISIZE_MIN;
+        root.best = NONE;
+        root.inbound = NIL;
+        root.rub = ISIZE_MAX;
+        root.theta = std::nullopt;
+        root.flags = NodeFlags::new_exact();
+        root.depth = input.residual->depth;
+        nodes.push_back(root);
+        next_l.emplace(root.state, 0);
+        next_order.push_back(0);
+        edgelists.push_back(EdgesList{NONE, NONE});
+        curr_depth = input.residual->depth;
+    }
+
+    /// clean.rs:407-414
+    void _finalize(const CompilationInput<S>& input) {
+        _finalize_layers();
+        _find_best_node();
+        _finalize_exact(input);
+        _finalize_cutset(input);
+        _compute_local_bounds(input);
+        _compute_thresholds(input);
+    }
+
+    /// clean.rs:448-475
+    void _compute_local_bounds(const CompilationInput<S>& input) {
+        if (*lel < layers.size() && input.comp_type == CompilationType::Relaxed) {
+            Layer last = layers.back();
+            for (size_t i = last.from; i < last.to; ++i) {
+                nodes[i].value_bot = 0;
+                nodes[i].flags.set_marked(true);
+            }
+            for (size_t li = layers.size(); li-- > 0;) {
+                Layer l = layers[li];
+                for (size_t id = l.from; id < l.to; ++id) {
+                    isize value = nodes[id].value_bot;
+                    if (nodes[id].flags.is_marked()) {
+                        foreach_edge_of(id, [&](const Edge& edge) {
+                            isize using_edge = sat_add(value, edge.cost);
+                            Node& parent = nodes[edge.from];
+                            parent.flags.set_marked(true);
+                            parent.value_bot = std::max(parent.value_bot, using_edge);
+                        });
+                    }
+                }
+            }
+        }
+    }
+
+    /// clean.rs:478-532
+    void _compute_thresholds(const CompilationInput<S>& input) {
+        if (input.comp_type == CompilationType::Relaxed || is_exact_) {
+            isize best_known = input.best_lb;
+            if (best_exact_node) {
+                isize bev = nodes[*best_exact_node].value_top;
+                best_known = std::max(best_known, bev);
+                for (size_t id : next_order) {
+                    if ((CUTSET_TYPE == LAST_EXACT_LAYER && is_exact_) ||
+                        (CUTSET_TYPE == FRONTIER && nodes[id].flags.is_exact())) {
+                        nodes[id].theta = best_known;
+                    }
+                }
+            }
+            for (size_t li = layers.size(); li-- > 0;) {
+                Layer l = layers[li];
+                for (size_t id = l.from; id < l.to; ++id) {
+                    Node& node = nodes[id];
+                    if (node.flags.is_deleted()) continue;
+                    if (!node.flags.is_pruned_by_cache()) {
+                        isize tot_rub = sat_add(node.value_top, node.rub);
+                        if (tot_rub <= best_known) {
+                            node.theta = sat_sub(best_known, node.rub);
+                        } else if (node.flags.is_cutset()) {
+                            isize tot_locb = sat_add(node.value_top, node.value_bot);
+                            if (tot_locb <= best_known) {
+                                isize theta = node.theta.value_or(ISIZE_MAX);
+                                node.theta = std::min(theta, sat_sub(best_known, node.value_bot));
+                            } else {
+                                node.theta = node.value_top;
+                            }
+                        } else if (node.flags.is_exact() && !node.theta) {
+                            node.theta = ISIZE_MAX;
+                        }
+                        _maybe_update_cache(node, input);
+                    }
+                    if (node.theta) {
+                        isize my_theta = *node.theta;
+                        foreach_edge_of(id, [&](const Edge& edge) {
+                            Node& parent = nodes[edge.from];
+                            isize theta = parent.theta.value_or(ISIZE_MAX);
+                            parent.theta = std::min(theta, sat_sub(my_theta, edge.cost));
+                        });
+                    }
+                }
+            }
+        }
+    }
+
+    /// clean.rs:534-545
+    static void _maybe_update_cache(const Node& node, const CompilationInput<S>& input) {
+        if (node.theta && node.flags.is_above_cutset()) {
+            input.cache->update_threshold(node.state, node.depth, *node.theta, !node.flags.is_cutset());
+        }
+    }
+
+    /// clean.rs:547-564
+    void _finalize_cutset(const CompilationInput<S>& input) {
+        if (!lel) lel = layers.size();
+        if (input.comp_type == CompilationType::Relaxed || is_exact_) {
+            if (CUTSET_TYPE == LAST_EXACT_LAYER) _compute_last_exact_layer_cutset(*lel);
+            else _compute_frontier_cutset();
+        }
+    }
+
+    /// clean.rs:566-583
+    void _compute_last_exact_layer_cutset(size_t lel_id) {
+        if (lel_id < layers.size()) {
+            Layer l = layers[lel_id];
+            for (size_t id = l.from; id < l.to; ++id) {
+                cutset.push_back(id);
+                nodes[id].flags.bits |= (NodeFlags::F_CUTSET | NodeFlags::F_ABOVE_CUTSET);
+            }
+        }
+        size_t upto = std::min(lel_id, layers.size());
+        for (size_t li = upto; li-- > 0;) {
+            Layer l = layers[li];
+            for (size_t id = l.from; id < l.to; ++id) nodes[id].flags.set_above_cutset(true);
+        }
+    }
+
+    /// clean.rs:586-606
+    void _compute_frontier_cutset() {
+        for (size_t li = layers.size(); li-- > 0;) {
+            Layer l = layers[li];
+            for (size_t id = l.from; id < l.to; ++id) {
+                if (nodes[id].flags.is_exact()) {
+                    nodes[id].flags.set_above_cutset(true);
+                } else {
+                    foreach_edge_of(id, [&](const Edge& edge) {
+                        Node& parent = nodes[edge.from];
+                        if (parent.flags.is_exact() && !parent.flags.is_cutset()) {
+                            cutset.push_back(edge.from);
+                            parent.flags.set_cutset(true);
+                        }
+                    });
+                }
+            }
+        }
+    }
+
+    /// clean.rs:608-618
+    void _finalize_layers() {
+        if (!next_l.empty()) {
+            if (layers.empty()) layers.push_back(Layer{0, nodes.size()});
+            else layers.push_back(Layer{layers.back().to, nodes.size()});
+        }
+    }
+
+    /// clean.rs:620-632.  Iterator::max_by_key keeps the LAST maximum.
+    void _find_best_node() {
+        best_node.reset();
+        best_exact_node.reset();
+        for (size_t id : next_order) {
+            if (!best_node || nodes[id].value_top >= nodes[*best_node].value_top) best_node = id;
+            if (nodes[id].flags.is_exact()) {
+                if (!best_exact_node || nodes[id].value_top >= nodes[*best_exact_node].value_top) best_exact_node = id;
+            }
+        }
+    }
+
+    /// clean.rs:634-641
+    void _finalize_exact(const CompilationInput<S>& input) {
+        is_exact_ = !lel.has_value();
+        has_exact_best_path_ = input.comp_type == CompilationType::Relaxed && _has_exact_best_path(best_node);
+        if (has_exact_best_path_) best_exact_node = best_node;
+    }
+
+    /// clean.rs:643-655
+    bool _has_exact_best_path(std::optional<size_t> node) const {
+        while (node) {
+            const Node& n = nodes[*node];
+            if (n.flags.is_exact()) return true;
+            if (n.flags.is_relaxed()) return false;
+            if (n.best == NONE) node.reset();
+            else node = edges[n.best].from;
+        }
+        return true;
+    }
+
+    /// clean.rs:657-687
+    bool _move_to_next_layer(const CompilationInput<S>& input, std::vector<size_t>& curr_l) {
+        prev_l.clear();
+        for (size_t id : curr_l) prev_l.push_back(id);
+        curr_l.clear();
+        for (size_t id : next_order) curr_l.push_back(id);
+        next_l.clear();
+        next_order.clear();
+
+        if (curr_l.empty()) {
+            layers.push_back(Layer{0, 0});
+            return false;
+        }
+        if (!layers.empty()) _filter_with_cache(input, curr_l);
+        _filter_with_dominance(input, curr_l);
+        _squash_if_needed(input, curr_l);
+        if (layers.empty()) layers.push_back(Layer{0, nodes.size()});
+        else layers.push_back(Layer{layers.back().to, nodes.size()});
+        return true;
+    }
+
+    /// clean.rs:689-708
+    void _filter_with_dominance(const CompilationInput<S>& input, std::vector<size_t>& curr_l) {
+        std::sort(curr_l.begin(), curr_l.end(), [&](size_t a, size_t b) {
+            // sort by dominance.cmp(a, b).reverse()  => "a before b" iff cmp(a,b) > 0
+            return input.dominance->cmp(*nodes[a].state, nodes[a].value_top, *nodes[b].state, nodes[b].value_top) > 0;
+        });
+        size_t w = 0;
+        for (size_t i = 0; i < curr_l.size(); ++i) {
+            size_t id = curr_l[i];
+            Node& node = nodes[id];
+            bool keep = true;
+            if (node.flags.is_exact()) {
+                DominanceCheckResult r = input.dominance->is_dominated_or_insert(node.state, node.depth, node.value_top);
+                if (r.dominated) {
+                    node.theta = r.threshold;
+                    keep = false;
+                }
+            }
+            if (keep) curr_l[w++] = id;
+        }
+        curr_l.resize(w);
+    }
+
+    /// clean.rs:710-726
+    void _filter_with_cache(const CompilationInput<S>& input, std::vector<size_t>& curr_l) {
+        size_t w = 0;
+        for (size_t i = 0; i < curr_l.size(); ++i) {
+            size_t id = curr_l[i];
+            Node& node = nodes[id];
+            auto t = input.cache->get_threshold(*node.state, node.depth);
+            bool keep = true;
+            if (t) {
+                if (!(node.value_top > t->value)) {
+                    node.flags.set_pruned_by_cache(true);
+                    node.theta = t->value;
+                    keep = false;
+                }
+            }
+            if (keep) curr_l[w++] = id;
+        }
+        curr_l.resize(w);
+    }
+
+    /// clean.rs:728-776
+    void _branch_on(size_t from_id, Decision decision, const Problem<S>& problem) {
+        last_counters.arcs += 1;
+        const S& state = *nodes[from_id].state;
+        auto next_state = std::make_shared<const S>(problem.transition(state, decision));
+        isize cost = problem.transition_cost(state, *next_state, decision);
+
+        auto it = next_l.find(next_state);
+        if (it == next_l.end()) {
+            const Node& parent = nodes[from_id];
+            size_t node_id = nodes.size();
+            NodeFlags flags = NodeFlags::new_exact();
+            flags.set_exact(parent.flags.is_exact());
+            Node n;
+            n.state = next_state;
+            n.value_top = sat_add(parent.value_top, cost);
+            n.value_bot = ISIZE_MIN;
+            n.best = NONE;
+            n.inbound = NIL;
+            n.rub = ISIZE_MAX;
+            n.theta = std::nullopt;
+            n.flags = flags;
+            n.depth = parent.depth + 1;
+            nodes.push_back(std::move(n));
+            append_edge_to(Edge{from_id, node_id, decision, cost});
+            next_l.emplace(next_state, node_id);
+            next_order.push_back(node_id);
+        } else {
+            append_edge_to(Edge{from_id, it->second, decision, cost});
+        }
+    }
+
+    /// clean.rs:779-795
+    void _squash_if_needed(const CompilationInput<S>& input, std::vector<size_t>& curr_l) {
+        switch (input.comp_type) {
+            case CompilationType::Exact: break;
+            case CompilationType::Restricted:
+                if (curr_l.size() > input.max_width) {
+                    _maybe_save_lel();
+                    _restrict(input, curr_l);
+                }
+                break;
+            case CompilationType::Relaxed:
+                if (curr_l.size() > input.max_width && layers.size() > 1) {
+                    _maybe_save_lel();
+                    _relax(input, curr_l);
+                }
+                break;
+        }
+    }
+    /// clean.rs:796-800
+    void _maybe_save_lel() {
+        if (!lel) lel = layers.size() - 1;
+    }
+
+    /// the comparator of clean.rs:803-808 / :819-824: descending (value_top, ranking)
+    void _sort_layer(const CompilationInput<S>& input, std::vector<size_t>& curr_l) {
+        std::sort(curr_l.begin(), curr_l.end(), [&](size_t a, size_t b) {
+            if (nodes[a].value_top != nodes[b].value_top) return nodes[a].value_top > nodes[b].value_top;
+            return input.ranking->compare(*nodes[a].state, *nodes[b].state) > 0;
+        });
+    }
+
+    /// clean.rs:802-815
+    void _restrict(const CompilationInput<S>& input, std::vector<size_t>& curr_l) {
+        _sort_layer(input, curr_l);
+        for (size_t i = input.max_width; i < curr_l.size(); ++i) nodes[curr_l[i]].flags.set_deleted(true);
+        curr_l.resize(input.max_width);
+    }
+
+    /// clean.rs:818-876
+    void _relax(const CompilationInput<S>& input, std::vector<size_t>& curr_l) {
+        _sort_layer(input, curr_l);
+        size_t nkeep = input.max_width - 1;
+        const size_t* merge_b = curr_l.data() + nkeep;
+        const size_t* merge_e = curr_l.data() + curr_l.size();
+        IdsIter it(nodes, merge_b, merge_e);
+        auto merged = std::make_shared<const S>(input.relaxation->merge(it));
+
+        std::optional<size_t> recycled;
+        for (size_t i = 0; i < nkeep; ++i) {
+            if (*nodes[curr_l[i]].state == *merged) {
+                recycled = curr_l[i];
+                break;
+            }
+        }
+        size_t merged_id;
+        if (recycled) {
+            merged_id = *recycled;
+        } else {
+            merged_id = nodes.size();
+            Node n;
+            n.state = merged;
+            n.value_top = ISIZE_MIN;
+            n.value_bot = ISIZE_MIN;
+            n.best = NONE;
+            n.inbound = NIL;
+            n.rub = ISIZE_MAX;
+            n.theta = std::nullopt;
+            n.flags = NodeFlags::new_relaxed();
+            n.depth = nodes[*merge_b].depth;
+            nodes.push_back(std::move(n));
+        }
+        nodes[merged_id].flags.set_relaxed(true);
+
+        for (const size_t* p = merge_b; p < merge_e; ++p) {
+            size_t drop_id = *p;
+            nodes[drop_id].flags.set_deleted(true);
+            // NB: the edges appended below go to merged_id's list, never to
+            // drop_id's list, so walking drop_id's list while appending is safe.
+            foreach_edge_of(drop_id, [&](const Edge& edge) {
+                const S& src = *nodes[edge.from].state;
+                const S& dst = *nodes[edge.to].state;
+                isize rcost = input.relaxation->relax(src, dst, *merged, edge.decision, edge.cost);
+                append_edge_to(Edge{edge.from, merged_id, edge.decision, rcost});
+            });
+        }
+
+        if (recycled) {
+            curr_l.resize(input.max_width);
+            size_t saved_id = curr_l[input.max_width - 1];
+            nodes[saved_id].flags.set_deleted(false);
+        } else {
+            curr_l.resize(input.max_width - 1);
+            curr_l.push_back(merged_id);
+        }
+    }
+};
+
+template <class S>
+using DefaultMDDLEL = Mdd<S, LAST_EXACT_LAYER>;
+template <class S>
+using DefaultMDDFC = Mdd<S, FRONTIER>;
+
+// ---------------------------------------------------------------------------
+// abstraction/solver.rs:32-97
+// ---------------------------------------------------------------------------
+template <class S>
+struct Solver {
+    virtual ~Solver() = default;
+    virtual Completion maximize() = 0;
+    virtual std::optional<isize> best_value() const = 0;
+    virtual std::optional<Solution> best_solution() const = 0;
+    virtual isize best_lower_bound() const = 0;
+    virtual isize best_upper_bound() const = 0;
+    virtual void set_primal(isize value, Solution solution) = 0;
+    virtual size_t explored() const = 0;
+    /// solver.rs:80-93
+    double gap() const {
+        isize ub = best_upper_bound(), lb = best_lower_bound();
+        if (ub == ISIZE_MAX || lb == ISIZE_MIN) return 1.0;
+        double aub = std::abs((double)ub), alb = std::abs((double)lb);
+        double u = std::max(aub, alb), l = std::min(aub, alb);
+        if (u == 0.0) return 0.0;
+        return (u - l) / u;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// implementation/solver/sequential.rs:202-527
+// ---------------------------------------------------------------------------
+template <class S, class D = DefaultMDDLEL<S>, class C = EmptyCache<S>>
+class SequentialSolver : public Solver<S> {
+    const Problem<S>& problem;
+    const Relaxation<S>& relaxation;
+    const StateRanking<S>& ranking;
+    const WidthHeuristic<S>& width_heu;
+    const Cutoff& cutoff;
+    Fringe<S>& fringe;
+    size_t explored_ = 0;
+    std::vector<size_t> open_by_layer;
+    size_t first_active_layer = 0;
+    isize best_lb = ISIZE_MIN;
+    isize best_ub = ISIZE_MAX;
+    std::optional<Solution> best_sol;
+    std::optional<Reason> abort_proof;
+    D mdd;
+    C cache;
+    DominanceChecker<S>& dominance;
+
+  public:
+    /// Optional observer invoked after every compile (test/parity hook; not in the reference).
+    std::function<void(const SubProblem<S>&, CompilationType, size_t width, isize best_lb, D&)> on_compile;
+
+    /// sequential.rs:263-303 (`new` == `custom`)
+    SequentialSolver(const Problem<S>& problem, const Relaxation<S>& relaxation, const StateRanking<S>& ranking,
+                     const WidthHeuristic<S>& width, DominanceChecker<S>& dominance, const Cutoff& cutoff,
+                     Fringe<S>& fringe)
+        : problem(problem), relaxation(relaxation), ranking(ranking), width_heu(width), cutoff(cutoff), fringe(fringe),
+          open_by_layer(problem.nb_variables() + 1, 0), dominance(dominance) {}
+
+    const MddCounters& counters() const { return mdd.counters; }
+
+    /// sequential.rs:475-494
+    Completion maximize() override {
+        initialize();
+        for (;;) {
+            // get_workload, sequential.rs:433-461
+            while (first_active_layer < problem.nb_variables() && open_by_layer[first_active_layer] == 0) {
+                cache.clear_layer(first_active_layer);
+                first_active_layer += 1;
+            }
+            if (fringe.is_empty()) {
+                best_ub = best_lb;
+                break;
+            }
+            if (abort_proof) break;
+            SubProblem<S> nn = *fringe.pop();
+            explored_ += 1;
+            open_by_layer[nn.depth] -= 1;
+            best_ub = nn.ub;
+
+            if (!process_one_node(nn)) {
+                abort_search(Reason::CutoffOccurred);
+                break;
+            }
+        }
+        if (best_sol)
+            std::sort(best_sol->begin(), best_sol->end(),
+                      [](const Decision& a, const Decision& b) { return a.variable < b.variable; });
+        Completion c;
+        c.is_exact = !abort_proof.has_value();
+        if (best_sol) c.best_value = best_lb;
+        return c;
+    }
+    std::optional<Solution> best_solution() const override { return best_sol; }
+    std::optional<isize> best_value() const override {
+        if (best_sol) return best_lb;
+        return std::nullopt;
+    }
+    isize best_lower_bound() const override { return best_lb; }
+    isize best_upper_bound() const override { return best_ub; }
+    void set_primal(isize value, Solution solution) override {
+        if (value > best_lb) {
+            best_sol = std::move(solution);
+            best_lb = value;
+        }
+    }
+    size_t explored() const override { return explored_; }
+
+  private:
+    /// sequential.rs:308-323
+    void initialize() {
+        SubProblem<S> root;
+        root.state = std::make_shared<const S>(problem.initial_state());
+        root.value = problem.initial_value();
+        root.ub = ISIZE_MAX;
+        root.depth = 0;
+        cache.initialize(problem);
+        fringe.push(std::move(root));
+        open_by_layer[0] += 1;
+    }
+
+    /// sequential.rs:329-389; returns false on cutoff
+    bool process_one_node(const SubProblem<S>& node) {
+        isize node_ub = node.ub;
+        isize lb = best_lb;
+        if (node_ub <= lb) return true;
+        if (!cache.must_explore(node)) return true;
+
+        size_t width = width_heu.max_width(node);
+        CompilationInput<S> in{CompilationType::Restricted, &problem, &relaxation, &ranking, &cutoff, width, &node, lb,
+                               &cache, &dominance};
+        auto c = mdd.compile(in);
+        if (!c) return false;
+        if (on_compile) on_compile(node, CompilationType::Restricted, width, lb, mdd);
+        maybe_update_best();
+        if (c->is_exact) return true;
+
+        lb = best_lb;
+        in.comp_type = CompilationType::Relaxed;
+        in.best_lb = lb;
+        c = mdd.compile(in);
+        if (!c) return false;
+        if (on_compile) on_compile(node, CompilationType::Relaxed, width, lb, mdd);
+        maybe_update_best();
+        if (!c->is_exact) enqueue_cutset(node_ub);
+        return true;
+    }
+    /// sequential.rs:394-400
+    void maybe_update_best() {
+        isize v = mdd.best_exact_value().value_or(ISIZE_MIN);
+        if (v > best_lb) {
+            best_lb = v;
+            best_sol = mdd.best_exact_solution();
+        }
+    }
+    /// sequential.rs:403-416
+    void enqueue_cutset(isize ub) {
+        isize lb = best_lb;
+        mdd.drain_cutset([&](SubProblem<S> cn) {
+            cn.ub = std::min(ub, cn.ub);
+            if (cn.ub > lb) {
+                size_t depth = cn.depth;
+                size_t before = fringe.len();
+                fringe.push(std::move(cn));
+                size_t after = fringe.len();
+                open_by_layer[depth] += after - before;
+            }
+        });
+    }
+    /// sequential.rs:418-422
+    void abort_search(Reason r) {
+        abort_proof = r;
+        fringe.clear();
+        cache.clear();
+    }
+};
+
+// ---------------------------------------------------------------------------
+// implementation/solver/parallel.rs:32-641
+// ---------------------------------------------------------------------------
+template <class S, class D = DefaultMDDLEL<S>, class C = EmptyCache<S>>
+class ParallelSolver : public Solver<S> {
+    /// parallel.rs:32-81
+    struct Critical {
+        Fringe<S>* fringe;
+        size_t ongoing = 0;
+        size_t explored = 0;
+        std::vector<size_t> open_by_layer;
+        std::vector<size_t> ongoing_by_layer;
+        size_t first_active_layer = 0;
+        isize best_lb = ISIZE_MIN;
+        isize best_ub = ISIZE_MAX;
+        std::optional<Solution> best_sol;
+        std::vector<isize> upper_bounds;
+        std::optional<Reason> abort_proof;
+    };
+    /// parallel.rs:85-114
+    const Problem<S>& problem;
+    const Relaxation<S>& relaxation;
+    const StateRanking<S>& ranking;
+    const WidthHeuristic<S>& width_heu;
+    const Cutoff& cutoff;
+    C cache;
+    DominanceChecker<S>& dominance;
+    mutable std::mutex mtx;
+    std::condition_variable monitor;
+    Critical critical;
+    size_t nb_threads;
+    MddCounters total_counters;
+
+    enum class WorkKind { Complete, Aborted, Starvation, WorkItem };
+    struct WorkLoad {
+        WorkKind kind;
+        SubProblem<S> node;
+    };
+
+  public:
+    /// parallel.rs:320-358 (`new` uses num_cpus::get(), :317)
+    ParallelSolver(const Problem<S>& problem, const Relaxation<S>& relaxation, const StateRanking<S>& ranking,
+                   const WidthHeuristic<S>& width, DominanceChecker<S>& dominance, const Cutoff& cutoff,
+                   Fringe<S>& fringe, size_t nb_threads = std::thread::hardware_concurrency())
+        : problem(problem), relaxation(relaxation), ranking(ranking), width_heu(width), cutoff(cutoff),
+          dominance(dominance), nb_threads(nb_threads) {
+        critical.fringe = &fringe;
+        critical.upper_bounds.assign(nb_threads, ISIZE_MAX);
+        critical.open_by_layer.assign(problem.nb_variables() + 1, 0);
+        critical.ongoing_by_layer.assign(problem.nb_variables() + 1, 0);
+    }
+    ParallelSolver& with_nb_threads(size_t n) {
+        nb_threads = n;
+        critical.upper_bounds.assign(n, ISIZE_MAX);
+        return *this;
+    }
+    const MddCounters& counters() const { return total_counters; }
+
+    /// parallel.rs:573-607
+    Completion maximize() override {
+        initialize();
+        std::vector<std::thread> workers;
+        for (size_t i = 0; i < nb_threads; ++i) {
+            workers.emplace_back([this, i]() {
+                D mdd;
+                for (;;) {
+                    WorkLoad w = get_workload(i);
+                    if (w.kind == WorkKind::Complete || w.kind == WorkKind::Aborted) break;
+                    if (w.kind == WorkKind::Starvation) continue;
+                    isize ub = w.node.ub;
+                    size_t depth = w.node.depth;
+                    bool ok = process_one_node(mdd, w.node);
+                    if (!ok) {
+                        abort_search(Reason::CutoffOccurred, ub);
+                        notify_node_finished(i, depth);
+                        break;
+                    }
+                    notify_node_finished(i, depth);
+                }
+                std::lock_guard<std::mutex> g(mtx);
+                total_counters.add(mdd.counters);
+            });
+        }
+        for (auto& t : workers) t.join();
+
+        std::lock_guard<std::mutex> g(mtx);
+        if (critical.best_sol)
+            std::sort(critical.best_sol->begin(), critical.best_sol->end(),
+                      [](const Decision& a, const Decision& b) { return a.variable < b.variable; });
+        Completion c;
+        c.is_exact = !critical.abort_proof.has_value();
+        if (critical.best_sol) c.best_value = critical.best_lb;
+        return c;
+    }
+    std::optional<Solution> best_solution() const override {
+        std::lock_guard<std::mutex> g(mtx);
+        return critical.best_sol;
+    }
+    std::optional<isize> best_value() const override {
+        std::lock_guard<std::mutex> g(mtx);
+        if (critical.best_sol) return critical.best_lb;
+        return std::nullopt;
+    }
+    isize best_lower_bound() const override {
+        std::lock_guard<std::mutex> g(mtx);
+        return critical.best_lb;
+    }
+    isize best_upper_bound() const override {
+        std::lock_guard<std::mutex> g(mtx);
+        return critical.best_ub;
+    }
+    void set_primal(isize value, Solution solution) override {
+        std::lock_guard<std::mutex> g(mtx);
+        if (value > critical.best_lb) {
+            critical.best_sol = std::move(solution);
+            critical.best_lb = value;
+        }
+    }
+    size_t explored() const override {
+        std::lock_guard<std::mutex> g(mtx);
+        return critical.explored;
+    }
+
+  private:
+    /// parallel.rs:368-385
+    void initialize() {
+        SubProblem<S> root;
+        root.state = std::make_shared<const S>(problem.initial_state());
+        root.value = problem.initial_value();
+        root.ub = ISIZE_MAX;
+        root.depth = 0;
+        cache.initialize(problem);
+        std::lock_guard<std::mutex> g(mtx);
+        critical.fringe->push(std::move(root));
+        critical.open_by_layer[0] += 1;
+    }
+    isize read_best_lb() {
+        std::lock_guard<std::mutex> g(mtx);
+        return critical.best_lb;
+    }
+    /// parallel.rs:391-437
+    bool process_one_node(D& mdd, const SubProblem<S>& node) {
+        isize node_ub = node.ub;
+        isize lb = read_best_lb();
+        if (node_ub <= lb) return true;
+        size_t width = width_heu.max_width(node);
+        CompilationInput<S> in{CompilationType::Restricted, &problem, &relaxation, &ranking, &cutoff, width, &node, lb,
+                               &cache, &dominance};
+        auto c = mdd.compile(in);
+        if (!c) return false;
+        maybe_update_best(mdd);
+        if (c->is_exact) return true;
+
+        lb = read_best_lb();
+        in.comp_type = CompilationType::Relaxed;
+        in.best_lb = lb;
+        c = mdd.compile(in);
+        if (!c) return false;
+        maybe_update_best(mdd);
+        if (!c->is_exact) enqueue_cutset(mdd, node_ub);
+        return true;
+    }
+    /// parallel.rs:446-453
+    void maybe_update_best(D& mdd) {
+        std::lock_guard<std::mutex> g(mtx);
+        isize v = mdd.best_exact_value().value_or(ISIZE_MIN);
+        if (v > critical.best_lb) {
+            critical.best_lb = v;
+            critical.best_sol = mdd.best_exact_solution();
+        }
+    }
+    /// parallel.rs:456-469
+    void enqueue_cutset(D& mdd, isize ub) {
+        std::lock_guard<std::mutex> g(mtx);
+        isize lb = critical.best_lb;
+        mdd.drain_cutset([&](SubProblem<S> cn) {
+            cn.ub = std::min(ub, cn.ub);
+            if (cn.ub > lb) {
+                size_t depth = cn.depth;
+                size_t before = critical.fringe->len();
+                critical.fringe->push(std::move(cn));
+                size_t after = critical.fringe->len();
+                critical.open_by_layer[depth] += after - before;
+            }
+        });
+    }
+    /// parallel.rs:471-477
+    void notify_node_finished(size_t thread_id, size_t depth) {
+        std::lock_guard<std::mutex> g(mtx);
+        critical.ongoing -= 1;
+        critical.upper_bounds[thread_id] = ISIZE_MAX;
+        critical.ongoing_by_layer[depth] -= 1;
+        monitor.notify_all();
+    }
+    /// parallel.rs:479-489
+    void abort_search(Reason r, isize current_ub) {
+        std::lock_guard<std::mutex> g(mtx);
+        critical.abort_proof = r;
+        if (critical.best_ub == ISIZE_MAX) critical.best_ub = current_ub;
+        else critical.best_ub = std::max(current_ub, critical.best_ub);
+        critical.fringe->clear();
+        cache.clear();
+    }
+    /// parallel.rs:500-559
+    WorkLoad get_workload(size_t thread_id) {
+        std::unique_lock<std::mutex> lk(mtx);
+        while (critical.first_active_layer < problem.nb_variables() &&
+               critical.open_by_layer[critical.first_active_layer] +
+                       critical.ongoing_by_layer[critical.first_active_layer] == 0) {
+            cache.clear_layer(critical.first_active_layer);
+            critical.first_active_layer += 1;
+        }
+        if (critical.ongoing == 0 && critical.fringe->is_empty()) {
+            critical.best_ub = critical.best_lb;
+            return {WorkKind::Complete, {}};
+        }
+        if (critical.abort_proof) return {WorkKind::Aborted, {}};
+        if (critical.fringe->is_empty()) {
+            monitor.wait(lk);
+            return {WorkKind::Starvation, {}};
+        }
+        SubProblem<S> nn = *critical.fringe->pop();
+        for (;;) {
+            if (nn.ub <= critical.best_lb) {
+                critical.fringe->clear();
+                for (auto& o : critical.open_by_layer) o = 0;
+                return {WorkKind::Starvation, {}};
+            }
+            if (cache.must_explore(nn)) {
+                cache.update_threshold(nn.state, nn.depth, nn.value, true);
+                break;
+            } else {
+                critical.open_by_layer[nn.depth] -= 1;
+                if (critical.fringe->is_empty()) return {WorkKind::Starvation, {}};
+                nn = *critical.fringe->pop();
+            }
+        }
+        critical.ongoing += 1;
+        critical.explored += 1;
+        critical.upper_bounds[thread_id] = nn.ub;
+        critical.open_by_layer[nn.depth] -= 1;
+        critical.ongoing_by_layer[nn.depth] += 1;
+        return {WorkKind::WorkItem, std::move(nn)};
+    }
+};
+
+}  // namespace ddo

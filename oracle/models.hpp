@@ -1,0 +1,386 @@
+// =============================================================================
+// models.hpp -- CPU restatement of the ddo example models that sit on the hot
+// path: MISP (examples/misp/main.rs) and 0/1 knapsack (examples/knapsack/main.rs).
+//
+// *** TEST INFRASTRUCTURE (parity oracle + CPU baseline), see ddo_oracle.hpp ***
+//
+// MISP states are `bit_set::BitSet` in the reference (crate bit-set 0.5.3 on
+// bit-vec 0.6.3, pinned in /root/reference/Cargo.lock:96-106; the crate source
+// is NOT vendored under /root/reference).  The semantics relied on -- set
+// algebra on blocks, len = popcount, Eq/Hash/Ord over the ascending sequence
+// of members -- are restated here from the crate's documented behaviour and
+// anchored on the reference's call sites (examples/misp/main.rs:70-208) and
+// its known-answer tests (examples/misp/tests.rs).
+// =============================================================================
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <regex>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+
+#include "ddo_oracle.hpp"
+
+namespace ddo {
+
+// ---------------------------------------------------------------------------
+// BitSet: heap-allocated block vector like bit_vec::BitVec (one allocation per
+// state, as in the reference).
+// ---------------------------------------------------------------------------
+struct BitSet {
+    std::vector<uint64_t> w;
+
+    BitSet() = default;
+    explicit BitSet(size_t nbits) : w((nbits + 63) / 64, 0) {}
+    static BitSet full(size_t n) {
+        BitSet b(n);
+        for (size_t i = 0; i < n; ++i) b.insert(i);
+        return b;
+    }
+    void insert(size_t i) {
+        if (i / 64 >= w.size()) w.resize(i / 64 + 1, 0);
+        w[i / 64] |= (uint64_t)1 << (i % 64);
+    }
+    void remove(size_t i) {
+        if (i / 64 < w.size()) w[i / 64] &= ~((uint64_t)1 << (i % 64));
+    }
+    bool contains(size_t i) const { return i / 64 < w.size() && ((w[i / 64] >> (i % 64)) & 1); }
+    void intersect_with(const BitSet& o) {
+        for (size_t k = 0; k < w.size(); ++k) w[k] &= (k < o.w.size() ? o.w[k] : 0);
+    }
+    void union_with(const BitSet& o) {
+        if (o.w.size() > w.size()) w.resize(o.w.size(), 0);
+        for (size_t k = 0; k < o.w.size(); ++k) w[k] |= o.w[k];
+    }
+    size_t len() const {
+        size_t c = 0;
+        for (uint64_t x : w) c += (size_t)__builtin_popcountll(x);
+        return c;
+    }
+    /// BitSet::iter(): ascending members
+    template <class F>
+    void for_each(F&& f) const {
+        for (size_t k = 0; k < w.size(); ++k) {
+            uint64_t x = w[k];
+            while (x) {
+                f(k * 64 + (size_t)__builtin_ctzll(x));
+                x &= x - 1;
+            }
+        }
+    }
+    /// Eq over members, independent of allocated length
+    bool operator==(const BitSet& o) const {
+        size_t n = std::max(w.size(), o.w.size());
+        for (size_t k = 0; k < n; ++k) {
+            uint64_t a = k < w.size() ? w[k] : 0, b = k < o.w.size() ? o.w[k] : 0;
+            if (a != b) return false;
+        }
+        return true;
+    }
+    /// Ord: lexicographic order of the ascending member lists:
+    /// at the lowest differing bit p, the set containing p has the smaller
+    /// next member, hence is the smaller sequence -- unless the other set has
+    /// no member >= p at all (it is then a strict prefix, hence smaller).
+    int cmp(const BitSet& o) const {
+        size_t n = std::max(w.size(), o.w.size());
+        for (size_t k = 0; k < n; ++k) {
+            uint64_t a = k < w.size() ? w[k] : 0, b = k < o.w.size() ? o.w[k] : 0;
+            uint64_t x = a ^ b;
+            if (x) {
+                uint64_t t = x & (~x + 1);
+                bool a_has = (a & t) != 0;
+                // does the set NOT containing p have any member above p ?
+                const BitSet& other = a_has ? o : *this;
+                bool other_has_more = false;
+                uint64_t above = ~(t | (t - 1));
+                uint64_t ow = k < other.w.size() ? other.w[k] : 0;
+                if (ow & above) other_has_more = true;
+                for (size_t j = k + 1; !other_has_more && j < other.w.size(); ++j)
+                    if (other.w[j]) other_has_more = true;
+                if (a_has) return other_has_more ? -1 : 1;   // a has p; b continues later => a < b; else b is prefix => b < a
+                else return other_has_more ? 1 : -1;
+            }
+        }
+        return 0;
+    }
+};
+
+/// fxhash 0.2.1 (Cargo.lock:402-403), 64-bit: h = (rotl(h,5) ^ x) * K per
+/// usize written.  bit-set's Hash feeds every member as a usize -- O(popcount)
+/// per hash, which is part of the reference's CPU cost.
+template <>
+struct StateHash<BitSet> {
+    size_t operator()(const BitSet& s) const {
+        uint64_t h = 0;
+        s.for_each([&](size_t i) {
+            h = ((h << 5) | (h >> 59)) ^ (uint64_t)i;
+            h *= 0x517cc1b727220a95ULL;
+        });
+        return (size_t)h;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// MISP -- examples/misp/main.rs
+// ---------------------------------------------------------------------------
+constexpr isize MISP_YES = 1, MISP_NO = 0;
+
+/// main.rs:37-51
+struct Misp : Problem<BitSet> {
+    size_t nb_vars = 0;
+    std::vector<BitSet> neighbors;  // COMPLEMENT adjacency rows (bit i itself stays set)
+    std::vector<isize> weight;
+
+    size_t nb_variables() const override { return nb_vars; }
+    /// main.rs:69-71
+    BitSet initial_state() const override { return BitSet::full(nb_vars); }
+    isize initial_value() const override { return 0; }
+    /// main.rs:77-85
+    BitSet transition(const BitSet& state, Decision d) const override {
+        BitSet res = state;
+        res.remove(d.variable);
+        if (d.value == MISP_YES) res.intersect_with(neighbors[d.variable]);
+        return res;
+    }
+    /// main.rs:87-93
+    isize transition_cost(const BitSet&, const BitSet&, Decision d) const override {
+        return d.value == MISP_NO ? 0 : weight[d.variable];
+    }
+    /// main.rs:95-102
+    void for_each_in_domain(Variable var, const BitSet& state, DecisionCallback& f) const override {
+        if (state.contains(var.id)) {
+            f.apply(Decision{var.id, MISP_YES});
+            f.apply(Decision{var.id, MISP_NO});
+        } else {
+            f.apply(Decision{var.id, MISP_NO});
+        }
+    }
+    /// main.rs:109-143: the variable occurring in the fewest states of the next
+    /// layer (counts > 0), first index on ties (Iterator::min_by_key keeps the first).
+    std::optional<Variable> next_variable(size_t, StateIter<BitSet>& next_layer) const override {
+        static thread_local std::vector<size_t> heu;
+        heu.assign(nb_vars, 0);
+        while (const BitSet* s = next_layer.next()) s->for_each([&](size_t i) { heu[i] += 1; });
+        std::optional<Variable> best;
+        size_t best_cnt = 0;
+        for (size_t i = 0; i < nb_vars; ++i) {
+            if (heu[i] > 0 && (!best || heu[i] < best_cnt)) {
+                best = Variable{i};
+                best_cnt = heu[i];
+            }
+        }
+        return best;
+    }
+    /// main.rs:145-147
+    bool is_impacted_by(Variable var, const BitSet& state) const override { return state.contains(var.id); }
+};
+
+/// main.rs:168-194
+struct MispRelax : Relaxation<BitSet> {
+    const Misp& pb;
+    explicit MispRelax(const Misp& p) : pb(p) {}
+    BitSet merge(StateIter<BitSet>& states) const override {
+        BitSet s(pb.nb_vars);
+        while (const BitSet* x = states.next()) s.union_with(*x);
+        return s;
+    }
+    isize relax(const BitSet&, const BitSet&, const BitSet&, Decision, isize cost) const override { return cost; }
+    isize fast_upper_bound(const BitSet& state) const override {
+        isize sum = 0;
+        state.for_each([&](size_t i) { sum += pb.weight[i]; });
+        return sum;
+    }
+};
+
+/// main.rs:201-209
+struct MispRanking : StateRanking<BitSet> {
+    int compare(const BitSet& a, const BitSet& b) const override {
+        size_t la = a.len(), lb = b.len();
+        if (la != lb) return la < lb ? -1 : 1;
+        return a.cmp(b);
+    }
+};
+
+/// main.rs:258-317.  Regexes: comment `^c\s.*$`, `^p\s+edge\s+(\d+)\s+(\d+)$`,
+/// `^n\s+(\d+)\s+(-?\d+)`, `^e\s+(\d+)\s+(\d+)`; anything else is a format error.
+inline Misp read_misp_instance(const std::string& fname) {
+    std::ifstream f(fname);
+    if (!f) throw std::runtime_error("io error: cannot open " + fname);
+    static const std::regex comment(R"(^c\s.*$)");
+    static const std::regex pb_decl(R"(^p\s+edge\s+(\d+)\s+(\d+)$)");
+    static const std::regex node_decl(R"(^n\s+(\d+)\s+(-?\d+))");
+    static const std::regex edge_decl(R"(^e\s+(\d+)\s+(\d+))");
+    Misp g;
+    std::string raw;
+    while (std::getline(f, raw)) {
+        size_t b = raw.find_first_not_of(" \t\r\n\f\v");
+        if (b == std::string::npos) continue;
+        size_t e = raw.find_last_not_of(" \t\r\n\f\v");
+        std::string line = raw.substr(b, e - b + 1);
+        std::smatch m;
+        if (std::regex_match(line, comment)) continue;
+        if (std::regex_match(line, m, pb_decl)) {
+            size_t n = std::stoull(m[1]);
+            g.nb_vars = n;
+            g.neighbors.assign(n, BitSet::full(n));
+            g.weight.assign(n, 1);
+            continue;
+        }
+        if (std::regex_search(line, m, node_decl)) {
+            size_t n = std::stoull(m[1]);
+            isize w = std::stoll(m[2]);
+            g.weight.at(n - 1) = w;
+            continue;
+        }
+        if (std::regex_search(line, m, edge_decl)) {
+            size_t src = std::stoull(m[1]) - 1, dst = std::stoull(m[2]) - 1;
+            g.neighbors.at(src).remove(dst);
+            g.neighbors.at(dst).remove(src);
+            continue;
+        }
+        throw std::runtime_error("ill formed instance");
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// Knapsack -- examples/knapsack/main.rs
+// ---------------------------------------------------------------------------
+/// main.rs:37-44
+struct KnapsackState {
+    size_t depth;
+    size_t capacity;
+    bool operator==(const KnapsackState& o) const { return depth == o.depth && capacity == o.capacity; }
+};
+template <>
+struct StateHash<KnapsackState> {
+    size_t operator()(const KnapsackState& s) const {
+        uint64_t h = 0;
+        h = (((h << 5) | (h >> 59)) ^ (uint64_t)s.depth) * 0x517cc1b727220a95ULL;
+        h = (((h << 5) | (h >> 59)) ^ (uint64_t)s.capacity) * 0x517cc1b727220a95ULL;
+        return (size_t)h;
+    }
+};
+
+constexpr isize TAKE_IT = 1, LEAVE_IT_OUT = 0;
+
+/// main.rs:53-72
+struct Knapsack : Problem<KnapsackState> {
+    size_t capacity;
+    std::vector<isize> profit;
+    std::vector<size_t> weight;
+    std::vector<size_t> order;
+
+    Knapsack(size_t capacity, std::vector<isize> profit, std::vector<size_t> weight)
+        : capacity(capacity), profit(std::move(profit)), weight(std::move(weight)) {
+        order.resize(this->profit.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        // sort_unstable_by_key(OrderedFloat(-profit/weight)); ties: index order (documented deviation:
+        // Rust's unstable sort leaves tie order unspecified)
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+            double ka = -(double)this->profit[a] / (double)this->weight[a];
+            double kb = -(double)this->profit[b] / (double)this->weight[b];
+            return ka < kb;
+        });
+    }
+    size_t nb_variables() const override { return profit.size(); }
+    /// main.rs:93-99
+    void for_each_in_domain(Variable var, const KnapsackState& s, DecisionCallback& f) const override {
+        if (s.capacity >= weight[var.id]) f.apply(Decision{var.id, TAKE_IT});
+        f.apply(Decision{var.id, LEAVE_IT_OUT});
+    }
+    KnapsackState initial_state() const override { return KnapsackState{0, capacity}; }
+    isize initial_value() const override { return 0; }
+    /// main.rs:106-113
+    KnapsackState transition(const KnapsackState& s, Decision d) const override {
+        KnapsackState r = s;
+        r.depth += 1;
+        if (d.value == TAKE_IT) r.capacity -= weight[d.variable];
+        return r;
+    }
+    isize transition_cost(const KnapsackState&, const KnapsackState&, Decision d) const override {
+        return profit[d.variable] * d.value;
+    }
+    /// main.rs:118-125
+    std::optional<Variable> next_variable(size_t depth, StateIter<KnapsackState>&) const override {
+        if (depth < nb_variables()) return Variable{order[depth]};
+        return std::nullopt;
+    }
+};
+
+/// main.rs:146-184
+struct KPRelax : Relaxation<KnapsackState> {
+    const Knapsack& pb;
+    explicit KPRelax(const Knapsack& p) : pb(p) {}
+    /// max_by_key(capacity): the LAST maximum
+    KnapsackState merge(StateIter<KnapsackState>& states) const override {
+        const KnapsackState* best = nullptr;
+        while (const KnapsackState* s = states.next())
+            if (!best || s->capacity >= best->capacity) best = s;
+        return *best;
+    }
+    isize relax(const KnapsackState&, const KnapsackState&, const KnapsackState&, Decision, isize cost) const override {
+        return cost;
+    }
+    isize fast_upper_bound(const KnapsackState& state) const override {
+        size_t depth = state.depth;
+        isize max_profit = 0;
+        size_t cap = state.capacity;
+        while (cap > 0 && depth < pb.profit.size()) {
+            size_t item = pb.order[depth];
+            if (cap >= pb.weight[item]) {
+                max_profit += pb.profit[item];
+                cap -= pb.weight[item];
+            } else {
+                double ratio = (double)cap / (double)pb.weight[item];
+                double p = ratio * (double)pb.profit[item];
+                max_profit += (isize)std::floor(p);
+                cap = 0;
+            }
+            depth += 1;
+        }
+        return max_profit;
+    }
+};
+
+/// main.rs:187-194
+struct KPRanking : StateRanking<KnapsackState> {
+    int compare(const KnapsackState& a, const KnapsackState& b) const override {
+        return a.capacity < b.capacity ? -1 : (a.capacity > b.capacity ? 1 : 0);
+    }
+};
+
+/// main.rs:267-303: lines starting with 'c' skipped; first line "n capacity";
+/// then n lines "profit weight".
+inline Knapsack read_knapsack_instance(const std::string& fname) {
+    std::ifstream f(fname);
+    if (!f) throw std::runtime_error("io error: cannot open " + fname);
+    std::string line;
+    bool is_first = true;
+    size_t n = 0, count = 0, capa = 0;
+    std::vector<isize> profit;
+    std::vector<size_t> weight;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line[0] == 'c') continue;
+        if (is_first) {
+            is_first = false;
+            std::istringstream ss(line);
+            ss >> n >> capa;
+        } else {
+            if (count >= n) break;
+            std::istringstream ss(line);
+            isize p;
+            size_t w;
+            if (!(ss >> p >> w)) continue;
+            profit.push_back(p);
+            weight.push_back(w);
+            count += 1;
+        }
+    }
+    return Knapsack(capa, std::move(profit), std::move(weight));
+}
+
+}  // namespace ddo

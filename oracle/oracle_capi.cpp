@@ -1,0 +1,418 @@
+// =============================================================================
+// oracle_capi.cpp -- C entry points over the CPU oracle, loaded with ctypes by
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+//
+// *** TEST INFRASTRUCTURE *** (see ddo_oracle.hpp).  The product library
+// (ddo_amd/csrc) never links or calls this file.
+// =============================================================================
+#include <chrono>
+#include <cstring>
+#include <string>
+
+#include "ddo_oracle.hpp"
+#include "models.hpp"
+
+using namespace ddo;
+
+namespace {
+
+struct MispHandle {
+    Misp pb;
+    size_t ws;  // 64-bit words per state
+};
+
+/// One recorded compile() of a sequential solve (input + everything observable).
+struct TraceRec {
+    int comp_type;  // 1 = Relaxed, 2 = Restricted (CompilationType order: Exact=0)
+    uint64_t width;
+    int64_t best_lb;
+    std::vector<uint64_t> state;
+    int64_t value;
+    int64_t ub;
+    uint64_t depth;
+    // outputs
+    int is_exact;
+    int has_best;
+    int64_t best_value;
+    int has_best_exact;
+    int64_t best_exact_value;
+    uint64_t nodes_expanded, arcs, layers;
+    // cut-set (relaxed only): flattened
+    std::vector<uint64_t> cs_states;  // n_cs * ws
+    std::vector<int64_t> cs_value, cs_ub;
+    std::vector<uint64_t> cs_depth;
+};
+
+struct Trace {
+    std::vector<TraceRec> recs;
+    size_t ws = 0;
+};
+
+void state_to_words(const BitSet& s, size_t ws, uint64_t* out) {
+    for (size_t k = 0; k < ws; ++k) out[k] = k < s.w.size() ? s.w[k] : 0;
+}
+
+template <class D>
+void record(Trace& tr, size_t ws, const SubProblem<BitSet>& node, CompilationType t, size_t width, isize lb, D& mdd,
+            bool with_cutset) {
+    TraceRec r;
+    r.comp_type = (int)t;
+    r.width = width;
+    r.best_lb = lb;
+    r.state.resize(ws);
+    state_to_words(*node.state, ws, r.state.data());
+    r.value = node.value;
+    r.ub = node.ub;
+    r.depth = node.depth;
+    r.is_exact = mdd.is_exact();
+    auto bv = mdd.best_value();
+    r.has_best = bv.has_value();
+    r.best_value = bv.value_or(0);
+    auto bev = mdd.best_exact_value();
+    r.has_best_exact = bev.has_value();
+    r.best_exact_value = bev.value_or(0);
+    r.nodes_expanded = mdd.last_counters.nodes_expanded;
+    r.arcs = mdd.last_counters.arcs;
+    r.layers = mdd.last_counters.layers;
+    if (with_cutset) {
+        // drain_cutset consumes the cut-set; take a copy of the DD so the solver still sees it
+        D copy = mdd;
+        copy.drain_cutset([&](SubProblem<BitSet> sp) {
+            size_t off = r.cs_states.size();
+            r.cs_states.resize(off + ws);
+            state_to_words(*sp.state, ws, r.cs_states.data() + off);
+            r.cs_value.push_back(sp.value);
+            r.cs_ub.push_back(sp.ub);
+            r.cs_depth.push_back(sp.depth);
+        });
+    }
+    tr.recs.push_back(std::move(r));
+}
+
+}  // namespace
+
+extern "C" {
+
+struct oracle_solve_out {
+    int has_value;
+    int is_exact;
+    int64_t best_value;
+    int64_t best_lb;
+    int64_t best_ub;
+    uint64_t explored;
+    uint64_t nodes_expanded;
+    uint64_t arcs;
+    uint64_t layers;
+    uint64_t compiles;
+    double wall_s;
+    int n_solution;          // number of decisions written to `solution`
+};
+
+void* oracle_misp_load(const char* path) {
+    try {
+        auto* h = new MispHandle{read_misp_instance(path), 0};
+        h->ws = (h->pb.nb_vars + 63) / 64;
+        return h;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "oracle_misp_load: %s\n", e.what());
+        return nullptr;
+    }
+}
+void oracle_misp_free(void* h) { delete (MispHandle*)h; }
+int oracle_misp_nb_vars(void* h) { return (int)((MispHandle*)h)->pb.nb_vars; }
+int oracle_misp_state_words(void* h) { return (int)((MispHandle*)h)->ws; }
+/// complement-adjacency rows (n * ws words) and weights (n)
+void oracle_misp_export(void* hh, uint64_t* rows, int64_t* weights) {
+    auto* h = (MispHandle*)hh;
+    for (size_t i = 0; i < h->pb.nb_vars; ++i) {
+        state_to_words(h->pb.neighbors[i], h->ws, rows + i * h->ws);
+        weights[i] = h->pb.weight[i];
+    }
+}
+
+/// Full branch-and-bound.  width == 0 -> NbUnassignedWidth (the policy of examples/misp/tests.rs);
+/// nthreads == 0 -> SequentialSolver, else ParallelSolver with that many threads;
+/// timeout_s <= 0 -> NoCutoff.  solution: (variable,value) pairs sorted by variable, capacity 2*n int64.
+int oracle_misp_solve(void* hh, uint64_t width, int nthreads, double timeout_s, oracle_solve_out* out,
+                      int64_t* solution) {
+    auto* h = (MispHandle*)hh;
+    Misp& pb = h->pb;
+    MispRelax relax(pb);
+    MispRanking rank;
+    FixedWidth<BitSet> fixed(width);
+    NbUnassignedWidth<BitSet> unassigned(pb.nb_vars);
+    const WidthHeuristic<BitSet>& w = width ? (const WidthHeuristic<BitSet>&)fixed : unassigned;
+    EmptyDominanceChecker<BitSet> dom;
+    NoCutoff nocut;
+    TimeBudget budget(timeout_s > 0 ? timeout_s : 1e9);
+    const Cutoff& cut = timeout_s > 0 ? (const Cutoff&)budget : nocut;
+    MaxUB<BitSet> mx(rank);
+    NoDupFringe<BitSet> fringe(mx);
+
+    auto t0 = std::chrono::steady_clock::now();
+    Completion c;
+    std::optional<Solution> sol;
+    MddCounters cnt;
+    if (nthreads <= 0) {
+        SequentialSolver<BitSet> s(pb, relax, rank, w, dom, cut, fringe);
+        c = s.maximize();
+        out->best_lb = s.best_lower_bound();
+        out->best_ub = s.best_upper_bound();
+        out->explored = s.explored();
+        sol = s.best_solution();
+        cnt = s.counters();
+    } else {
+        ParallelSolver<BitSet> s(pb, relax, rank, w, dom, cut, fringe, (size_t)nthreads);
+        c = s.maximize();
+        out->best_lb = s.best_lower_bound();
+        out->best_ub = s.best_upper_bound();
+        out->explored = s.explored();
+        sol = s.best_solution();
+        cnt = s.counters();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    out->wall_s = std::chrono::duration<double>(t1 - t0).count();
+    out->has_value = c.best_value.has_value();
+    out->best_value = c.best_value.value_or(-1);
+    out->is_exact = c.is_exact;
+    out->nodes_expanded = cnt.nodes_expanded;
+    out->arcs = cnt.arcs;
+    out->layers = cnt.layers;
+    out->compiles = cnt.compiles;
+    out->n_solution = 0;
+    if (sol && solution) {
+        for (const Decision& d : *sol) {
+            solution[2 * out->n_solution] = (int64_t)d.variable;
+            solution[2 * out->n_solution + 1] = d.value;
+            out->n_solution++;
+        }
+    }
+    return 0;
+}
+
+// ---- traced sequential solve: every compile() recorded for replay on the GPU -------------------
+void* oracle_misp_trace_solve(void* hh, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {
+    auto* h = (MispHandle*)hh;
+    Misp& pb = h->pb;
+    MispRelax relax(pb);
+    MispRanking rank;
+    FixedWidth<BitSet> fixed(width);
+    NbUnassignedWidth<BitSet> unassigned(pb.nb_vars);
+    const WidthHeuristic<BitSet>& w = width ? (const WidthHeuristic<BitSet>&)fixed : unassigned;
+    EmptyDominanceChecker<BitSet> dom;
+    struct CountCutoff : Cutoff {
+        const Trace* tr;
+        uint64_t max;
+        bool must_stop() const override { return max && tr->recs.size() >= max; }
+    } cut;
+    MaxUB<BitSet> mx(rank);
+    NoDupFringe<BitSet> fringe(mx);
+    auto* tr = new Trace();
+    tr->ws = h->ws;
+    cut.tr = tr;
+    cut.max = max_compiles;
+    SequentialSolver<BitSet> s(pb, relax, rank, w, dom, cut, fringe);
+    s.on_compile = [&](const SubProblem<BitSet>& node, CompilationType t, size_t width_, isize lb,
+                       DefaultMDDLEL<BitSet>& mdd) {
+        record(*tr, h->ws, node, t, width_, lb, mdd, t == CompilationType::Relaxed);
+    };
+    auto t0 = std::chrono::steady_clock::now();
+    Completion c = s.maximize();
+    auto t1 = std::chrono::steady_clock::now();
+    if (out) {
+        out->wall_s = std::chrono::duration<double>(t1 - t0).count();
+        out->has_value = c.best_value.has_value();
+        out->best_value = c.best_value.value_or(-1);
+        out->is_exact = c.is_exact;
+        out->best_lb = s.best_lower_bound();
+        out->best_ub = s.best_upper_bound();
+        out->explored = s.explored();
+        out->nodes_expanded = s.counters().nodes_expanded;
+        out->arcs = s.counters().arcs;
+        out->layers = s.counters().layers;
+        out->compiles = s.counters().compiles;
+        out->n_solution = 0;
+    }
+    return tr;
+}
+void oracle_trace_free(void* t) { delete (Trace*)t; }
+uint64_t oracle_trace_len(void* t) { return ((Trace*)t)->recs.size(); }
+
+struct oracle_trace_hdr {
+    int comp_type;
+    int is_exact;
+    int has_best;
+    int has_best_exact;
+    uint64_t width;
+    int64_t best_lb;
+    int64_t value;
+    int64_t ub;
+    uint64_t depth;
+    int64_t best_value;
+    int64_t best_exact_value;
+    uint64_t nodes_expanded, arcs, layers;
+    uint64_t n_cutset;
+};
+void oracle_trace_get(void* t, uint64_t i, oracle_trace_hdr* hdr, uint64_t* state) {
+    const TraceRec& r = ((Trace*)t)->recs[i];
+    hdr->comp_type = r.comp_type;
+    hdr->is_exact = r.is_exact;
+    hdr->has_best = r.has_best;
+    hdr->has_best_exact = r.has_best_exact;
+    hdr->width = r.width;
+    hdr->best_lb = r.best_lb;
+    hdr->value = r.value;
+    hdr->ub = r.ub;
+    hdr->depth = r.depth;
+    hdr->best_value = r.best_value;
+    hdr->best_exact_value = r.best_exact_value;
+    hdr->nodes_expanded = r.nodes_expanded;
+    hdr->arcs = r.arcs;
+    hdr->layers = r.layers;
+    hdr->n_cutset = r.cs_value.size();
+    std::memcpy(state, r.state.data(), r.state.size() * sizeof(uint64_t));
+}
+void oracle_trace_get_cutset(void* t, uint64_t i, uint64_t* states, int64_t* value, int64_t* ub, uint64_t* depth) {
+    const TraceRec& r = ((Trace*)t)->recs[i];
+    std::memcpy(states, r.cs_states.data(), r.cs_states.size() * sizeof(uint64_t));
+    std::memcpy(value, r.cs_value.data(), r.cs_value.size() * sizeof(int64_t));
+    std::memcpy(ub, r.cs_ub.data(), r.cs_ub.size() * sizeof(int64_t));
+    std::memcpy(depth, r.cs_depth.data(), r.cs_depth.size() * sizeof(uint64_t));
+}
+
+// ---- one compile() on an arbitrary residual sub-problem -----------------------------------------
+/// comp_type: 0 Exact, 1 Relaxed, 2 Restricted.  Cut-set buffers sized by the caller (cap entries).
+/// Returns the number of cut-set entries (or -1 when cap is too small).
+int64_t oracle_misp_compile(void* hh, int comp_type, uint64_t width, int64_t best_lb, const uint64_t* state,
+                            int64_t value, uint64_t depth, oracle_trace_hdr* hdr, uint64_t cap, uint64_t* cs_states,
+                            int64_t* cs_value, int64_t* cs_ub, uint64_t* cs_depth, int64_t* best_path,
+                            int64_t* n_best_path) {
+    auto* h = (MispHandle*)hh;
+    Misp& pb = h->pb;
+    MispRelax relax(pb);
+    MispRanking rank;
+    NoCutoff nocut;
+    EmptyCache<BitSet> cache;
+    EmptyDominanceChecker<BitSet> dom;
+    SubProblem<BitSet> node;
+    BitSet s(pb.nb_vars);
+    for (size_t k = 0; k < h->ws; ++k) s.w[k] = state[k];
+    node.state = std::make_shared<const BitSet>(s);
+    node.value = value;
+    node.depth = depth;
+    node.ub = ISIZE_MAX;
+    CompilationInput<BitSet> in{(CompilationType)comp_type, &pb, &relax, &rank, &nocut, width, &node, best_lb,
+                                &cache, &dom};
+    DefaultMDDLEL<BitSet> mdd;
+    auto c = mdd.compile(in);
+    if (!c) return -2;
+    Trace tr;
+    record(tr, h->ws, node, (CompilationType)comp_type, width, best_lb, mdd, true);
+    const TraceRec& r = tr.recs[0];
+    hdr->comp_type = comp_type;
+    hdr->is_exact = r.is_exact;
+    hdr->has_best = r.has_best;
+    hdr->has_best_exact = r.has_best_exact;
+    hdr->width = width;
+    hdr->best_lb = best_lb;
+    hdr->value = value;
+    hdr->ub = ISIZE_MAX;
+    hdr->depth = depth;
+    hdr->best_value = r.best_value;
+    hdr->best_exact_value = r.best_exact_value;
+    hdr->nodes_expanded = r.nodes_expanded;
+    hdr->arcs = r.arcs;
+    hdr->layers = r.layers;
+    hdr->n_cutset = r.cs_value.size();
+    if (n_best_path) {
+        *n_best_path = 0;
+        auto sol = mdd.best_solution();
+        if (sol && best_path) {
+            for (const Decision& d : *sol) {
+                best_path[2 * *n_best_path] = (int64_t)d.variable;
+                best_path[2 * *n_best_path + 1] = d.value;
+                (*n_best_path)++;
+            }
+        }
+    }
+    if (r.cs_value.size() > cap) return -1;
+    if (!r.cs_value.empty()) {
+        std::memcpy(cs_states, r.cs_states.data(), r.cs_states.size() * sizeof(uint64_t));
+        std::memcpy(cs_value, r.cs_value.data(), r.cs_value.size() * sizeof(int64_t));
+        std::memcpy(cs_ub, r.cs_ub.data(), r.cs_ub.size() * sizeof(int64_t));
+        std::memcpy(cs_depth, r.cs_depth.data(), r.cs_depth.size() * sizeof(uint64_t));
+    }
+    return (int64_t)r.cs_value.size();
+}
+
+// ---- knapsack (config C1: plumbing, CPU only) ----------------------------------------------------
+/// profits/weights of n items, capacity; width 0 -> NbUnassignedWidth.  Returns optimum (or -1).
+int64_t oracle_knapsack_solve(int n, const int64_t* profit, const uint64_t* weight, uint64_t capacity, uint64_t width,
+                              int nthreads, int64_t* sol_values, oracle_solve_out* out) {
+    std::vector<isize> p(profit, profit + n);
+    std::vector<size_t> wv(weight, weight + n);
+    Knapsack pb(capacity, p, wv);
+    KPRelax relax(pb);
+    KPRanking rank;
+    FixedWidth<KnapsackState> fixed(width);
+    NbUnassignedWidth<KnapsackState> unassigned(pb.nb_variables());
+    const WidthHeuristic<KnapsackState>& w = width ? (const WidthHeuristic<KnapsackState>&)fixed : unassigned;
+    EmptyDominanceChecker<KnapsackState> dom;
+    NoCutoff cut;
+    MaxUB<KnapsackState> mx(rank);
+    NoDupFringe<KnapsackState> fringe(mx);
+    Completion c;
+    std::optional<Solution> sol;
+    auto t0 = std::chrono::steady_clock::now();
+    if (nthreads <= 0) {
+        SequentialSolver<KnapsackState> s(pb, relax, rank, w, dom, cut, fringe);
+        c = s.maximize();
+        sol = s.best_solution();
+        if (out) {
+            out->explored = s.explored();
+            out->best_lb = s.best_lower_bound();
+            out->best_ub = s.best_upper_bound();
+            out->nodes_expanded = s.counters().nodes_expanded;
+            out->arcs = s.counters().arcs;
+            out->layers = s.counters().layers;
+            out->compiles = s.counters().compiles;
+        }
+    } else {
+        ParallelSolver<KnapsackState> s(pb, relax, rank, w, dom, cut, fringe, (size_t)nthreads);
+        c = s.maximize();
+        sol = s.best_solution();
+        if (out) {
+            out->explored = s.explored();
+            out->best_lb = s.best_lower_bound();
+            out->best_ub = s.best_upper_bound();
+            out->nodes_expanded = s.counters().nodes_expanded;
+            out->arcs = s.counters().arcs;
+            out->layers = s.counters().layers;
+            out->compiles = s.counters().compiles;
+        }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (out) {
+        out->wall_s = std::chrono::duration<double>(t1 - t0).count();
+        out->has_value = c.best_value.has_value();
+        out->best_value = c.best_value.value_or(-1);
+        out->is_exact = c.is_exact;
+        out->n_solution = sol ? (int)sol->size() : 0;
+    }
+    if (sol && sol_values)
+        for (const Decision& d : *sol) sol_values[d.variable] = d.value;
+    return c.best_value.value_or(-1);
+}
+int64_t oracle_knapsack_solve_file(const char* path, uint64_t width, int nthreads, oracle_solve_out* out) {
+    try {
+        Knapsack pb = read_knapsack_instance(path);
+        std::vector<int64_t> p(pb.profit.begin(), pb.profit.end());
+        std::vector<uint64_t> w(pb.weight.begin(), pb.weight.end());
+        return oracle_knapsack_solve((int)p.size(), p.data(), w.data(), pb.capacity, width, nthreads, nullptr, out);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "oracle_knapsack_solve_file: %s\n", e.what());
+        return -2;
+    }
+}
+
+}  // extern "C"
