@@ -1,0 +1,124 @@
+// =============================================================================
+// dd_types.h -- POD records shared by the device kernel and the host side of
+// the engine (device<->host wire format of one compile).
+// =============================================================================
+#pragma once
+#include <stdint.h>
+
+namespace ddo_hip {
+
+constexpr int MAX_WS = 16;               // 64-bit words per state supported (n <= 1024)
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+
+// comp_type values follow include/ddo_hip.h (== mdd.rs:41-48 order)
+constexpr int CT_EXACT = 0, CT_RELAXED = 1, CT_RESTRICTED = 2;
+
+// DDInput.flags
+constexpr uint32_t IN_FUSED = 1u;          // restricted, then (if inexact) relaxed: parallel.rs:391-437 on device
+constexpr uint32_t IN_FILTER_CUTSET = 2u;  // emit only cut-set nodes with ub > best_lb (parallel.rs:461)
+constexpr uint32_t IN_WANT_PATHS = 4u;     // always emit best paths (else only when value > best_lb)
+
+/// One sub-problem to compile (mdd.rs:51-71 CompilationInput, minus the trait objects).
+struct DDInput {
+    int32_t comp_type;
+    uint32_t flags;
+    int32_t width;
+    int32_t value;     // residual.value
+    int32_t depth;     // residual.depth
+    int32_t pad;
+    int64_t best_lb;
+    uint64_t state[MAX_WS];
+};
+
+// DDResult.status
+constexpr int ST_OK = 0, ST_CUTOFF = 1, ST_ERR_CAPACITY = -3, ST_ERR_INTERNAL = -5, ST_NOT_RUN = 77;
+
+/// Everything observable about one compiled DD (clean.rs:237-266).  Variable
+/// sized data lives in the output arena at `arena_off` (8-byte units):
+///   best path        : best_len     x u32   (variable << 1 | value), terminal first
+///   best exact path  : exact_len    x u32
+///   cut-set states   : n_cutset x ws x u64  (row major)
+///   cut-set value    : n_cutset x i32
+///   cut-set ub       : n_cutset x i32
+///   cut-set paths    : n_cutset x lel x u32 (node first, towards the root)
+struct DDResult {
+    int32_t status;
+    int32_t comp_type;
+    int32_t is_exact;              // lel.is_none()                      (clean.rs:635)
+    int32_t has_exact_best_path;   // EBPO                               (clean.rs:636)
+    int32_t has_best;              // best_node.is_some()
+    int32_t has_best_exact;
+    int32_t best_value;
+    int32_t best_exact_value;
+    int32_t n_layers;              // layers.len()
+    int32_t lel;                   // index of the last exact layer, -1 when none
+    int32_t n_cutset;
+    int32_t best_len;
+    int32_t exact_len;
+    int32_t exact_same_as_best;    // best exact path == best path (not stored twice)
+    uint32_t recycled_merges;      // how many times clean.rs:830 found a recycled node
+    uint32_t pad;
+    uint64_t arena_off;            // byte offset of this DD's block in the arena
+    uint64_t arena_bytes;
+    uint64_t nodes_expanded;
+    uint64_t arcs;
+    uint64_t layers;
+    uint64_t path_off, exact_off, cs_state_off, cs_value_off, cs_ub_off, cs_path_off;  // byte offsets from arena_off
+};
+
+/// Kernel arguments: model tables, capacities, per-slot workspace and batch I/O.
+struct EngineParams {
+    // ---- model (MISP: examples/misp/main.rs:37-51)
+    int32_t n;                 // nb_vars
+    int32_t ws;                // words per state
+    int32_t unit_weights;      // all weights == 1 -> rub = popcount (main.rs:191-193)
+    int32_t npad;              // n rounded up to 64
+    const uint64_t* adj;       // [n][ws] complement-adjacency rows
+    const int32_t* weight;     // [n]
+    // ---- capacities
+    int32_t capN;              // max nodes per layer (width + 2)
+    int32_t capC1;             // 2*capN + 1 candidate slots (last one = merged node)
+    int32_t max_layers;        // n + 2
+    int32_t table_cap;         // hash table slots available (power of two)
+    int32_t table_in_lds;      // 1: table lives in LDS, 0: in HBM (gtable)
+    int32_t nslots;
+    // ---- per-slot workspace (slot = workgroup)
+    uint64_t* cstate;          // [slot][2][ws][capC1]   SoA candidate states (word major)
+    uint64_t* ckey;            // [slot][2][capC1]       (biased value << 32) | best candidate
+    uint32_t* cpop;            // [slot][2][capC1]       popcount of the state
+    uint32_t* cflags;          // [slot][2][capC1]       NF_* bits
+    uint32_t* ctarget;         // [slot][2*capN]         arc -> winner candidate (dedup result)
+    uint32_t* keep;            // [slot][capN]           node position -> candidate index
+    uint32_t* posmap;          // [slot][capC1]          candidate -> node position
+    uint8_t* cls;              // [slot][capC1]          0 none / 1 kept / 2 deleted
+    uint32_t* ninfo;           // [slot][max_layers][capN]   best arc + flags per node per layer
+    uint32_t* arct;            // [slot][max_layers][2*capN] arc -> child position (relaxed, below LEL)
+    int32_t* nlayer;           // [slot][max_layers]     nodes per layer
+    int32_t* lvar;             // [slot][max_layers]     variable branched below each layer
+    int32_t* ldup;             // [slot][max_layers][2]  recycled-merge duplicate (from pos, to pos)
+    uint64_t* cs_state;        // [slot][ws][capN]       copy of the last exact layer
+    int32_t* cs_value;         // [slot][capN]
+    uint32_t* cs_pop;          // [slot][capN]
+    uint32_t* gtable;          // [slot][table_cap] when !table_in_lds
+    // ---- batch I/O
+    const DDInput* inputs;
+    DDResult* results;         // [nbatch][2]  (index 1 only used by IN_FUSED)
+    int32_t nbatch;
+    int32_t pad0;
+    int32_t* work_counter;
+    unsigned long long* arena_head;
+    uint8_t* arena;
+    uint64_t arena_cap;
+    const int32_t* cutoff_flag; // device-visible flag, polled once per layer
+};
+
+// node flag bits (node_flags.rs:48-185 restricted to what the device needs)
+constexpr uint32_t NF_INEXACT = 1u;   // !F_EXACT
+constexpr uint32_t NF_RELAXED = 2u;   // F_RELAXED
+// ninfo word: bits 0..27 best arc (parent position << 1 | decision), 28 = no arc (root), 30/31 flags
+constexpr uint32_t NI_ARC_MASK = 0x0FFFFFFFu;
+constexpr uint32_t NI_NOARC = 0x10000000u;
+constexpr uint32_t NI_INEXACT = 0x40000000u;
+constexpr uint32_t NI_RELAXED = 0x80000000u;
+
+}  // namespace ddo_hip

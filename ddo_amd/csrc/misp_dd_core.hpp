@@ -1,0 +1,1292 @@
+// =============================================================================
+// misp_dd_core.hpp -- one workgroup compiles one decision diagram (MISP).
+//
+// Restates, for fixed-width bitset states, the layer loop of
+// /root/reference/ddo/src/implementation/mdd/clean.rs:345-876 with the MISP model
+// callbacks of /root/reference/ddo/examples/misp/main.rs:62-209 inlined:
+//   next_variable  (main.rs:109-143)  -> per-vertex occurrence counters kept in LDS,
+//                                        maintained by +/- deltas, argmin each layer
+//   transition / transition_cost / for_each_in_domain (main.rs:77-102) -> expand phase
+//   next_l dedup (clean.rs:738-775)   -> open-addressing table (LDS), tag + index entries,
+//                                        full state compare on tag hit, 64-bit atomicMax of
+//                                        (value, arc) == `value >= value_top` best-edge rule
+//   _restrict / _relax (clean.rs:802-876) + MispRanking (main.rs:205-208)
+//                                     -> exact top-K radix select on (value, popcount,
+//                                        lexicographic member order), compaction, OR-merge
+//   _finalize_* / _compute_local_bounds / _drain_cutset (clean.rs:407-475, 547-655)
+//                                     -> backward pass over the stored arcs, LDS atomicMax
+//
+// Layout: candidate states are SoA, word-major (`cstate[w][c]`), so a wavefront reading
+// word w of 64 consecutive candidates issues one contiguous 512-byte request.
+//
+// The file is written in "phase" style -- PAR_BEGIN ... PAR_END blocks separated by
+// workgroup barriers, no thread-private state carried across a barrier -- so that
+// the very same source also builds as a lock-step host emulation
+// (-DDDO_HOST_EMULATION, used ONLY by tests/ to exercise the logic without a GPU).
+// The product library never contains the emulation.
+// =============================================================================
+#pragma once
+#include "dd_types.h"
+
+#if defined(DDO_HOST_EMULATION)
+// ---------------------------------------------------------------- host emulation (tests only)
+#include <algorithm>
+#include <cstring>
+#define DDO_DEV inline
+#define PAR_BEGIN for (int tid = 0; tid < NT; ++tid) {
+#define PAR_END }
+#define DDO_TID_DECL
+namespace ddo_hip {
+template <class T> inline T emu_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T emu_atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T emu_atomic_min(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T emu_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T emu_atomic_and(T* p, T v) { T o = *p; *p = o & v; return o; }
+inline uint32_t emu_atomic_cas(uint32_t* p, uint32_t cmp, uint32_t v) { uint32_t o = *p; if (o == cmp) *p = v; return o; }
+#define LDS_ADD_I32(p, v) emu_atomic_add<int32_t>((p), (v))
+#define LDS_ADD_U32(p, v) emu_atomic_add<uint32_t>((p), (v))
+#define LDS_MIN_U32(p, v) emu_atomic_min<uint32_t>((p), (v))
+#define LDS_MAX_I32(p, v) emu_atomic_max<int32_t>((p), (v))
+#define LDS_OR_U64(p, v) emu_atomic_or<uint64_t>((p), (v))
+#define LDS_AND_U64(p, v) emu_atomic_and<uint64_t>((p), (v))
+#define LDS_MAX_U64(p, v) emu_atomic_max<uint64_t>((p), (v))
+#define LDS_ADD_U64(p, v) emu_atomic_add<uint64_t>((p), (v))
+#define TAB_CAS(p, c, v) emu_atomic_cas((p), (c), (v))
+#define GLB_MAX_U64(p, v) emu_atomic_max<uint64_t>((p), (v))
+#define GLB_OR_U32(p, v) emu_atomic_or<uint32_t>((p), (v))
+#define GLB_ADD_U64(p, v) emu_atomic_add<unsigned long long>((p), (v))
+#define GLB_ADD_I32(p, v) emu_atomic_add<int32_t>((p), (v))
+#define LD_U64(p) (*(p))
+#define LD_U32(p) (*(p))
+#define LD_I32(p) (*(p))
+#define FENCE_BLOCK()
+inline int dd_popc(uint64_t x) { return __builtin_popcountll(x); }
+inline int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
+inline uint64_t dd_brev(uint64_t x) {
+    x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    return __builtin_bswap64(x);
+}
+}  // namespace ddo_hip
+#else
+// ---------------------------------------------------------------- gfx950 device build
+#include <hip/hip_runtime.h>
+#define DDO_DEV __device__ __forceinline__
+#define PAR_BEGIN {
+#define PAR_END } __syncthreads();
+namespace ddo_hip {
+#define LDS_ADD_I32(p, v) atomicAdd((p), (v))
+#define LDS_ADD_U32(p, v) atomicAdd((p), (v))
+#define LDS_MIN_U32(p, v) atomicMin((p), (v))
+#define LDS_MAX_I32(p, v) atomicMax((p), (v))
+#define LDS_OR_U64(p, v) atomicOr((unsigned long long*)(p), (unsigned long long)(v))
+#define LDS_AND_U64(p, v) atomicAnd((unsigned long long*)(p), (unsigned long long)(v))
+#define LDS_MAX_U64(p, v) atomicMax((unsigned long long*)(p), (unsigned long long)(v))
+#define LDS_ADD_U64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(v))
+#define TAB_CAS(p, c, v) atomicCAS((p), (c), (v))
+#define GLB_MAX_U64(p, v) atomicMax((unsigned long long*)(p), (unsigned long long)(v))
+#define GLB_OR_U32(p, v) atomicOr((p), (v))
+#define GLB_ADD_U64(p, v) atomicAdd((p), (v))
+#define GLB_ADD_I32(p, v) atomicAdd((p), (v))
+// Words that other waves update with L2 atomics (ckey, cflags) or have just stored
+// (dedup compare) are read with agent-scope relaxed atomic loads: they bypass the CU's
+// vector L1 (MI355X_MICROARCH.md, "sc1 loads bypass L1 only").
+#define LD_U64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LD_U32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LD_I32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FENCE_BLOCK() __threadfence_block()
+__device__ __forceinline__ int dd_popc(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
+__device__ __forceinline__ uint64_t dd_brev(uint64_t x) { return __brevll(x); }
+}  // namespace ddo_hip
+#endif
+
+namespace ddo_hip {
+
+constexpr uint32_t TAB_EMPTY = 0xFFFFFFFFu;
+constexpr int32_t VB_UNMARKED = INT32_MIN;  // value_bot = isize::MIN  <=> !MARKED (clean.rs:392, 464)
+
+/// Workgroup-shared scalars (one per workgroup, lives in LDS).
+struct DDShared {
+    int32_t work;
+    uint32_t varkey;
+    int32_t nU;          // unique candidates (== next_l.len())
+    int32_t status;
+    int32_t cutoff;
+    int32_t scan_total;
+    int32_t sel_digit, sel_above, sel_bucket;
+    int32_t nkept, merged_pos, recycled, dup_from, dup_to;
+    int32_t ncut, ncut2;
+    int32_t xbest;       // recycled merge: candidate re-added to the layer (clean.rs:868-872)
+    uint32_t recycled_merges;
+    uint64_t k1and, k1or;
+    uint64_t pivK1;
+    uint64_t pivLex[MAX_WS];
+    uint64_t merged[MAX_WS];
+    uint64_t mergedKey;
+    uint64_t bestKey, bestExactKey;
+    uint64_t nodes, arcs;
+    uint64_t arena_off;
+    int32_t xcand[64];   // per-lane partial results of the recycled-merge search
+};
+
+/// Everything one workgroup needs: model, slot-local workspace and LDS carve-up.
+template <int WS>
+struct DDCtx {
+    // model
+    int n, npad, unit_weights;
+    const uint64_t* adj;
+    const int32_t* weight;
+    // capacity
+    int capN, capC1, max_layers;
+    // slot workspace
+    uint64_t* cstate[2];
+    uint64_t* ckey[2];
+    uint32_t* cpop[2];
+    uint32_t* cflags[2];
+    uint32_t* ctarget;
+    uint32_t* keep;
+    uint32_t* posmap;
+    uint8_t* cls;
+    uint32_t* ninfo;
+    uint32_t* arct;
+    int32_t* nlayer;
+    int32_t* lvar;
+    int32_t* ldup;
+    uint64_t* cs_state;
+    int32_t* cs_value;
+    uint32_t* cs_pop;
+    // LDS
+    uint32_t* table;     // table_cap u32 (also reused as 2 x capN i32 value_bot arrays)
+    int table_cap;
+    int32_t* cnt;        // npad
+    uint32_t* hist;      // 256
+    int32_t* tcount;     // NT
+    int32_t* tcount2;    // NT
+    DDShared* sh;
+    // output
+    uint8_t* arena;
+    uint64_t arena_cap;
+    unsigned long long* arena_head;
+    const int32_t* cutoff_flag;
+    int NT;
+#if !defined(DDO_HOST_EMULATION)
+    int tid_;
+#endif
+};
+
+#if defined(DDO_HOST_EMULATION)
+#define DD_TID_SETUP(c) const int NT = (c).NT;
+#else
+#define DD_TID_SETUP(c) const int NT = (c).NT; const int tid = (c).tid_;
+#endif
+
+DDO_DEV uint32_t bias32(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+DDO_DEV int32_t unbias32(uint32_t v) { return (int32_t)(v ^ 0x80000000u); }
+
+/// 64-bit mix of the state words (any good mix is equivalent to FxHash for dedup purposes).
+template <int WS>
+DDO_DEV uint64_t hash_state(const uint64_t* s) {
+    uint64_t h = 0x243F6A8885A308D3ULL;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        h ^= s[k];
+        h *= 0x9E3779B97F4A7C15ULL;
+        h ^= h >> 29;
+    }
+    h *= 0xBF58476D1CE4E5B9ULL;
+    h ^= h >> 32;
+    return h;
+}
+
+/// cnt[i] += delta for every member i of the state (delta maintenance of the
+/// next_variable counters, main.rs:130-135).
+template <int WS>
+DDO_DEV void add_bits(int32_t* cnt, const uint64_t* s, int delta) {
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        uint64_t x = s[k];
+        while (x) {
+            int b = dd_ctz(x);
+            LDS_ADD_I32(&cnt[k * 64 + b], delta);
+            x &= x - 1;
+        }
+    }
+}
+
+/// MispRelax::fast_upper_bound (main.rs:191-193)
+template <int WS>
+DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop) {
+    if (c.unit_weights) return pop;
+    int32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        uint64_t x = s[k];
+        while (x) {
+            int b = dd_ctz(x);
+            sum += c.weight[k * 64 + b];
+            x &= x - 1;
+        }
+    }
+    return sum;
+}
+
+/// candidate numbering: NO-children of parent position p live at p, YES-children at capN + p,
+/// the merged node of a relaxed layer at 2*capN.
+DDO_DEV int lin2cand(int j, int nprev, int capN) { return j < nprev ? j : capN + (j - nprev); }
+
+/// 48-bit primary ranking key: (value_top, popcount) -- clean.rs:803-808 then MispRanking's len().
+DDO_DEV uint64_t k1_of(uint64_t key, uint32_t pop) { return ((key >> 32) << 16) | (uint64_t)(pop & 0xFFFFu); }
+
+/// Workgroup exclusive scan of a[0..NT) (Hillis-Steele, double buffered); total in sh->scan_total.
+template <int WS>
+DDO_DEV void block_exclusive_scan(DDCtx<WS>& c, int32_t* a, int32_t* tmp) {
+    DD_TID_SETUP(c)
+    int32_t* src = a;
+    int32_t* dst = tmp;
+    for (int d = 1; d < NT; d <<= 1) {
+        PAR_BEGIN
+        dst[tid] = src[tid] + (tid >= d ? src[tid - d] : 0);
+        PAR_END
+        int32_t* t = src;
+        src = dst;
+        dst = t;
+    }
+    // src holds the inclusive scan; write the exclusive one into `a`
+    PAR_BEGIN
+    int32_t incl = src[tid];
+    int32_t excl = tid ? src[tid - 1] : 0;
+    if (tid == NT - 1) c.sh->scan_total = incl;
+    dst[tid] = excl;
+    PAR_END
+    if (dst != a) {
+        PAR_BEGIN
+        a[tid] = dst[tid];
+        PAR_END
+    }
+}
+
+/// Exact K-th largest (1 <= K < nU) among the unique candidates of buffer `cur` by the total
+/// order (value_top, popcount, BitSet::cmp) -- MSD radix select, 8-bit digits, skipping the
+/// digits that are constant over the layer.  Result: sh->pivK1 / sh->pivLex with the
+/// unresolved low digits zero-filled, so that "key >= pivot" <=> kept.
+template <int WS>
+DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
+    DD_TID_SETUP(c)
+    DDShared* sh = c.sh;
+    const int ncl = 2 * nprev;
+    const int q = (ncl + NT - 1) / NT;
+    const uint64_t* key = c.ckey[cur];
+    const uint32_t* pop = c.cpop[cur];
+    const uint64_t* st = c.cstate[cur];
+    const int capC1 = c.capC1;
+
+    PAR_BEGIN
+    if (tid == 0) {
+        sh->k1and = ~0ULL;
+        sh->k1or = 0;
+        sh->pivK1 = 0;
+        for (int k = 0; k < WS; ++k) sh->pivLex[k] = 0;
+    }
+    PAR_END
+    PAR_BEGIN
+    uint64_t a = ~0ULL, o = 0;
+    int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+    for (int j = lo; j < hi; ++j) {
+        int cd = lin2cand(j, nprev, c.capN);
+        if (c.ctarget[cd] == (uint32_t)cd) {
+            uint64_t k1 = k1_of(LD_U64(&key[cd]), pop[cd]);
+            a &= k1;
+            o |= k1;
+        }
+    }
+    if (lo < hi) {
+        LDS_AND_U64(&sh->k1and, a);
+        LDS_OR_U64(&sh->k1or, o);
+    }
+    PAR_END
+
+    int need = K;
+    bool done = false;
+    const uint64_t diff = sh->k1and ^ sh->k1or;
+    uint64_t pivK1 = 0;
+    // ---- primary key: 6 bytes, most significant first
+    for (int b = 5; b >= 0 && !done; --b) {
+        const int shift = 8 * b;
+        if (((diff >> shift) & 0xFF) == 0) {
+            pivK1 |= sh->k1and & (0xFFULL << shift);
+            continue;
+        }
+        PAR_BEGIN
+        if (tid < 256) c.hist[tid] = 0;
+        PAR_END
+        PAR_BEGIN
+        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+        for (int j = lo; j < hi; ++j) {
+            int cd = lin2cand(j, nprev, c.capN);
+            if (c.ctarget[cd] == (uint32_t)cd) {
+                uint64_t k1 = k1_of(LD_U64(&key[cd]), pop[cd]);
+                bool active = (shift + 8 >= 48) || ((k1 >> (shift + 8)) == (pivK1 >> (shift + 8)));
+                if (active) LDS_ADD_U32(&c.hist[(k1 >> shift) & 0xFF], 1u);
+            }
+        }
+        PAR_END
+        PAR_BEGIN
+        if (tid < 256) {
+            int above = 0;
+            for (int x = tid + 1; x < 256; ++x) above += (int)c.hist[x];
+            int mine = (int)c.hist[tid];
+            if (above < need && need <= above + mine) {
+                sh->sel_digit = tid;
+                sh->sel_above = above;
+                sh->sel_bucket = mine;
+            }
+        }
+        PAR_END
+        pivK1 |= (uint64_t)sh->sel_digit << shift;
+        need -= sh->sel_above;
+        if (need == sh->sel_bucket) done = true;  // the whole bucket is kept: stop refining
+    }
+    // ---- tie-break: lexicographic member order; digit = byte of brev(~word), MSB first
+    uint64_t pivLex[WS];
+#pragma unroll
+    for (int k = 0; k < WS; ++k) pivLex[k] = 0;
+    for (int qd = 0; qd < 8 * WS && !done; ++qd) {
+        const int wj = qd >> 3;
+        const int shift = 8 * (7 - (qd & 7));
+        PAR_BEGIN
+        if (tid < 256) c.hist[tid] = 0;
+        PAR_END
+        PAR_BEGIN
+        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+        for (int j = lo; j < hi; ++j) {
+            int cd = lin2cand(j, nprev, c.capN);
+            if (c.ctarget[cd] != (uint32_t)cd) continue;
+            if (k1_of(LD_U64(&key[cd]), pop[cd]) != pivK1) continue;
+            bool active = true;
+            for (int k = 0; k < wj && active; ++k)
+                active = dd_brev(~st[(size_t)k * capC1 + cd]) == pivLex[k];
+            if (!active) continue;
+            uint64_t lw = dd_brev(~st[(size_t)wj * capC1 + cd]);
+            if (shift + 8 < 64 && (lw >> (shift + 8)) != (pivLex[wj] >> (shift + 8))) continue;
+            LDS_ADD_U32(&c.hist[(lw >> shift) & 0xFF], 1u);
+        }
+        PAR_END
+        PAR_BEGIN
+        if (tid < 256) {
+            int above = 0;
+            for (int x = tid + 1; x < 256; ++x) above += (int)c.hist[x];
+            int mine = (int)c.hist[tid];
+            if (above < need && need <= above + mine) {
+                sh->sel_digit = tid;
+                sh->sel_above = above;
+                sh->sel_bucket = mine;
+            }
+        }
+        PAR_END
+        pivLex[wj] |= (uint64_t)sh->sel_digit << shift;
+        need -= sh->sel_above;
+        if (need == sh->sel_bucket) done = true;
+    }
+    PAR_BEGIN
+    if (tid == 0) {
+        sh->pivK1 = pivK1;
+        for (int k = 0; k < WS; ++k) sh->pivLex[k] = pivLex[k];
+    }
+    PAR_END
+}
+
+/// key(cand) >= pivot under (K1, lexkey words).
+template <int WS>
+DDO_DEV bool ge_pivot(const DDCtx<WS>& c, int cur, int cd, uint64_t k1) {
+    const DDShared* sh = c.sh;
+    if (k1 != sh->pivK1) return k1 > sh->pivK1;
+    const uint64_t* st = c.cstate[cur];
+    for (int k = 0; k < WS; ++k) {
+        uint64_t lw = dd_brev(~st[(size_t)k * c.capC1 + cd]);
+        if (lw != sh->pivLex[k]) return lw > sh->pivLex[k];
+    }
+    return true;
+}
+
+/// full-order "a ranks above b" for two candidates of buffer `cur`
+template <int WS>
+DDO_DEV bool ranks_above(const DDCtx<WS>& c, int cur, int a, int b) {
+    uint64_t ka = k1_of(LD_U64(&c.ckey[cur][a]), c.cpop[cur][a]);
+    uint64_t kb = k1_of(LD_U64(&c.ckey[cur][b]), c.cpop[cur][b]);
+    if (ka != kb) return ka > kb;
+    const uint64_t* st = c.cstate[cur];
+    for (int k = 0; k < WS; ++k) {
+        uint64_t la = dd_brev(~st[(size_t)k * c.capC1 + a]);
+        uint64_t lb = dd_brev(~st[(size_t)k * c.capC1 + b]);
+        if (la != lb) return la > lb;
+    }
+    return false;
+}
+
+/// Inserts candidate `cd` (state s, already stored in buffer nxt) into the dedup table.
+/// Returns the winner candidate (== cd when this state is new).  clean.rs:738-775.
+template <int WS>
+DDO_DEV uint32_t dedup_insert(const DDCtx<WS>& c, int nxt, uint32_t cd, const uint64_t* s, int mask) {
+    const uint64_t h = hash_state<WS>(s);
+    const uint32_t tag = (uint32_t)(h >> 52);  // 12 bits
+    const uint32_t mine = (tag << 20) | cd;
+    uint32_t slot = (uint32_t)h & (uint32_t)mask;
+    const uint64_t* st = c.cstate[nxt];
+    for (;;) {
+        uint32_t e = *(volatile uint32_t*)&c.table[slot];
+        if (e == TAB_EMPTY) {
+            e = TAB_CAS(&c.table[slot], TAB_EMPTY, mine);
+            if (e == TAB_EMPTY) return cd;
+        }
+        if ((e >> 20) == tag) {
+            const uint32_t w = e & 0xFFFFFu;
+            bool eq = true;
+            for (int k = 0; k < WS && eq; ++k) eq = LD_U64(&st[(size_t)k * c.capC1 + w]) == s[k];
+            if (eq) return w;
+        }
+        slot = (slot + 1) & (uint32_t)mask;
+    }
+}
+
+/// read-only probe (recycled-merge detection, clean.rs:830): candidate holding state s, or NONE32
+template <int WS>
+DDO_DEV uint32_t dedup_find(const DDCtx<WS>& c, int buf, const uint64_t* s, int mask) {
+    const uint64_t h = hash_state<WS>(s);
+    const uint32_t tag = (uint32_t)(h >> 52);
+    uint32_t slot = (uint32_t)h & (uint32_t)mask;
+    const uint64_t* st = c.cstate[buf];
+    for (;;) {
+        uint32_t e = c.table[slot];
+        if (e == TAB_EMPTY) return NONE32;
+        if ((e >> 20) == tag) {
+            const uint32_t w = e & 0xFFFFFu;
+            bool eq = true;
+            for (int k = 0; k < WS && eq; ++k) eq = st[(size_t)k * c.capC1 + w] == s[k];
+            if (eq) return w;
+        }
+        slot = (slot + 1) & (uint32_t)mask;
+    }
+}
+
+DDO_DEV int table_size_for(int ncand_max, int cap) {
+    int h = 1024;
+    while (h < cap && h * 2 < ncand_max * 3) h <<= 1;  // load factor <= 2/3
+    return h;
+}
+
+/// One compile() -- clean.rs:345-381 -- of the sub-problem `in` with the given type.
+template <int WS>
+DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
+    DD_TID_SETUP(c)
+    DDShared* sh = c.sh;
+    const int capN = c.capN, capC1 = c.capC1;
+    const int W = in.width;
+    const int MERGED = 2 * capN;
+    const bool relaxed = comp_type == CT_RELAXED;
+    const bool restricted = comp_type == CT_RESTRICTED;
+
+    // ---------------------------------------------------------------- _clear + _initialize
+    int cur = 0;
+    const int hsize = table_size_for(2 * (W + 2) + 1, c.table_cap);
+    const int hmask = hsize - 1;
+    PAR_BEGIN
+    for (int i = tid; i < c.npad; i += NT) c.cnt[i] = 0;
+    if (tid == 0) {
+        sh->nU = 1;
+        sh->status = ST_OK;
+        sh->nodes = 0;
+        sh->arcs = 0;
+        sh->recycled_merges = 0;
+        sh->cutoff = 0;
+        for (int k = 0; k < WS; ++k) c.cstate[0][(size_t)k * capC1] = in.state[k];
+        int pop = 0;
+        for (int k = 0; k < WS; ++k) pop += dd_popc(in.state[k]);
+        c.ckey[0][0] = ((uint64_t)bias32(in.value) << 32) | NONE32;
+        c.cpop[0][0] = (uint32_t)pop;
+        c.cflags[0][0] = 0;
+        c.ctarget[0] = 0;        // the root is its own "winner"
+        c.ctarget[capN] = NONE32;
+    }
+    PAR_END
+    PAR_BEGIN
+    if (tid == 0) add_bits<WS>(c.cnt, in.state, +1);
+    // the table must describe the current unique layer (needed by recycled-merge probes)
+    for (int i = tid; i < hsize; i += NT) c.table[i] = TAB_EMPTY;
+    PAR_END
+
+    int nprev = 1;   // parents that produced the current candidates
+    int lel = -1;    // Option<LayerId>
+    int L = 0;       // layers.len()
+    int var = -1;
+    bool failed = false;
+
+    for (;;) {
+        // ------------------------------------------------------------ next_variable (main.rs:109-143)
+        PAR_BEGIN
+        if (tid == 0) {
+            sh->varkey = 0xFFFFFFFFu;
+            if (c.cutoff_flag) sh->cutoff = LD_I32(c.cutoff_flag);
+        }
+        PAR_END
+        PAR_BEGIN
+        for (int i = tid; i < c.n; i += NT) {
+            int cv = c.cnt[i];
+            if (cv > 0) LDS_MIN_U32(&sh->varkey, ((uint32_t)cv << 12) | (uint32_t)i);
+            else if (cv < 0) sh->status = ST_ERR_INTERNAL;
+        }
+        PAR_END
+        var = sh->varkey == 0xFFFFFFFFu ? -1 : (int)(sh->varkey & 0xFFFu);
+        if (var < 0) break;
+        if (sh->cutoff) {  // clean.rs:352-354
+            PAR_BEGIN
+            if (tid == 0) sh->status = ST_CUTOFF;
+            PAR_END
+            failed = true;
+            break;
+        }
+        const int nU = sh->nU;
+        if (L >= c.max_layers - 1 || sh->status != ST_OK) { failed = true; break; }
+
+        // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
+        const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
+        if (!squash && nU > capN) {  // Exact DD wider than the workspace
+            PAR_BEGIN
+            if (tid == 0) sh->status = ST_ERR_CAPACITY;
+            PAR_END
+            failed = true;
+            break;
+        }
+        const int ncl = 2 * nprev;
+        const int q = (ncl + NT - 1) / NT;
+        int K = 0;
+        if (squash) {
+            if (lel < 0) {
+                lel = L - 1;  // _maybe_save_lel
+                if (relaxed) {
+                    // keep a copy of the last exact layer: it becomes the cut-set (clean.rs:566-573)
+                    PAR_BEGIN
+                    for (int pos = tid; pos < nprev; pos += NT) {
+                        uint32_t p = c.keep[pos];
+                        for (int k = 0; k < WS; ++k)
+                            c.cs_state[(size_t)k * capN + pos] = c.cstate[cur ^ 1][(size_t)k * capC1 + p];
+                        c.cs_value[pos] = unbias32((uint32_t)(LD_U64(&c.ckey[cur ^ 1][p]) >> 32));
+                        c.cs_pop[pos] = c.cpop[cur ^ 1][p];
+                    }
+                    PAR_END
+                }
+            }
+            K = restricted ? W : W - 1;
+            if (K > 0) select_pivot<WS>(c, cur, nprev, K);
+        }
+
+        // ------------------------------------------------------------ classify + count (pass 1)
+        PAR_BEGIN
+        if (tid == 0) {
+            sh->mergedKey = 0;
+            for (int k = 0; k < WS; ++k) sh->merged[k] = 0;
+            sh->recycled = 0;
+            sh->dup_from = -1;
+            sh->dup_to = -1;
+            sh->xbest = -1;
+        }
+        PAR_END
+        PAR_BEGIN
+        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+        int kept = 0;
+        uint64_t mor[WS];
+#pragma unroll
+        for (int k = 0; k < WS; ++k) mor[k] = 0;
+        uint64_t mkey = 0;
+        bool anydel = false;
+        for (int j = lo; j < hi; ++j) {
+            int cd = lin2cand(j, nprev, capN);
+            uint8_t cl = 0;
+            if (c.ctarget[cd] == (uint32_t)cd) {
+                cl = 1;
+                if (squash) {
+                    uint64_t key = LD_U64(&c.ckey[cur][cd]);
+                    bool keepit = K > 0 && ge_pivot<WS>(c, cur, cd, k1_of(key, c.cpop[cur][cd]));
+                    if (!keepit) {
+                        cl = 2;
+                        uint64_t s[WS];
+#pragma unroll
+                        for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + cd];
+                        add_bits<WS>(c.cnt, s, -1);  // it leaves the layer
+                        if (relaxed) {
+#pragma unroll
+                            for (int k = 0; k < WS; ++k) mor[k] |= s[k];
+                            if (key > mkey) mkey = key;
+                            anydel = true;
+                        }
+                    }
+                }
+                kept += (cl == 1);
+            }
+            c.cls[cd] = cl;
+        }
+        c.tcount[tid] = kept;
+        if (anydel) {
+#pragma unroll
+            for (int k = 0; k < WS; ++k)
+                if (mor[k]) LDS_OR_U64(&sh->merged[k], mor[k]);   // MispRelax::merge (main.rs:172-178)
+            LDS_MAX_U64(&sh->mergedKey, mkey);
+        }
+        PAR_END
+        block_exclusive_scan<WS>(c, c.tcount, c.tcount2);
+        const int nkept = sh->scan_total;
+
+        // ------------------------------------------------------------ assign positions (pass 2)
+        PAR_BEGIN
+        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+        int pos = c.tcount[tid];
+        for (int j = lo; j < hi; ++j) {
+            int cd = lin2cand(j, nprev, capN);
+            if (c.cls[cd] == 1) {
+                c.keep[pos] = (uint32_t)cd;
+                c.posmap[cd] = (uint32_t)pos;
+                ++pos;
+            }
+        }
+        PAR_END
+
+        int n = nkept;
+        int merged_pos = -1;
+        if (squash && relaxed) {
+            // ------------------------------------------------------------ _relax: merged node (clean.rs:826-875)
+            PAR_BEGIN
+            if (tid == 0) {
+                uint64_t ms[WS];
+                for (int k = 0; k < WS; ++k) ms[k] = sh->merged[k];
+                uint32_t r = dedup_find<WS>(c, cur, ms, hmask);
+                if (r != NONE32 && c.cls[r] == 1) {
+                    sh->recycled = 1;  // clean.rs:830
+                    sh->recycled_merges += 1;
+                    sh->merged_pos = (int32_t)c.posmap[r];
+                    uint64_t old = LD_U64(&c.ckey[cur][r]);
+                    if (sh->mergedKey > old) c.ckey[cur][r] = sh->mergedKey;
+                    c.cflags[cur][r] = LD_U32(&c.cflags[cur][r]) | NF_RELAXED;
+                } else {
+                    int pop = 0;
+                    for (int k = 0; k < WS; ++k) {
+                        c.cstate[cur][(size_t)k * capC1 + MERGED] = ms[k];
+                        pop += dd_popc(ms[k]);
+                    }
+                    c.ckey[cur][MERGED] = sh->mergedKey;
+                    c.cpop[cur][MERGED] = (uint32_t)pop;
+                    c.cflags[cur][MERGED] = NF_RELAXED | NF_INEXACT;
+                    c.keep[nkept] = (uint32_t)MERGED;
+                    c.posmap[MERGED] = (uint32_t)nkept;
+                    c.cls[MERGED] = 1;
+                    sh->merged_pos = nkept;
+                    add_bits<WS>(c.cnt, ms, +1);
+                }
+            }
+            PAR_END
+            merged_pos = sh->merged_pos;
+            if (!sh->recycled) {
+                n = nkept + 1;
+            } else {
+                // clean.rs:868-872: the layer is truncated to W entries, i.e. the best-ranked node of
+                // the merged set stays in the layer (un-deleted) next to the recycled node.
+                PAR_BEGIN
+                if (tid < 64) {
+                    int best = -1;
+                    for (int j = tid; j < ncl; j += 64) {
+                        int cd = lin2cand(j, nprev, capN);
+                        if (c.cls[cd] == 2 && (best < 0 || ranks_above<WS>(c, cur, cd, best))) best = cd;
+                    }
+                    sh->xcand[tid] = best;
+                }
+                PAR_END
+                PAR_BEGIN
+                if (tid == 0) {
+                    int best = -1;
+                    for (int l = 0; l < 64; ++l) {
+                        int cd = sh->xcand[l];
+                        if (cd >= 0 && (best < 0 || ranks_above<WS>(c, cur, cd, best))) best = cd;
+                    }
+                    sh->xbest = best;
+                    uint64_t s[WS];
+                    for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + best];
+                    add_bits<WS>(c.cnt, s, +1);
+                    c.cls[best] = 1;
+                    c.keep[nkept] = (uint32_t)best;
+                    c.posmap[best] = (uint32_t)nkept;
+                    sh->dup_from = nkept;
+                    sh->dup_to = sh->merged_pos;
+                }
+                PAR_END
+                n = nkept + 1;
+            }
+        }
+
+        // ------------------------------------------------------------ layers.push (clean.rs:678-684)
+        PAR_BEGIN
+        if (tid == 0) {
+            c.nlayer[L] = n;
+            c.lvar[L] = var;
+            c.ldup[2 * L] = sh->dup_from;
+            c.ldup[2 * L + 1] = sh->dup_to;
+        }
+        uint32_t* ni = c.ninfo + (size_t)L * capN;
+        for (int pos = tid; pos < n; pos += NT) {
+            uint32_t cd = c.keep[pos];
+            uint32_t arc = (uint32_t)LD_U64(&c.ckey[cur][cd]);
+            uint32_t fl = LD_U32(&c.cflags[cur][cd]);
+            uint32_t w;
+            if (arc == NONE32) w = NI_NOARC;
+            else {
+                uint32_t d = arc >= (uint32_t)capN ? 1u : 0u;
+                uint32_t pp = arc - d * (uint32_t)capN;
+                w = (pp << 1) | d;
+            }
+            if (fl & NF_INEXACT) w |= NI_INEXACT;
+            if (fl & NF_RELAXED) w |= NI_RELAXED;
+            ni[pos] = w;
+        }
+        // arcs entering this layer, translated to node positions (needed by the backward pass)
+        if (relaxed && lel >= 0 && L >= 1) {
+            uint32_t* at = c.arct + (size_t)L * 2 * capN;
+            for (int j = tid; j < ncl; j += NT) {
+                int cd = lin2cand(j, nprev, capN);
+                uint32_t t = c.ctarget[cd];
+                uint32_t out = NONE32;
+                if (t != NONE32) out = c.cls[t] == 1 ? c.posmap[t] : (uint32_t)merged_pos;
+                at[cd] = out;
+            }
+        }
+        PAR_END
+
+        // ------------------------------------------------------------ expand (clean.rs:360-370, 728-776)
+        const int nxt = cur ^ 1;
+        PAR_BEGIN
+        for (int i = tid; i < hsize; i += NT) c.table[i] = TAB_EMPTY;
+        if (tid == 0) sh->nU = 0;
+        PAR_END
+        PAR_BEGIN
+        uint64_t adjv[WS];
+#pragma unroll
+        for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
+        const int vw = var >> 6;
+        const uint64_t vbit = 1ULL << (var & 63);
+        const int32_t wv = c.weight[var];
+        int myarcs = 0, myuniq = 0;
+        for (int pos = tid; pos < n; pos += NT) {
+            const uint32_t p = c.keep[pos];
+            uint64_t s[WS];
+#pragma unroll
+            for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + p];
+            const uint64_t pkey = LD_U64(&c.ckey[cur][p]);
+            const int32_t val = unbias32((uint32_t)(pkey >> 32));
+            const int pop = (int)c.cpop[cur][p];
+            const uint32_t pfl = LD_U32(&c.cflags[cur][p]);
+            const uint32_t inexact = (pfl & (NF_INEXACT | NF_RELAXED)) ? NF_INEXACT : 0u;
+            const int32_t rub = rub_of<WS>(c, s, pop);
+            if ((int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded
+                add_bits<WS>(c.cnt, s, -1);
+                c.ctarget[pos] = NONE32;
+                c.ctarget[capN + pos] = NONE32;
+                continue;
+            }
+            bool hasv = false;
+#pragma unroll
+            for (int k = 0; k < WS; ++k)
+                if (k == vw) hasv = (s[k] & vbit) != 0;
+            // ---- decision NO (main.rs:77-85 with value == NO): state minus the variable
+            if (hasv) {
+#pragma unroll
+                for (int k = 0; k < WS; ++k)
+                    if (k == vw) s[k] &= ~vbit;
+                LDS_ADD_I32(&c.cnt[var], -1);
+            }
+            {
+                const uint32_t cd = (uint32_t)pos;
+#pragma unroll
+                for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = s[k];
+                const uint64_t mykey = ((uint64_t)bias32(val) << 32) | cd;
+                c.ckey[nxt][cd] = mykey;
+                c.cpop[nxt][cd] = (uint32_t)(pop - (hasv ? 1 : 0));
+                c.cflags[nxt][cd] = inexact;
+                FENCE_BLOCK();
+                const uint32_t w = dedup_insert<WS>(c, nxt, cd, s, hmask);
+                c.ctarget[cd] = w;
+                ++myarcs;
+                if (w == cd) ++myuniq;
+                else {
+                    GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
+                    if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
+                    add_bits<WS>(c.cnt, s, -1);                      // duplicate: not a new member of next_l
+                }
+            }
+            // ---- decision YES (only when the variable is in the state, main.rs:95-102)
+            if (hasv) {
+                uint64_t y[WS];
+                int ypop = 0;
+#pragma unroll
+                for (int k = 0; k < WS; ++k) {
+                    y[k] = s[k] & adjv[k];
+                    ypop += dd_popc(y[k]);
+                }
+                const uint32_t cd = (uint32_t)(capN + pos);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
+                const uint64_t mykey = ((uint64_t)bias32(val + wv) << 32) | cd;
+                c.ckey[nxt][cd] = mykey;
+                c.cpop[nxt][cd] = (uint32_t)ypop;
+                c.cflags[nxt][cd] = inexact;
+                FENCE_BLOCK();
+                const uint32_t w = dedup_insert<WS>(c, nxt, cd, y, hmask);
+                c.ctarget[cd] = w;
+                ++myarcs;
+                if (w == cd) {
+                    ++myuniq;
+                    add_bits<WS>(c.cnt, y, +1);
+                } else {
+                    GLB_MAX_U64(&c.ckey[nxt][w], mykey);
+                    if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
+                }
+            } else {
+                c.ctarget[capN + pos] = NONE32;
+            }
+        }
+        if (myarcs) LDS_ADD_U64(&sh->arcs, (uint64_t)myarcs);
+        if (myuniq) LDS_ADD_I32(&sh->nU, myuniq);
+        if (tid == 0) sh->nodes += (uint64_t)n;
+        PAR_END
+
+        cur = nxt;
+        nprev = n;
+        L += 1;
+    }
+
+    // ==================================================================== _finalize (clean.rs:407-414)
+    int n_layers = L;
+    int nT = 0;          // nodes of the terminal layer
+    const int nU = sh->nU;
+    const int ncl = 2 * nprev;
+    const int q = (ncl + NT - 1) / NT;
+    if (!failed && nU > capN) {
+        PAR_BEGIN
+        if (tid == 0) sh->status = ST_ERR_CAPACITY;
+        PAR_END
+        failed = true;
+    }
+    if (!failed && nU > 0) {
+        // _finalize_layers: the terminal layer is whatever is in next_l, never squashed (clean.rs:608-618)
+        PAR_BEGIN
+        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+        int kept = 0;
+        for (int j = lo; j < hi; ++j) {
+            int cd = lin2cand(j, nprev, capN);
+            uint8_t cl = c.ctarget[cd] == (uint32_t)cd ? 1 : 0;
+            c.cls[cd] = cl;
+            kept += cl;
+        }
+        c.tcount[tid] = kept;
+        if (tid == 0) {
+            sh->bestKey = 0;
+            sh->bestExactKey = 0;
+        }
+        PAR_END
+        block_exclusive_scan<WS>(c, c.tcount, c.tcount2);
+        nT = sh->scan_total;
+        PAR_BEGIN
+        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+        int pos = c.tcount[tid];
+        for (int j = lo; j < hi; ++j) {
+            int cd = lin2cand(j, nprev, capN);
+            if (c.cls[cd] == 1) {
+                c.keep[pos] = (uint32_t)cd;
+                c.posmap[cd] = (uint32_t)pos;
+                ++pos;
+            }
+        }
+        PAR_END
+        PAR_BEGIN
+        if (tid == 0) {
+            c.nlayer[L] = nT;
+            c.lvar[L] = -1;
+            c.ldup[2 * L] = -1;
+            c.ldup[2 * L + 1] = -1;
+        }
+        uint32_t* ni = c.ninfo + (size_t)L * capN;
+        for (int pos = tid; pos < nT; pos += NT) {
+            uint32_t cd = c.keep[pos];
+            uint64_t key = LD_U64(&c.ckey[cur][cd]);
+            uint32_t arc = (uint32_t)key;
+            uint32_t fl = LD_U32(&c.cflags[cur][cd]);
+            uint32_t w;
+            if (arc == NONE32) w = NI_NOARC;
+            else {
+                uint32_t d = arc >= (uint32_t)capN ? 1u : 0u;
+                w = ((arc - d * (uint32_t)capN) << 1) | d;
+            }
+            if (fl & NF_INEXACT) w |= NI_INEXACT;
+            if (fl & NF_RELAXED) w |= NI_RELAXED;
+            ni[pos] = w;
+            // _find_best_node (clean.rs:620-632): max value_top; position breaks ties deterministically
+            uint64_t bk = (key & 0xFFFFFFFF00000000ULL) | (uint32_t)pos;
+            LDS_MAX_U64(&sh->bestKey, bk + 1);  // +1 so that 0 means "none"
+            if (!(fl & (NF_INEXACT | NF_RELAXED))) LDS_MAX_U64(&sh->bestExactKey, bk + 1);
+        }
+        if (relaxed && lel >= 0 && L >= 1) {
+            uint32_t* at = c.arct + (size_t)L * 2 * capN;
+            for (int j = tid; j < ncl; j += NT) {
+                int cd = lin2cand(j, nprev, capN);
+                uint32_t t = c.ctarget[cd];
+                at[cd] = t != NONE32 ? c.posmap[t] : NONE32;
+            }
+        }
+        PAR_END
+        n_layers = L + 1;
+    } else if (!failed) {
+        PAR_BEGIN
+        if (tid == 0) {
+            sh->bestKey = 0;
+            sh->bestExactKey = 0;
+        }
+        PAR_END
+    }
+
+    // ---------------------------------------------------------------- results
+    const bool is_exact = lel < 0;                                     // clean.rs:635
+    const bool has_best = !failed && sh->bestKey != 0;
+    int best_pos = -1, best_value = 0;
+    if (has_best) {
+        uint64_t bk = sh->bestKey - 1;
+        best_pos = (int)(uint32_t)bk;
+        best_value = unbias32((uint32_t)(bk >> 32));
+    }
+    bool has_best_exact = !failed && sh->bestExactKey != 0;
+    int exact_pos = -1, exact_value = 0;
+    if (has_best_exact) {
+        uint64_t bk = sh->bestExactKey - 1;
+        exact_pos = (int)(uint32_t)bk;
+        exact_value = unbias32((uint32_t)(bk >> 32));
+    }
+    // _has_exact_best_path (clean.rs:643-655), EBPO
+    bool ebpo = false;
+    if (relaxed && !failed) {
+        PAR_BEGIN
+        if (tid == 0) {
+            int res_e = 1;
+            if (has_best) {
+                int Lc = n_layers - 1, p = best_pos;
+                for (;;) {
+                    uint32_t w = c.ninfo[(size_t)Lc * capN + p];
+                    bool ex = !(w & (NI_INEXACT | NI_RELAXED));
+                    if (ex) { res_e = 1; break; }
+                    if (w & NI_RELAXED) { res_e = 0; break; }
+                    if (w & NI_NOARC) { res_e = 1; break; }
+                    p = (int)((w & NI_ARC_MASK) >> 1);
+                    Lc -= 1;
+                }
+            }
+            sh->sel_digit = res_e;
+        }
+        PAR_END
+        ebpo = sh->sel_digit != 0;
+        if (ebpo && has_best) {  // clean.rs:638-640
+            has_best_exact = true;
+            exact_pos = best_pos;
+            exact_value = best_value;
+        } else if (ebpo && !has_best) {
+            // best_node == None => has_exact_best_path(None) == true, best_exact_node stays None
+        }
+    }
+
+    // ---------------------------------------------------------------- local bounds (clean.rs:448-475)
+    const bool want_cutset = relaxed && !failed && lel >= 0 && lel < n_layers && has_best;
+    int32_t* vbA = (int32_t*)c.table;
+    int32_t* vbB = vbA + capN;
+    if (want_cutset) {
+        const int T = n_layers - 1;
+        PAR_BEGIN
+        for (int pos = tid; pos < c.nlayer[T]; pos += NT) vbA[pos] = 0;
+        PAR_END
+        for (int Lc = T; Lc > lel; --Lc) {
+            const int nP = c.nlayer[Lc - 1];
+            PAR_BEGIN
+            for (int pos = tid; pos < nP; pos += NT) vbB[pos] = VB_UNMARKED;
+            PAR_END
+            PAR_BEGIN
+            const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
+            const int32_t wv = c.weight[c.lvar[Lc - 1]];
+            const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
+            for (int j = tid; j < 2 * nP; j += NT) {
+                const int d = j >= nP ? 1 : 0;
+                const int pp = j - d * nP;
+                const uint32_t t = at[d * capN + pp];
+                if (t == NONE32) continue;
+                const int32_t cost = d ? wv : 0;
+                int32_t v = vbA[t];
+                if (v != VB_UNMARKED) LDS_MAX_I32(&vbB[pp], v + cost);
+                if ((int)t == dfrom) {  // arcs of the re-added node were also redirected (clean.rs:851-866)
+                    int32_t v2 = vbA[dto];
+                    if (v2 != VB_UNMARKED) LDS_MAX_I32(&vbB[pp], v2 + cost);
+                }
+            }
+            PAR_END
+            int32_t* t = vbA;
+            vbA = vbB;
+            vbB = t;
+        }
+    }
+
+    // ---------------------------------------------------------------- cut-set size (clean.rs:417-445)
+    const int ncs_layer = want_cutset ? c.nlayer[lel] : 0;
+    const bool filter = (in.flags & IN_FILTER_CUTSET) != 0;
+    PAR_BEGIN
+    if (tid == 0) {
+        sh->ncut = 0;
+        sh->ncut2 = 0;
+    }
+    PAR_END
+    if (want_cutset) {
+        PAR_BEGIN
+        int mine = 0;
+        for (int pos = tid; pos < ncs_layer; pos += NT) {
+            int32_t vb = vbA[pos];
+            if (vb == VB_UNMARKED) continue;
+            if (filter) {
+                uint64_t s[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) s[k] = c.cs_state[(size_t)k * capN + pos];
+                int64_t v = c.cs_value[pos];
+                int64_t ub = v + rub_of<WS>(c, s, (int)c.cs_pop[pos]);
+                if (v + vb < ub) ub = v + vb;
+                if (best_value < ub) ub = best_value;
+                if (ub <= best_lb) continue;
+            }
+            ++mine;
+        }
+        if (mine) LDS_ADD_I32(&sh->ncut, mine);
+        PAR_END
+    }
+    const int ncut = sh->ncut;
+    const bool want_paths = (in.flags & IN_WANT_PATHS) != 0;
+    const bool emit_best = has_best && (want_paths || (int64_t)best_value > best_lb);
+    const bool emit_exact = has_best_exact && (want_paths || (int64_t)exact_value > best_lb);
+    const bool same = emit_best && emit_exact && exact_pos == best_pos;
+    const int path_len = n_layers > 0 ? n_layers - 1 : 0;
+    const int best_len = emit_best ? path_len : 0;
+    const int exact_len = (emit_exact && !same) ? path_len : 0;
+    const int cs_path_len = lel > 0 ? lel : 0;
+
+    // arena layout (all 8-byte aligned)
+    uint64_t off = 0;
+    const uint64_t path_off = off;
+    off += ((uint64_t)best_len * 4 + 7) & ~7ULL;
+    const uint64_t exact_off = off;
+    off += ((uint64_t)exact_len * 4 + 7) & ~7ULL;
+    const uint64_t cs_state_off = off;
+    off += (uint64_t)ncut * WS * 8;
+    const uint64_t cs_value_off = off;
+    off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
+    const uint64_t cs_ub_off = off;
+    off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
+    const uint64_t cs_path_off = off;
+    off += ((uint64_t)ncut * cs_path_len * 4 + 7) & ~7ULL;
+    const uint64_t total = off;
+
+    PAR_BEGIN
+    if (tid == 0) {
+        unsigned long long a = total ? GLB_ADD_U64(c.arena_head, (unsigned long long)total) : 0ULL;
+        sh->arena_off = a;
+        if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY;
+    }
+    PAR_END
+    const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;
+    uint8_t* base = c.arena + sh->arena_off;
+
+    if (arena_ok && !failed) {
+        PAR_BEGIN
+        // best paths (clean.rs:329-343): decisions from the terminal node back to the DD root
+        if (tid == 0 && best_len) {
+            uint32_t* out = (uint32_t*)(base + path_off);
+            int p = best_pos;
+            for (int Lc = n_layers - 1, i = 0; Lc >= 1; --Lc, ++i) {
+                uint32_t w = c.ninfo[(size_t)Lc * capN + p];
+                uint32_t arc = w & NI_ARC_MASK;
+                out[i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
+                p = (int)(arc >> 1);
+            }
+        }
+        if (tid == 64 % NT && exact_len) {
+            uint32_t* out = (uint32_t*)(base + exact_off);
+            int p = exact_pos;
+            for (int Lc = n_layers - 1, i = 0; Lc >= 1; --Lc, ++i) {
+                uint32_t w = c.ninfo[(size_t)Lc * capN + p];
+                uint32_t arc = w & NI_ARC_MASK;
+                out[i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
+                p = (int)(arc >> 1);
+            }
+        }
+        // cut-set nodes (clean.rs:421-443)
+        if (want_cutset && ncut) {
+            uint64_t* o_state = (uint64_t*)(base + cs_state_off);
+            int32_t* o_value = (int32_t*)(base + cs_value_off);
+            int32_t* o_ub = (int32_t*)(base + cs_ub_off);
+            uint32_t* o_path = (uint32_t*)(base + cs_path_off);
+            for (int pos = tid; pos < ncs_layer; pos += NT) {
+                int32_t vb = vbA[pos];
+                if (vb == VB_UNMARKED) continue;
+                uint64_t s[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) s[k] = c.cs_state[(size_t)k * capN + pos];
+                int64_t v = c.cs_value[pos];
+                int64_t ub = v + rub_of<WS>(c, s, (int)c.cs_pop[pos]);
+                if (v + vb < ub) ub = v + vb;
+                if (best_value < ub) ub = best_value;
+                if (filter && ub <= best_lb) continue;
+                int idx = LDS_ADD_I32(&sh->ncut2, 1);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) o_state[(size_t)idx * WS + k] = s[k];
+                o_value[idx] = (int32_t)v;
+                o_ub[idx] = (int32_t)ub;
+                int p = pos;
+                for (int Lc = lel, i = 0; Lc >= 1; --Lc, ++i) {
+                    uint32_t w = c.ninfo[(size_t)Lc * capN + p];
+                    uint32_t arc = w & NI_ARC_MASK;
+                    o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
+                    p = (int)(arc >> 1);
+                }
+            }
+        }
+        PAR_END
+    }
+
+    PAR_BEGIN
+    if (tid == 0) {
+        DDResult r;
+        r.status = sh->status;
+        r.comp_type = comp_type;
+        r.is_exact = is_exact ? 1 : 0;
+        r.has_exact_best_path = ebpo ? 1 : 0;
+        r.has_best = has_best ? 1 : 0;
+        r.has_best_exact = has_best_exact ? 1 : 0;
+        r.best_value = best_value;
+        r.best_exact_value = exact_value;
+        r.n_layers = n_layers;
+        r.lel = lel;
+        r.n_cutset = arena_ok ? ncut : 0;
+        r.best_len = arena_ok ? best_len : 0;
+        r.exact_len = arena_ok ? (same ? best_len : exact_len) : 0;
+        r.exact_same_as_best = same ? 1 : 0;
+        r.recycled_merges = sh->recycled_merges;
+        r.pad = 0;
+        r.arena_off = sh->arena_off;
+        r.arena_bytes = total;
+        r.nodes_expanded = sh->nodes;
+        r.arcs = sh->arcs;
+        r.layers = (uint64_t)L;
+        r.path_off = path_off;
+        r.exact_off = same ? path_off : exact_off;
+        r.cs_state_off = cs_state_off;
+        r.cs_value_off = cs_value_off;
+        r.cs_ub_off = cs_ub_off;
+        r.cs_path_off = cs_path_off;
+        *res = r;
+    }
+    PAR_END
+}
+
+/// Restricted, then -- when that was not exact -- relaxed: the device half of
+/// ParallelSolver::process_one_node (parallel.rs:391-437).
+template <int WS>
+DDO_DEV void run_work_item(DDCtx<WS>& c, const DDInput& in, DDResult* res2) {
+    DD_TID_SETUP(c)
+    (void)NT;
+    if (in.flags & IN_FUSED) {
+        run_dd<WS>(c, in, CT_RESTRICTED, in.best_lb, &res2[0]);
+        // all threads read the restricted result through shared memory state written by thread 0
+        PAR_BEGIN
+        if (tid == 0) {
+            c.sh->sel_above = (res2[0].status == ST_OK && !res2[0].is_exact) ? 1 : 0;
+            c.sh->sel_bucket = res2[0].has_best_exact ? 1 : 0;
+            c.sh->sel_digit = res2[0].best_exact_value;
+        }
+        PAR_END
+        const bool go = c.sh->sel_above != 0;
+        int64_t lb = in.best_lb;
+        if (c.sh->sel_bucket && (int64_t)c.sh->sel_digit > lb) lb = c.sh->sel_digit;  // maybe_update_best
+        if (go) run_dd<WS>(c, in, CT_RELAXED, lb, &res2[1]);
+        else {
+            PAR_BEGIN
+            if (tid == 0) res2[1].status = ST_NOT_RUN;
+            PAR_END
+        }
+    } else {
+        run_dd<WS>(c, in, in.comp_type, in.best_lb, &res2[0]);
+        PAR_BEGIN
+        if (tid == 0) res2[1].status = ST_NOT_RUN;
+        PAR_END
+    }
+}
+
+/// LDS bytes needed by one workgroup.
+inline size_t dd_lds_bytes(int table_cap_lds, int npad, int nthreads) {
+    size_t b = (size_t)table_cap_lds * 4;
+    b += (size_t)npad * 4;
+    b += 256 * 4;
+    b += (size_t)nthreads * 4 * 2;
+    b += (sizeof(DDShared) + 15) & ~(size_t)15;
+    return (b + 15) & ~(size_t)15;
+}
+
+/// Binds slot `slot` of the workspace and the LDS block `lds` to a context.
+template <int WS>
+DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned char* lds, uint32_t* table, int nthreads) {
+    c.n = P.n;
+    c.npad = P.npad;
+    c.unit_weights = P.unit_weights;
+    c.adj = P.adj;
+    c.weight = P.weight;
+    c.capN = P.capN;
+    c.capC1 = P.capC1;
+    c.max_layers = P.max_layers;
+    const size_t capC1 = (size_t)P.capC1, capN = (size_t)P.capN, ml = (size_t)P.max_layers, s = (size_t)slot;
+    for (int b = 0; b < 2; ++b) {
+        c.cstate[b] = P.cstate + (s * 2 + b) * (size_t)WS * capC1;
+        c.ckey[b] = P.ckey + (s * 2 + b) * capC1;
+        c.cpop[b] = P.cpop + (s * 2 + b) * capC1;
+        c.cflags[b] = P.cflags + (s * 2 + b) * capC1;
+    }
+    c.ctarget = P.ctarget + s * 2 * capN;
+    c.keep = P.keep + s * capN;
+    c.posmap = P.posmap + s * capC1;
+    c.cls = P.cls + s * capC1;
+    c.ninfo = P.ninfo + s * ml * capN;
+    c.arct = P.arct + s * ml * 2 * capN;
+    c.nlayer = P.nlayer + s * ml;
+    c.lvar = P.lvar + s * ml;
+    c.ldup = P.ldup + s * ml * 2;
+    c.cs_state = P.cs_state + s * (size_t)WS * capN;
+    c.cs_value = P.cs_value + s * capN;
+    c.cs_pop = P.cs_pop + s * capN;
+    c.table_cap = P.table_cap;
+    unsigned char* p = lds;
+    if (table) c.table = table;
+    else {
+        c.table = (uint32_t*)p;
+        p += (size_t)P.table_cap * 4;
+    }
+    c.cnt = (int32_t*)p;
+    p += (size_t)P.npad * 4;
+    c.hist = (uint32_t*)p;
+    p += 256 * 4;
+    c.tcount = (int32_t*)p;
+    p += (size_t)nthreads * 4;
+    c.tcount2 = (int32_t*)p;
+    p += (size_t)nthreads * 4;
+    c.sh = (DDShared*)p;
+    c.arena = P.arena;
+    c.arena_cap = P.arena_cap;
+    c.arena_head = P.arena_head;
+    c.cutoff_flag = P.cutoff_flag;
+    c.NT = nthreads;
+}
+
+}  // namespace ddo_hip

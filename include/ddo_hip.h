@@ -1,0 +1,197 @@
+/* =============================================================================
+ * ddo_hip.h -- C ABI of the MI355X-native MDD compilation engine.
+ *
+ * This is the drop-in boundary for ddo's hot path.  Every entry point below
+ * replaces one item of the reference's `DecisionDiagram` trait
+ * (/root/reference/ddo/src/abstraction/mdd.rs:75-114) or of its `Solver` trait
+ * (abstraction/solver.rs:32-97); a Rust shim `impl DecisionDiagram for HipMdd`
+ * binds them 1:1 through `extern "C"`.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  All functions are
+ * thread-compatible: one ddo_mdd is used by one host thread at a time (the
+ * reference's `&mut self`, parallel.rs:580), distinct ddo_mdd objects may be
+ * used concurrently.  Functions returning `int` return DDO_OK (0) or a
+ * negative DDO_ERR_* code unless stated otherwise; ddo_last_error() gives text.
+ *
+ * The engine FAILS LOUDLY (DDO_ERR_NO_DEVICE) when no HIP device is present:
+ * there is no CPU fallback behind this ABI.
+ * ========================================================================== */
+#ifndef DDO_HIP_H
+#define DDO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+#define DDO_OK 0
+/** compile() was interrupted by the cutoff flag == Err(Reason::CutoffOccurred), common.rs:108-111 */
+#define DDO_CUTOFF 1
+#define DDO_ERR_NO_DEVICE (-1)   /* no HIP device / HIP runtime error            */
+#define DDO_ERR_INVALID (-2)     /* bad argument                                 */
+#define DDO_ERR_CAPACITY (-3)    /* width / layer / output exceeds the capacity  */
+#define DDO_ERR_UNSUPPORTED (-4) /* feature not built into the device engine     */
+#define DDO_ERR_INTERNAL (-5)    /* device-side invariant violated               */
+
+/* ---- mdd.rs:41-48  enum CompilationType --------------------------------- */
+#define DDO_EXACT 0
+#define DDO_RELAXED 1
+#define DDO_RESTRICTED 2
+
+/* ---- mdd.rs:24-28  cut-set types ---------------------------------------- */
+#define DDO_LAST_EXACT_LAYER 1
+#define DDO_FRONTIER 2 /* not implemented on device yet: DDO_ERR_UNSUPPORTED */
+
+/** common.rs:58-61  struct Decision { variable: Variable, value: isize } */
+typedef struct ddo_decision {
+    int64_t variable;
+    int64_t value;
+} ddo_decision;
+
+/** common.rs:75-87  struct SubProblem<T>.  `state` is the fixed-width state of
+ *  the model: for MISP ceil(n/64) little-endian 64-bit words, bit i of word
+ *  i/64 <=> vertex i still eligible (examples/misp/main.rs:37-51). */
+typedef struct ddo_subproblem {
+    const uint64_t* state;
+    size_t state_words;
+    int64_t value;
+    int64_t ub;
+    size_t depth;
+    const ddo_decision* path; /* decisions from the problem root, may be NULL when path_len == 0 */
+    size_t path_len;
+} ddo_subproblem;
+
+/** mdd.rs:51-71  struct CompilationInput.  problem / relaxation / ranking are
+ *  fixed by the ddo_model the mdd was created from (the device cannot call
+ *  `&dyn Problem`); cache and dominance are the Empty* implementations.
+ *  `cutoff` points to a host flag polled between launches (heuristics.rs:100-105
+ *  Cutoff::must_stop); NULL == NoCutoff. */
+typedef struct ddo_compile_input {
+    int comp_type; /* DDO_EXACT | DDO_RELAXED | DDO_RESTRICTED */
+    size_t max_width;
+    int64_t best_lb;
+    ddo_subproblem residual;
+    const volatile int* cutoff;
+} ddo_compile_input;
+
+/** common.rs:115-121  struct Completion { is_exact, best_value: Option<isize> } */
+typedef struct ddo_completion {
+    int is_exact;
+    int has_best_value;
+    int64_t best_value;
+} ddo_completion;
+
+/** Counters the reference lacks.  nodes_expanded = iterations of
+ *  the loop at clean.rs:360, arcs = `_branch_on` calls (clean.rs:367). */
+typedef struct ddo_counters {
+    uint64_t nodes_expanded;
+    uint64_t arcs;
+    uint64_t layers;
+    uint64_t compiles;
+} ddo_counters;
+
+typedef struct ddo_model ddo_model;
+typedef struct ddo_mdd ddo_mdd;
+typedef struct ddo_solver ddo_solver;
+
+const char* ddo_last_error(void);
+/** Number of visible HIP devices (0 when none / runtime missing). */
+int ddo_device_count(void);
+
+/* ---- model descriptors: the closed set of `Problem + Relaxation + StateRanking` ----------- */
+/** MISP (examples/misp/main.rs:37-209).  `compl_adj_rows`: n rows of ceil(n/64) words, row i =
+ *  COMPLEMENT adjacency of vertex i (bit i itself may be set, main.rs:280-310); `weights`: n values. */
+ddo_model* ddo_model_create_misp(int n, const uint64_t* compl_adj_rows, const int64_t* weights);
+/** Reads a DIMACS-like .clq file exactly as examples/misp/main.rs:258-317 does. */
+ddo_model* ddo_model_read_misp(const char* path);
+void ddo_model_destroy(ddo_model* model);
+int ddo_model_nb_variables(const ddo_model* model);
+int ddo_model_state_words(const ddo_model* model);
+/** Problem::initial_state / initial_value (dp.rs:43-48) */
+int ddo_model_initial_state(const ddo_model* model, uint64_t* state_out);
+int64_t ddo_model_initial_value(const ddo_model* model);
+/** StateRanking::compare (heuristics.rs:69-77) evaluated on the host: <0, 0, >0 */
+int ddo_model_compare_states(const ddo_model* model, const uint64_t* a, const uint64_t* b);
+/** Copies the descriptor back (n rows * words, n weights); buffers may be NULL. */
+int ddo_model_export_misp(const ddo_model* model, uint64_t* compl_adj_rows, int64_t* weights);
+
+/* ---- DecisionDiagram (mdd.rs:75-114) -------------------------------------------------------- */
+/** == `D::default()` bound to a model and a device.  `max_width` is the largest width any
+ *  compile() on this object will ask for (sizes the HBM workspace). */
+ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, size_t max_width);
+void ddo_mdd_destroy(ddo_mdd* mdd);
+/** mdd.rs:83  fn compile(&mut self, input) -> Result<Completion, Reason>.
+ *  Returns DDO_OK, DDO_CUTOFF, or DDO_ERR_*. */
+int ddo_mdd_compile(ddo_mdd* mdd, const ddo_compile_input* input, ddo_completion* out);
+/** Extension (not in the reference): B independent compiles in one device launch.
+ *  statuses[i] receives the per-compile DDO_OK / DDO_CUTOFF / error. */
+int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs, ddo_completion* outs,
+                          int* statuses, size_t count);
+/** mdd.rs:86 */
+int ddo_mdd_is_exact(const ddo_mdd* mdd);
+/** mdd.rs:89 / :97 -- return 1 and write *value when Some, 0 when None */
+int ddo_mdd_best_value(const ddo_mdd* mdd, int64_t* value);
+int ddo_mdd_best_exact_value(const ddo_mdd* mdd, int64_t* value);
+/** mdd.rs:92 / :100 -- residual path followed by the DD's best-edge chain (terminal first),
+ *  same order as clean.rs:329-343.  *len: in = capacity of buf, out = number of decisions.
+ *  Return 1 when Some, 0 when None, DDO_ERR_CAPACITY when buf is too small (*len = needed). */
+int ddo_mdd_best_solution(const ddo_mdd* mdd, ddo_decision* buf, size_t* len);
+int ddo_mdd_best_exact_solution(const ddo_mdd* mdd, ddo_decision* buf, size_t* len);
+/** mdd.rs:107-113 drain_cutset: calls cb once per cut-set sub-problem; pointers inside the
+ *  ddo_subproblem are valid during the callback only.  May be called once per compile. */
+typedef void (*ddo_cutset_cb)(const ddo_subproblem* node, void* user);
+int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user);
+/** Counters of the latest compile on this object. */
+int ddo_mdd_last_counters(const ddo_mdd* mdd, ddo_counters* out);
+
+/* ---- Solver (solver.rs:32-97; parallel.rs:287-641) ------------------------------------------ */
+#define DDO_WIDTH_FIXED 0         /* width.rs:166-171 FixedWidth(w)            */
+#define DDO_WIDTH_NB_UNASSIGNED 1 /* width.rs:397-402 NbUnassignedWidth(n)     */
+
+typedef struct ddo_solver_config {
+    int device;            /* HIP device ordinal                                                   */
+    int width_policy;      /* DDO_WIDTH_FIXED | DDO_WIDTH_NB_UNASSIGNED                             */
+    size_t width;          /* FixedWidth value (ignored for NB_UNASSIGNED)                          */
+    int nb_concurrent;     /* sub-problems compiled concurrently on the device == the reference's
+                              nb_threads (parallel.rs:328); 1 reproduces SequentialSolver exactly   */
+    double time_budget_s;  /* <= 0: NoCutoff; else TimeBudget (cutoff.rs:302-323)                   */
+    int rank;              /* fringe shard owned by this solver ...                                 */
+    int world_size;        /* ... out of this many (1 = whole problem); see ddo_solver_step        */
+} ddo_solver_config;
+
+ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg);
+void ddo_solver_destroy(ddo_solver* s);
+/** solver.rs:37 maximize() -> Completion */
+int ddo_solver_maximize(ddo_solver* s, ddo_completion* out);
+/** solver.rs:70-96 */
+int ddo_solver_best_value(const ddo_solver* s, int64_t* value);
+int ddo_solver_best_solution(const ddo_solver* s, ddo_decision* buf, size_t* len);
+int64_t ddo_solver_best_lower_bound(const ddo_solver* s);
+int64_t ddo_solver_best_upper_bound(const ddo_solver* s);
+int ddo_solver_set_primal(ddo_solver* s, int64_t value, const ddo_decision* solution, size_t len);
+double ddo_solver_gap(const ddo_solver* s);
+uint64_t ddo_solver_explored(const ddo_solver* s);
+int ddo_solver_counters(const ddo_solver* s, ddo_counters* out);
+
+/** Stepwise driving (one step = pop up to nb_concurrent sub-problems, restricted + relaxed compile,
+ *  enqueue cut-sets), used by multi-GPU hosts that exchange the incumbent between steps.
+ *  Returns 1 while work remains on this shard, 0 when its fringe is exhausted, DDO_CUTOFF on
+ *  cutoff, <0 on error. */
+int ddo_solver_step(ddo_solver* s);
+/** Lower bound seen by the next step (max-reduced across ranks by the caller, parallel.rs:439-453). */
+int ddo_solver_import_lower_bound(ddo_solver* s, int64_t best_lb);
+/** Open sub-problems on this shard (fringe length), for termination detection (parallel.rs:512). */
+uint64_t ddo_solver_fringe_len(const ddo_solver* s);
+/** Largest upper bound left on this shard's fringe (INT64_MIN when empty). */
+int64_t ddo_solver_fringe_best_ub(const ddo_solver* s);
+/** Milliseconds spent inside device compile launches so far (HIP events on the engine's stream)
+ *  and the number of launches. */
+int ddo_solver_device_time(const ddo_solver* s, double* kernel_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDO_HIP_H */

@@ -1,0 +1,151 @@
+// =============================================================================
+// emul_capi.cpp -- TEST INFRASTRUCTURE ONLY.
+// Builds ddo_amd/csrc/misp_dd_core.hpp as a lock-step host emulation
+// (-DDDO_HOST_EMULATION: every PAR block is a sequential loop over thread ids) so
+// that the workgroup logic of the device kernel can be checked against the CPU
+// oracle inside this GPU-less container.  It is NOT part of the product library,
+// is never loaded by ddo_amd/, and proves nothing about the HIP build beyond
+// shared control flow -- the `-m gpu` tests are the parity tests proper.
+// =============================================================================
+#define DDO_HOST_EMULATION 1
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../ddo_amd/csrc/misp_dd_core.hpp"
+
+using namespace ddo_hip;
+
+namespace {
+struct Emul {
+    EngineParams P;
+    std::vector<uint64_t> adj;
+    std::vector<int32_t> weight;
+    std::vector<unsigned char> mem;   // workspace
+    std::vector<unsigned char> lds;
+    std::vector<unsigned char> arena;
+    unsigned long long arena_head = 0;
+    int32_t work_counter = 0;
+    int nthreads = 256;
+    int wsT = 0;  // template WS used
+};
+
+template <class T>
+T* carve(unsigned char*& p, size_t count) {
+    T* r = (T*)p;
+    p += (count * sizeof(T) + 15) & ~(size_t)15;
+    return r;
+}
+
+int pick_ws(int ws) {
+    const int opts[] = {1, 2, 4, 7, 8, 16};
+    for (int o : opts)
+        if (ws <= o) return o;
+    return -1;
+}
+
+template <int WS>
+void run(Emul& e, const DDInput& in, DDResult* res2) {
+    DDCtx<WS> c;
+    dd_bind<WS>(c, e.P, 0, e.lds.data(), nullptr, e.nthreads);
+    run_work_item<WS>(c, in, res2);
+}
+}  // namespace
+
+extern "C" {
+
+void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int max_width, int nthreads,
+                  uint64_t arena_bytes) {
+    Emul* e = new Emul();
+    int ws = (n + 63) / 64;
+    int wsT = pick_ws(ws);
+    if (wsT < 0) return nullptr;
+    e->wsT = wsT;
+    e->nthreads = nthreads;
+    e->adj.assign((size_t)n * wsT, 0);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < ws; ++k) e->adj[(size_t)i * wsT + k] = adj_rows[(size_t)i * ws + k];
+    e->weight.resize(n);
+    bool unit = true;
+    for (int i = 0; i < n; ++i) {
+        e->weight[i] = (int32_t)weights[i];
+        unit &= weights[i] == 1;
+    }
+    EngineParams& P = e->P;
+    std::memset(&P, 0, sizeof(P));
+    P.n = n;
+    P.ws = wsT;
+    P.unit_weights = unit;
+    P.npad = (n + 63) / 64 * 64;
+    P.adj = e->adj.data();
+    P.weight = e->weight.data();
+    P.capN = max_width + 2;
+    P.capC1 = 2 * P.capN + 1;
+    P.max_layers = n + 2;
+    int tc = 1024;
+    while (tc * 2 < P.capC1 * 3 || tc < 2 * P.capN) tc <<= 1;
+    P.table_cap = tc;
+    P.table_in_lds = 1;
+    P.nslots = 1;
+    const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers;
+    size_t bytes = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
+                   ml * capN * 4 + ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 + 64 * 32;
+    e->mem.assign(bytes, 0xCD);  // poison
+    unsigned char* p = e->mem.data();
+    P.cstate = carve<uint64_t>(p, 2 * wsT * capC1);
+    P.ckey = carve<uint64_t>(p, 2 * capC1);
+    P.cpop = carve<uint32_t>(p, 2 * capC1);
+    P.cflags = carve<uint32_t>(p, 2 * capC1);
+    P.ctarget = carve<uint32_t>(p, 2 * capN);
+    P.keep = carve<uint32_t>(p, capN);
+    P.posmap = carve<uint32_t>(p, capC1);
+    P.cls = carve<uint8_t>(p, capC1);
+    P.ninfo = carve<uint32_t>(p, ml * capN);
+    P.arct = carve<uint32_t>(p, ml * 2 * capN);
+    P.nlayer = carve<int32_t>(p, ml);
+    P.lvar = carve<int32_t>(p, ml);
+    P.ldup = carve<int32_t>(p, ml * 2);
+    P.cs_state = carve<uint64_t>(p, wsT * capN);
+    P.cs_value = carve<int32_t>(p, capN);
+    P.cs_pop = carve<uint32_t>(p, capN);
+    if ((size_t)(p - e->mem.data()) > bytes) {
+        std::fprintf(stderr, "emul: workspace overflow\n");
+        std::abort();
+    }
+    e->lds.assign(dd_lds_bytes(P.table_cap, P.npad, nthreads), 0xEE);
+    e->arena.assign(arena_bytes, 0);
+    P.arena = e->arena.data();
+    P.arena_cap = arena_bytes;
+    P.arena_head = &e->arena_head;
+    P.work_counter = &e->work_counter;
+    P.cutoff_flag = nullptr;
+    return e;
+}
+void emul_destroy(void* h) { delete (Emul*)h; }
+int emul_state_words(void* h) { return ((Emul*)h)->wsT; }
+uint64_t emul_lds_bytes(void* h) { return ((Emul*)h)->lds.size(); }
+
+/// Compiles one sub-problem.  res2: two DDResult records; the arena is reset first and its
+/// base pointer returned through *arena_out.
+int emul_compile(void* h, const DDInput* in, DDResult* res2, const uint8_t** arena_out) {
+    Emul* e = (Emul*)h;
+    e->arena_head = 0;
+    std::memset(res2, 0, 2 * sizeof(DDResult));
+    if (in->width + 2 > e->P.capN) return -3;
+    switch (e->wsT) {
+        case 1: run<1>(*e, *in, res2); break;
+        case 2: run<2>(*e, *in, res2); break;
+        case 4: run<4>(*e, *in, res2); break;
+        case 7: run<7>(*e, *in, res2); break;
+        case 8: run<8>(*e, *in, res2); break;
+        case 16: run<16>(*e, *in, res2); break;
+        default: return -2;
+    }
+    *arena_out = e->arena.data();
+    return 0;
+}
+uint64_t emul_sizeof_input(void) { return sizeof(DDInput); }
+uint64_t emul_sizeof_result(void) { return sizeof(DDResult); }
+}

@@ -1,0 +1,79 @@
+"""Builds and binds the lock-step host emulation of the device kernel (tests/emul).
+TEST INFRASTRUCTURE: lets the CPU-only suite exercise the workgroup logic of
+ddo_amd/csrc/misp_dd_core.hpp; never used by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tests.dd_wire import DDInput, DDResult, parse_result, MAX_WS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def build_emul():
+    src = os.path.join(HERE, "emul", "emul_capi.cpp")
+    out = os.path.join(HERE, "emul", "libddo_emul.so")
+    deps = [src, os.path.join(ROOT, "ddo_amd", "csrc", "misp_dd_core.hpp"), os.path.join(ROOT, "ddo_amd", "csrc", "dd_types.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", out, src],
+                       check=True)
+    return out
+
+
+class Emul:
+    def __init__(self, n, rows, weights, max_width, nthreads=256, arena_bytes=64 << 20):
+        L = C.CDLL(build_emul())
+        L.emul_create.restype = C.c_void_p
+        L.emul_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+        L.emul_destroy.argtypes = [C.c_void_p]
+        L.emul_state_words.argtypes = [C.c_void_p]
+        L.emul_compile.argtypes = [C.c_void_p, C.POINTER(DDInput), C.POINTER(DDResult), C.POINTER(C.c_void_p)]
+        L.emul_sizeof_input.restype = C.c_uint64
+        L.emul_sizeof_result.restype = C.c_uint64
+        assert L.emul_sizeof_input() == C.sizeof(DDInput), (L.emul_sizeof_input(), C.sizeof(DDInput))
+        assert L.emul_sizeof_result() == C.sizeof(DDResult), (L.emul_sizeof_result(), C.sizeof(DDResult))
+        self.L = L
+        self.n = n
+        self.ws_in = (n + 63) // 64
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        weights = np.ascontiguousarray(weights, dtype=np.int64)
+        self.h = L.emul_create(n, rows.ctypes.data_as(C.c_void_p), weights.ctypes.data_as(C.c_void_p), max_width, nthreads,
+                               arena_bytes)
+        if not self.h:
+            raise RuntimeError("emul_create failed")
+        self.ws = L.emul_state_words(self.h)
+
+    def __del__(self):
+        try:
+            self.L.emul_destroy(self.h)
+        except Exception:
+            pass
+
+    def compile(self, comp_type, width, best_lb, state, value, depth, flags=4):
+        inp = DDInput()
+        inp.comp_type = comp_type
+        inp.flags = flags
+        inp.width = int(width)
+        inp.value = int(value)
+        inp.depth = int(depth)
+        inp.best_lb = int(max(min(best_lb, (1 << 62)), -(1 << 62)))
+        for k in range(MAX_WS):
+            inp.state[k] = int(state[k]) if k < len(state) else 0
+        res = (DDResult * 2)()
+        arena = C.c_void_p()
+        rc = self.L.emul_compile(self.h, C.byref(inp), res, C.byref(arena))
+        if rc != 0:
+            raise RuntimeError(f"emul_compile rc={rc}")
+        out = []
+        for r in res:
+            if r.status == 77:
+                out.append(None)
+                continue
+            d = parse_result(r, arena.value, self.ws, depth)
+            # trim padded state words
+            d["cutset"] = sorted((s[:self.ws_in], v, u, dp) for (s, v, u, dp) in d["cutset"])
+            out.append(d)
+        return out

@@ -1,0 +1,162 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).  TEST INFRASTRUCTURE."""
+import ctypes as C
+
+import numpy as np
+
+
+class SolveOut(C.Structure):
+    _fields_ = [("has_value", C.c_int), ("is_exact", C.c_int), ("best_value", C.c_int64), ("best_lb", C.c_int64),
+                ("best_ub", C.c_int64), ("explored", C.c_uint64), ("nodes_expanded", C.c_uint64), ("arcs", C.c_uint64),
+                ("layers", C.c_uint64), ("compiles", C.c_uint64), ("wall_s", C.c_double), ("n_solution", C.c_int)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class TraceHdr(C.Structure):
+    _fields_ = [("comp_type", C.c_int), ("is_exact", C.c_int), ("has_best", C.c_int), ("has_best_exact", C.c_int),
+                ("width", C.c_uint64), ("best_lb", C.c_int64), ("value", C.c_int64), ("ub", C.c_int64),
+                ("depth", C.c_uint64), ("best_value", C.c_int64), ("best_exact_value", C.c_int64),
+                ("nodes_expanded", C.c_uint64), ("arcs", C.c_uint64), ("layers", C.c_uint64), ("n_cutset", C.c_uint64)]
+
+
+def _canon(hdr, state, cs_states, cs_value, cs_ub, cs_depth, ws):
+    """Canonical, order-independent description of one compile()."""
+    cut = sorted((tuple(int(x) for x in cs_states[i * ws:(i + 1) * ws]), int(cs_value[i]), int(cs_ub[i]), int(cs_depth[i]))
+                 for i in range(len(cs_value)))
+    return {
+        "comp_type": hdr.comp_type, "width": hdr.width, "best_lb": hdr.best_lb,
+        "state": tuple(int(x) for x in state), "value": hdr.value, "ub": hdr.ub, "depth": hdr.depth,
+        "is_exact": bool(hdr.is_exact),
+        "best_value": hdr.best_value if hdr.has_best else None,
+        "best_exact_value": hdr.best_exact_value if hdr.has_best_exact else None,
+        "nodes_expanded": hdr.nodes_expanded, "arcs": hdr.arcs, "layers": hdr.layers,
+        "cutset": cut,
+    }
+
+
+class MispInstance:
+    def __init__(self, oracle, path):
+        self.o = oracle
+        self.L = oracle.L
+        self.h = self.L.oracle_misp_load(path.encode())
+        if not self.h:
+            raise RuntimeError(f"oracle could not load {path}")
+        self.n = self.L.oracle_misp_nb_vars(self.h)
+        self.ws = self.L.oracle_misp_state_words(self.h)
+        self.rows = np.zeros(self.n * self.ws, dtype=np.uint64)
+        self.weights = np.zeros(self.n, dtype=np.int64)
+        self.L.oracle_misp_export(self.h, self.rows.ctypes.data_as(C.c_void_p), self.weights.ctypes.data_as(C.c_void_p))
+
+    def __del__(self):
+        try:
+            self.L.oracle_misp_free(self.h)
+        except Exception:
+            pass
+
+    def root_state(self):
+        s = np.zeros(self.ws, dtype=np.uint64)
+        for i in range(self.n):
+            s[i // 64] |= np.uint64(1) << np.uint64(i % 64)
+        return s
+
+    def solve(self, width=0, nthreads=0, timeout=0.0):
+        out = SolveOut()
+        sol = np.zeros(2 * self.n + 2, dtype=np.int64)
+        self.L.oracle_misp_solve(self.h, width, nthreads, timeout, C.byref(out), sol.ctypes.data_as(C.c_void_p))
+        d = out.asdict()
+        d["solution"] = [(int(sol[2 * i]), int(sol[2 * i + 1])) for i in range(out.n_solution)]
+        return d
+
+    def trace_solve(self, width=0, max_compiles=0):
+        """Sequential B&B recording every compile(); returns (summary, [canonical records])."""
+        out = SolveOut()
+        t = self.L.oracle_misp_trace_solve(self.h, width, max_compiles, C.byref(out))
+        recs = []
+        try:
+            n = self.L.oracle_trace_len(t)
+            for i in range(n):
+                hdr = TraceHdr()
+                st = np.zeros(self.ws, dtype=np.uint64)
+                self.L.oracle_trace_get(t, i, C.byref(hdr), st.ctypes.data_as(C.c_void_p))
+                k = int(hdr.n_cutset)
+                cs = np.zeros(max(k, 1) * self.ws, dtype=np.uint64)
+                cv = np.zeros(max(k, 1), dtype=np.int64)
+                cu = np.zeros(max(k, 1), dtype=np.int64)
+                cd = np.zeros(max(k, 1), dtype=np.uint64)
+                if k:
+                    self.L.oracle_trace_get_cutset(t, i, cs.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
+                                                   cu.ctypes.data_as(C.c_void_p), cd.ctypes.data_as(C.c_void_p))
+                recs.append(_canon(hdr, st, cs, cv[:k], cu[:k], cd[:k], self.ws))
+        finally:
+            self.L.oracle_trace_free(t)
+        return out.asdict(), recs
+
+    def compile(self, comp_type, width, best_lb, state, value, depth):
+        """One compile() of an arbitrary residual sub-problem -> canonical record (+ best path)."""
+        hdr = TraceHdr()
+        cap = int(width) + 8 if width < (1 << 40) else 1 << 16
+        st = np.ascontiguousarray(state, dtype=np.uint64)
+        cs = np.zeros(cap * self.ws, dtype=np.uint64)
+        cv = np.zeros(cap, dtype=np.int64)
+        cu = np.zeros(cap, dtype=np.int64)
+        cd = np.zeros(cap, dtype=np.uint64)
+        bp = np.zeros(2 * self.n + 2, dtype=np.int64)
+        nbp = C.c_int64(0)
+        k = self.L.oracle_misp_compile(self.h, comp_type, width, best_lb, st.ctypes.data_as(C.c_void_p), value, depth,
+                                       C.byref(hdr), cap, cs.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
+                                       cu.ctypes.data_as(C.c_void_p), cd.ctypes.data_as(C.c_void_p),
+                                       bp.ctypes.data_as(C.c_void_p), C.byref(nbp))
+        if k < 0:
+            raise RuntimeError(f"oracle_misp_compile failed: {k}")
+        rec = _canon(hdr, st, cs, cv[:k], cu[:k], cd[:k], self.ws)
+        rec["best_path"] = [(int(bp[2 * i]), int(bp[2 * i + 1])) for i in range(nbp.value)]
+        return rec
+
+
+class Oracle:
+    def __init__(self, libpath):
+        L = C.CDLL(libpath)
+        L.oracle_misp_load.restype = C.c_void_p
+        L.oracle_misp_load.argtypes = [C.c_char_p]
+        L.oracle_misp_free.argtypes = [C.c_void_p]
+        L.oracle_misp_nb_vars.argtypes = [C.c_void_p]
+        L.oracle_misp_state_words.argtypes = [C.c_void_p]
+        L.oracle_misp_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_misp_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.POINTER(SolveOut), C.c_void_p]
+        L.oracle_misp_trace_solve.restype = C.c_void_p
+        L.oracle_misp_trace_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(SolveOut)]
+        L.oracle_trace_free.argtypes = [C.c_void_p]
+        L.oracle_trace_len.restype = C.c_uint64
+        L.oracle_trace_len.argtypes = [C.c_void_p]
+        L.oracle_trace_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(TraceHdr), C.c_void_p]
+        L.oracle_trace_get_cutset.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_misp_compile.restype = C.c_int64
+        L.oracle_misp_compile.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_int64, C.c_uint64,
+                                          C.POINTER(TraceHdr), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.oracle_knapsack_solve.restype = C.c_int64
+        L.oracle_knapsack_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int,
+                                            C.c_void_p, C.POINTER(SolveOut)]
+        L.oracle_knapsack_solve_file.restype = C.c_int64
+        L.oracle_knapsack_solve_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(SolveOut)]
+        self.L = L
+
+    def misp(self, path):
+        return MispInstance(self, path)
+
+    def knapsack(self, profit, weight, capacity, width=0, nthreads=0):
+        p = np.ascontiguousarray(profit, dtype=np.int64)
+        w = np.ascontiguousarray(weight, dtype=np.uint64)
+        sol = np.zeros(len(p), dtype=np.int64)
+        out = SolveOut()
+        v = self.L.oracle_knapsack_solve(len(p), p.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), capacity,
+                                         width, nthreads, sol.ctypes.data_as(C.c_void_p), C.byref(out))
+        d = out.asdict()
+        d["solution"] = [int(x) for x in sol]
+        return int(v), d
+
+    def knapsack_file(self, path, width=0, nthreads=0):
+        out = SolveOut()
+        v = self.L.oracle_knapsack_solve_file(path.encode(), width, nthreads, C.byref(out))
+        return int(v), out.asdict()
