@@ -1,0 +1,12 @@
+"""ddo_amd -- MI355X-native MDD compilation engine behind ddo's API (MISP hot path).
+
+Python here is plumbing only: a ctypes view of the C ABI in ``include/ddo_hip.h``
+(``ddo_amd/_build/libddo_hip.so``, built by ``__graft_entry__.build()``) with the
+names of the reference's own types, so tests read like the reference's tests
+(/root/reference/ddo/examples/misp/tests.rs).  There is no CPU fallback: importing
+works without a GPU (symbol checks), creating an ``Mdd``/solver without one raises.
+"""
+from .binding import (  # noqa: F401
+    CompilationType, Completion, Decision, DdoError, FixedWidth, LAST_EXACT_LAYER, FRONTIER, Mdd, DefaultMDD,
+    DefaultMDDLEL, Misp, NbUnassignedWidth, NoCutoff, ParallelSolver, DefaultSolver, SubProblem, TimeBudget, lib,
+    library_path, device_count, ABI_SYMBOLS)

@@ -1,0 +1,452 @@
+"""ctypes binding of include/ddo_hip.h.  Names follow the reference crate (ddo/src/lib.rs:497-503)."""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# every symbol include/ddo_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "ddo_last_error", "ddo_device_count", "ddo_model_create_misp", "ddo_model_read_misp", "ddo_model_destroy",
+    "ddo_model_nb_variables", "ddo_model_state_words", "ddo_model_initial_state", "ddo_model_initial_value",
+    "ddo_model_compare_states", "ddo_model_export_misp", "ddo_mdd_create", "ddo_mdd_destroy", "ddo_mdd_compile",
+    "ddo_mdd_compile_batch", "ddo_mdd_is_exact", "ddo_mdd_best_value", "ddo_mdd_best_exact_value",
+    "ddo_mdd_best_solution", "ddo_mdd_best_exact_solution", "ddo_mdd_drain_cutset", "ddo_mdd_last_counters",
+    "ddo_solver_create", "ddo_solver_destroy", "ddo_solver_maximize", "ddo_solver_best_value",
+    "ddo_solver_best_solution", "ddo_solver_best_lower_bound", "ddo_solver_best_upper_bound", "ddo_solver_set_primal",
+    "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step",
+    "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time",
+]
+
+DDO_OK, DDO_CUTOFF = 0, 1
+LAST_EXACT_LAYER, FRONTIER = 1, 2
+
+
+class DdoError(RuntimeError):
+    pass
+
+
+class CompilationType:  # mdd.rs:41-48
+    Exact, Relaxed, Restricted = 0, 1, 2
+
+
+class _Decision(C.Structure):
+    _fields_ = [("variable", C.c_int64), ("value", C.c_int64)]
+
+
+class _SubProblem(C.Structure):
+    _fields_ = [("state", C.POINTER(C.c_uint64)), ("state_words", C.c_size_t), ("value", C.c_int64), ("ub", C.c_int64),
+                ("depth", C.c_size_t), ("path", C.POINTER(_Decision)), ("path_len", C.c_size_t)]
+
+
+class _CompileInput(C.Structure):
+    _fields_ = [("comp_type", C.c_int), ("max_width", C.c_size_t), ("best_lb", C.c_int64), ("residual", _SubProblem),
+                ("cutoff", C.POINTER(C.c_int))]
+
+
+class _Completion(C.Structure):
+    _fields_ = [("is_exact", C.c_int), ("has_best_value", C.c_int), ("best_value", C.c_int64)]
+
+
+class _Counters(C.Structure):
+    _fields_ = [("nodes_expanded", C.c_uint64), ("arcs", C.c_uint64), ("layers", C.c_uint64), ("compiles", C.c_uint64)]
+
+
+class _SolverConfig(C.Structure):
+    _fields_ = [("device", C.c_int), ("width_policy", C.c_int), ("width", C.c_size_t), ("nb_concurrent", C.c_int),
+                ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int)]
+
+
+_CUTSET_CB = C.CFUNCTYPE(None, C.POINTER(_SubProblem), C.c_void_p)
+
+_lib = None
+
+
+def library_path():
+    return os.path.join(_HERE, "_build", "libddo_hip.so")
+
+
+def lib():
+    """Loads the HIP engine.  Fails loudly when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise DdoError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); ddo_amd has no CPU fallback")
+    L = C.CDLL(path)
+    L.ddo_last_error.restype = C.c_char_p
+    L.ddo_model_create_misp.restype = C.c_void_p
+    L.ddo_model_create_misp.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.ddo_model_read_misp.restype = C.c_void_p
+    L.ddo_model_read_misp.argtypes = [C.c_char_p]
+    L.ddo_model_destroy.argtypes = [C.c_void_p]
+    L.ddo_model_nb_variables.argtypes = [C.c_void_p]
+    L.ddo_model_state_words.argtypes = [C.c_void_p]
+    L.ddo_model_initial_state.argtypes = [C.c_void_p, C.c_void_p]
+    L.ddo_model_initial_value.restype = C.c_int64
+    L.ddo_model_initial_value.argtypes = [C.c_void_p]
+    L.ddo_model_compare_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ddo_model_export_misp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ddo_mdd_create.restype = C.c_void_p
+    L.ddo_mdd_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+    L.ddo_mdd_destroy.argtypes = [C.c_void_p]
+    L.ddo_mdd_compile.argtypes = [C.c_void_p, C.POINTER(_CompileInput), C.POINTER(_Completion)]
+    L.ddo_mdd_compile_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(_CompileInput), C.POINTER(_Completion),
+                                        C.POINTER(C.c_int), C.c_size_t]
+    L.ddo_mdd_is_exact.argtypes = [C.c_void_p]
+    L.ddo_mdd_best_value.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.ddo_mdd_best_exact_value.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.ddo_mdd_best_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
+    L.ddo_mdd_best_exact_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
+    L.ddo_mdd_drain_cutset.argtypes = [C.c_void_p, _CUTSET_CB, C.c_void_p]
+    L.ddo_mdd_last_counters.argtypes = [C.c_void_p, C.POINTER(_Counters)]
+    L.ddo_solver_create.restype = C.c_void_p
+    L.ddo_solver_create.argtypes = [C.c_void_p, C.POINTER(_SolverConfig)]
+    L.ddo_solver_destroy.argtypes = [C.c_void_p]
+    L.ddo_solver_maximize.argtypes = [C.c_void_p, C.POINTER(_Completion)]
+    L.ddo_solver_best_value.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.ddo_solver_best_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
+    L.ddo_solver_best_lower_bound.restype = C.c_int64
+    L.ddo_solver_best_lower_bound.argtypes = [C.c_void_p]
+    L.ddo_solver_best_upper_bound.restype = C.c_int64
+    L.ddo_solver_best_upper_bound.argtypes = [C.c_void_p]
+    L.ddo_solver_set_primal.argtypes = [C.c_void_p, C.c_int64, C.POINTER(_Decision), C.c_size_t]
+    L.ddo_solver_gap.restype = C.c_double
+    L.ddo_solver_gap.argtypes = [C.c_void_p]
+    L.ddo_solver_explored.restype = C.c_uint64
+    L.ddo_solver_explored.argtypes = [C.c_void_p]
+    L.ddo_solver_counters.argtypes = [C.c_void_p, C.POINTER(_Counters)]
+    L.ddo_solver_step.argtypes = [C.c_void_p]
+    L.ddo_solver_import_lower_bound.argtypes = [C.c_void_p, C.c_int64]
+    L.ddo_solver_fringe_len.restype = C.c_uint64
+    L.ddo_solver_fringe_len.argtypes = [C.c_void_p]
+    L.ddo_solver_fringe_best_ub.restype = C.c_int64
+    L.ddo_solver_fringe_best_ub.argtypes = [C.c_void_p]
+    L.ddo_solver_device_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    _lib = L
+    return L
+
+
+def _err():
+    return lib().ddo_last_error().decode(errors="replace")
+
+
+def device_count():
+    return lib().ddo_device_count()
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Decision:  # common.rs:58-61
+    variable: int
+    value: int
+
+
+@dataclass
+class SubProblem:  # common.rs:75-87
+    state: np.ndarray
+    value: int = 0
+    path: List[Decision] = field(default_factory=list)
+    ub: int = (1 << 63) - 1
+    depth: int = 0
+
+
+@dataclass
+class Completion:  # common.rs:115-121
+    is_exact: bool
+    best_value: Optional[int]
+
+
+class FixedWidth:  # width.rs:166-171
+    def __init__(self, w):
+        self.w = int(w)
+
+
+class NbUnassignedWidth:  # width.rs:397-402
+    def __init__(self, nb_vars):
+        self.nb_vars = int(nb_vars)
+
+
+class NoCutoff:  # cutoff.rs:160-163
+    seconds = 0.0
+
+
+class TimeBudget:  # cutoff.rs:302-323
+    def __init__(self, seconds):
+        self.seconds = float(seconds)
+
+
+class Misp:
+    """MISP model == `Misp` + `MispRelax` + `MispRanking` (examples/misp/main.rs:37-209)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise DdoError("could not create the MISP model: " + _err())
+        self._h = handle
+        L = lib()
+        self.n = L.ddo_model_nb_variables(handle)
+        self.ws = L.ddo_model_state_words(handle)
+
+    @classmethod
+    def read_instance(cls, path):  # main.rs:258
+        return cls(lib().ddo_model_read_misp(os.fspath(path).encode()))
+
+    @classmethod
+    def from_rows(cls, n, rows, weights):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        weights = np.ascontiguousarray(weights, dtype=np.int64)
+        return cls(lib().ddo_model_create_misp(n, rows.ctypes.data_as(C.c_void_p), weights.ctypes.data_as(C.c_void_p)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ddo_model_destroy(self._h)
+        except Exception:
+            pass
+
+    def nb_variables(self):
+        return self.n
+
+    def initial_state(self):
+        s = np.zeros(self.ws, dtype=np.uint64)
+        lib().ddo_model_initial_state(self._h, s.ctypes.data_as(C.c_void_p))
+        return s
+
+    def initial_value(self):
+        return lib().ddo_model_initial_value(self._h)
+
+    def compare(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        return lib().ddo_model_compare_states(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+
+    def export(self):
+        rows = np.zeros(self.n * self.ws, dtype=np.uint64)
+        w = np.zeros(self.n, dtype=np.int64)
+        lib().ddo_model_export_misp(self._h, rows.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p))
+        return rows, w
+
+    def root(self):
+        return SubProblem(state=self.initial_state(), value=self.initial_value(), path=[], depth=0)
+
+
+def _fill_input(model, comp_type, max_width, residual, best_lb, keep):
+    ci = _CompileInput()
+    ci.comp_type = comp_type
+    ci.max_width = int(max_width)
+    ci.best_lb = int(max(min(best_lb, (1 << 63) - 1), -(1 << 63)))
+    st = np.ascontiguousarray(residual.state, dtype=np.uint64)
+    path = (_Decision * max(1, len(residual.path)))()
+    for i, d in enumerate(residual.path):
+        path[i].variable, path[i].value = d.variable, d.value
+    keep.extend([st, path])
+    ci.residual.state = st.ctypes.data_as(C.POINTER(C.c_uint64))
+    ci.residual.state_words = model.ws
+    ci.residual.value = int(residual.value)
+    ci.residual.ub = int(min(residual.ub, (1 << 63) - 1))
+    ci.residual.depth = int(residual.depth)
+    ci.residual.path = path
+    ci.residual.path_len = len(residual.path)
+    ci.cutoff = None
+    return ci
+
+
+class Mdd:
+    """`impl DecisionDiagram for Mdd<T, LAST_EXACT_LAYER>` (mdd.rs:75-114) on the device."""
+
+    def __init__(self, model, max_width, device=0, cutset_type=LAST_EXACT_LAYER):
+        self.model = model
+        self._h = lib().ddo_mdd_create(model._h, device, cutset_type, int(max_width))
+        if not self._h:
+            raise DdoError("ddo_mdd_create failed: " + _err())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ddo_mdd_destroy(self._h)
+        except Exception:
+            pass
+
+    def compile(self, comp_type, max_width, residual, best_lb):
+        keep = []
+        ci = _fill_input(self.model, comp_type, max_width, residual, best_lb, keep)
+        out = _Completion()
+        rc = lib().ddo_mdd_compile(self._h, C.byref(ci), C.byref(out))
+        if rc == DDO_CUTOFF:
+            return None  # Err(Reason::CutoffOccurred)
+        if rc != DDO_OK:
+            raise DdoError(f"ddo_mdd_compile rc={rc}: {_err()}")
+        return Completion(bool(out.is_exact), out.best_value if out.has_best_value else None)
+
+    @staticmethod
+    def compile_batch(mdds, comp_types, max_widths, residuals, best_lbs):
+        n = len(mdds)
+        keep = []
+        cis = (_CompileInput * n)()
+        for i in range(n):
+            cis[i] = _fill_input(mdds[i].model, comp_types[i], max_widths[i], residuals[i], best_lbs[i], keep)
+        hs = (C.c_void_p * n)(*[m._h for m in mdds])
+        outs = (_Completion * n)()
+        sts = (C.c_int * n)()
+        rc = lib().ddo_mdd_compile_batch(hs, cis, outs, sts, n)
+        if rc < 0:
+            raise DdoError(f"ddo_mdd_compile_batch rc={rc}: {_err()} statuses={list(sts)}")
+        return [Completion(bool(o.is_exact), o.best_value if o.has_best_value else None) for o in outs]
+
+    def is_exact(self):
+        return bool(lib().ddo_mdd_is_exact(self._h))
+
+    def best_value(self):
+        v = C.c_int64()
+        return v.value if lib().ddo_mdd_best_value(self._h, C.byref(v)) == 1 else None
+
+    def best_exact_value(self):
+        v = C.c_int64()
+        return v.value if lib().ddo_mdd_best_exact_value(self._h, C.byref(v)) == 1 else None
+
+    def _solution(self, fn):
+        cap = 2 * self.model.n + 8
+        buf = (_Decision * cap)()
+        ln = C.c_size_t(cap)
+        rc = fn(self._h, buf, C.byref(ln))
+        if rc == 0:
+            return None
+        if rc != 1:
+            raise DdoError(f"solution query rc={rc}: {_err()}")
+        return [Decision(buf[i].variable, buf[i].value) for i in range(ln.value)]
+
+    def best_solution(self):
+        return self._solution(lib().ddo_mdd_best_solution)
+
+    def best_exact_solution(self):
+        return self._solution(lib().ddo_mdd_best_exact_solution)
+
+    def drain_cutset(self, func=None):
+        out = []
+        ws = self.model.ws
+
+        def cb(sp, _user):
+            s = sp.contents
+            state = np.array([s.state[k] for k in range(ws)], dtype=np.uint64)
+            path = [Decision(s.path[i].variable, s.path[i].value) for i in range(s.path_len)]
+            node = SubProblem(state=state, value=s.value, path=path, ub=s.ub, depth=s.depth)
+            out.append(node)
+            if func:
+                func(node)
+
+        rc = lib().ddo_mdd_drain_cutset(self._h, _CUTSET_CB(cb), None)
+        if rc != DDO_OK:
+            raise DdoError(f"ddo_mdd_drain_cutset rc={rc}: {_err()}")
+        return out
+
+    def counters(self):
+        c = _Counters()
+        lib().ddo_mdd_last_counters(self._h, C.byref(c))
+        return {"nodes_expanded": c.nodes_expanded, "arcs": c.arcs, "layers": c.layers, "compiles": c.compiles}
+
+
+DefaultMDD = DefaultMDDLEL = Mdd  # mdd/mod.rs:42-49
+
+
+class ParallelSolver:
+    """`ParallelSolver::custom(problem, relaxation, ranking, width, dominance, cutoff, fringe, nb_threads)`
+    (parallel.rs:320-358); relaxation / ranking are carried by the model, dominance is the empty checker,
+    the fringe is the NoDupFringe<MaxUB>.  `nb_threads` = sub-problems compiled concurrently on the GPU."""
+
+    def __init__(self, problem, width, cutoff=None, nb_threads=256, device=0, rank=0, world_size=1):
+        self.problem = problem
+        cfg = _SolverConfig()
+        cfg.device = device
+        if isinstance(width, FixedWidth):
+            cfg.width_policy, cfg.width = 0, width.w
+        elif isinstance(width, NbUnassignedWidth):
+            cfg.width_policy, cfg.width = 1, 0
+        else:
+            raise TypeError("width must be FixedWidth or NbUnassignedWidth")
+        cfg.nb_concurrent = int(nb_threads)
+        cfg.time_budget_s = float(getattr(cutoff, "seconds", 0.0) or 0.0)
+        cfg.rank, cfg.world_size = int(rank), int(world_size)
+        self._h = lib().ddo_solver_create(problem._h, C.byref(cfg))
+        if not self._h:
+            raise DdoError("ddo_solver_create failed: " + _err())
+
+    custom = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ddo_solver_destroy(self._h)
+        except Exception:
+            pass
+
+    def maximize(self):
+        out = _Completion()
+        rc = lib().ddo_solver_maximize(self._h, C.byref(out))
+        if rc < 0:
+            raise DdoError(f"ddo_solver_maximize rc={rc}: {_err()}")
+        return Completion(bool(out.is_exact), out.best_value if out.has_best_value else None)
+
+    def step(self):
+        rc = lib().ddo_solver_step(self._h)
+        if rc < 0:
+            raise DdoError(f"ddo_solver_step rc={rc}: {_err()}")
+        return rc
+
+    def best_value(self):
+        v = C.c_int64()
+        return v.value if lib().ddo_solver_best_value(self._h, C.byref(v)) == 1 else None
+
+    def best_solution(self):
+        cap = 2 * self.problem.n + 8
+        buf = (_Decision * cap)()
+        ln = C.c_size_t(cap)
+        rc = lib().ddo_solver_best_solution(self._h, buf, C.byref(ln))
+        if rc != 1:
+            return None
+        return [Decision(buf[i].variable, buf[i].value) for i in range(ln.value)]
+
+    def best_lower_bound(self):
+        return lib().ddo_solver_best_lower_bound(self._h)
+
+    def best_upper_bound(self):
+        return lib().ddo_solver_best_upper_bound(self._h)
+
+    def set_primal(self, value, solution):
+        buf = (_Decision * max(1, len(solution)))()
+        for i, d in enumerate(solution):
+            buf[i].variable, buf[i].value = d.variable, d.value
+        lib().ddo_solver_set_primal(self._h, int(value), buf, len(solution))
+
+    def import_lower_bound(self, lb):
+        lib().ddo_solver_import_lower_bound(self._h, int(lb))
+
+    def gap(self):
+        return lib().ddo_solver_gap(self._h)
+
+    def explored(self):
+        return lib().ddo_solver_explored(self._h)
+
+    def fringe_len(self):
+        return lib().ddo_solver_fringe_len(self._h)
+
+    def fringe_best_ub(self):
+        return lib().ddo_solver_fringe_best_ub(self._h)
+
+    def counters(self):
+        c = _Counters()
+        lib().ddo_solver_counters(self._h, C.byref(c))
+        return {"nodes_expanded": c.nodes_expanded, "arcs": c.arcs, "layers": c.layers, "compiles": c.compiles}
+
+    def device_time(self):
+        ms = C.c_double()
+        n = C.c_uint64()
+        lib().ddo_solver_device_time(self._h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+
+DefaultSolver = ParallelSolver  # solver/mod.rs:28

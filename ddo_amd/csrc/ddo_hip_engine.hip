@@ -1,0 +1,648 @@
+// =============================================================================
+// ddo_hip_engine.hip -- gfx950 kernels + the device engine + the model / mdd
+// half of the C ABI (include/ddo_hip.h).
+//
+// Execution model: one persistent workgroup per concurrently compiled decision
+// diagram ("slot").  A launch of min(batch, nslots) workgroups drains a batch of
+// sub-problems through a device work counter; every workgroup runs the complete
+// layer loop of its DD (misp_dd_core.hpp) out of its own HBM slot + LDS, so a
+// compile needs no host round trip and no inter-workgroup synchronisation.
+// =============================================================================
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/ddo_hip.h"
+#include "engine.hpp"
+#include "misp_dd_core.hpp"
+
+namespace ddo_hip {
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <int WS, bool TLDS>
+__global__ void __launch_bounds__(1024) misp_compile_kernel(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    DDCtx<WS> c;
+    dd_bind<WS, TLDS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
+    c.tid_ = (int)threadIdx.x;
+    for (;;) {
+        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
+        __syncthreads();
+        const int w = c.sh->work;
+        __syncthreads();
+        if (w >= P.nbatch) break;
+        run_work_item<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+    }
+}
+
+typedef void (*kernel_fn)(EngineParams);
+template <bool TLDS>
+static kernel_fn pick_kernel(int wsT) {
+    switch (wsT) {
+        case 1: return misp_compile_kernel<1, TLDS>;
+        case 2: return misp_compile_kernel<2, TLDS>;
+        case 4: return misp_compile_kernel<4, TLDS>;
+        case 7: return misp_compile_kernel<7, TLDS>;
+        case 8: return misp_compile_kernel<8, TLDS>;
+        case 16: return misp_compile_kernel<16, TLDS>;
+        default: return nullptr;
+    }
+}
+static int pick_ws(int ws) {
+    const int opts[] = {1, 2, 4, 7, 8, 16};
+    for (int o : opts)
+        if (ws <= o) return o;
+    return -1;
+}
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+const char* get_error() { return g_error.c_str(); }
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+            return DDO_ERR_NO_DEVICE;                                                            \
+        }                                                                                        \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Model
+// ---------------------------------------------------------------------------
+int Model::popcount(const uint64_t* a) const {
+    int c = 0;
+    for (int k = 0; k < ws; ++k) c += __builtin_popcountll(a[k]);
+    return c;
+}
+int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
+    int pa = popcount(a), pb = popcount(b);
+    if (pa != pb) return pa < pb ? -1 : 1;
+    // equal popcounts: at the lowest differing member, the set owning it is the smaller one
+    for (int k = 0; k < ws; ++k) {
+        uint64_t x = a[k] ^ b[k];
+        if (x) {
+            uint64_t t = x & (~x + 1);
+            return (a[k] & t) ? -1 : 1;
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Engine
+// ---------------------------------------------------------------------------
+std::shared_ptr<Engine> Engine::get(Model* model, int device, long max_width) {
+    std::lock_guard<std::mutex> g(model->mtx);
+    auto key = std::make_pair(device, max_width);
+    auto it = model->engines.find(key);
+    if (it != model->engines.end()) {
+        if (auto sp = it->second.lock()) return sp;
+    }
+    std::shared_ptr<Engine> e(new Engine());
+    if (e->init(model, device, max_width) != DDO_OK) return nullptr;
+    model->engines[key] = e;
+    return e;
+}
+
+template <class T>
+static int dev_alloc(std::vector<void*>& allocs, T*& ptr, size_t count) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+        return DDO_ERR_NO_DEVICE;
+    }
+    allocs.push_back(p);
+    ptr = (T*)p;
+    return DDO_OK;
+}
+
+int Engine::init(Model* model, int device, long max_width) {
+    model_ = model;
+    device_ = device;
+    max_width_ = max_width;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device is visible: the MDD engine has no CPU fallback");
+        return DDO_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("invalid device ordinal");
+        return DDO_ERR_INVALID;
+    }
+    if (max_width < 1 || max_width > 400000) {
+        set_error("max_width out of range [1, 400000]");
+        return DDO_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+
+    EngineParams& P = P_;
+    std::memset(&P, 0, sizeof(P));
+    P.n = model->n;
+    P.ws = model->wsT;
+    P.unit_weights = model->unit_weights ? 1 : 0;
+    P.npad = (model->n + 63) / 64 * 64;
+    P.capN = (int)max_width + 2;
+    P.capC1 = 2 * P.capN + 1;
+    P.max_layers = model->n + 2;
+    int tc = 1024;
+    while (tc * 2 < P.capC1 * 3 || tc < 2 * P.capN) tc <<= 1;
+    P.table_cap = tc;
+    threads_ = max_width >= 2048 ? 1024 : 256;
+    if (const char* env = std::getenv("DDO_HIP_THREADS")) {
+        int t = std::atoi(env);
+        if (t >= 256 && t <= 1024 && t % 64 == 0) threads_ = t;
+    }
+    const size_t lds_max = 160 * 1024;
+    size_t lds_with_table = dd_lds_bytes(P.table_cap, P.npad, threads_);
+    table_lds_ = lds_with_table <= lds_max;
+    lds_bytes_ = table_lds_ ? lds_with_table : dd_lds_bytes(0, P.npad, threads_);
+    P.table_in_lds = table_lds_ ? 1 : 0;
+
+    // ---- how many DDs in flight: residency of the kernel, then HBM
+    int blocks_per_cu = (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(2048 / threads_));
+    blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+    int nslots = prop.multiProcessorCount * blocks_per_cu;
+    if (const char* env = std::getenv("DDO_HIP_SLOTS")) {
+        int s = std::atoi(env);
+        if (s > 0) nslots = s;
+    }
+    const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers, wsT = model->wsT;
+    size_t per_slot = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
+                      ml * capN * 4 + ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
+                      (table_lds_ ? 0 : (size_t)P.table_cap * 4);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t arena_mb = 1024;
+    if (const char* env = std::getenv("DDO_HIP_ARENA_MB")) arena_mb = (size_t)std::max(16, std::atoi(env));
+    arena_cap_ = arena_mb << 20;
+    size_t budget = free_b > (arena_cap_ + (2ull << 30)) ? (size_t)((free_b - arena_cap_ - (1ull << 30)) * 0.8) : 0;
+    if (budget / per_slot < (size_t)nslots) nslots = (int)(budget / per_slot);
+    if (nslots < 1) {
+        set_error("not enough device memory for one decision-diagram slot");
+        return DDO_ERR_CAPACITY;
+    }
+    nslots_ = nslots;
+    P.nslots = nslots;
+    const size_t S = nslots;
+
+    // ---- model tables
+    std::vector<uint64_t> adjT((size_t)model->n * wsT, 0);
+    for (int i = 0; i < model->n; ++i)
+        for (int k = 0; k < model->ws; ++k) adjT[(size_t)i * wsT + k] = model->adj[(size_t)i * model->ws + k];
+    std::vector<int32_t> w32(model->n);
+    for (int i = 0; i < model->n; ++i) w32[i] = (int32_t)model->weight[i];
+    uint64_t* d_adj = nullptr;
+    int32_t* d_w = nullptr;
+    int rc;
+    if ((rc = dev_alloc(allocs_, d_adj, adjT.size()))) return rc;
+    if ((rc = dev_alloc(allocs_, d_w, w32.size()))) return rc;
+    HIP_TRY(hipMemcpy(d_adj, adjT.data(), adjT.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_w, w32.data(), w32.size() * 4, hipMemcpyHostToDevice));
+    P.adj = d_adj;
+    P.weight = d_w;
+
+    // ---- workspace
+    if ((rc = dev_alloc(allocs_, P.cstate, S * 2 * wsT * capC1))) return rc;
+    if ((rc = dev_alloc(allocs_, P.ckey, S * 2 * capC1))) return rc;
+    if ((rc = dev_alloc(allocs_, P.cpop, S * 2 * capC1))) return rc;
+    if ((rc = dev_alloc(allocs_, P.cflags, S * 2 * capC1))) return rc;
+    if ((rc = dev_alloc(allocs_, P.ctarget, S * 2 * capN))) return rc;
+    if ((rc = dev_alloc(allocs_, P.keep, S * capN))) return rc;
+    if ((rc = dev_alloc(allocs_, P.posmap, S * capC1))) return rc;
+    if ((rc = dev_alloc(allocs_, P.cls, S * capC1))) return rc;
+    if ((rc = dev_alloc(allocs_, P.ninfo, S * ml * capN))) return rc;
+    if ((rc = dev_alloc(allocs_, P.arct, S * ml * 2 * capN))) return rc;
+    if ((rc = dev_alloc(allocs_, P.nlayer, S * ml))) return rc;
+    if ((rc = dev_alloc(allocs_, P.lvar, S * ml))) return rc;
+    if ((rc = dev_alloc(allocs_, P.ldup, S * ml * 2))) return rc;
+    if ((rc = dev_alloc(allocs_, P.cs_state, S * wsT * capN))) return rc;
+    if ((rc = dev_alloc(allocs_, P.cs_value, S * capN))) return rc;
+    if ((rc = dev_alloc(allocs_, P.cs_pop, S * capN))) return rc;
+    if (!table_lds_) {
+        if ((rc = dev_alloc(allocs_, P.gtable, S * (size_t)P.table_cap))) return rc;
+    }
+    if ((rc = dev_alloc(allocs_, d_arena_, arena_cap_))) return rc;
+    P.arena = d_arena_;
+    P.arena_cap = arena_cap_;
+    uint8_t* cnt = nullptr;
+    if ((rc = dev_alloc(allocs_, cnt, 64))) return rc;
+    d_counters_ = cnt;
+    HIP_TRY(hipMemset(cnt, 0, 64));
+    P.work_counter = (int32_t*)cnt;
+    P.arena_head = (unsigned long long*)(cnt + 8);
+    P.cutoff_flag = (const int32_t*)(cnt + 16);
+
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    stream_ = st;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    ev0_ = e0;
+    ev1_ = e1;
+
+    kernel_fn fn = table_lds_ ? pick_kernel<true>(model->wsT) : pick_kernel<false>(model->wsT);
+    if (!fn) {
+        set_error("unsupported state width");
+        return DDO_ERR_UNSUPPORTED;
+    }
+    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_));
+    return DDO_OK;
+}
+
+Engine::~Engine() {
+    if (device_ >= 0) (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize((hipStream_t)stream_);
+    for (void* p : allocs_) (void)hipFree(p);
+    if (d_inputs_) (void)hipFree(d_inputs_);
+    if (d_results_) (void)hipFree(d_results_);
+    if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
+    if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
+    if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
+}
+
+void Engine::set_cutoff(bool on) {
+    int32_t v = on ? 1 : 0;
+    (void)hipSetDevice(device_);
+    (void)hipMemcpy((uint8_t*)d_counters_ + 16, &v, 4, hipMemcpyHostToDevice);
+}
+
+void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) const {
+    out.clear();
+    out.hdr = r;
+    out.valid = true;
+    if (r.status != ST_OK) return;
+    const int ws = model_->ws, wsT = model_->wsT;
+    const uint8_t* base = arena + r.arena_off;
+    if (r.best_len) {
+        const uint32_t* p = (const uint32_t*)(base + r.path_off);
+        out.best_path.assign(p, p + r.best_len);
+    }
+    if (r.exact_len) {
+        const uint32_t* p = (const uint32_t*)(base + r.exact_off);
+        out.exact_path.assign(p, p + r.exact_len);
+    }
+    out.n_cutset = r.n_cutset;
+    out.cs_path_len = r.lel > 0 ? r.lel : 0;
+    if (r.n_cutset) {
+        const uint64_t* s = (const uint64_t*)(base + r.cs_state_off);
+        out.cs_state.resize((size_t)r.n_cutset * ws);
+        for (int i = 0; i < r.n_cutset; ++i)
+            for (int k = 0; k < ws; ++k) out.cs_state[(size_t)i * ws + k] = s[(size_t)i * wsT + k];
+        const int32_t* v = (const int32_t*)(base + r.cs_value_off);
+        out.cs_value.assign(v, v + r.n_cutset);
+        const int32_t* u = (const int32_t*)(base + r.cs_ub_off);
+        out.cs_ub.assign(u, u + r.n_cutset);
+        const uint32_t* pth = (const uint32_t*)(base + r.cs_path_off);
+        out.cs_path.assign(pth, pth + (size_t)r.n_cutset * out.cs_path_len);
+    }
+}
+
+int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results) {
+    std::lock_guard<std::mutex> g(mtx_);
+    results.resize((size_t)count * 2);
+    if (count <= 0) return DDO_OK;
+    HIP_TRY(hipSetDevice(device_));
+    hipStream_t st = (hipStream_t)stream_;
+    if (count > in_cap_) {
+        if (d_inputs_) HIP_TRY(hipFree(d_inputs_));
+        if (d_results_) HIP_TRY(hipFree(d_results_));
+        d_inputs_ = d_results_ = nullptr;
+        int cap = std::max(count, 256);
+        HIP_TRY(hipMalloc(&d_inputs_, (size_t)cap * sizeof(DDInput)));
+        HIP_TRY(hipMalloc(&d_results_, (size_t)cap * 2 * sizeof(DDResult)));
+        in_cap_ = cap;
+    }
+    for (int i = 0; i < count; ++i) {
+        if (inputs[i].width + 2 > P_.capN || inputs[i].width < 1) {
+            set_error("compile width exceeds the max_width the mdd was created with (or is < 1)");
+            return DDO_ERR_CAPACITY;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_inputs_, inputs, (size_t)count * sizeof(DDInput), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_counters_, 0, 16, st));  // work counter + arena head (the cutoff flag is kept)
+    EngineParams P = P_;
+    P.inputs = (const DDInput*)d_inputs_;
+    P.results = (DDResult*)d_results_;
+    P.nbatch = count;
+    const int grid = std::min(count, nslots_);
+    kernel_fn fn = table_lds_ ? pick_kernel<true>(model_->wsT) : pick_kernel<false>(model_->wsT);
+    HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord((hipEvent_t)ev1_, st));
+    h_results_.resize((size_t)count * 2);
+    HIP_TRY(hipMemcpyAsync(h_results_.data(), d_results_, (size_t)count * 2 * sizeof(DDResult), hipMemcpyDeviceToHost, st));
+    unsigned long long head = 0;
+    HIP_TRY(hipMemcpyAsync(&head, (uint8_t*)d_counters_ + 8, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
+    last_kernel_ms_ = ms;
+    kernel_ms_ += ms;
+    launches_ += 1;
+    size_t used = (size_t)std::min<unsigned long long>(head, arena_cap_);
+    if (h_arena_.size() < used) h_arena_.resize(used);
+    if (used) HIP_TRY(hipMemcpy(h_arena_.data(), d_arena_, used, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; ++i) {
+        for (int k = 0; k < 2; ++k) {
+            const DDResult& r = h_results_[(size_t)i * 2 + k];
+            HostResult& out = results[(size_t)i * 2 + k];
+            if (r.status == ST_NOT_RUN) {
+                out.clear();
+                out.hdr = r;
+                continue;
+            }
+            if (r.status == ST_OK && r.arena_off + r.arena_bytes > used) {
+                out.clear();
+                out.hdr = r;
+                out.hdr.status = ST_ERR_CAPACITY;
+                out.valid = true;
+                continue;
+            }
+            decode(r, h_arena_.data(), out);
+        }
+    }
+    return DDO_OK;
+}
+
+}  // namespace ddo_hip
+
+// =============================================================================
+// C ABI: models and decision diagrams
+// =============================================================================
+using namespace ddo_hip;
+
+struct ddo_mdd {
+    Model* model = nullptr;
+    std::shared_ptr<Engine> engine;
+    int cutset_type = DDO_LAST_EXACT_LAYER;
+    HostResult res;
+    // residual of the latest compile (clean.rs:149 path_to_root, :398 depth)
+    std::vector<ddo_decision> path_to_root;
+    size_t depth = 0;
+    bool drained = false;
+};
+
+extern "C" {
+
+const char* ddo_last_error(void) { return get_error(); }
+
+int ddo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+ddo_model* ddo_model_create_misp(int n, const uint64_t* rows, const int64_t* weights) {
+    if (n < 1 || !rows || !weights) {
+        set_error("ddo_model_create_misp: invalid arguments");
+        return nullptr;
+    }
+    int ws = (n + 63) / 64;
+    int wsT = pick_ws(ws);
+    if (wsT < 0 || n > 64 * MAX_WS) {
+        set_error("ddo_model_create_misp: at most 1024 variables are supported");
+        return nullptr;
+    }
+    ddo_model* m = new ddo_model();
+    m->m.n = n;
+    m->m.ws = ws;
+    m->m.wsT = wsT;
+    m->m.adj.assign(rows, rows + (size_t)n * ws);
+    // bits beyond n never belong to a state
+    if (n % 64) {
+        uint64_t mask = (1ULL << (n % 64)) - 1;
+        for (int i = 0; i < n; ++i) m->m.adj[(size_t)i * ws + ws - 1] &= mask;
+    }
+    m->m.weight.assign(weights, weights + n);
+    m->m.unit_weights = true;
+    m->m.weight_abs_sum = 0;
+    for (int i = 0; i < n; ++i) {
+        m->m.unit_weights &= weights[i] == 1;
+        m->m.weight_abs_sum += weights[i] < 0 ? -weights[i] : weights[i];
+    }
+    if (m->m.weight_abs_sum >= (1LL << 30)) {
+        set_error("ddo_model_create_misp: sum of |weights| must stay below 2^30 (device values are int32)");
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+
+ddo_model* ddo_model_read_misp(const char* path) {
+    int n = 0;
+    std::vector<uint64_t> rows;
+    std::vector<int64_t> weights;
+    if (!path || !read_misp_clq(path, n, rows, weights)) return nullptr;
+    return ddo_model_create_misp(n, rows.data(), weights.data());
+}
+
+void ddo_model_destroy(ddo_model* model) { delete model; }
+int ddo_model_nb_variables(const ddo_model* model) { return model ? model->m.n : DDO_ERR_INVALID; }
+int ddo_model_state_words(const ddo_model* model) { return model ? model->m.ws : DDO_ERR_INVALID; }
+
+int ddo_model_initial_state(const ddo_model* model, uint64_t* out) {
+    if (!model || !out) return DDO_ERR_INVALID;
+    const Model& m = model->m;
+    for (int k = 0; k < m.ws; ++k) out[k] = 0;
+    for (int i = 0; i < m.n; ++i) out[i / 64] |= 1ULL << (i % 64);  // main.rs:69-71
+    return DDO_OK;
+}
+int64_t ddo_model_initial_value(const ddo_model*) { return 0; }  // main.rs:73-75
+int ddo_model_compare_states(const ddo_model* model, const uint64_t* a, const uint64_t* b) {
+    return model->m.compare_states(a, b);
+}
+int ddo_model_export_misp(const ddo_model* model, uint64_t* rows, int64_t* weights) {
+    if (!model) return DDO_ERR_INVALID;
+    if (rows) std::memcpy(rows, model->m.adj.data(), model->m.adj.size() * 8);
+    if (weights) std::memcpy(weights, model->m.weight.data(), model->m.weight.size() * 8);
+    return DDO_OK;
+}
+
+ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, size_t max_width) {
+    if (!model) {
+        set_error("ddo_mdd_create: null model");
+        return nullptr;
+    }
+    if (cutset_type != DDO_LAST_EXACT_LAYER) {
+        set_error("ddo_mdd_create: only the LAST_EXACT_LAYER cut-set is implemented on device");
+        return nullptr;
+    }
+    Model* m = const_cast<Model*>(&model->m);
+    auto eng = Engine::get(m, device, (long)max_width);
+    if (!eng) return nullptr;
+    ddo_mdd* d = new ddo_mdd();
+    d->model = m;
+    d->engine = eng;
+    d->cutset_type = cutset_type;
+    return d;
+}
+void ddo_mdd_destroy(ddo_mdd* mdd) { delete mdd; }
+
+static int fill_input(const Model& m, const ddo_compile_input* in, DDInput& out, uint32_t flags) {
+    if (!in || !in->residual.state) return DDO_ERR_INVALID;
+    if (in->comp_type != DDO_EXACT && in->comp_type != DDO_RELAXED && in->comp_type != DDO_RESTRICTED) return DDO_ERR_INVALID;
+    if (in->residual.state_words != 0 && (int)in->residual.state_words != m.ws) return DDO_ERR_INVALID;
+    std::memset(&out, 0, sizeof(out));
+    out.comp_type = in->comp_type;
+    out.flags = flags;
+    // Exact compiles use the whole workspace as "width"
+    out.width = (int32_t)std::min<size_t>(in->max_width, 1u << 30);
+    const int64_t lim = (1LL << 30);
+    if (in->residual.value <= -lim || in->residual.value >= lim) return DDO_ERR_INVALID;
+    out.value = (int32_t)in->residual.value;
+    out.depth = (int32_t)in->residual.depth;
+    out.best_lb = in->best_lb;
+    for (int k = 0; k < m.ws; ++k) out.state[k] = in->residual.state[k];
+    return DDO_OK;
+}
+
+int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs, ddo_completion* outs, int* statuses,
+                          size_t count) {
+    if (!mdds || !inputs || count == 0) return DDO_ERR_INVALID;
+    Engine* eng = mdds[0]->engine.get();
+    std::vector<DDInput> din;
+    std::vector<size_t> active;
+    din.reserve(count);
+    for (size_t i = 0; i < count; ++i) {
+        if (!mdds[i] || mdds[i]->engine.get() != eng) {
+            set_error("ddo_mdd_compile_batch: all mdds must come from the same model, device and max_width");
+            return DDO_ERR_INVALID;
+        }
+        mdds[i]->res.clear();
+        mdds[i]->drained = false;
+        if (inputs[i].cutoff && *inputs[i].cutoff) {  // Cutoff::must_stop() polled before the first layer (clean.rs:352)
+            if (statuses) statuses[i] = DDO_CUTOFF;
+            if (outs) outs[i] = ddo_completion{0, 0, 0};
+            continue;
+        }
+        DDInput di;
+        int rc = fill_input(*mdds[i]->model, &inputs[i], di, IN_WANT_PATHS);
+        if (rc != DDO_OK) {
+            set_error("ddo_mdd_compile: invalid compile input");
+            return rc;
+        }
+        if (inputs[i].comp_type == DDO_EXACT) di.width = (int32_t)eng->max_width();
+        if (di.width > eng->max_width() || di.width < 1) {
+            set_error("ddo_mdd_compile: max_width must be in [1, width the mdd was created with]");
+            return DDO_ERR_CAPACITY;
+        }
+        din.push_back(di);
+        active.push_back(i);
+    }
+    std::vector<HostResult> res;
+    int rc = eng->run_batch(din.data(), (int)din.size(), res);
+    if (rc != DDO_OK) return rc;
+    int worst = DDO_OK;
+    for (size_t a = 0; a < active.size(); ++a) {
+        const size_t i = active[a];
+        ddo_mdd* d = mdds[i];
+        d->res = std::move(res[2 * a]);
+        d->depth = inputs[i].residual.depth;
+        d->path_to_root.assign(inputs[i].residual.path, inputs[i].residual.path + inputs[i].residual.path_len);
+        int st = d->res.hdr.status;
+        int code = st == ST_OK ? DDO_OK : (st == ST_CUTOFF ? DDO_CUTOFF : st);
+        if (statuses) statuses[i] = code;
+        if (code < 0 && worst >= 0) worst = code;
+        if (code != DDO_OK) d->res.valid = false;
+        if (outs) {
+            outs[i].is_exact = ddo_mdd_is_exact(d);
+            outs[i].has_best_value = d->res.valid ? d->res.hdr.has_best : 0;
+            outs[i].best_value = outs[i].has_best_value ? d->res.hdr.best_value : 0;
+        }
+    }
+    if (worst < 0) set_error("device compile failed (capacity or internal error), see per-item status");
+    return worst;
+}
+
+int ddo_mdd_compile(ddo_mdd* mdd, const ddo_compile_input* input, ddo_completion* out) {
+    int status = DDO_OK;
+    int rc = ddo_mdd_compile_batch(&mdd, input, out, &status, 1);
+    if (rc < 0) return rc;
+    return status;
+}
+
+int ddo_mdd_is_exact(const ddo_mdd* mdd) {  // clean.rs:241-243
+    return mdd && mdd->res.valid && (mdd->res.hdr.is_exact || mdd->res.hdr.has_exact_best_path) ? 1 : 0;
+}
+int ddo_mdd_best_value(const ddo_mdd* mdd, int64_t* value) {
+    if (!mdd || !mdd->res.valid || !mdd->res.hdr.has_best) return 0;
+    if (value) *value = mdd->res.hdr.best_value;
+    return 1;
+}
+int ddo_mdd_best_exact_value(const ddo_mdd* mdd, int64_t* value) {
+    if (!mdd || !mdd->res.valid || !mdd->res.hdr.has_best_exact) return 0;
+    if (value) *value = mdd->res.hdr.best_exact_value;
+    return 1;
+}
+static int emit_path(const ddo_mdd* mdd, const std::vector<uint32_t>& p, ddo_decision* buf, size_t* len) {
+    size_t need = mdd->path_to_root.size() + p.size();
+    if (!len) return DDO_ERR_INVALID;
+    if (!buf || *len < need) {
+        *len = need;
+        return DDO_ERR_CAPACITY;
+    }
+    size_t k = 0;
+    for (const ddo_decision& d : mdd->path_to_root) buf[k++] = d;
+    for (uint32_t x : p) buf[k++] = ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)};
+    *len = need;
+    return 1;
+}
+int ddo_mdd_best_solution(const ddo_mdd* mdd, ddo_decision* buf, size_t* len) {
+    if (!mdd || !mdd->res.valid || !mdd->res.hdr.has_best) return 0;
+    return emit_path(mdd, mdd->res.best_path, buf, len);
+}
+int ddo_mdd_best_exact_solution(const ddo_mdd* mdd, ddo_decision* buf, size_t* len) {
+    if (!mdd || !mdd->res.valid || !mdd->res.hdr.has_best_exact) return 0;
+    return emit_path(mdd, mdd->res.hdr.exact_same_as_best ? mdd->res.best_path : mdd->res.exact_path, buf, len);
+}
+int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
+    if (!mdd || !cb) return DDO_ERR_INVALID;
+    if (!mdd->res.valid || mdd->drained) return DDO_OK;
+    mdd->drained = true;
+    const HostResult& r = mdd->res;
+    const int ws = mdd->model->ws;
+    std::vector<ddo_decision> path;
+    for (int i = 0; i < r.n_cutset; ++i) {
+        path = mdd->path_to_root;
+        for (int k = 0; k < r.cs_path_len; ++k) {
+            uint32_t x = r.cs_path[(size_t)i * r.cs_path_len + k];
+            path.push_back(ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)});
+        }
+        ddo_subproblem sp;
+        sp.state = r.cs_state.data() + (size_t)i * ws;
+        sp.state_words = (size_t)ws;
+        sp.value = r.cs_value[i];
+        sp.ub = r.cs_ub[i];
+        sp.depth = mdd->depth + (size_t)r.cs_path_len;
+        sp.path = path.data();
+        sp.path_len = path.size();
+        cb(&sp, user);
+    }
+    return DDO_OK;
+}
+int ddo_mdd_last_counters(const ddo_mdd* mdd, ddo_counters* out) {
+    if (!mdd || !out) return DDO_ERR_INVALID;
+    out->nodes_expanded = mdd->res.hdr.nodes_expanded;
+    out->arcs = mdd->res.hdr.arcs;
+    out->layers = mdd->res.hdr.layers;
+    out->compiles = mdd->res.valid ? 1 : 0;
+    return DDO_OK;
+}
+
+}  // extern "C"

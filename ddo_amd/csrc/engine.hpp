@@ -1,0 +1,123 @@
+// =============================================================================
+// engine.hpp -- host-side objects behind include/ddo_hip.h: model descriptors,
+// the per-(model, device, width) device engine and its batch interface.
+// =============================================================================
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dd_types.h"
+
+namespace ddo_hip {
+
+void set_error(const std::string& msg);
+const char* get_error();
+
+/// MISP model descriptor (examples/misp/main.rs:37-51): the closed-form stand-in for
+/// `&dyn Problem + &dyn Relaxation + &dyn StateRanking`.
+struct Model {
+    int n = 0;
+    int ws = 0;                      // ceil(n / 64): words per state at the ABI
+    int wsT = 0;                     // words per state in the device kernel (template instance)
+    std::vector<uint64_t> adj;       // [n][ws]   complement adjacency rows
+    std::vector<int64_t> weight;     // [n]
+    bool unit_weights = true;
+    int64_t weight_abs_sum = 0;
+
+    std::mutex mtx;
+    std::map<std::pair<int, long>, std::weak_ptr<class Engine>> engines;  // (device, max_width)
+
+    /// MispRanking::compare (main.rs:205-208): popcount, then BitSet::cmp
+    int compare_states(const uint64_t* a, const uint64_t* b) const;
+    int popcount(const uint64_t* a) const;
+};
+
+/// One decoded compile() result living on the host.
+struct HostResult {
+    DDResult hdr{};
+    std::vector<uint32_t> best_path;    // (var << 1 | value), terminal first
+    std::vector<uint32_t> exact_path;
+    int n_cutset = 0;
+    int cs_path_len = 0;
+    std::vector<uint64_t> cs_state;     // n_cutset x ws (ABI words)
+    std::vector<int32_t> cs_value, cs_ub;
+    std::vector<uint32_t> cs_path;      // n_cutset x cs_path_len, node first
+    bool valid = false;
+    void clear() {
+        valid = false;
+        best_path.clear();
+        exact_path.clear();
+        n_cutset = 0;
+        cs_path_len = 0;
+        cs_state.clear();
+        cs_value.clear();
+        cs_ub.clear();
+        cs_path.clear();
+    }
+};
+
+/// Device engine: HBM workspace for `nslots` concurrent decision diagrams + batch launcher.
+class Engine {
+  public:
+    static std::shared_ptr<Engine> get(Model* model, int device, long max_width);
+    ~Engine();
+
+    /// Runs `count` work items in one launch.  results: 2 per item ([1] used by IN_FUSED).
+    /// Returns DDO_OK or a negative error.  Thread-safe (serialised internally).
+    int run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results);
+
+    int device() const { return device_; }
+    long max_width() const { return max_width_; }
+    int nslots() const { return nslots_; }
+    int threads() const { return threads_; }
+    size_t lds_bytes() const { return lds_bytes_; }
+    double kernel_ms() const { return kernel_ms_; }
+    uint64_t launches() const { return launches_; }
+    double last_kernel_ms() const { return last_kernel_ms_; }
+    /// device-visible cutoff flag (set asynchronously by the host to abort running compiles)
+    void set_cutoff(bool on);
+
+  private:
+    Engine() = default;
+    int init(Model* model, int device, long max_width);
+    void decode(const DDResult& r, const uint8_t* arena, HostResult& out) const;
+
+    Model* model_ = nullptr;
+    int device_ = 0;
+    long max_width_ = 0;
+    int nslots_ = 0;
+    int threads_ = 0;
+    size_t lds_bytes_ = 0;
+    bool table_lds_ = true;
+    EngineParams P_{};
+    std::vector<void*> allocs_;
+    void* stream_ = nullptr;
+    void* ev0_ = nullptr;
+    void* ev1_ = nullptr;
+    void* d_inputs_ = nullptr;
+    void* d_results_ = nullptr;
+    int in_cap_ = 0;
+    void* d_counters_ = nullptr;   // [0] work counter (i32), [8..16) arena head (u64), [16] cutoff flag
+    uint8_t* d_arena_ = nullptr;
+    size_t arena_cap_ = 0;
+    std::vector<uint8_t> h_arena_;
+    std::vector<DDResult> h_results_;
+    double kernel_ms_ = 0, last_kernel_ms_ = 0;
+    uint64_t launches_ = 0;
+    std::mutex mtx_;
+};
+
+/// Reads a DIMACS-like .clq file the way examples/misp/main.rs:258-317 does.
+/// Returns false (and sets the error text) on IO / format errors.
+bool read_misp_clq(const std::string& path, int& n, std::vector<uint64_t>& rows, std::vector<int64_t>& weights);
+
+}  // namespace ddo_hip
+
+// opaque ABI types
+struct ddo_model {
+    ddo_hip::Model m;
+};

@@ -1,0 +1,562 @@
+// =============================================================================
+// host_solver.cpp -- branch-and-bound host over the device engine: the Solver
+// half of include/ddo_hip.h.
+//
+// Mirrors ParallelSolver (/root/reference/ddo/src/implementation/solver/parallel.rs:287-641)
+// with `nb_concurrent` sub-problems compiled concurrently on the device instead of
+// `nb_threads` OS threads, a NoDupFringe (fringe/no_duplicate.rs:52-324) ordered by
+// MaxUB (heuristics/subproblem_ranking.rs:76-91) over MispRanking, FixedWidth /
+// NbUnassignedWidth (heuristics/width.rs:166-171, 397-402) and NoCutoff / TimeBudget
+// (heuristics/cutoff.rs:160-163, 302-323).  The reference host is Rust; there is no
+// Rust toolchain in this image, so the host above the C ABI is C++ (INTEGRATION.md
+// shows the Rust binding a maintainer would add).
+//
+// Storage: a fringe entry does not own its state and path.  Every relaxed DD
+// contributes one ref-counted CutsetBlock (states, values, per-node decision rows and
+// a link to the parent sub-problem's path); entries are (block, row) handles, so a
+// push is a hash probe plus a heap sift and no copy.
+// =============================================================================
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cstring>
+#include <limits>
+
+#include "../../include/ddo_hip.h"
+#include "engine.hpp"
+
+using namespace ddo_hip;
+
+namespace {
+
+constexpr int64_t I64_MIN = std::numeric_limits<int64_t>::min();
+constexpr int64_t I64_MAX = std::numeric_limits<int64_t>::max();
+
+/// The cut-set of one relaxed DD (or the problem root), shared by its fringe entries.
+struct CutsetBlock {
+    int refs = 0;
+    CutsetBlock* parent = nullptr;   // block holding the sub-problem this DD was compiled from
+    int parent_row = 0;
+    int depth = 0;                   // depth of every node of this block
+    int path_len = 0;                // decisions per row (relative to the parent sub-problem)
+    int ws = 0;
+    std::vector<uint64_t> states;    // rows x ws
+    std::vector<int32_t> values;
+    std::vector<uint32_t> paths;     // rows x path_len, node first (clean.rs:329-343 order)
+    const uint64_t* state(int row) const { return states.data() + (size_t)row * ws; }
+};
+
+void block_ref(CutsetBlock* b) {
+    if (b) b->refs++;
+}
+void block_unref(CutsetBlock* b) {
+    while (b && --b->refs == 0) {
+        CutsetBlock* p = b->parent;
+        delete b;
+        b = p;
+    }
+}
+
+/// path of (block,row) from the problem root: parent path first, then this row's decisions
+void materialize_path(const CutsetBlock* b, int row, std::vector<ddo_decision>& out) {
+    std::vector<std::pair<const CutsetBlock*, int>> chain;
+    while (b) {
+        chain.push_back({b, row});
+        row = b->parent_row;
+        b = b->parent;
+    }
+    for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
+        const CutsetBlock* blk = it->first;
+        const uint32_t* p = blk->paths.data() + (size_t)it->second * blk->path_len;
+        for (int k = 0; k < blk->path_len; ++k) out.push_back(ddo_decision{(int64_t)(p[k] >> 1), (int64_t)(p[k] & 1)});
+    }
+}
+
+struct Entry {   // SubProblem (common.rs:75-87) as a handle
+    CutsetBlock* block;
+    int32_t row;
+    int32_t depth;
+    int64_t value;
+    int64_t ub;
+    uint64_t hash;
+};
+
+uint64_t hash_words(const uint64_t* s, int ws) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+    for (int k = 0; k < ws; ++k) {
+        h ^= s[k];
+        h *= 0xFF51AFD7ED558CCDULL;
+        h ^= h >> 32;
+    }
+    return h;
+}
+
+/// NoDupFringe<MaxUB<MispRanking>> -- no_duplicate.rs:52-324
+class NoDupFringe {
+  public:
+    explicit NoDupFringe(const Model* m) : model_(m), ws_(m->ws) { rehash(1024); }
+    ~NoDupFringe() { clear(); }
+
+    size_t len() const { return heap_.size(); }
+    bool empty() const { return heap_.empty(); }
+
+    /// no_duplicate.rs:88-140.  Takes one reference on e.block when the entry is stored.
+    void push(const Entry& e) {
+        const uint64_t* st = e.block->state(e.row);
+        size_t slot = find_slot(st, e.hash);
+        if (table_[slot] != EMPTY) {
+            uint32_t id = table_[slot];
+            Entry& old = nodes_[id];
+            const int64_t old_lp = old.value, old_ub = old.ub;
+            Entry cand = e;
+            cand.ub = std::max(e.ub, old_ub);                       // :102
+            const bool up = compare(cand, old) > 0;                 // :104
+            if (e.value > old_lp) {                                 // :110-112 keep the longer path
+                block_ref(cand.block);
+                block_unref(old.block);
+                old = cand;
+            }
+            if (e.ub > old_ub) nodes_[id].ub = e.ub;                // :113-115
+            if (up) bubble_up(id);
+            return;
+        }
+        uint32_t id;
+        if (!recycle_.empty()) {
+            id = recycle_.back();
+            recycle_.pop_back();
+            nodes_[id] = e;
+        } else {
+            id = (uint32_t)nodes_.size();
+            nodes_.push_back(e);
+            pos_.push_back(0);
+        }
+        block_ref(e.block);
+        table_[slot] = id;
+        if (++used_ * 10 > table_.size() * 6) rehash(table_.size() * 2);
+        heap_.push_back(id);
+        pos_[id] = (uint32_t)heap_.size() - 1;
+        bubble_up(id);
+    }
+
+    /// no_duplicate.rs:144-164.  The caller inherits the entry's block reference.
+    bool pop(Entry& out) {
+        if (heap_.empty()) return false;
+        uint32_t id = heap_[0];
+        heap_[0] = heap_.back();
+        heap_.pop_back();
+        if (!heap_.empty()) {
+            pos_[heap_[0]] = 0;
+            bubble_down(heap_[0]);
+        }
+        out = nodes_[id];
+        erase_from_table(id);
+        recycle_.push_back(id);
+        return true;
+    }
+    const Entry* peek() const { return heap_.empty() ? nullptr : &nodes_[heap_[0]]; }
+
+    void clear() {
+        for (uint32_t id : heap_) block_unref(nodes_[id].block);
+        heap_.clear();
+        nodes_.clear();
+        pos_.clear();
+        recycle_.clear();
+        std::fill(table_.begin(), table_.end(), EMPTY);
+        used_ = 0;
+    }
+
+  private:
+    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    /// MaxUB::compare (subproblem_ranking.rs:86-90): ub, then value, then the state ranking
+    int compare(const Entry& l, const Entry& r) const {
+        if (l.ub != r.ub) return l.ub < r.ub ? -1 : 1;
+        if (l.value != r.value) return l.value < r.value ? -1 : 1;
+        return model_->compare_states(l.block->state(l.row), r.block->state(r.row));
+    }
+    size_t find_slot(const uint64_t* st, uint64_t h) const {
+        size_t mask = table_.size() - 1, slot = (size_t)h & mask;
+        for (;;) {
+            uint32_t id = table_[slot];
+            if (id == EMPTY) return slot;
+            const Entry& n = nodes_[id];
+            if (n.hash == h && std::memcmp(n.block->state(n.row), st, (size_t)ws_ * 8) == 0) return slot;
+            slot = (slot + 1) & mask;
+        }
+    }
+    void erase_from_table(uint32_t id) {   // linear probing, backward-shift deletion
+        size_t mask = table_.size() - 1, slot = (size_t)nodes_[id].hash & mask;
+        while (table_[slot] != id) slot = (slot + 1) & mask;
+        size_t hole = slot;
+        for (;;) {
+            slot = (slot + 1) & mask;
+            uint32_t other = table_[slot];
+            if (other == EMPTY) break;
+            size_t home = (size_t)nodes_[other].hash & mask;
+            // can `other` move into the hole ?  (its home must not lie cyclically in (hole, slot])
+            bool between = hole <= slot ? (home > hole && home <= slot) : (home > hole || home <= slot);
+            if (!between) {
+                table_[hole] = other;
+                hole = slot;
+            }
+        }
+        table_[hole] = EMPTY;
+        used_--;
+    }
+    void rehash(size_t cap) {
+        std::vector<uint32_t> old;
+        old.swap(table_);
+        table_.assign(cap, EMPTY);
+        size_t mask = cap - 1;
+        for (uint32_t id : old) {
+            if (id == EMPTY) continue;
+            size_t slot = (size_t)nodes_[id].hash & mask;
+            while (table_[slot] != EMPTY) slot = (slot + 1) & mask;
+            table_[slot] = id;
+        }
+    }
+    void bubble_up(uint32_t id) {          // :227-242
+        size_t me = pos_[id];
+        while (me > 0) {
+            size_t par = (me - 1) / 2;
+            if (compare(nodes_[heap_[me]], nodes_[heap_[par]]) <= 0) break;
+            std::swap(heap_[me], heap_[par]);
+            pos_[heap_[me]] = (uint32_t)me;
+            pos_[heap_[par]] = (uint32_t)par;
+            me = par;
+        }
+    }
+    void bubble_down(uint32_t id) {        // :244-259
+        size_t me = pos_[id], size = heap_.size();
+        for (;;) {
+            size_t l = 2 * me + 1, r = l + 1, kid;
+            if (l >= size) break;
+            if (r >= size) kid = l;
+            else kid = compare(nodes_[heap_[l]], nodes_[heap_[r]]) > 0 ? l : r;
+            if (compare(nodes_[heap_[me]], nodes_[heap_[kid]]) >= 0) break;
+            std::swap(heap_[me], heap_[kid]);
+            pos_[heap_[me]] = (uint32_t)me;
+            pos_[heap_[kid]] = (uint32_t)kid;
+            me = kid;
+        }
+    }
+
+    const Model* model_;
+    int ws_;
+    std::vector<Entry> nodes_;
+    std::vector<uint32_t> pos_, heap_, recycle_, table_;
+    size_t used_ = 0;
+};
+
+}  // namespace
+
+struct ddo_solver {
+    Model* model = nullptr;
+    ddo_solver_config cfg{};
+    std::shared_ptr<Engine> engine;
+    NoDupFringe* fringe = nullptr;
+    // Critical (parallel.rs:32-81)
+    uint64_t explored = 0;
+    int64_t best_lb = I64_MIN;
+    int64_t best_ub = I64_MAX;
+    bool has_sol = false;
+    std::vector<ddo_decision> best_sol;
+    bool aborted = false;       // abort_proof
+    bool initialized = false;
+    bool finished = false;
+    ddo_counters counters{};
+    std::chrono::steady_clock::time_point t_start;
+    // scratch
+    std::vector<DDInput> inputs;
+    std::vector<Entry> items;
+    std::vector<HostResult> results;
+
+    ~ddo_solver() { delete fringe; }
+
+    long engine_width() const {
+        return cfg.width_policy == DDO_WIDTH_FIXED ? (long)cfg.width : (long)std::max(1, model->n);
+    }
+    /// WidthHeuristic::max_width (width.rs:168-170 / :399-401; path.len() == depth for MISP)
+    int width_of(const Entry& e) const {
+        if (cfg.width_policy == DDO_WIDTH_FIXED) return (int)cfg.width;
+        return std::max(1, model->n - e.depth);
+    }
+    bool budget_exhausted() const {
+        if (cfg.time_budget_s <= 0) return false;
+        double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        return el >= cfg.time_budget_s;
+    }
+
+    /// parallel.rs:368-385
+    void initialize() {
+        if (initialized) return;
+        initialized = true;
+        t_start = std::chrono::steady_clock::now();
+        CutsetBlock* root = new CutsetBlock();
+        root->ws = model->ws;
+        root->states.assign(model->ws, 0);
+        for (int i = 0; i < model->n; ++i) root->states[i / 64] |= 1ULL << (i % 64);
+        root->values.push_back(0);
+        Entry e{root, 0, 0, 0, I64_MAX, hash_words(root->states.data(), model->ws)};
+        block_ref(root);   // keep alive while pushing
+        fringe->push(e);
+        block_unref(root);
+    }
+
+    /// maybe_update_best (parallel.rs:446-453)
+    void maybe_update_best(const Entry& it, const HostResult& r) {
+        if (!r.hdr.has_best_exact) return;
+        int64_t v = r.hdr.best_exact_value;
+        if (v > best_lb) {
+            best_lb = v;
+            best_sol.clear();
+            materialize_path(it.block, it.row, best_sol);
+            const std::vector<uint32_t>& p = r.hdr.exact_same_as_best ? r.best_path : r.exact_path;
+            for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)});
+            has_sol = true;
+        }
+    }
+
+    /// enqueue_cutset (parallel.rs:456-469); at the root of a sharded run the cut-set is dealt
+    /// round-robin over the ranks in fringe order.
+    void enqueue_cutset(const Entry& it, HostResult& r) {
+        if (r.n_cutset == 0) return;
+        CutsetBlock* b = new CutsetBlock();
+        b->parent = it.block;
+        b->parent_row = it.row;
+        block_ref(it.block);
+        b->depth = it.depth + r.cs_path_len;
+        b->path_len = r.cs_path_len;
+        b->ws = model->ws;
+        b->states = std::move(r.cs_state);
+        b->values = std::move(r.cs_value);
+        b->paths = std::move(r.cs_path);
+        block_ref(b);
+        std::vector<int> order(r.n_cutset);
+        for (int j = 0; j < r.n_cutset; ++j) order[j] = j;
+        const bool deal = cfg.world_size > 1 && it.depth == 0 && it.block->parent == nullptr;
+        if (deal) {
+            std::sort(order.begin(), order.end(), [&](int x, int y) {
+                int64_t ux = std::min<int64_t>(it.ub, r.cs_ub[x]), uy = std::min<int64_t>(it.ub, r.cs_ub[y]);
+                if (ux != uy) return ux > uy;
+                if (b->values[x] != b->values[y]) return b->values[x] > b->values[y];
+                return model->compare_states(b->state(x), b->state(y)) > 0;
+            });
+        }
+        for (int k = 0; k < r.n_cutset; ++k) {
+            const int j = order[k];
+            if (deal && (k % cfg.world_size) != cfg.rank) continue;
+            int64_t ub = std::min<int64_t>(it.ub, r.cs_ub[j]);   // :460
+            if (ub > best_lb) {                                   // :461
+                Entry e{b, j, b->depth, b->values[j], ub, hash_words(b->state(j), model->ws)};
+                fringe->push(e);
+            }
+        }
+        block_unref(b);
+    }
+
+    /// One round of get_workload + process_one_node for up to nb_concurrent sub-problems.
+    int step() {
+        initialize();
+        if (finished) return 0;
+        if (aborted) return DDO_CUTOFF;
+        // ---- get_workload (parallel.rs:500-559)
+        if (fringe->empty()) {
+            if (cfg.world_size <= 1) best_ub = best_lb;   // :512-515
+            finished = true;
+            return 0;
+        }
+        if (budget_exhausted()) {                            // TimeBudget -> abort_search (:479-489)
+            aborted = true;
+            const Entry* top = fringe->peek();
+            best_ub = top ? top->ub : best_lb;
+            fringe->clear();
+            return DDO_CUTOFF;
+        }
+        items.clear();
+        const int B = std::max(1, cfg.nb_concurrent);
+        Entry nn;
+        while ((int)items.size() < B && fringe->pop(nn)) {
+            if (nn.ub <= best_lb) {                          // :531-535 nothing relevant is left
+                block_unref(nn.block);
+                fringe->clear();
+                break;
+            }
+            items.push_back(nn);
+            explored += 1;                                   // :553
+        }
+        if (items.empty()) {
+            if (cfg.world_size <= 1) best_ub = best_lb;
+            finished = true;
+            return 0;
+        }
+        if (cfg.world_size <= 1) best_ub = items[0].ub;     // best-first: the first popped bounds the rest
+        // ---- process_one_node on the device (parallel.rs:391-437), restricted + relaxed fused
+        inputs.resize(items.size());
+        const int64_t lim = (int64_t)1 << 40;
+        for (size_t i = 0; i < items.size(); ++i) {
+            DDInput& in = inputs[i];
+            std::memset(&in, 0, sizeof(in));
+            in.comp_type = CT_RESTRICTED;
+            in.flags = IN_FUSED | IN_FILTER_CUTSET;
+            in.width = width_of(items[i]);
+            in.value = (int32_t)items[i].value;
+            in.depth = items[i].depth;
+            in.best_lb = std::max(-lim, std::min(lim, best_lb));
+            std::memcpy(in.state, items[i].block->state(items[i].row), (size_t)model->ws * 8);
+        }
+        int rc = engine->run_batch(inputs.data(), (int)inputs.size(), results);
+        if (rc != DDO_OK) {
+            for (Entry& e : items) block_unref(e.block);
+            return rc;
+        }
+        int err = DDO_OK;
+        for (size_t i = 0; i < items.size() && err == DDO_OK; ++i) {
+            if (results[2 * i].hdr.status == ST_ERR_CAPACITY || results[2 * i + 1].hdr.status == ST_ERR_CAPACITY) {
+                // the shared output arena overflowed: redo this sub-problem on its own
+                std::vector<HostResult> solo;
+                int rc2 = engine->run_batch(&inputs[i], 1, solo);
+                if (rc2 != DDO_OK || solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY) {
+                    set_error("device compile failed: output arena too small for one sub-problem");
+                    err = DDO_ERR_CAPACITY;
+                    break;
+                }
+                results[2 * i] = std::move(solo[0]);
+                results[2 * i + 1] = std::move(solo[1]);
+            }
+            for (int k = 0; k < 2; ++k) {
+                HostResult* r = &results[2 * i + k];
+                if (r->hdr.status == ST_NOT_RUN) continue;
+                if (r->hdr.status != ST_OK) {
+                    set_error("device compile failed with status " + std::to_string(r->hdr.status));
+                    err = r->hdr.status == ST_CUTOFF ? DDO_CUTOFF : DDO_ERR_INTERNAL;
+                    break;
+                }
+                counters.nodes_expanded += r->hdr.nodes_expanded;
+                counters.arcs += r->hdr.arcs;
+                counters.layers += r->hdr.layers;
+                counters.compiles += 1;
+                maybe_update_best(items[i], *r);
+                const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;
+                if (k == 1 && !exact) enqueue_cutset(items[i], *r);
+            }
+        }
+        for (Entry& e : items) block_unref(e.block);
+        if (err != DDO_OK) return err;
+        return 1;
+    }
+};
+
+extern "C" {
+
+ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg) {
+    if (!model || !cfg) {
+        set_error("ddo_solver_create: null argument");
+        return nullptr;
+    }
+    if (cfg->width_policy == DDO_WIDTH_FIXED && cfg->width < 1) {
+        set_error("ddo_solver_create: FixedWidth must be >= 1");
+        return nullptr;
+    }
+    ddo_solver* s = new ddo_solver();
+    s->model = const_cast<Model*>(&model->m);
+    s->cfg = *cfg;
+    if (s->cfg.world_size < 1) s->cfg.world_size = 1;
+    if (s->cfg.rank < 0 || s->cfg.rank >= s->cfg.world_size) s->cfg.rank = 0;
+    s->engine = Engine::get(s->model, cfg->device, s->engine_width());
+    if (!s->engine) {
+        delete s;
+        return nullptr;
+    }
+    s->fringe = new NoDupFringe(s->model);
+    return s;
+}
+void ddo_solver_destroy(ddo_solver* s) { delete s; }
+
+int ddo_solver_step(ddo_solver* s) {
+    if (!s) return DDO_ERR_INVALID;
+    return s->step();
+}
+
+int ddo_solver_maximize(ddo_solver* s, ddo_completion* out) {
+    if (!s) return DDO_ERR_INVALID;
+    int rc;
+    while ((rc = s->step()) == 1) {
+    }
+    if (rc < 0) return rc;
+    if (out) {   // parallel.rs:604-606
+        out->is_exact = s->aborted ? 0 : 1;
+        out->has_best_value = s->has_sol ? 1 : 0;
+        out->best_value = s->has_sol ? s->best_lb : 0;
+    }
+    return rc == DDO_CUTOFF ? DDO_CUTOFF : DDO_OK;
+}
+int ddo_solver_best_value(const ddo_solver* s, int64_t* value) {
+    if (!s || !s->has_sol) return 0;
+    if (value) *value = s->best_lb;
+    return 1;
+}
+int ddo_solver_best_solution(const ddo_solver* s, ddo_decision* buf, size_t* len) {
+    if (!s || !s->has_sol) return 0;
+    if (!len) return DDO_ERR_INVALID;
+    if (!buf || *len < s->best_sol.size()) {
+        *len = s->best_sol.size();
+        return DDO_ERR_CAPACITY;
+    }
+    std::vector<ddo_decision> sol = s->best_sol;   // parallel.rs:605: sorted by variable
+    std::sort(sol.begin(), sol.end(), [](const ddo_decision& a, const ddo_decision& b) { return a.variable < b.variable; });
+    std::memcpy(buf, sol.data(), sol.size() * sizeof(ddo_decision));
+    *len = sol.size();
+    return 1;
+}
+int64_t ddo_solver_best_lower_bound(const ddo_solver* s) { return s->best_lb; }
+int64_t ddo_solver_best_upper_bound(const ddo_solver* s) { return s->best_ub; }
+int ddo_solver_set_primal(ddo_solver* s, int64_t value, const ddo_decision* solution, size_t len) {
+    if (!s) return DDO_ERR_INVALID;
+    if (value > s->best_lb) {   // parallel.rs:630-636
+        s->best_lb = value;
+        s->best_sol.assign(solution, solution + len);
+        s->has_sol = true;
+    }
+    return DDO_OK;
+}
+double ddo_solver_gap(const ddo_solver* s) {   // solver.rs:80-93
+    int64_t ub = s->best_ub, lb = s->best_lb;
+    if (ub == I64_MAX || lb == I64_MIN) return 1.0;
+    double aub = std::abs((double)ub), alb = std::abs((double)lb);
+    double u = std::max(aub, alb), l = std::min(aub, alb);
+    if (u == 0.0) return 0.0;
+    return (u - l) / u;
+}
+uint64_t ddo_solver_explored(const ddo_solver* s) { return s->explored; }
+int ddo_solver_counters(const ddo_solver* s, ddo_counters* out) {
+    if (!s || !out) return DDO_ERR_INVALID;
+    *out = s->counters;
+    return DDO_OK;
+}
+int ddo_solver_import_lower_bound(ddo_solver* s, int64_t best_lb) {
+    if (!s) return DDO_ERR_INVALID;
+    // the value comes from another rank's incumbent: the bound is valid here, its solution stays there
+    if (best_lb > s->best_lb) {
+        s->best_lb = best_lb;
+        s->has_sol = false;
+        s->best_sol.clear();
+    }
+    return DDO_OK;
+}
+uint64_t ddo_solver_fringe_len(const ddo_solver* s) {
+    if (!s) return 0;
+    if (!s->initialized) return 1;
+    return s->fringe->len();
+}
+int64_t ddo_solver_fringe_best_ub(const ddo_solver* s) {
+    const Entry* top = s->fringe->peek();
+    return top ? top->ub : I64_MIN;
+}
+int ddo_solver_device_time(const ddo_solver* s, double* kernel_ms, uint64_t* launches) {
+    if (!s) return DDO_ERR_INVALID;
+    if (kernel_ms) *kernel_ms = s->engine->kernel_ms();
+    if (launches) *launches = s->engine->launches();
+    return DDO_OK;
+}
+
+}  // extern "C"

@@ -434,8 +434,8 @@ DDO_DEV uint32_t dedup_insert(const DDCtx<WS>& c, int nxt, uint32_t cd, const ui
     const uint32_t mine = (tag << 20) | cd;
     uint32_t slot = (uint32_t)h & (uint32_t)mask;
     const uint64_t* st = c.cstate[nxt];
-    for (;;) {
-        uint32_t e = *(volatile uint32_t*)&c.table[slot];
+    for (int probes = 0; probes <= mask; ++probes) {   // bounded: a full table is an internal error, not a hang
+        uint32_t e = LD_U32(&c.table[slot]);
         if (e == TAB_EMPTY) {
             e = TAB_CAS(&c.table[slot], TAB_EMPTY, mine);
             if (e == TAB_EMPTY) return cd;
@@ -448,6 +448,8 @@ DDO_DEV uint32_t dedup_insert(const DDCtx<WS>& c, int nxt, uint32_t cd, const ui
         }
         slot = (slot + 1) & (uint32_t)mask;
     }
+    c.sh->status = ST_ERR_INTERNAL;
+    return cd;
 }
 
 /// read-only probe (recycled-merge detection, clean.rs:830): candidate holding state s, or NONE32
@@ -457,7 +459,7 @@ DDO_DEV uint32_t dedup_find(const DDCtx<WS>& c, int buf, const uint64_t* s, int 
     const uint32_t tag = (uint32_t)(h >> 52);
     uint32_t slot = (uint32_t)h & (uint32_t)mask;
     const uint64_t* st = c.cstate[buf];
-    for (;;) {
+    for (int probes = 0; probes <= mask; ++probes) {
         uint32_t e = c.table[slot];
         if (e == TAB_EMPTY) return NONE32;
         if ((e >> 20) == tag) {
@@ -468,6 +470,7 @@ DDO_DEV uint32_t dedup_find(const DDCtx<WS>& c, int buf, const uint64_t* s, int 
         }
         slot = (slot + 1) & (uint32_t)mask;
     }
+    return NONE32;
 }
 
 DDO_DEV int table_size_for(int ncand_max, int cap) {
@@ -1236,9 +1239,10 @@ inline size_t dd_lds_bytes(int table_cap_lds, int npad, int nthreads) {
     return (b + 15) & ~(size_t)15;
 }
 
-/// Binds slot `slot` of the workspace and the LDS block `lds` to a context.
-template <int WS>
-DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned char* lds, uint32_t* table, int nthreads) {
+/// Binds slot `slot` of the workspace and the LDS block `lds` to a context.  TLDS: the dedup
+/// table lives in LDS (else in HBM: P.gtable, for widths whose table exceeds 160 KB of LDS).
+template <int WS, bool TLDS>
+DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned char* lds, int nthreads) {
     c.n = P.n;
     c.npad = P.npad;
     c.unit_weights = P.unit_weights;
@@ -1268,10 +1272,11 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.cs_pop = P.cs_pop + s * capN;
     c.table_cap = P.table_cap;
     unsigned char* p = lds;
-    if (table) c.table = table;
-    else {
+    if (TLDS) {
         c.table = (uint32_t*)p;
         p += (size_t)P.table_cap * 4;
+    } else {
+        c.table = P.gtable + s * (size_t)P.table_cap;
     }
     c.cnt = (int32_t*)p;
     p += (size_t)P.npad * 4;

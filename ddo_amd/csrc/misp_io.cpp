@@ -1,0 +1,141 @@
+// =============================================================================
+// misp_io.cpp -- DIMACS-like .clq reader with the grammar and quirks of
+// /root/reference/ddo/examples/misp/main.rs:258-317:
+//   every line is trimmed, empty lines are skipped;
+//   `^c\s.*$`                          comment
+//   `^p\s+edge\s+(\d+)\s+(\d+)$`       n vertices: all rows = {0..n-1}, all weights = 1
+//   `^n\s+(\d+)\s+(-?\d+)`             weight[id-1] = w          (prefix match)
+//   `^e\s+(\d+)\s+(\d+)`               clear bit dst in row src and vice versa (1-based, prefix match)
+//   anything else                      format error
+// The rows are therefore COMPLEMENT adjacency rows and keep their own diagonal bit.
+// =============================================================================
+#include <cctype>
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+#include "engine.hpp"
+
+namespace ddo_hip {
+namespace {
+struct Cursor {
+    const std::string& s;
+    size_t i = 0;
+    explicit Cursor(const std::string& s) : s(s) {}
+    bool lit(char c) {
+        if (i < s.size() && s[i] == c) { ++i; return true; }
+        return false;
+    }
+    bool word(const char* w) {
+        size_t k = i;
+        for (; *w; ++w, ++k)
+            if (k >= s.size() || s[k] != *w) return false;
+        i = k;
+        return true;
+    }
+    bool spaces1() {  // \s+
+        size_t k = i;
+        while (k < s.size() && std::isspace((unsigned char)s[k])) ++k;
+        if (k == i) return false;
+        i = k;
+        return true;
+    }
+    bool digits(unsigned long long& out) {  // \d+
+        size_t k = i;
+        unsigned long long v = 0;
+        while (k < s.size() && std::isdigit((unsigned char)s[k])) {
+            v = v * 10 + (unsigned)(s[k] - '0');
+            ++k;
+        }
+        if (k == i) return false;
+        i = k;
+        out = v;
+        return true;
+    }
+    bool sdigits(long long& out) {  // -?\d+
+        size_t save = i;
+        bool neg = lit('-');
+        unsigned long long v;
+        if (!digits(v)) { i = save; return false; }
+        out = neg ? -(long long)v : (long long)v;
+        return true;
+    }
+    bool end() const { return i == s.size(); }
+};
+}  // namespace
+
+bool read_misp_clq(const std::string& path, int& n, std::vector<uint64_t>& rows, std::vector<int64_t>& weights) {
+    std::ifstream f(path);
+    if (!f) {
+        set_error("io error: cannot open " + path);
+        return false;
+    }
+    n = 0;
+    int ws = 0;
+    rows.clear();
+    weights.clear();
+    std::string raw;
+    size_t lineno = 0;
+    while (std::getline(f, raw)) {
+        ++lineno;
+        size_t b = 0, e = raw.size();
+        while (b < e && std::isspace((unsigned char)raw[b])) ++b;
+        while (e > b && std::isspace((unsigned char)raw[e - 1])) --e;
+        if (b == e) continue;
+        const std::string line = raw.substr(b, e - b);
+        {   // comment
+            Cursor c(line);
+            if (c.lit('c') && c.i < line.size() && std::isspace((unsigned char)line[c.i])) continue;
+        }
+        {   // problem declaration (anchored at both ends)
+            Cursor c(line);
+            unsigned long long nv, ne;
+            if (c.lit('p') && c.spaces1() && c.word("edge") && c.spaces1() && c.digits(nv) && c.spaces1() && c.digits(ne) &&
+                c.end()) {
+                n = (int)nv;
+                ws = (n + 63) / 64;
+                rows.assign((size_t)n * ws, 0);
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) rows[(size_t)i * ws + j / 64] |= 1ULL << (j % 64);
+                weights.assign(n, 1);
+                continue;
+            }
+        }
+        {   // node weight
+            Cursor c(line);
+            unsigned long long id;
+            long long w;
+            if (c.lit('n') && c.spaces1() && c.digits(id) && c.spaces1() && c.sdigits(w)) {
+                if (id < 1 || id > (unsigned long long)n) {
+                    set_error("ill formed instance: vertex id out of range at line " + std::to_string(lineno));
+                    return false;
+                }
+                weights[id - 1] = w;
+                continue;
+            }
+        }
+        {   // edge
+            Cursor c(line);
+            unsigned long long a, d;
+            if (c.lit('e') && c.spaces1() && c.digits(a) && c.spaces1() && c.digits(d)) {
+                if (a < 1 || d < 1 || a > (unsigned long long)n || d > (unsigned long long)n) {
+                    set_error("ill formed instance: vertex id out of range at line " + std::to_string(lineno));
+                    return false;
+                }
+                size_t src = a - 1, dst = d - 1;
+                rows[src * ws + dst / 64] &= ~(1ULL << (dst % 64));
+                rows[dst * ws + src / 64] &= ~(1ULL << (src % 64));
+                continue;
+            }
+        }
+        set_error("ill formed instance (line " + std::to_string(lineno) + ")");
+        return false;
+    }
+    if (n <= 0) {
+        set_error("ill formed instance: no `p edge` line");
+        return false;
+    }
+    return true;
+}
+
+}  // namespace ddo_hip

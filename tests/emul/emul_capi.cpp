@@ -49,7 +49,7 @@ int pick_ws(int ws) {
 template <int WS>
 void run(Emul& e, const DDInput& in, DDResult* res2) {
     DDCtx<WS> c;
-    dd_bind<WS>(c, e.P, 0, e.lds.data(), nullptr, e.nthreads);
+    dd_bind<WS, true>(c, e.P, 0, e.lds.data(), e.nthreads);
     run_work_item<WS>(c, in, res2);
 }
 }  // namespace
