@@ -1,0 +1,103 @@
+"""CPU suite, part 2: the C-ABI library loads, exports every symbol include/ddo_hip.h declares, refuses to
+run without a GPU (no CPU fallback), and its host-side logic (parser, ranking) agrees with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ddo_amd
+from tests.conftest import ROOT, data_path
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ddo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddo_[a-z_0-9]+)\s*\(", text)) - {"ddo_cutset_cb"})
+
+
+def test_library_exports_every_declared_symbol():
+    L = ddo_amd.lib()
+    declared = _declared_functions()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(L, name), f"libddo_hip.so does not export {name}"
+    assert sorted(ddo_amd.ABI_SYMBOLS) == declared
+
+
+def test_product_library_does_not_link_the_oracle():
+    out = os.popen(f"nm -D --defined-only {ddo_amd.library_path()} | grep -i oracle").read()
+    assert out.strip() == ""
+    for f in os.listdir(os.path.join(ROOT, "ddo_amd", "csrc")):
+        src = open(os.path.join(ROOT, "ddo_amd", "csrc", f), errors="replace").read()
+        assert "oracle/" not in src.replace("parity oracle", "") or f.endswith(".md"), f
+
+
+@pytest.mark.skipif(ddo_amd.device_count() > 0, reason="checks the no-GPU behaviour")
+def test_fails_loudly_without_a_gpu():
+    model = ddo_amd.Misp.read_instance(data_path("misp", "johnson8-2-4.clq"))
+    with pytest.raises(ddo_amd.DdoError, match="no HIP device"):
+        ddo_amd.Mdd(model, 10)
+    with pytest.raises(ddo_amd.DdoError, match="no HIP device"):
+        ddo_amd.ParallelSolver(model, ddo_amd.FixedWidth(10))
+
+
+@pytest.mark.parametrize("name", ["johnson8-2-4", "MANN_a9", "brock200_2", "p_hat300-1", "brock400_1", "c-fat500-1"])
+def test_clq_reader_matches_the_oracle_reader(oracle, name):
+    path = data_path("misp", name + ".clq")
+    inst = oracle.misp(path)
+    model = ddo_amd.Misp.read_instance(path)
+    rows, w = model.export()
+    assert (model.n, model.ws) == (inst.n, inst.ws)
+    assert np.array_equal(rows, inst.rows) and np.array_equal(w, inst.weights)
+    assert np.array_equal(model.initial_state(), inst.root_state()) and model.initial_value() == 0
+    # rows are complement adjacency rows and keep their diagonal bit (examples/misp/main.rs:280-310)
+    for i in (0, model.n // 2, model.n - 1):
+        assert (int(rows[i * model.ws + i // 64]) >> (i % 64)) & 1
+
+
+def test_clq_reader_grammar(tmp_path):
+    def load(text):
+        p = tmp_path / "x.clq"
+        p.write_text(text)
+        return ddo_amd.Misp.read_instance(str(p))
+
+    m = load("c a comment\n\n  p edge 3 1  \nn 2 -5\ne 1 3 trailing ok\n")
+    rows, w = m.export()
+    assert list(w) == [1, -5, 1] and [int(r) for r in rows] == [0b011, 0b111, 0b110]
+    for bad in ["p edge 3 1\nx 1 2\n", "c\np edge 3 1\n", "p edge 3 1 extra\n", "e 1 2\n", "p edge 2 1\ne 1 5\n"]:
+        with pytest.raises(ddo_amd.DdoError):
+            load(bad)
+
+
+def test_state_ranking_is_popcount_then_member_order():
+    """MispRanking (examples/misp/main.rs:205-208) == (len, BitSet::cmp); checked against a naive restatement."""
+    m = ddo_amd.Misp.read_instance(data_path("misp", "p_hat300-1.clq"))
+    rng = np.random.RandomState(3)
+
+    def members(s):
+        return [i for i in range(m.n) if (int(s[i // 64]) >> (i % 64)) & 1]
+
+    for _ in range(300):
+        a = rng.randint(0, 1 << 62, size=m.ws).astype(np.uint64) & rng.randint(0, 1 << 62, size=m.ws).astype(np.uint64)
+        b = a.copy() if rng.rand() < 0.2 else rng.randint(0, 1 << 62, size=m.ws).astype(np.uint64) & a
+        if rng.rand() < 0.5:
+            b[rng.randint(m.ws)] ^= np.uint64(1) << np.uint64(rng.randint(60))
+        a[-1] &= np.uint64((1 << (m.n % 64)) - 1)
+        b[-1] &= np.uint64((1 << (m.n % 64)) - 1)
+        ma, mb = members(a), members(b)
+        expect = (len(ma) > len(mb)) - (len(ma) < len(mb)) or (ma > mb) - (ma < mb)
+        got = m.compare(a, b)
+        assert (got > 0) - (got < 0) == expect
+
+
+def test_wire_structs_match_the_device_header():
+    """tests/dd_wire.py mirrors ddo_amd/csrc/dd_types.h; the emulation library reports the C sizes."""
+    from tests.dd_wire import DDInput, DDResult
+    from tests.emul_binding import build_emul
+
+    L = ctypes.CDLL(build_emul())
+    L.emul_sizeof_input.restype = ctypes.c_uint64
+    L.emul_sizeof_result.restype = ctypes.c_uint64
+    assert L.emul_sizeof_input() == ctypes.sizeof(DDInput) and L.emul_sizeof_result() == ctypes.sizeof(DDResult)
