@@ -110,6 +110,21 @@ struct EngineParams {
     uint8_t* arena;
     uint64_t arena_cap;
     const int32_t* cutoff_flag; // device-visible flag, polled once per layer
+    // ---- in-place engine (misp_dd_inplace.hpp): persistent node slots instead of per-layer candidate arrays
+    int32_t capS;              // node slots per DD (2*width + 8)
+    int32_t capW;              // work-list capacity (width + 4)
+    int32_t tab2_cap;          // persistent dedup table slots (power of two, HBM)
+    int32_t vbase_off;         // lowest reachable value relative to the residual value (sum of negative weights)
+    uint64_t* s_state;         // [slot][ws][capS]  node states, word major
+    uint64_t* s_path;          // [slot][ws][capS]  decisions of the best path to the node, one bit per layer
+    uint64_t* s_hash;          // [slot][capS]      cached state hash
+    uint64_t* s_wkey;          // [slot][capS]      (value ^ 2^31) << 32 | incoming-arc code of the current transition
+    uint32_t* s_tab;           // [slot][tab2_cap]  open-addressing table: tag:12 | node slot:20, tombstones
+    uint32_t* s_ev;            // [slot][ev_cap]    per-transition event records for the backward pass
+    uint32_t* s_evoff;         // [slot][max_layers+1][4] offsets / counts per transition
+    uint64_t ev_cap;
+    uint32_t* s_cs_slot;       // [slot][capW]      node slots of the last exact layer (cut-set)
+    uint64_t* s_cs_path;       // [slot][ws][capW]  their path bits
 };
 
 // node flag bits (node_flags.rs:48-185 restricted to what the device needs)

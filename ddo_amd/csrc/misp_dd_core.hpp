@@ -31,6 +31,8 @@
 #if defined(DDO_HOST_EMULATION)
 // ---------------------------------------------------------------- host emulation (tests only)
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #define DDO_DEV inline
 #define PAR_BEGIN for (int tid = 0; tid < NT; ++tid) {
@@ -239,9 +241,9 @@ DDO_DEV int lin2cand(int j, int nprev, int capN) { return j < nprev ? j : capN +
 /// 48-bit primary ranking key: (value_top, popcount) -- clean.rs:803-808 then MispRanking's len().
 DDO_DEV uint64_t k1_of(uint64_t key, uint32_t pop) { return ((key >> 32) << 16) | (uint64_t)(pop & 0xFFFFu); }
 
-/// Workgroup exclusive scan of a[0..NT) (Hillis-Steele, double buffered); total in sh->scan_total.
-template <int WS>
-DDO_DEV void block_exclusive_scan(DDCtx<WS>& c, int32_t* a, int32_t* tmp) {
+/// Workgroup exclusive scan of a[0..NT) (Hillis-Steele, double buffered); total in *total.
+template <class Ctx>
+DDO_DEV void block_exclusive_scan_any(Ctx& c, int32_t* a, int32_t* tmp, int32_t* total) {
     DD_TID_SETUP(c)
     int32_t* src = a;
     int32_t* dst = tmp;
@@ -257,7 +259,7 @@ DDO_DEV void block_exclusive_scan(DDCtx<WS>& c, int32_t* a, int32_t* tmp) {
     PAR_BEGIN
     int32_t incl = src[tid];
     int32_t excl = tid ? src[tid - 1] : 0;
-    if (tid == NT - 1) c.sh->scan_total = incl;
+    if (tid == NT - 1) *total = incl;
     dst[tid] = excl;
     PAR_END
     if (dst != a) {
@@ -265,6 +267,10 @@ DDO_DEV void block_exclusive_scan(DDCtx<WS>& c, int32_t* a, int32_t* tmp) {
         a[tid] = dst[tid];
         PAR_END
     }
+}
+template <int WS>
+DDO_DEV void block_exclusive_scan(DDCtx<WS>& c, int32_t* a, int32_t* tmp) {
+    block_exclusive_scan_any(c, a, tmp, &c.sh->scan_total);
 }
 
 /// Exact K-th largest (1 <= K < nU) among the unique candidates of buffer `cur` by the total
@@ -858,6 +864,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (myuniq) LDS_ADD_I32(&sh->nU, myuniq);
         if (tid == 0) sh->nodes += (uint64_t)n;
         PAR_END
+#if defined(DDO_HOST_EMULATION)
+        if (getenv("DD_TRACE")) std::printf("E1 L=%d var=%d n=%d arcs=%llu nU_next=%d squash=%d\n", L, var, n, (unsigned long long)sh->arcs, sh->nU, (int)squash);
+#endif
 
         cur = nxt;
         nprev = n;

@@ -1,0 +1,1313 @@
+// =============================================================================
+// misp_dd_inplace.hpp -- second-generation device engine: IN-PLACE layers.
+//
+// Same contract and same results as misp_dd_core.hpp (clean.rs:345-876 with the
+// MISP callbacks of examples/misp/main.rs:62-209), different data structure.
+//
+// Observation (rocprof, profiles/r01): `next_variable` (main.rs:109-143) picks the
+// vertex that occurs in the FEWEST states of the layer, so ~93 % of the nodes of a
+// layer do not contain the branching vertex: their only child is the NO-child with
+// the very same state, value and best path (transition(s, NO) == s, cost 0).  The
+// first engine copied them anyway (read 56 B, write 56 B, re-hash, re-select: 8.5x
+// the algorithmic HBM traffic).  Here a node lives in a persistent SLOT:
+//   * an unaffected node is not touched at all: it simply stays alive;
+//   * an affected node s is updated in place (NO-child = s minus the vertex: one word
+//     rewritten, hash patched incrementally) and spawns its YES-child into a free slot;
+//   * only changed / new states go through the (persistent, HBM) dedup table;
+//   * the ranking keys (value, popcount) of all slots live in LDS, so the exact top-K
+//     selection of _restrict/_relax never leaves the CU except for lexicographic ties;
+//   * the best path to a node is a bit string (one decision bit per layer) stored with
+//     the node, copied only when a node is created or its best parent changes -- no
+//     per-layer parent arrays, no path walks;
+//   * the backward pass for local bounds (clean.rs:448-475) replays per-transition EVENT
+//     lists (affected parents, deleted nodes, merged node) instead of per-layer arc arrays:
+//     an unaffected node keeps its value_bot without any work.
+// Written in the same PAR_BEGIN/PAR_END phase style, so tests/ can run it as a lock-step
+// host emulation.
+// =============================================================================
+#pragma once
+#include "misp_dd_core.hpp"
+
+namespace ddo_hip {
+
+constexpr uint32_t T2_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t T2_TOMB = 0xFFFFFFFEu;
+constexpr uint32_t EV_CREATED = 0x80000000u;  // flag on a YES target: the slot was created by this arc
+constexpr int KEY_POP_BITS = 11;              // key32 = (value - vbase) << 11 | popcount
+constexpr uint32_t KEY_POP_MASK = (1u << KEY_POP_BITS) - 1;
+
+#if defined(DDO_HOST_EMULATION)
+#define LDS_OR_U32(p, v) emu_atomic_or<uint32_t>((p), (v))
+#define LDS_AND_U32(p, v) emu_atomic_and<uint32_t>((p), (v))
+#define LDS_MAX_U32(p, v) emu_atomic_max<uint32_t>((p), (v))
+#define GLB_ST_U32(p, v) (*(p) = (v))
+#else
+#define LDS_OR_U32(p, v) atomicOr((p), (v))
+#define LDS_AND_U32(p, v) atomicAnd((p), (v))
+#define LDS_MAX_U32(p, v) atomicMax((p), (v))
+#define GLB_ST_U32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
+struct DD2Shared {
+    int32_t work, status, cutoff;
+    uint32_t varkey;
+    int32_t nlive;
+    int32_t nwl, nrec, nnew, nvict, nfl;
+    int32_t npruned, nyes, ndup;
+    int32_t scan_total, sel_digit, sel_above, sel_bucket;
+    int32_t tab_used;
+    int32_t hiw;            // slots [0, hiw) have been used at least once
+    int32_t merged_slot, recycled, xslot, free_slot;
+    int32_t ncut, ncut2;
+    uint32_t recycled_merges;
+    uint32_t kand, kor, pivKey;
+    uint32_t gs[64];
+    uint64_t pivLex[MAX_WS];
+    uint64_t merged[MAX_WS];
+    uint64_t mergedKey;     // key32 << 32 | slot of the best victim
+    uint64_t bestKey, bestExactKey;
+    uint64_t nodes, arcs;
+    uint64_t arena_off;
+    uint64_t ev_pos;
+    int32_t xcand[64];
+};
+
+template <int WS>
+struct DD2Ctx {
+    int n, npad, unit_weights;
+    const uint64_t* adj;
+    const int32_t* weight;
+    int capS, capW, max_layers, nbw;
+    // HBM, per engine slot
+    uint64_t* st;      // [ws][capS]
+    uint64_t* pb;      // [ws][capS]
+    uint64_t* hsh;     // [capS]
+    uint32_t* tab;
+    int tab_cap;
+    uint32_t* ev;
+    uint64_t ev_cap;
+    uint32_t* evoff;   // [max_layers][8]: aff_off_lo, aff_off_hi, n_aff, del_off_lo, del_off_hi, n_del, merged|dup.., var
+    int32_t* lvar;
+    int32_t* ldup;     // [max_layers][2] (dup from, dup to)
+    int32_t* lmerge;   // [max_layers]   merged slot (-1 none)
+    uint32_t* cs_slot;
+    uint64_t* cs_state;
+    uint64_t* cs_path;
+    int32_t* cs_value;
+    uint32_t* cs_pop;
+    // LDS
+    uint32_t* key32;   // capS   (aliased by the value_bot array of the backward pass)
+    uint32_t* live;    // nbw
+    uint32_t* inex;    // nbw
+    uint32_t* okb;     // nbw
+    uint32_t* fresh;   // nbw
+    int32_t* cnt;      // npad
+    uint32_t* hist;    // 2048
+    uint16_t* wl;      // capW
+    uint16_t* fl;      // capW   (wl+fl together are reused as int32 tmp[capW] in the backward pass)
+    int32_t* tcount;   // NT
+    int32_t* tcount2;  // NT
+    DD2Shared* sh;
+    uint8_t* arena;
+    uint64_t arena_cap;
+    unsigned long long* arena_head;
+    const int32_t* cutoff_flag;
+    int vbase_off;
+    int NT;
+#if !defined(DDO_HOST_EMULATION)
+    int tid_;
+#endif
+};
+
+DDO_DEV bool bm_test(const uint32_t* bm, int s) { return (bm[s >> 5] >> (s & 31)) & 1u; }
+DDO_DEV void bm_set(uint32_t* bm, int s) { LDS_OR_U32(&bm[s >> 5], 1u << (s & 31)); }
+DDO_DEV void bm_clr(uint32_t* bm, int s) { LDS_AND_U32(&bm[s >> 5], ~(1u << (s & 31))); }
+DDO_DEV void bm_put(uint32_t* bm, int s, bool v) { if (v) bm_set(bm, s); else bm_clr(bm, s); }
+
+/// per-word mix of the incremental state hash: H(state) = XOR_k mixw(word_k, k)
+DDO_DEV uint64_t mixw(uint64_t w, int k) {
+    uint64_t x = w + 0x9E3779B97F4A7C15ULL * (uint64_t)(k + 1);
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+template <int WS>
+DDO_DEV uint64_t hash2_state(const uint64_t* s) {
+    uint64_t h = 0;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) h ^= mixw(s[k], k);
+    return h;
+}
+
+template <int WS>
+DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
+#pragma unroll
+    for (int k = 0; k < WS; ++k) s[k] = LD_U64(&c.st[(size_t)k * c.capS + slot]);
+}
+
+/// insert node `x` (hash h, state in HBM) -> x when new, else the live node holding the same state
+template <int WS>
+DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint64_t h, const uint64_t* s) {
+    const uint32_t mask = (uint32_t)c.tab_cap - 1;
+    const uint32_t tag = (uint32_t)(h >> 52);
+    const uint32_t mine = (tag << 20) | (uint32_t)x;
+    uint32_t slot = (uint32_t)h & mask;
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        uint32_t e = LD_U32(&c.tab[slot]);
+        if (e == T2_EMPTY) {
+            e = TAB_CAS(&c.tab[slot], T2_EMPTY, mine);
+            if (e == T2_EMPTY) return x;
+        }
+        if (e != T2_TOMB && (e >> 20) == tag) {
+            const int w = (int)(e & 0xFFFFFu);
+            bool eq = true;
+            for (int k = 0; k < WS && eq; ++k) eq = LD_U64(&c.st[(size_t)k * c.capS + w]) == s[k];
+            if (eq) return w;
+        }
+        slot = (slot + 1) & mask;
+    }
+    c.sh->status = ST_ERR_INTERNAL;
+    return x;
+}
+/// insert without duplicate check (table rebuild: all live states are distinct)
+template <int WS>
+DDO_DEV void tab2_insert_unique(const DD2Ctx<WS>& c, int x, uint64_t h) {
+    const uint32_t mask = (uint32_t)c.tab_cap - 1;
+    const uint32_t mine = ((uint32_t)(h >> 52) << 20) | (uint32_t)x;
+    uint32_t slot = (uint32_t)h & mask;
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        if (LD_U32(&c.tab[slot]) == T2_EMPTY && TAB_CAS(&c.tab[slot], T2_EMPTY, mine) == T2_EMPTY) return;
+        slot = (slot + 1) & mask;
+    }
+    c.sh->status = ST_ERR_INTERNAL;
+}
+/// tombstone the entry of node x
+template <int WS>
+DDO_DEV void tab2_remove(const DD2Ctx<WS>& c, int x, uint64_t h) {
+    const uint32_t mask = (uint32_t)c.tab_cap - 1;
+    const uint32_t mine = ((uint32_t)(h >> 52) << 20) | (uint32_t)x;
+    uint32_t slot = (uint32_t)h & mask;
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        uint32_t e = LD_U32(&c.tab[slot]);
+        if (e == mine) {
+            GLB_ST_U32(&c.tab[slot], T2_TOMB);
+            return;
+        }
+        if (e == T2_EMPTY) break;
+        slot = (slot + 1) & mask;
+    }
+    c.sh->status = ST_ERR_INTERNAL;
+}
+/// node holding state s (hash h), or -1
+template <int WS>
+DDO_DEV int tab2_find(const DD2Ctx<WS>& c, uint64_t h, const uint64_t* s) {
+    const uint32_t mask = (uint32_t)c.tab_cap - 1;
+    const uint32_t tag = (uint32_t)(h >> 52);
+    uint32_t slot = (uint32_t)h & mask;
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        uint32_t e = LD_U32(&c.tab[slot]);
+        if (e == T2_EMPTY) return -1;
+        if (e != T2_TOMB && (e >> 20) == tag) {
+            const int w = (int)(e & 0xFFFFFu);
+            bool eq = true;
+            for (int k = 0; k < WS && eq; ++k) eq = LD_U64(&c.st[(size_t)k * c.capS + w]) == s[k];
+            if (eq) return w;
+        }
+        slot = (slot + 1) & mask;
+    }
+    return -1;
+}
+
+template <int WS>
+DDO_DEV int32_t rub2_of(const DD2Ctx<WS>& c, const uint64_t* s) {
+    int32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        uint64_t x = s[k];
+        while (x) {
+            int b = dd_ctz(x);
+            sum += c.weight[k * 64 + b];
+            x &= x - 1;
+        }
+    }
+    return sum;
+}
+
+/// full-order "node a ranks above node b": (key32, lexkey words)
+template <int WS>
+DDO_DEV bool ranks_above2(const DD2Ctx<WS>& c, int a, int b) {
+    uint32_t ka = c.key32[a], kb = c.key32[b];
+    if (ka != kb) return ka > kb;
+    for (int k = 0; k < WS; ++k) {
+        uint64_t la = dd_brev(~c.st[(size_t)k * c.capS + a]);
+        uint64_t lb = dd_brev(~c.st[(size_t)k * c.capS + b]);
+        if (la != lb) return la > lb;
+    }
+    return false;
+}
+
+/// Exact K-th largest among the live nodes by (value, popcount, member order); result in
+/// sh->pivKey / sh->pivLex (unresolved low digits zero): node kept <=> key >= pivot.
+template <int WS>
+DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
+    DD_TID_SETUP(c)
+    DD2Shared* sh = c.sh;
+    const int hi = sh->hiw;
+    PAR_BEGIN
+    if (tid == 0) {
+        sh->kand = 0xFFFFFFFFu;
+        sh->kor = 0;
+    }
+    PAR_END
+    PAR_BEGIN
+    uint32_t a = 0xFFFFFFFFu, o = 0;
+    for (int s = tid; s < hi; s += NT)
+        if (bm_test(c.live, s)) {
+            uint32_t k = c.key32[s];
+            a &= k;
+            o |= k;
+        }
+    if (a != 0xFFFFFFFFu || o != 0) {
+        LDS_AND_U32(&sh->kand, a);
+        LDS_OR_U32(&sh->kor, o);
+    }
+    PAR_END
+    int need = K;
+    bool done = false;
+    const uint32_t diff = sh->kand ^ sh->kor;
+    uint32_t piv = 0;
+    // digits of key32, most significant first: bits 22..31, 11..21, 0..10
+    const int dshift[3] = {22, 11, 0};
+    const int dbits[3] = {10, 11, 11};
+    for (int d = 0; d < 3 && !done; ++d) {
+        const int shift = dshift[d];
+        const uint32_t dmask = (1u << dbits[d]) - 1;
+        if (((diff >> shift) & dmask) == 0) {
+            piv |= sh->kand & (dmask << shift);
+            continue;
+        }
+        const int nb = 1 << dbits[d];
+        PAR_BEGIN
+        for (int i = tid; i < nb; i += NT) c.hist[i] = 0;
+        PAR_END
+        PAR_BEGIN
+        const int up = shift + dbits[d];
+        for (int s = tid; s < hi; s += NT)
+            if (bm_test(c.live, s)) {
+                uint32_t k = c.key32[s];
+                bool active = up >= 32 || (k >> up) == (piv >> up);
+                if (active) LDS_ADD_U32(&c.hist[(k >> shift) & dmask], 1u);
+            }
+        PAR_END
+        PAR_BEGIN  // group sums: 64 groups of nb/64 bins
+        if (tid < 64) {
+            const int g = nb >> 6;
+            uint32_t sum = 0;
+            for (int i = 0; i < g; ++i) sum += c.hist[tid * g + i];
+            sh->gs[tid] = sum;
+        }
+        PAR_END
+        PAR_BEGIN
+        const int g = nb >> 6;
+        for (int b = tid; b < nb; b += NT) {
+            const int grp = b / g;
+            int above = 0;
+            for (int x = grp + 1; x < 64; ++x) above += (int)sh->gs[x];
+            for (int x = b + 1; x < (grp + 1) * g; ++x) above += (int)c.hist[x];
+            const int mine = (int)c.hist[b];
+            if (above < need && need <= above + mine) {
+                sh->sel_digit = b;
+                sh->sel_above = above;
+                sh->sel_bucket = mine;
+            }
+        }
+        PAR_END
+        piv |= (uint32_t)sh->sel_digit << shift;
+        need -= sh->sel_above;
+        if (need == sh->sel_bucket) done = true;
+    }
+    uint64_t pivLex[WS];
+#pragma unroll
+    for (int k = 0; k < WS; ++k) pivLex[k] = 0;
+    for (int qd = 0; qd < 8 * WS && !done; ++qd) {
+        const int wj = qd >> 3;
+        const int shift = 8 * (7 - (qd & 7));
+        PAR_BEGIN
+        if (tid < 256) c.hist[tid] = 0;
+        PAR_END
+        PAR_BEGIN
+        for (int s = tid; s < hi; s += NT) {
+            if (!bm_test(c.live, s) || c.key32[s] != piv) continue;
+            bool active = true;
+            for (int k = 0; k < wj && active; ++k) active = dd_brev(~c.st[(size_t)k * c.capS + s]) == pivLex[k];
+            if (!active) continue;
+            uint64_t lw = dd_brev(~c.st[(size_t)wj * c.capS + s]);
+            if (shift + 8 < 64 && (lw >> (shift + 8)) != (pivLex[wj] >> (shift + 8))) continue;
+            LDS_ADD_U32(&c.hist[(lw >> shift) & 0xFF], 1u);
+        }
+        PAR_END
+        PAR_BEGIN
+        if (tid < 256) {
+            int above = 0;
+            for (int x = tid + 1; x < 256; ++x) above += (int)c.hist[x];
+            int mine = (int)c.hist[tid];
+            if (above < need && need <= above + mine) {
+                sh->sel_digit = tid;
+                sh->sel_above = above;
+                sh->sel_bucket = mine;
+            }
+        }
+        PAR_END
+        pivLex[wj] |= (uint64_t)sh->sel_digit << shift;
+        need -= sh->sel_above;
+        if (need == sh->sel_bucket) done = true;
+    }
+    PAR_BEGIN
+    if (tid == 0) {
+        sh->pivKey = piv;
+        for (int k = 0; k < WS; ++k) sh->pivLex[k] = pivLex[k];
+    }
+    PAR_END
+}
+
+template <int WS>
+DDO_DEV bool ge_pivot2(const DD2Ctx<WS>& c, int s, uint32_t key) {
+    const DD2Shared* sh = c.sh;
+    if (key != sh->pivKey) return key > sh->pivKey;
+    for (int k = 0; k < WS; ++k) {
+        uint64_t lw = dd_brev(~c.st[(size_t)k * c.capS + s]);
+        if (lw != sh->pivLex[k]) return lw > sh->pivLex[k];
+    }
+    return true;
+}
+
+/// rebuilds the dedup table from the live nodes (drops all tombstones)
+template <int WS>
+DDO_DEV void tab2_rebuild(DD2Ctx<WS>& c) {
+    DD_TID_SETUP(c)
+    PAR_BEGIN
+    for (int i = tid; i < c.tab_cap; i += NT) GLB_ST_U32(&c.tab[i], T2_EMPTY);
+    PAR_END
+    PAR_BEGIN
+    for (int s = tid; s < c.sh->hiw; s += NT)
+        if (bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, c.hsh[s]);
+    if (tid == 0) c.sh->tab_used = c.sh->nlive;
+    PAR_END
+}
+
+/// One compile() (clean.rs:345-381) with in-place layers.
+///
+/// Event records (u32 stream `ev`, per transition L -> L+1, 4 words per affected or pruned parent):
+///   [0] parent slot   [1] NO target | flags   [2] YES target | flags   [3] slot allocated for the YES-child
+/// flags: EV_CREATED (bit 31, YES target is the new node), EV_RAISED (bit 30, the arc raised its target's key).
+/// The squash of layer L (deleted slots, merged slot, re-added duplicate) is stored with iteration L.
+constexpr uint32_t EV_RAISED = 0x40000000u;
+constexpr uint32_t EV_SLOT_MASK = 0x000FFFFFu;
+
+template <int WS>
+DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
+    DD_TID_SETUP(c)
+    DD2Shared* sh = c.sh;
+    const int capS = c.capS;
+    const int W = in.width;
+    const bool relaxed = comp_type == CT_RELAXED;
+    const bool restricted = comp_type == CT_RESTRICTED;
+    const int32_t vbase = in.value + c.vbase_off;
+
+    // ---------------------------------------------------------------- _clear + _initialize
+    PAR_BEGIN
+    for (int i = tid; i < c.npad; i += NT) c.cnt[i] = 0;
+    for (int i = tid; i < c.nbw; i += NT) {
+        c.live[i] = 0;
+        c.inex[i] = 0;
+        c.okb[i] = 0;
+        c.fresh[i] = 0;
+    }
+    for (int i = tid; i < c.tab_cap; i += NT) GLB_ST_U32(&c.tab[i], T2_EMPTY);
+    if (tid == 0) {
+        sh->status = ST_OK;
+        sh->nodes = 0;
+        sh->arcs = 0;
+        sh->recycled_merges = 0;
+        sh->cutoff = 0;
+        sh->nlive = 1;
+        sh->hiw = 1;
+        sh->tab_used = 1;
+        sh->ev_pos = 0;
+        int pop = 0;
+        for (int k = 0; k < WS; ++k) {
+            c.st[(size_t)k * capS] = in.state[k];
+            c.pb[(size_t)k * capS] = 0;
+            pop += dd_popc(in.state[k]);
+        }
+        c.key32[0] = ((uint32_t)(in.value - vbase) << KEY_POP_BITS) | (uint32_t)pop;
+        c.hsh[0] = hash2_state<WS>(in.state);
+    }
+    PAR_END
+    PAR_BEGIN
+    if (tid == 0) {
+        add_bits<WS>(c.cnt, in.state, +1);
+        c.live[0] = 1u;
+        c.okb[0] = 1u;
+        c.fresh[0] = 1u;
+        tab2_insert_unique<WS>(c, 0, c.hsh[0]);
+    }
+    PAR_END
+
+    int lel = -1;
+    int snapL = -1;  // layer whose snapshot sits in the cut-set buffers
+    int ncs = 0;
+    int L = 0;
+    int var = -1;
+    bool failed = false;
+
+    for (;;) {
+        // ------------------------------------------------------------ next_variable (main.rs:109-143)
+        PAR_BEGIN
+        if (tid == 0) {
+            sh->varkey = 0xFFFFFFFFu;
+            if (c.cutoff_flag) sh->cutoff = LD_I32(c.cutoff_flag);
+        }
+        PAR_END
+        PAR_BEGIN
+        for (int i = tid; i < c.n; i += NT) {
+            int cv = c.cnt[i];
+            if (cv > 0) LDS_MIN_U32(&sh->varkey, ((uint32_t)cv << 12) | (uint32_t)i);
+            else if (cv < 0) sh->status = ST_ERR_INTERNAL;
+        }
+        PAR_END
+        var = sh->varkey == 0xFFFFFFFFu ? -1 : (int)(sh->varkey & 0xFFFu);
+        if (var < 0) break;
+        if (sh->cutoff) {
+            PAR_BEGIN
+            if (tid == 0) sh->status = ST_CUTOFF;
+            PAR_END
+            failed = true;
+            break;
+        }
+        if (L >= c.max_layers - 1 || sh->status != ST_OK) { failed = true; break; }
+        const int nU = sh->nlive;
+
+        // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
+        const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
+        int merged_slot = -1, dup_from = -1, dup_to = -1;
+        const uint64_t del_off = sh->ev_pos;
+        int n_del = 0;
+        if (squash) {
+            if (lel < 0) {
+                lel = L - 1;   // _maybe_save_lel
+                if (relaxed && snapL != lel) {  // cannot happen: see the snapshot rule below
+                    PAR_BEGIN
+                    if (tid == 0) sh->status = ST_ERR_INTERNAL;
+                    PAR_END
+                    failed = true;
+                    break;
+                }
+            }
+            const int K = restricted ? W : W - 1;
+            if (K > 0) select_pivot2<WS>(c, K);
+            PAR_BEGIN
+            if (tid == 0) {
+                sh->nvict = 0;
+                sh->mergedKey = 0;
+                for (int k = 0; k < WS; ++k) sh->merged[k] = 0;
+                sh->recycled = 0;
+                sh->xslot = -1;
+                sh->merged_slot = -1;
+                sh->free_slot = 0x7FFFFFFF;
+            }
+            PAR_END
+            PAR_BEGIN   // victims: live nodes ranked below the pivot (clean.rs:810-812 / :851-852)
+            for (int s = tid; s < sh->hiw; s += NT) {
+                if (!bm_test(c.live, s)) continue;
+                const uint32_t key = c.key32[s];
+                if (K > 0 && ge_pivot2<WS>(c, s, key)) continue;
+                int i = LDS_ADD_I32(&sh->nvict, 1);
+                if (i < c.capW) c.wl[i] = (uint16_t)s;
+            }
+            PAR_END
+            const int nv = sh->nvict;
+            if (nv > c.capW || sh->ev_pos + (uint64_t)nv + 8 > c.ev_cap) {
+                PAR_BEGIN
+                if (tid == 0) sh->status = ST_ERR_CAPACITY;
+                PAR_END
+                failed = true;
+                break;
+            }
+            PAR_BEGIN
+            for (int i = tid; i < nv; i += NT) {
+                const int s = c.wl[i];
+                uint64_t st[WS];
+                ld_state<WS>(c, s, st);
+                add_bits<WS>(c.cnt, st, -1);
+                tab2_remove<WS>(c, s, c.hsh[s]);
+                bm_clr(c.live, s);
+                bm_clr(c.fresh, s);
+                if (relaxed) {
+#pragma unroll
+                    for (int k = 0; k < WS; ++k)
+                        if (st[k]) LDS_OR_U64(&sh->merged[k], st[k]);   // MispRelax::merge (main.rs:172-178)
+                    LDS_MAX_U64(&sh->mergedKey, ((uint64_t)c.key32[s] << 32) | (uint32_t)s);
+                }
+                c.ev[del_off + i] = (uint32_t)s;
+            }
+            if (tid == 0) {
+                sh->nlive -= nv;
+                sh->ev_pos += (uint64_t)nv;
+            }
+            PAR_END
+            n_del = nv;
+            if (relaxed) {
+                // ---------------------------------------------------- merged node (clean.rs:826-875)
+                PAR_BEGIN
+                if (tid == 0) {
+                    uint64_t ms[WS];
+                    for (int k = 0; k < WS; ++k) ms[k] = sh->merged[k];
+                    const uint64_t mh = hash2_state<WS>(ms);
+                    const int r = tab2_find<WS>(c, mh, ms);
+                    sh->recycled = (r >= 0 && bm_test(c.live, r)) ? 1 : 0;   // clean.rs:830
+                    sh->merged_slot = r;
+                }
+                for (int w = tid; w < c.nbw; w += NT) {   // lowest slot that is not live
+                    uint32_t freebits = ~c.live[w];
+                    if (freebits) {
+                        int s = w * 32 + dd_ctz((uint64_t)freebits);
+                        if (s < capS) LDS_MIN_U32((uint32_t*)&sh->free_slot, (uint32_t)s);
+                    }
+                }
+                PAR_END
+                if (sh->recycled) {
+                    // clean.rs:868-872: the best-ranked node of the merged set stays in the layer
+                    PAR_BEGIN
+                    if (tid < 64) {
+                        int best = -1;
+                        for (int i = tid; i < nv; i += 64) {
+                            int s = c.wl[i];
+                            if (best < 0 || ranks_above2<WS>(c, s, best)) best = s;
+                        }
+                        sh->xcand[tid] = best;
+                    }
+                    PAR_END
+                    PAR_BEGIN
+                    if (tid == 0) {
+                        int best = -1;
+                        for (int l = 0; l < 64; ++l) {
+                            int s = sh->xcand[l];
+                            if (s >= 0 && (best < 0 || ranks_above2<WS>(c, s, best))) best = s;
+                        }
+                        sh->xslot = best;
+                        sh->recycled_merges += 1;
+                        const int r = sh->merged_slot;
+                        const uint32_t mkey = (uint32_t)(sh->mergedKey >> 32);
+                        const int bestv = (int)(uint32_t)sh->mergedKey;
+                        if ((mkey >> KEY_POP_BITS) > (c.key32[r] >> KEY_POP_BITS)) {   // the best redirected arc wins
+                            c.key32[r] = (mkey & ~KEY_POP_MASK) | (c.key32[r] & KEY_POP_MASK);
+                            for (int k = 0; k < WS; ++k) c.pb[(size_t)k * capS + r] = c.pb[(size_t)k * capS + bestv];
+                        }
+                        bm_set(c.inex, r);
+                        bm_clr(c.okb, r);       // F_RELAXED: best paths through r are not exact
+                        uint64_t xs[WS];       // re-add X: it is un-deleted (clean.rs:870-871)
+                        ld_state<WS>(c, best, xs);
+                        add_bits<WS>(c.cnt, xs, +1);
+                        bm_set(c.live, best);
+                        bm_set(c.fresh, best);   // its fresh mark was dropped with the victims: check it (again)
+                        tab2_insert_unique<WS>(c, best, c.hsh[best]);
+                        sh->tab_used += 1;
+                        sh->nlive += 1;
+                        for (int i = 0; i < nv; ++i)
+                            if (c.ev[del_off + i] == (uint32_t)best) c.ev[del_off + i] = NONE32;
+                    }
+                    PAR_END
+                    merged_slot = sh->merged_slot;
+                    dup_from = sh->xslot;
+                    dup_to = sh->merged_slot;
+                } else {
+                    if (sh->free_slot >= capS) {
+                        PAR_BEGIN
+                        if (tid == 0) sh->status = ST_ERR_CAPACITY;
+                        PAR_END
+                        failed = true;
+                        break;
+                    }
+                    PAR_BEGIN
+                    if (tid == 0) {
+                        const int m = sh->free_slot;
+                        const int bestv = (int)(uint32_t)sh->mergedKey;
+                        int pop = 0;
+                        uint64_t ms[WS];
+                        for (int k = 0; k < WS; ++k) {
+                            ms[k] = sh->merged[k];
+                            c.st[(size_t)k * capS + m] = ms[k];
+                            c.pb[(size_t)k * capS + m] = c.pb[(size_t)k * capS + bestv];
+                            pop += dd_popc(ms[k]);
+                        }
+                        const uint32_t mkey = (uint32_t)(sh->mergedKey >> 32);
+                        c.key32[m] = (mkey & ~KEY_POP_MASK) | (uint32_t)pop;
+                        const uint64_t mh = hash2_state<WS>(ms);
+                        c.hsh[m] = mh;
+                        bm_set(c.live, m);
+                        bm_set(c.inex, m);
+                        bm_clr(c.okb, m);
+                        bm_set(c.fresh, m);
+                        add_bits<WS>(c.cnt, ms, +1);
+                        tab2_insert_unique<WS>(c, m, mh);
+                        sh->tab_used += 1;
+                        sh->nlive += 1;
+                        if (m >= sh->hiw) sh->hiw = m + 1;
+                        sh->merged_slot = m;
+                    }
+                    PAR_END
+                    merged_slot = sh->merged_slot;
+                }
+            }
+        }
+        const int n = sh->nlive;   // |layer L| after squash
+        const int naff_bound = c.cnt[var] > 0 ? c.cnt[var] : 0;   // live states containing the variable
+
+        // ------------------------------------------------------------ candidate last exact layer: snapshot
+        // Layer L+1 can only be squashed when n + (#YES-children) > W; only then is layer L copied, so the
+        // cut-set (clean.rs:566-573) is available although layers are updated in place.
+        if (relaxed && lel < 0 && n + naff_bound > W && L >= 1) {
+            PAR_BEGIN
+            if (tid == 0) sh->ncut = 0;
+            PAR_END
+            PAR_BEGIN
+            for (int s = tid; s < sh->hiw; s += NT) {
+                if (!bm_test(c.live, s)) continue;
+                int i = LDS_ADD_I32(&sh->ncut, 1);
+                if (i >= c.capW) continue;
+                c.cs_slot[i] = (uint32_t)s;
+                for (int k = 0; k < WS; ++k) {
+                    c.cs_state[(size_t)k * c.capW + i] = c.st[(size_t)k * capS + s];
+                    c.cs_path[(size_t)k * c.capW + i] = c.pb[(size_t)k * capS + s];
+                }
+                const uint32_t key = c.key32[s];
+                c.cs_value[i] = vbase + (int32_t)(key >> KEY_POP_BITS);
+                c.cs_pop[i] = key & KEY_POP_MASK;
+            }
+            PAR_END
+            ncs = sh->ncut;
+            snapL = L;
+        }
+
+        // ------------------------------------------------------------ work list: affected or fresh nodes
+        PAR_BEGIN
+        if (tid == 0) {
+            sh->nwl = 0;
+            sh->nrec = 0;
+            sh->nnew = 0;
+            sh->nfl = 0;
+            sh->npruned = 0;
+            sh->nyes = 0;
+            c.lvar[L] = var;
+            c.lmerge[L] = merged_slot;
+            c.ldup[2 * L] = dup_from;
+            c.ldup[2 * L + 1] = dup_to;
+            uint32_t* eo = c.evoff + (size_t)L * 8;
+            eo[3] = (uint32_t)del_off;
+            eo[4] = (uint32_t)(del_off >> 32);
+            eo[5] = (uint32_t)n_del;
+        }
+        PAR_END
+        const int vw = var >> 6;
+        const uint64_t vbit = 1ULL << (var & 63);
+        PAR_BEGIN
+        for (int s = tid; s < sh->hiw; s += NT) {
+            if (!bm_test(c.live, s)) continue;
+            const bool hasv = (c.st[(size_t)vw * capS + s] & vbit) != 0;
+            if (hasv || bm_test(c.fresh, s)) {
+                int i = LDS_ADD_I32(&sh->nwl, 1);
+                if (i < c.capW) c.wl[i] = (uint16_t)s;
+            }
+        }
+        PAR_END
+        const int nwl = sh->nwl;
+        if (nwl > c.capW || n > c.capW || sh->ev_pos + 4ull * (uint64_t)nwl + 8 > c.ev_cap) {
+            PAR_BEGIN
+            if (tid == 0) sh->status = ST_ERR_CAPACITY;
+            PAR_END
+            failed = true;
+            break;
+        }
+        // ------------------------------------------------------------ free slots for the YES-children
+        PAR_BEGIN
+        {
+            int cntf = 0;
+            for (int ww = tid; ww < c.nbw; ww += NT) {
+                uint32_t freebits = ~c.live[ww];
+                const int base = ww * 32;
+                if (base + 32 > capS) freebits &= ((1u << (capS - base)) - 1u);
+                cntf += dd_popc((uint64_t)freebits);
+            }
+            c.tcount[tid] = cntf;
+        }
+        PAR_END
+        block_exclusive_scan_any(c, c.tcount, c.tcount2, &sh->scan_total);
+        PAR_BEGIN
+        {
+            int pos = c.tcount[tid];
+            for (int ww = tid; ww < c.nbw && pos < c.capW; ww += NT) {
+                uint32_t freebits = ~c.live[ww];
+                const int base = ww * 32;
+                if (base + 32 > capS) freebits &= ((1u << (capS - base)) - 1u);
+                while (freebits && pos < c.capW) {
+                    int b = dd_ctz((uint64_t)freebits);
+                    c.fl[pos++] = (uint16_t)(base + b);
+                    freebits &= freebits - 1;
+                }
+            }
+        }
+        if (tid == 0) sh->nfl = sh->scan_total < c.capW ? sh->scan_total : c.capW;
+        PAR_END
+        // table pressure: drop the tombstones when the table fills up
+        if (sh->tab_used + 2 * nwl + 2 > (c.tab_cap / 10) * 7) {
+            tab2_rebuild<WS>(c);
+            if (sh->tab_used + 2 * nwl + 2 > (c.tab_cap / 10) * 9) {
+                PAR_BEGIN
+                if (tid == 0) sh->status = ST_ERR_CAPACITY;
+                PAR_END
+                failed = true;
+                break;
+            }
+        }
+
+        // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
+        const uint64_t aff_off = sh->ev_pos;
+        PAR_BEGIN
+        uint64_t adjv[WS];
+#pragma unroll
+        for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
+        const int32_t wv = c.weight[var];
+        for (int i = tid; i < nwl; i += NT) {
+            const int s = c.wl[i];
+            const uint32_t key = c.key32[s];
+            const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
+            const int pop = (int)(key & KEY_POP_MASK);
+            uint64_t st[WS];
+            ld_state<WS>(c, s, st);
+            const int32_t rub = c.unit_weights ? pop : rub2_of<WS>(c, st);   // main.rs:191-193
+            bm_clr(c.fresh, s);
+            if ((int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365: no children
+                add_bits<WS>(c.cnt, st, -1);
+                tab2_remove<WS>(c, s, c.hsh[s]);
+                bm_clr(c.live, s);
+                LDS_ADD_I32(&sh->nlive, -1);
+                const int r = LDS_ADD_I32(&sh->nrec, 1);
+                uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
+                rec[0] = (uint32_t)s;
+                rec[1] = NONE32;
+                rec[2] = NONE32;
+                rec[3] = NONE32;
+                LDS_ADD_I32(&sh->npruned, 1);
+                continue;
+            }
+            bool hasv = false;
+#pragma unroll
+            for (int k = 0; k < WS; ++k)
+                if (k == vw) hasv = (st[k] & vbit) != 0;
+            if (!hasv) continue;   // fresh but unaffected: its NO-child is the node itself
+            // ---- decision NO, in place (main.rs:77-85)
+            const uint64_t oldh = c.hsh[s];
+            tab2_remove<WS>(c, s, oldh);
+            uint64_t oldw = 0, neww = 0;
+#pragma unroll
+            for (int k = 0; k < WS; ++k)
+                if (k == vw) {
+                    oldw = st[k];
+                    st[k] &= ~vbit;
+                    neww = st[k];
+                    c.st[(size_t)k * capS + s] = neww;
+                }
+            c.hsh[s] = oldh ^ mixw(oldw, vw) ^ mixw(neww, vw);
+            c.key32[s] = key - 1;          // popcount - 1, same value (cost 0)
+            LDS_ADD_I32(&c.cnt[var], -1);
+            // ---- decision YES into a free slot (main.rs:95-102)
+            const int fi = LDS_ADD_I32(&sh->nnew, 1);
+            int ny = -1;
+            if (fi < sh->nfl) {
+                ny = c.fl[fi];
+                uint64_t y[WS];
+                int ypop = 0;
+#pragma unroll
+                for (int k = 0; k < WS; ++k) {
+                    y[k] = st[k] & adjv[k];
+                    ypop += dd_popc(y[k]);
+                    c.st[(size_t)k * capS + ny] = y[k];
+                    uint64_t pw = c.pb[(size_t)k * capS + s];
+                    if (k == (L >> 6)) pw |= 1ULL << (L & 63);
+                    c.pb[(size_t)k * capS + ny] = pw;
+                }
+                c.hsh[ny] = hash2_state<WS>(y);
+                c.key32[ny] = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop;
+                bm_put(c.inex, ny, bm_test(c.inex, s));
+                bm_put(c.okb, ny, bm_test(c.okb, s));
+            } else {
+                sh->status = ST_ERR_CAPACITY;
+            }
+            const int r = LDS_ADD_I32(&sh->nrec, 1);
+            uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
+            rec[0] = (uint32_t)s;
+            rec[1] = (uint32_t)s;                       // NO target, provisional: the node itself
+            rec[2] = ny >= 0 ? (uint32_t)ny : NONE32;   // YES target, provisional: the new slot
+            rec[3] = ny >= 0 ? (uint32_t)ny : NONE32;
+            LDS_ADD_I32(&sh->nyes, 1);
+        }
+        PAR_END
+        const int nrec = sh->nrec;
+        if (sh->status != ST_OK) { failed = true; break; }
+
+        // ------------------------------------------------------------ expand, phase 2: dedup (clean.rs:738-775)
+        PAR_BEGIN
+        for (int r = tid; r < nrec; r += NT) {
+            uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
+            if (rec[1] == NONE32) continue;   // pruned parent
+            for (int which = 0; which < 2; ++which) {
+                const int x = (int)rec[1 + which];
+                if (which == 1 && rec[2] == NONE32) continue;
+                uint64_t st[WS];
+                ld_state<WS>(c, x, st);
+                const int t = tab2_insert<WS>(c, x, c.hsh[x], st);
+                if (t == x) {
+                    LDS_ADD_I32(&sh->tab_used, 1);
+                    if (which == 0) {
+                        bm_set(c.fresh, x);     // its rub shrank: check it again before it is expanded
+                    } else {                    // a new node enters the layer
+                        bm_set(c.live, x);
+                        bm_set(c.fresh, x);
+                        add_bits<WS>(c.cnt, st, +1);
+                        LDS_ADD_I32(&sh->nlive, 1);
+                        LDS_MAX_I32(&sh->hiw, x + 1);
+                        rec[2] = (uint32_t)x | EV_CREATED;
+                    }
+                    continue;
+                }
+                // duplicate of node t: the arc enters t  (append_edge_to!, clean.rs:199-220)
+                const uint32_t kx = c.key32[x];
+                const uint32_t old = LDS_MAX_U32(&c.key32[t], kx);
+                rec[1 + which] = (uint32_t)t | (kx > old ? EV_RAISED : 0u);
+                if (bm_test(c.inex, x)) bm_set(c.inex, t);
+                if (which == 0) {               // the in-place NO-child dissolves into t
+                    add_bits<WS>(c.cnt, st, -1);
+                    bm_clr(c.live, x);
+                    LDS_ADD_I32(&sh->nlive, -1);
+                }
+            }
+        }
+        PAR_END
+        // ------------------------------------------------------------ expand, phase 3: new best parents
+        // The arc that RAISED its target's key and still equals the target's final key is the one that set
+        // the maximum (`value >= value_top`, clean.rs:215-218): the target inherits the loser's path.  Losers
+        // are dead, targets alive, so no path is read and written in the same phase.
+        PAR_BEGIN
+        for (int r = tid; r < nrec; r += NT) {
+            uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
+            if (rec[1] == NONE32) continue;
+            for (int which = 0; which < 2; ++which) {
+                const uint32_t w = rec[1 + which];
+                if (w == NONE32 || !(w & EV_RAISED)) continue;
+                const int t = (int)(w & EV_SLOT_MASK);
+                const int x = which == 0 ? (int)rec[0] : (int)rec[3];
+                if (c.key32[t] == c.key32[x]) {
+                    for (int k = 0; k < WS; ++k) c.pb[(size_t)k * capS + t] = c.pb[(size_t)k * capS + x];
+                    bm_put(c.okb, t, bm_test(c.okb, x));
+                }
+                rec[1 + which] = w & ~EV_RAISED;
+            }
+        }
+        if (tid == 0) {
+            uint32_t* eo = c.evoff + (size_t)L * 8;
+            eo[0] = (uint32_t)aff_off;
+            eo[1] = (uint32_t)(aff_off >> 32);
+            eo[2] = (uint32_t)nrec;
+            sh->ev_pos += 4ull * (uint64_t)nrec;
+            sh->nodes += (uint64_t)n;
+            sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
+#if defined(DDO_HOST_EMULATION)
+            if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
+#endif
+        }
+        PAR_END
+        L += 1;
+    }
+
+    // ==================================================================== _finalize (clean.rs:407-414)
+    const int nT = failed ? 0 : sh->nlive;          // terminal layer = the live nodes, never squashed
+    const int n_layers = failed ? L : (nT > 0 ? L + 1 : L);
+    PAR_BEGIN
+    if (tid == 0) {
+        sh->bestKey = 0;
+        sh->bestExactKey = 0;
+        if (L < c.max_layers) {
+            c.lmerge[L] = -1;
+            c.ldup[2 * L] = -1;
+            c.ldup[2 * L + 1] = -1;
+            c.evoff[(size_t)L * 8 + 5] = 0;
+        }
+    }
+    PAR_END
+    if (!failed && nT > 0) {
+        PAR_BEGIN   // _find_best_node (clean.rs:620-632)
+        for (int s = tid; s < sh->hiw; s += NT) {
+            if (!bm_test(c.live, s)) continue;
+            const uint64_t bk = (((uint64_t)c.key32[s] >> KEY_POP_BITS) << 32) | (uint32_t)s;
+            LDS_MAX_U64(&sh->bestKey, bk + 1);
+            if (!bm_test(c.inex, s)) LDS_MAX_U64(&sh->bestExactKey, bk + 1);
+        }
+        PAR_END
+    }
+    const bool is_exact = lel < 0;
+    const bool has_best = !failed && sh->bestKey != 0;
+    int best_slot = -1, best_value = 0;
+    if (has_best) {
+        const uint64_t bk = sh->bestKey - 1;
+        best_slot = (int)(uint32_t)bk;
+        best_value = vbase + (int32_t)(bk >> 32);
+    }
+    bool has_best_exact = !failed && sh->bestExactKey != 0;
+    int exact_slot = -1, exact_value = 0;
+    if (has_best_exact) {
+        const uint64_t bk = sh->bestExactKey - 1;
+        exact_slot = (int)(uint32_t)bk;
+        exact_value = vbase + (int32_t)(bk >> 32);
+    }
+    // EBPO (clean.rs:636-655): ok bit of the best terminal node
+    bool ebpo = false;
+    if (relaxed && !failed) {
+        ebpo = has_best ? bm_test(c.okb, best_slot) : true;
+        if (ebpo && has_best) {
+            has_best_exact = true;
+            exact_slot = best_slot;
+            exact_value = best_value;
+        }
+    }
+
+    // ---------------------------------------------------------------- local bounds (clean.rs:448-475)
+    const bool want_cutset = relaxed && !failed && lel >= 0 && has_best;
+    int32_t* vb = (int32_t*)c.key32;       // the ranking keys are dead now: reuse their LDS
+    int32_t* tmp = (int32_t*)c.wl;         // wl + fl = capW x int32
+    if (want_cutset) {
+        PAR_BEGIN   // terminal layer: value_bot = 0 and MARKED; everything else unmarked
+        for (int s = tid; s < capS; s += NT) vb[s] = (s < sh->hiw && bm_test(c.live, s)) ? 0 : VB_UNMARKED;
+        PAR_END
+        for (int tr = L - 1; tr >= lel; --tr) {
+            // (1) undo the squash of layer tr+1: arcs into a deleted node were redirected to the merged node
+            const uint32_t* eo1 = c.evoff + (size_t)(tr + 1) * 8;
+            const int nd = (int)eo1[5];
+            const int m = c.lmerge[tr + 1];
+            if (nd > 0 && m >= 0) {
+                const uint64_t doff = (uint64_t)eo1[3] | ((uint64_t)eo1[4] << 32);
+                const int dfrom = c.ldup[2 * (tr + 1)], dto = c.ldup[2 * (tr + 1) + 1];
+                PAR_BEGIN
+                const int32_t vm = vb[m];
+                for (int i = tid; i < nd; i += NT) {
+                    const uint32_t d = c.ev[doff + i];
+                    if (d != NONE32 && (int)d != m) vb[d] = vm;
+                }
+                PAR_END
+                if (dfrom >= 0) {
+                    PAR_BEGIN
+                    if (tid == 0) {
+                        int32_t a = vb[dfrom], b = vb[dto];
+                        vb[dfrom] = a > b ? a : b;   // X keeps its own arcs and they were also redirected (clean.rs:851-872)
+                    }
+                    PAR_END
+                }
+            }
+            // (2) parents of the transition tr -> tr+1
+            const uint32_t* eo = c.evoff + (size_t)tr * 8;
+            const int na = (int)eo[2];
+            const uint64_t aoff = (uint64_t)eo[0] | ((uint64_t)eo[1] << 32);
+            const int32_t wv = c.weight[c.lvar[tr]];
+            for (int base = 0; base < na; base += c.capW) {
+                const int cnt_here = na - base < c.capW ? na - base : c.capW;
+                PAR_BEGIN
+                for (int i = tid; i < cnt_here; i += NT) {
+                    const uint32_t* rec = c.ev + aoff + 4ull * (uint64_t)(base + i);
+                    int32_t best = VB_UNMARKED;
+                    if (rec[1] != NONE32) {
+                        int32_t v = vb[rec[1] & EV_SLOT_MASK];
+                        if (v != VB_UNMARKED) best = v;
+                    }
+                    if (rec[2] != NONE32) {
+                        int32_t v = vb[rec[2] & EV_SLOT_MASK];
+                        if (v != VB_UNMARKED && v + wv > best) best = v + wv;
+                    }
+                    tmp[i] = best;
+                }
+                PAR_END
+                PAR_BEGIN
+                for (int i = tid; i < cnt_here; i += NT) {
+                    const uint32_t* rec = c.ev + aoff + 4ull * (uint64_t)(base + i);
+                    vb[rec[0]] = tmp[i];
+                }
+                PAR_END
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- cut-set (clean.rs:417-445)
+    const int ncs_layer = want_cutset ? ncs : 0;
+    const bool filter = (in.flags & IN_FILTER_CUTSET) != 0;
+    PAR_BEGIN
+    if (tid == 0) {
+        sh->ncut = 0;
+        sh->ncut2 = 0;
+    }
+    PAR_END
+    if (want_cutset) {
+        PAR_BEGIN
+        int mine = 0;
+        for (int i = tid; i < ncs_layer; i += NT) {
+            const int32_t vbv = vb[c.cs_slot[i]];
+            if (vbv == VB_UNMARKED) continue;
+            if (filter) {
+                int64_t v = c.cs_value[i];
+                int64_t rub = c.cs_pop[i];
+                if (!c.unit_weights) {
+                    uint64_t s[WS];
+                    for (int k = 0; k < WS; ++k) s[k] = c.cs_state[(size_t)k * c.capW + i];
+                    rub = rub2_of<WS>(c, s);
+                }
+                int64_t ub = v + rub;
+                if (v + vbv < ub) ub = v + vbv;
+                if (best_value < ub) ub = best_value;
+                if (ub <= best_lb) continue;
+            }
+            ++mine;
+        }
+        if (mine) LDS_ADD_I32(&sh->ncut, mine);
+        PAR_END
+    }
+    const int ncut = sh->ncut;
+    const bool want_paths = (in.flags & IN_WANT_PATHS) != 0;
+    const bool emit_best = has_best && (want_paths || (int64_t)best_value > best_lb);
+    const bool emit_exact = has_best_exact && (want_paths || (int64_t)exact_value > best_lb);
+    const bool same = emit_best && emit_exact && exact_slot == best_slot;
+    const int path_len = n_layers > 0 ? n_layers - 1 : 0;
+    const int best_len = emit_best ? path_len : 0;
+    const int exact_len = (emit_exact && !same) ? path_len : 0;
+    const int cs_path_len = lel > 0 ? lel : 0;
+
+    uint64_t off = 0;
+    const uint64_t path_off = off;
+    off += ((uint64_t)best_len * 4 + 7) & ~7ULL;
+    const uint64_t exact_off = off;
+    off += ((uint64_t)exact_len * 4 + 7) & ~7ULL;
+    const uint64_t cs_state_off = off;
+    off += (uint64_t)ncut * WS * 8;
+    const uint64_t cs_value_off = off;
+    off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
+    const uint64_t cs_ub_off = off;
+    off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
+    const uint64_t cs_path_off = off;
+    off += ((uint64_t)ncut * cs_path_len * 4 + 7) & ~7ULL;
+    const uint64_t total = off;
+
+    PAR_BEGIN
+    if (tid == 0) {
+        unsigned long long a = total ? GLB_ADD_U64(c.arena_head, (unsigned long long)total) : 0ULL;
+        sh->arena_off = a;
+        if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY;
+    }
+    PAR_END
+    const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;
+    uint8_t* base = c.arena + sh->arena_off;
+
+    if (arena_ok && !failed) {
+        PAR_BEGIN
+        // best paths (clean.rs:329-343): one decision per transition, terminal first
+        if (best_len) {
+            uint32_t* out = (uint32_t*)(base + path_off);
+            for (int i = tid; i < best_len; i += NT) {
+                const int tr = path_len - 1 - i;
+                const uint64_t w = c.pb[(size_t)(tr >> 6) * capS + best_slot];
+                out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
+            }
+        }
+        if (exact_len) {
+            uint32_t* out = (uint32_t*)(base + exact_off);
+            for (int i = tid; i < exact_len; i += NT) {
+                const int tr = path_len - 1 - i;
+                const uint64_t w = c.pb[(size_t)(tr >> 6) * capS + exact_slot];
+                out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
+            }
+        }
+        if (want_cutset && ncut) {
+            uint64_t* o_state = (uint64_t*)(base + cs_state_off);
+            int32_t* o_value = (int32_t*)(base + cs_value_off);
+            int32_t* o_ub = (int32_t*)(base + cs_ub_off);
+            uint32_t* o_path = (uint32_t*)(base + cs_path_off);
+            for (int i = tid; i < ncs_layer; i += NT) {
+                const int32_t vbv = vb[c.cs_slot[i]];
+                if (vbv == VB_UNMARKED) continue;
+                uint64_t s[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) s[k] = c.cs_state[(size_t)k * c.capW + i];
+                const int64_t v = c.cs_value[i];
+                int64_t ub = v + (c.unit_weights ? (int64_t)c.cs_pop[i] : (int64_t)rub2_of<WS>(c, s));
+                if (v + vbv < ub) ub = v + vbv;
+                if (best_value < ub) ub = best_value;
+                if (filter && ub <= best_lb) continue;
+                const int idx = LDS_ADD_I32(&sh->ncut2, 1);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) o_state[(size_t)idx * WS + k] = s[k];
+                o_value[idx] = (int32_t)v;
+                o_ub[idx] = (int32_t)ub;
+                for (int j = 0; j < cs_path_len; ++j) {
+                    const int tr = cs_path_len - 1 - j;
+                    const uint64_t w = c.cs_path[(size_t)(tr >> 6) * c.capW + i];
+                    o_path[(size_t)idx * cs_path_len + j] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
+                }
+            }
+        }
+        PAR_END
+    }
+
+    PAR_BEGIN
+    if (tid == 0) {
+        DDResult r;
+        r.status = sh->status;
+        r.comp_type = comp_type;
+        r.is_exact = is_exact ? 1 : 0;
+        r.has_exact_best_path = ebpo ? 1 : 0;
+        r.has_best = has_best ? 1 : 0;
+        r.has_best_exact = has_best_exact ? 1 : 0;
+        r.best_value = best_value;
+        r.best_exact_value = exact_value;
+        r.n_layers = n_layers;
+        r.lel = lel;
+        r.n_cutset = arena_ok ? ncut : 0;
+        r.best_len = arena_ok ? best_len : 0;
+        r.exact_len = arena_ok ? (same ? best_len : exact_len) : 0;
+        r.exact_same_as_best = same ? 1 : 0;
+        r.recycled_merges = sh->recycled_merges;
+        r.pad = 0;
+        r.arena_off = sh->arena_off;
+        r.arena_bytes = total;
+        r.nodes_expanded = sh->nodes;
+        r.arcs = sh->arcs;
+        r.layers = (uint64_t)L;
+        r.path_off = path_off;
+        r.exact_off = same ? path_off : exact_off;
+        r.cs_state_off = cs_state_off;
+        r.cs_value_off = cs_value_off;
+        r.cs_ub_off = cs_ub_off;
+        r.cs_path_off = cs_path_off;
+        *res = r;
+    }
+    PAR_END
+}
+
+/// restricted, then (when inexact) relaxed: the device half of process_one_node (parallel.rs:391-437)
+template <int WS>
+DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
+    DD_TID_SETUP(c)
+    (void)NT;
+    if (in.flags & IN_FUSED) {
+        run_dd2<WS>(c, in, CT_RESTRICTED, in.best_lb, &res2[0]);
+        PAR_BEGIN
+        if (tid == 0) {
+            c.sh->sel_above = (res2[0].status == ST_OK && !res2[0].is_exact) ? 1 : 0;
+            c.sh->sel_bucket = res2[0].has_best_exact ? 1 : 0;
+            c.sh->sel_digit = res2[0].best_exact_value;
+        }
+        PAR_END
+        const bool go = c.sh->sel_above != 0;
+        int64_t lb = in.best_lb;
+        if (c.sh->sel_bucket && (int64_t)c.sh->sel_digit > lb) lb = c.sh->sel_digit;  // maybe_update_best
+        if (go) run_dd2<WS>(c, in, CT_RELAXED, lb, &res2[1]);
+        else {
+            PAR_BEGIN
+            if (tid == 0) res2[1].status = ST_NOT_RUN;
+            PAR_END
+        }
+    } else {
+        run_dd2<WS>(c, in, in.comp_type, in.best_lb, &res2[0]);
+        PAR_BEGIN
+        if (tid == 0) res2[1].status = ST_NOT_RUN;
+        PAR_END
+    }
+}
+
+/// LDS bytes of one in-place workgroup
+inline size_t dd2_lds_bytes(int capS, int capW, int npad, int nthreads) {
+    const size_t nbw = ((size_t)capS + 31) / 32;
+    size_t b = (size_t)capS * 4;           // key32 / value_bot
+    b = (b + 15) & ~(size_t)15;
+    b += 4 * nbw * 4;                      // live, inex, okb, fresh
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)npad * 4;                 // cnt
+    b += 2048 * 4;                         // hist
+    b += (size_t)capW * 2 * 2;             // wl + fl (== int32 tmp[capW])
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)nthreads * 4 * 2;         // scan scratch
+    b += (sizeof(DD2Shared) + 15) & ~(size_t)15;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <int WS>
+DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned char* lds, int nthreads) {
+    c.n = P.n;
+    c.npad = P.npad;
+    c.unit_weights = P.unit_weights;
+    c.adj = P.adj;
+    c.weight = P.weight;
+    c.capS = P.capS;
+    c.capW = P.capW;
+    c.max_layers = P.max_layers;
+    c.nbw = (P.capS + 31) / 32;
+    const size_t capS = (size_t)P.capS, capW = (size_t)P.capW, ml = (size_t)P.max_layers, s = (size_t)slot;
+    c.st = P.s_state + s * (size_t)WS * capS;
+    c.pb = P.s_path + s * (size_t)WS * capS;
+    c.hsh = P.s_hash + s * capS;
+    c.tab = P.s_tab + s * (size_t)P.tab2_cap;
+    c.tab_cap = P.tab2_cap;
+    c.ev = P.s_ev + s * P.ev_cap;
+    c.ev_cap = P.ev_cap;
+    c.evoff = P.s_evoff + s * ml * 8;
+    c.lvar = P.lvar + s * ml;
+    c.ldup = P.ldup + s * ml * 2;
+    c.lmerge = P.nlayer + s * ml;          // the per-layer node counts of engine 1 are not needed here
+    c.cs_slot = P.s_cs_slot + s * capW;
+    c.cs_state = P.cs_state + s * (size_t)WS * (size_t)P.capN;   // capN >= capW words per row are reserved
+    c.cs_path = P.s_cs_path + s * (size_t)WS * capW;
+    c.cs_value = P.cs_value + s * (size_t)P.capN;
+    c.cs_pop = P.cs_pop + s * (size_t)P.capN;
+    unsigned char* p = lds;
+    c.key32 = (uint32_t*)p;
+    p += ((size_t)P.capS * 4 + 15) & ~(size_t)15;
+    c.live = (uint32_t*)p;
+    p += (size_t)c.nbw * 4;
+    c.inex = (uint32_t*)p;
+    p += (size_t)c.nbw * 4;
+    c.okb = (uint32_t*)p;
+    p += (size_t)c.nbw * 4;
+    c.fresh = (uint32_t*)p;
+    p += (size_t)c.nbw * 4;
+    p = (unsigned char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    c.cnt = (int32_t*)p;
+    p += (size_t)P.npad * 4;
+    c.hist = (uint32_t*)p;
+    p += 2048 * 4;
+    c.wl = (uint16_t*)p;
+    p += (size_t)P.capW * 2;
+    c.fl = (uint16_t*)p;
+    p += (size_t)P.capW * 2;
+    p = (unsigned char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    c.tcount = (int32_t*)p;
+    p += (size_t)nthreads * 4;
+    c.tcount2 = (int32_t*)p;
+    p += (size_t)nthreads * 4;
+    c.sh = (DD2Shared*)p;
+    c.arena = P.arena;
+    c.arena_cap = P.arena_cap;
+    c.arena_head = P.arena_head;
+    c.cutoff_flag = P.cutoff_flag;
+    c.vbase_off = P.vbase_off;
+    c.NT = nthreads;
+}
+
+}  // namespace ddo_hip

@@ -14,7 +14,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../ddo_amd/csrc/misp_dd_core.hpp"
+#include "../../ddo_amd/csrc/misp_dd_inplace.hpp"
 
 using namespace ddo_hip;
 
@@ -30,6 +30,9 @@ struct Emul {
     int32_t work_counter = 0;
     int nthreads = 256;
     int wsT = 0;  // template WS used
+    int engine = 1;
+    std::vector<unsigned char> mem2;
+    std::vector<unsigned char> lds2;
 };
 
 template <class T>
@@ -48,6 +51,12 @@ int pick_ws(int ws) {
 
 template <int WS>
 void run(Emul& e, const DDInput& in, DDResult* res2) {
+    if (e.engine == 2) {
+        DD2Ctx<WS> c2;
+        dd2_bind<WS>(c2, e.P, 0, e.lds2.data(), e.nthreads);
+        run_work_item2<WS>(c2, in, res2);
+        return;
+    }
     DDCtx<WS> c;
     dd_bind<WS, true>(c, e.P, 0, e.lds.data(), e.nthreads);
     run_work_item<WS>(c, in, res2);
@@ -57,8 +66,9 @@ void run(Emul& e, const DDInput& in, DDResult* res2) {
 extern "C" {
 
 void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int max_width, int nthreads,
-                  uint64_t arena_bytes) {
+                  uint64_t arena_bytes, int engine) {
     Emul* e = new Emul();
+    e->engine = engine;
     int ws = (n + 63) / 64;
     int wsT = pick_ws(ws);
     if (wsT < 0) return nullptr;
@@ -121,6 +131,37 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
     P.arena_head = &e->arena_head;
     P.work_counter = &e->work_counter;
     P.cutoff_flag = nullptr;
+    // ---- in-place engine workspace
+    P.capS = 2 * max_width + 8;
+    P.capW = P.capN;
+    int t2 = 1024;
+    while (t2 < 8 * P.capW) t2 <<= 1;
+    P.tab2_cap = t2;
+    long long neg = 0;
+    for (int i = 0; i < n; ++i) if (weights[i] < 0) neg += weights[i];
+    P.vbase_off = (int32_t)neg;
+    P.ev_cap = (uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16);
+    {
+        const size_t capS = P.capS, capW = P.capW, mlz = P.max_layers;
+        size_t b2 = 2 * wsT * capS * 8 + capS * 8 * 2 + (size_t)P.tab2_cap * 4 + P.ev_cap * 4 + mlz * 8 * 4 + capW * 4 +
+                    wsT * capW * 8 + 64 * 16;
+        e->mem2.assign(b2, 0xCD);
+        unsigned char* q = e->mem2.data();
+        P.s_state = carve<uint64_t>(q, wsT * capS);
+        P.s_path = carve<uint64_t>(q, wsT * capS);
+        P.s_hash = carve<uint64_t>(q, capS);
+        P.s_wkey = carve<uint64_t>(q, capS);
+        P.s_tab = carve<uint32_t>(q, P.tab2_cap);
+        P.s_ev = carve<uint32_t>(q, P.ev_cap);
+        P.s_evoff = carve<uint32_t>(q, mlz * 8);
+        P.s_cs_slot = carve<uint32_t>(q, capW);
+        P.s_cs_path = carve<uint64_t>(q, wsT * capW);
+        if ((size_t)(q - e->mem2.data()) > b2) {
+            std::fprintf(stderr, "emul: workspace2 overflow\n");
+            std::abort();
+        }
+        e->lds2.assign(dd2_lds_bytes(P.capS, P.capW, P.npad, nthreads), 0xEE);
+    }
     return e;
 }
 void emul_destroy(void* h) { delete (Emul*)h; }

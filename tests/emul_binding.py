@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 def build_emul():
     src = os.path.join(HERE, "emul", "emul_capi.cpp")
     out = os.path.join(HERE, "emul", "libddo_emul.so")
-    deps = [src, os.path.join(ROOT, "ddo_amd", "csrc", "misp_dd_core.hpp"), os.path.join(ROOT, "ddo_amd", "csrc", "dd_types.h")]
+    deps = [src] + [os.path.join(ROOT, "ddo_amd", "csrc", f) for f in ("misp_dd_core.hpp", "misp_dd_inplace.hpp", "dd_types.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", out, src],
                        check=True)
@@ -24,10 +24,10 @@ def build_emul():
 
 
 class Emul:
-    def __init__(self, n, rows, weights, max_width, nthreads=256, arena_bytes=64 << 20):
+    def __init__(self, n, rows, weights, max_width, nthreads=256, arena_bytes=64 << 20, engine=1):
         L = C.CDLL(build_emul())
         L.emul_create.restype = C.c_void_p
-        L.emul_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+        L.emul_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int]
         L.emul_destroy.argtypes = [C.c_void_p]
         L.emul_state_words.argtypes = [C.c_void_p]
         L.emul_compile.argtypes = [C.c_void_p, C.POINTER(DDInput), C.POINTER(DDResult), C.POINTER(C.c_void_p)]
@@ -41,7 +41,7 @@ class Emul:
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         weights = np.ascontiguousarray(weights, dtype=np.int64)
         self.h = L.emul_create(n, rows.ctypes.data_as(C.c_void_p), weights.ctypes.data_as(C.c_void_p), max_width, nthreads,
-                               arena_bytes)
+                               arena_bytes, engine)
         if not self.h:
             raise RuntimeError("emul_create failed")
         self.ws = L.emul_state_words(self.h)

@@ -16,15 +16,19 @@ from tests.parity_util import cutset_digest, diff
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "misp_compile_golden.json")
 
 
+ENGINES = [1, 2]   # 1 = per-layer rebuild (misp_dd_core.hpp), 2 = in-place layers (misp_dd_inplace.hpp)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name,width,max_compiles", [
     ("johnson8-4-4", 0, 0), ("MANN_a9", 0, 0), ("brock200_2", 0, 400), ("brock200_2", 1000, 40), ("brock200_2", 1, 150),
     ("brock200_2", 3, 150), ("keller4", 7, 300), ("hamming8-4", 0, 120), ("p_hat300-1", 0, 200), ("c-fat500-1", 0, 0),
     ("brock400_1", 200, 60),
 ])
-def test_emulation_replays_oracle_trace(oracle, name, width, max_compiles):
+def test_emulation_replays_oracle_trace(oracle, name, width, max_compiles, engine):
     inst = oracle.misp(data_path("misp", name + ".clq"))
     _, recs = inst.trace_solve(width, max_compiles)
-    e = Emul(inst.n, inst.rows, inst.weights, max(r["width"] for r in recs))
+    e = Emul(inst.n, inst.rows, inst.weights, max(r["width"] for r in recs), engine=engine)
     recycled = 0
     for i, r in enumerate(recs):
         g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"])[0]
@@ -36,22 +40,47 @@ def test_emulation_replays_oracle_trace(oracle, name, width, max_compiles):
         assert recycled > 0  # the clean.rs:830 "recycled" merge is exercised
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("nthreads", [256, 512, 1024])
-def test_emulation_is_independent_of_the_workgroup_size(oracle, nthreads):
+def test_emulation_is_independent_of_the_workgroup_size(oracle, nthreads, engine):
     inst = oracle.misp(data_path("misp", "brock200_2.clq"))
     _, recs = inst.trace_solve(25, 60)
-    e = Emul(inst.n, inst.rows, inst.weights, 25, nthreads=nthreads)
+    e = Emul(inst.n, inst.rows, inst.weights, 25, nthreads=nthreads, engine=engine)
     for r in recs:
         g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"])[0]
         assert diff(r, g) is None
 
 
-def test_emulation_fused_restricted_then_relaxed(oracle):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_emulation_weighted_instance(oracle, tmp_path, engine):
+    """`n` lines with negative weights (main.rs:290-297): non-unit RUB and values below the residual value."""
+    rng = np.random.RandomState(11)
+    n = 70
+    edges = [(a, b) for a in range(n) for b in range(a + 1, n) if rng.rand() < 0.25]
+    weights = rng.randint(-4, 25, size=n)
+    p = tmp_path / "w.clq"
+    with open(p, "w") as f:
+        f.write(f"p edge {n} {len(edges)}\n")
+        for i, wv in enumerate(weights):
+            f.write(f"n {i + 1} {int(wv)}\n")
+        for a, b in edges:
+            f.write(f"e {a + 1} {b + 1}\n")
+    inst = oracle.misp(str(p))
+    for width in (0, 4, 16):
+        _, recs = inst.trace_solve(width, 400)
+        e = Emul(inst.n, inst.rows, inst.weights, max(r["width"] for r in recs), engine=engine)
+        for i, r in enumerate(recs):
+            g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"])[0]
+            assert diff(r, g) is None, (width, i, diff(r, g))
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_emulation_fused_restricted_then_relaxed(oracle, engine):
     """IN_FUSED == the device half of process_one_node (parallel.rs:391-437): the relaxed DD sees the lower bound
     improved by the restricted one."""
     inst = oracle.misp(data_path("misp", "brock200_2.clq"))
     root = inst.root_state()
-    e = Emul(inst.n, inst.rows, inst.weights, 40)
+    e = Emul(inst.n, inst.rows, inst.weights, 40, engine=engine)
     lb = -(1 << 40)
     r0, r1 = e.compile(CT_RESTRICTED, 40, lb, root, 0, 0, flags=IN_FUSED | IN_WANT_PATHS)
     o0 = inst.compile(CT_RESTRICTED, 40, lb, root, 0, 0)
@@ -71,10 +100,11 @@ def _golden_small():
         return [c for c in json.load(f)["cases"] if c["width"] <= 1000]
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("case", _golden_small(), ids=lambda c: c["id"])
-def test_emulation_matches_golden(oracle, case):
+def test_emulation_matches_golden(oracle, case, engine):
     inst = oracle.misp(data_path("misp", case["instance"] + ".clq"))
-    e = Emul(inst.n, inst.rows, inst.weights, case["width"])
+    e = Emul(inst.n, inst.rows, inst.weights, case["width"], engine=engine)
     state = np.array([int(x) for x in case["state"]], dtype=np.uint64)
     g = e.compile(case["comp_type"], case["width"], case["best_lb"], state, case["value"], case["depth"])[0]
     for k in ["is_exact", "best_value", "best_exact_value", "nodes_expanded", "arcs", "layers"]:
