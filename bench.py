@@ -44,7 +44,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--concurrent", type=int, default=0, help="sub-problems per step (0 = 2 x device slots)")
+    ap.add_argument("--concurrent", type=int, default=2048, help="sub-problems compiled per step (== the reference's nb_threads)")
+    ap.add_argument("--fringe", default="lazy", choices=["lazy", "nodup"],
+                    help="lazy: cut-sets stay in the device node pool, SimpleFringe/MaxUB order; nodup: host NoDupFringe")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline (32 = best of the 1/32/128/256 sweep on the GPU box; 0 = all)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -70,8 +72,9 @@ def main():
     from ddo_amd import FixedWidth, ParallelSolver
 
     model = ddo_amd.Misp.read_instance(os.path.join(ROOT, "data", "misp", args.instance + ".clq"))
-    conc = args.concurrent if args.concurrent > 0 else 512
-    solver = ParallelSolver(model, FixedWidth(args.width), nb_threads=conc, device=local_rank, rank=rank, world_size=world)
+    conc = args.concurrent
+    solver = ParallelSolver(model, FixedWidth(args.width), nb_threads=conc, device=local_rank, rank=rank, world_size=world,
+                            fringe=args.fringe)
 
     def barrier():
         torch.cuda.synchronize()
@@ -130,7 +133,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "real instance (DIMACS brock400_1 complement graph shipped with the reference); search state synthetic-free",
-            "config": {"workload": f"MISP {args.instance}.clq FixedWidth({args.width}) LEL cut-set, EmptyCache, NoDupFringe(MaxUB)",
+            "config": {"workload": f"MISP {args.instance}.clq FixedWidth({args.width}) LEL cut-set, EmptyCache, "
+                                   + ("SimpleFringe(MaxUB) kept in the device node pool" if args.fringe == "lazy" else "NoDupFringe(MaxUB) on the host"),
                        "subproblems_per_step": conc, "parallelism": f"fringe-shard x{world}"},
             "subproblems_per_s": subs / elapsed,
             "compiles": compiles,

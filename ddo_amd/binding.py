@@ -57,7 +57,7 @@ class _Counters(C.Structure):
 
 class _SolverConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("width_policy", C.c_int), ("width", C.c_size_t), ("nb_concurrent", C.c_int),
-                ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int)]
+                ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int), ("fringe", C.c_int)]
 
 
 _CUTSET_CB = C.CFUNCTYPE(None, C.POINTER(_SubProblem), C.c_void_p)
@@ -358,7 +358,7 @@ class ParallelSolver:
     (parallel.rs:320-358); relaxation / ranking are carried by the model, dominance is the empty checker,
     the fringe is the NoDupFringe<MaxUB>.  `nb_threads` = sub-problems compiled concurrently on the GPU."""
 
-    def __init__(self, problem, width, cutoff=None, nb_threads=256, device=0, rank=0, world_size=1):
+    def __init__(self, problem, width, cutoff=None, nb_threads=256, device=0, rank=0, world_size=1, fringe="nodup"):
         self.problem = problem
         cfg = _SolverConfig()
         cfg.device = device
@@ -371,6 +371,7 @@ class ParallelSolver:
         cfg.nb_concurrent = int(nb_threads)
         cfg.time_budget_s = float(getattr(cutoff, "seconds", 0.0) or 0.0)
         cfg.rank, cfg.world_size = int(rank), int(world_size)
+        cfg.fringe = {"nodup": 0, "lazy": 1}[fringe]  # NoDupFringe (exact ddo order) | lazy block SimpleFringe on device
         self._h = lib().ddo_solver_create(problem._h, C.byref(cfg))
         if not self._h:
             raise DdoError("ddo_solver_create failed: " + _err())

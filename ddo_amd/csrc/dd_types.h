@@ -5,6 +5,12 @@
 #pragma once
 #include <stdint.h>
 
+#if defined(__HIPCC__) && !defined(DDO_HOST_EMULATION)
+#define DD_HD __host__ __device__
+#else
+#define DD_HD
+#endif
+
 namespace ddo_hip {
 
 constexpr int MAX_WS = 16;               // 64-bit words per state supported (n <= 1024)
@@ -17,6 +23,27 @@ constexpr int CT_EXACT = 0, CT_RELAXED = 1, CT_RESTRICTED = 2;
 constexpr uint32_t IN_FUSED = 1u;          // restricted, then (if inexact) relaxed: parallel.rs:391-437 on device
 constexpr uint32_t IN_FILTER_CUTSET = 2u;  // emit only cut-set nodes with ub > best_lb (parallel.rs:461)
 constexpr uint32_t IN_WANT_PATHS = 4u;     // always emit best paths (else only when value > best_lb)
+constexpr uint32_t IN_POOL_OUT = 8u;       // keep the cut-set in the device node pool; ship only (ub, value) per node
+constexpr uint64_t NO_POOL_SRC = ~0ULL;    // DDInput.src_off: the residual state is inline (not a pool row)
+
+/// A cut-set block in the device node pool (all offsets in bytes from the block start, 8-byte aligned):
+///   header 64 B | lvar u32[lel] | states u64[ws][rows] | path bits u64[pw][rows] | value i32[rows] | ub i32[rows]
+struct PoolBlockHeader {
+    uint32_t rows, ws, lel, depth;     // depth of every row (common.rs:86)
+    uint64_t parent_off;               // block holding the sub-problem this DD was compiled from (NO_POOL_SRC: root)
+    uint32_t parent_row, pw;           // pw = words of path bits per row = ceil(lel / 64)
+    uint64_t off_lvar, off_states, off_paths, off_values, off_ubs;
+};
+DD_HD inline uint64_t pool_block_bytes(uint32_t rows, uint32_t ws, uint32_t lel) {
+    const uint64_t pw = (lel + 63) / 64;
+    uint64_t b = 64;
+    b += ((uint64_t)lel * 4 + 7) & ~7ULL;
+    b += (uint64_t)ws * rows * 8;
+    b += pw * rows * 8;
+    b += ((uint64_t)rows * 4 + 7) & ~7ULL;
+    b += ((uint64_t)rows * 4 + 7) & ~7ULL;
+    return b;
+}
 
 /// One sub-problem to compile (mdd.rs:51-71 CompilationInput, minus the trait objects).
 struct DDInput {
@@ -27,6 +54,9 @@ struct DDInput {
     int32_t depth;     // residual.depth
     int32_t pad;
     int64_t best_lb;
+    uint64_t src_off;  // NO_POOL_SRC, or the pool block whose row `src_row` is the residual state
+    uint32_t src_row;
+    uint32_t pad2;
     uint64_t state[MAX_WS];
 };
 
@@ -57,13 +87,15 @@ struct DDResult {
     int32_t exact_len;
     int32_t exact_same_as_best;    // best exact path == best path (not stored twice)
     uint32_t recycled_merges;      // how many times clean.rs:830 found a recycled node
-    uint32_t pad;
+    uint32_t max_width_seen;       // widest layer that was expanded
     uint64_t arena_off;            // byte offset of this DD's block in the arena
     uint64_t arena_bytes;
     uint64_t nodes_expanded;
     uint64_t arcs;
     uint64_t layers;
     uint64_t path_off, exact_off, cs_state_off, cs_value_off, cs_ub_off, cs_path_off;  // byte offsets from arena_off
+    uint64_t phase_clk[8];         // shader-clock ticks per phase (profiling aid; engine 2 only)
+    uint64_t pool_off;             // IN_POOL_OUT: byte offset of the cut-set block in the node pool
 };
 
 /// Kernel arguments: model tables, capacities, per-slot workspace and batch I/O.
@@ -125,6 +157,10 @@ struct EngineParams {
     uint64_t ev_cap;
     uint32_t* s_cs_slot;       // [slot][capW]      node slots of the last exact layer (cut-set)
     uint64_t* s_cs_path;       // [slot][ws][capW]  their path bits
+    // ---- device node pool (fringe payload stays in HBM)
+    uint8_t* pool;
+    uint64_t pool_cap;
+    unsigned long long* pool_head;
 };
 
 // node flag bits (node_flags.rs:48-185 restricted to what the device needs)

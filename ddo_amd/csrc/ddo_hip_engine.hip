@@ -17,7 +17,7 @@
 
 #include "../../include/ddo_hip.h"
 #include "engine.hpp"
-#include "misp_dd_core.hpp"
+#include "misp_dd_inplace.hpp"
 
 namespace ddo_hip {
 
@@ -40,7 +40,35 @@ __global__ void __launch_bounds__(1024) misp_compile_kernel(EngineParams P) {
     }
 }
 
+/// in-place engine (misp_dd_inplace.hpp)
+template <int WS>
+__global__ void __launch_bounds__(1024) misp_compile_kernel2(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    DD2Ctx<WS> c;
+    dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
+    c.tid_ = (int)threadIdx.x;
+    for (;;) {
+        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
+        __syncthreads();
+        const int w = c.sh->work;
+        __syncthreads();
+        if (w >= P.nbatch) break;
+        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+    }
+}
+
 typedef void (*kernel_fn)(EngineParams);
+static kernel_fn pick_kernel2(int wsT) {
+    switch (wsT) {
+        case 1: return misp_compile_kernel2<1>;
+        case 2: return misp_compile_kernel2<2>;
+        case 4: return misp_compile_kernel2<4>;
+        case 7: return misp_compile_kernel2<7>;
+        case 8: return misp_compile_kernel2<8>;
+        case 16: return misp_compile_kernel2<16>;
+        default: return nullptr;
+    }
+}
 template <bool TLDS>
 static kernel_fn pick_kernel(int wsT) {
     switch (wsT) {
@@ -171,6 +199,22 @@ int Engine::init(Model* model, int device, long max_width) {
     table_lds_ = lds_with_table <= lds_max;
     lds_bytes_ = table_lds_ ? lds_with_table : dd_lds_bytes(0, P.npad, threads_);
     P.table_in_lds = table_lds_ ? 1 : 0;
+    // ---- engine 2 (in-place layers) when its LDS footprint fits and values fit the packed 21-bit key
+    P.capS = 2 * (int)max_width + 8;
+    P.capW = P.capN;
+    int t2 = 1024;
+    while (t2 < 8 * P.capW) t2 <<= 1;
+    P.tab2_cap = t2;
+    long long neg = 0;
+    for (int i = 0; i < model->n; ++i)
+        if (model->weight[i] < 0) neg += model->weight[i];
+    P.vbase_off = (int32_t)neg;
+    P.ev_cap = (uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16);
+    engine_kind_ = 2;
+    if (const char* env = std::getenv("DDO_HIP_ENGINE")) engine_kind_ = std::atoi(env) == 1 ? 1 : 2;
+    const size_t lds2 = dd2_lds_bytes(P.capS, P.capW, P.npad, threads_);
+    if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
+    if (engine_kind_ == 2) lds_bytes_ = lds2;
 
     // ---- how many DDs in flight: residency of the kernel, then HBM
     int blocks_per_cu = (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(2048 / threads_));
@@ -181,9 +225,12 @@ int Engine::init(Model* model, int device, long max_width) {
         if (s > 0) nslots = s;
     }
     const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers, wsT = model->wsT;
-    size_t per_slot = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
-                      ml * capN * 4 + ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
-                      (table_lds_ ? 0 : (size_t)P.table_cap * 4);
+    size_t per_slot = engine_kind_ == 1
+                          ? 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
+                                ml * capN * 4 + ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
+                                (table_lds_ ? 0 : (size_t)P.table_cap * 4)
+                          : 2 * wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 + (size_t)P.tab2_cap * 4 + P.ev_cap * 4 + ml * 8 * 4 +
+                                ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t arena_mb = 1024;
@@ -216,23 +263,35 @@ int Engine::init(Model* model, int device, long max_width) {
     P.weight = d_w;
 
     // ---- workspace
-    if ((rc = dev_alloc(allocs_, P.cstate, S * 2 * wsT * capC1))) return rc;
-    if ((rc = dev_alloc(allocs_, P.ckey, S * 2 * capC1))) return rc;
-    if ((rc = dev_alloc(allocs_, P.cpop, S * 2 * capC1))) return rc;
-    if ((rc = dev_alloc(allocs_, P.cflags, S * 2 * capC1))) return rc;
-    if ((rc = dev_alloc(allocs_, P.ctarget, S * 2 * capN))) return rc;
-    if ((rc = dev_alloc(allocs_, P.keep, S * capN))) return rc;
-    if ((rc = dev_alloc(allocs_, P.posmap, S * capC1))) return rc;
-    if ((rc = dev_alloc(allocs_, P.cls, S * capC1))) return rc;
-    if ((rc = dev_alloc(allocs_, P.ninfo, S * ml * capN))) return rc;
-    if ((rc = dev_alloc(allocs_, P.arct, S * ml * 2 * capN))) return rc;
+    if (engine_kind_ == 1) {
+        if ((rc = dev_alloc(allocs_, P.cstate, S * 2 * wsT * capC1))) return rc;
+        if ((rc = dev_alloc(allocs_, P.ckey, S * 2 * capC1))) return rc;
+        if ((rc = dev_alloc(allocs_, P.cpop, S * 2 * capC1))) return rc;
+        if ((rc = dev_alloc(allocs_, P.cflags, S * 2 * capC1))) return rc;
+        if ((rc = dev_alloc(allocs_, P.ctarget, S * 2 * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.keep, S * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.posmap, S * capC1))) return rc;
+        if ((rc = dev_alloc(allocs_, P.cls, S * capC1))) return rc;
+        if ((rc = dev_alloc(allocs_, P.ninfo, S * ml * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.arct, S * ml * 2 * capN))) return rc;
+    } else {
+        const size_t capS = P.capS, capW = P.capW;
+        if ((rc = dev_alloc(allocs_, P.s_state, S * wsT * capS))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_path, S * wsT * capS))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_hash, S * capS))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_tab, S * (size_t)P.tab2_cap))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_ev, S * P.ev_cap))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_evoff, S * ml * 8))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_cs_slot, S * capW))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_cs_path, S * wsT * capW))) return rc;
+    }
     if ((rc = dev_alloc(allocs_, P.nlayer, S * ml))) return rc;
     if ((rc = dev_alloc(allocs_, P.lvar, S * ml))) return rc;
     if ((rc = dev_alloc(allocs_, P.ldup, S * ml * 2))) return rc;
     if ((rc = dev_alloc(allocs_, P.cs_state, S * wsT * capN))) return rc;
     if ((rc = dev_alloc(allocs_, P.cs_value, S * capN))) return rc;
     if ((rc = dev_alloc(allocs_, P.cs_pop, S * capN))) return rc;
-    if (!table_lds_) {
+    if (engine_kind_ == 1 && !table_lds_) {
         if ((rc = dev_alloc(allocs_, P.gtable, S * (size_t)P.table_cap))) return rc;
     }
     if ((rc = dev_alloc(allocs_, d_arena_, arena_cap_))) return rc;
@@ -245,6 +304,22 @@ int Engine::init(Model* model, int device, long max_width) {
     P.work_counter = (int32_t*)cnt;
     P.arena_head = (unsigned long long*)(cnt + 8);
     P.cutoff_flag = (const int32_t*)(cnt + 16);
+    P.pool_head = (unsigned long long*)(cnt + 32);
+    if (engine_kind_ == 2) {   // node pool: whatever HBM is left (capped), for cut-sets that stay on the device
+        size_t free2 = 0, total2 = 0;
+        HIP_TRY(hipMemGetInfo(&free2, &total2));
+        size_t want = (size_t)64 << 30;
+        if (const char* env = std::getenv("DDO_HIP_POOL_GB")) want = (size_t)std::max(0, std::atoi(env)) << 30;
+        size_t avail = free2 > ((size_t)6 << 30) ? free2 - ((size_t)6 << 30) : 0;
+        size_t pool_bytes = std::min(want, avail);
+        if (pool_bytes >= ((size_t)1 << 28)) {
+            uint8_t* pool = nullptr;
+            if (dev_alloc(allocs_, pool, pool_bytes) == DDO_OK) {
+                P.pool = pool;
+                P.pool_cap = pool_bytes;
+            }
+        }
+    }
 
     hipStream_t st;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -255,7 +330,8 @@ int Engine::init(Model* model, int device, long max_width) {
     ev0_ = e0;
     ev1_ = e1;
 
-    kernel_fn fn = table_lds_ ? pick_kernel<true>(model->wsT) : pick_kernel<false>(model->wsT);
+    kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model->wsT)
+                                     : (table_lds_ ? pick_kernel<true>(model->wsT) : pick_kernel<false>(model->wsT));
     if (!fn) {
         set_error("unsupported state width");
         return DDO_ERR_UNSUPPORTED;
@@ -281,10 +357,28 @@ void Engine::set_cutoff(bool on) {
     (void)hipMemcpy((uint8_t*)d_counters_ + 16, &v, 4, hipMemcpyHostToDevice);
 }
 
+int Engine::pool_reset() {
+    std::lock_guard<std::mutex> g(mtx_);
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipMemset((uint8_t*)d_counters_ + 32, 0, 8));
+    return DDO_OK;
+}
+int Engine::read_pool(uint64_t off, void* dst, size_t bytes) {
+    std::lock_guard<std::mutex> g(mtx_);
+    if (!P_.pool || off + bytes > P_.pool_cap) {
+        set_error("read_pool: out of range");
+        return DDO_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipMemcpy(dst, P_.pool + off, bytes, hipMemcpyDeviceToHost));
+    return DDO_OK;
+}
+
 void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) const {
     out.clear();
     out.hdr = r;
     out.valid = true;
+    out.pool_off = r.pool_off;
     if (r.status != ST_OK) return;
     const int ws = model_->ws, wsT = model_->wsT;
     const uint8_t* base = arena + r.arena_off;
@@ -298,7 +392,12 @@ void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) co
     }
     out.n_cutset = r.n_cutset;
     out.cs_path_len = r.lel > 0 ? r.lel : 0;
-    if (r.n_cutset) {
+    if (r.n_cutset && r.pool_off != NO_POOL_SRC) {
+        const int32_t* v = (const int32_t*)(base + r.cs_value_off);
+        out.cs_value.assign(v, v + r.n_cutset);
+        const int32_t* u = (const int32_t*)(base + r.cs_ub_off);
+        out.cs_ub.assign(u, u + r.n_cutset);
+    } else if (r.n_cutset) {
         const uint64_t* s = (const uint64_t*)(base + r.cs_state_off);
         out.cs_state.resize((size_t)r.n_cutset * ws);
         for (int i = 0; i < r.n_cutset; ++i)
@@ -340,7 +439,8 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
     P.results = (DDResult*)d_results_;
     P.nbatch = count;
     const int grid = std::min(count, nslots_);
-    kernel_fn fn = table_lds_ ? pick_kernel<true>(model_->wsT) : pick_kernel<false>(model_->wsT);
+    kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT)
+                                     : (table_lds_ ? pick_kernel<true>(model_->wsT) : pick_kernel<false>(model_->wsT));
     HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);
     HIP_TRY(hipGetLastError());
@@ -499,6 +599,7 @@ static int fill_input(const Model& m, const ddo_compile_input* in, DDInput& out,
     if (in->comp_type != DDO_EXACT && in->comp_type != DDO_RELAXED && in->comp_type != DDO_RESTRICTED) return DDO_ERR_INVALID;
     if (in->residual.state_words != 0 && (int)in->residual.state_words != m.ws) return DDO_ERR_INVALID;
     std::memset(&out, 0, sizeof(out));
+    out.src_off = NO_POOL_SRC;
     out.comp_type = in->comp_type;
     out.flags = flags;
     // Exact compiles use the whole workspace as "width"

@@ -46,6 +46,7 @@ struct HostResult {
     std::vector<uint64_t> cs_state;     // n_cutset x ws (ABI words)
     std::vector<int32_t> cs_value, cs_ub;
     std::vector<uint32_t> cs_path;      // n_cutset x cs_path_len, node first
+    uint64_t pool_off = ~0ULL;          // IN_POOL_OUT: the cut-set block stayed in the device node pool
     bool valid = false;
     void clear() {
         valid = false;
@@ -74,12 +75,19 @@ class Engine {
     long max_width() const { return max_width_; }
     int nslots() const { return nslots_; }
     int threads() const { return threads_; }
+    int engine_kind() const { return engine_kind_; }
     size_t lds_bytes() const { return lds_bytes_; }
     double kernel_ms() const { return kernel_ms_; }
     uint64_t launches() const { return launches_; }
     double last_kernel_ms() const { return last_kernel_ms_; }
     /// device-visible cutoff flag (set asynchronously by the host to abort running compiles)
     void set_cutoff(bool on);
+    /// device node pool (cut-set blocks that never leave HBM)
+    bool has_pool() const { return P_.pool != nullptr; }
+    uint64_t pool_capacity() const { return P_.pool_cap; }
+    int pool_reset();
+    int read_pool(uint64_t off, void* dst, size_t bytes);
+    int words_per_state_device() const { return P_.ws; }
 
   private:
     Engine() = default;
@@ -93,6 +101,7 @@ class Engine {
     int threads_ = 0;
     size_t lds_bytes_ = 0;
     bool table_lds_ = true;
+    int engine_kind_ = 2;            // 1: per-layer rebuild (misp_dd_core.hpp), 2: in-place layers (misp_dd_inplace.hpp)
     EngineParams P_{};
     std::vector<void*> allocs_;
     void* stream_ = nullptr;

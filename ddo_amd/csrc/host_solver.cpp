@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -247,6 +249,165 @@ class NoDupFringe {
     size_t used_ = 0;
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Lazy block fringe: SimpleFringe semantics (fringe/simple.rs:35-62: a max-heap on MaxUB, no
+// de-duplication) without ever materialising the nodes on the host.  Every relaxed DD leaves its
+// cut-set as ONE block in the device node pool; the host receives only (value, ub) per node,
+// counting-sorts them once, and keeps a heap of blocks keyed by each block's best remaining node.
+// A push costs O(rows) integer work per block instead of a hash probe + heap sift per node, and the
+// next batch reads its residual states straight from HBM.
+// ---------------------------------------------------------------------------------------------
+struct DevBlock {
+    int refs = 0;
+    DevBlock* parent = nullptr;
+    int parent_row = 0;
+    uint64_t off = NO_POOL_SRC;      // pool offset (NO_POOL_SRC: the problem root, state inline)
+    int rows = 0, depth = 0, lel = 0;
+    int64_t cap_ub = I64_MAX;        // ub of the sub-problem the DD was compiled from (parallel.rs:460)
+    std::vector<int32_t> value, ub;
+    std::vector<uint32_t> order;     // rows sorted by (ub, value) descending
+    size_t cursor = 0;
+    uint64_t id = 0;
+    int64_t head_ub() const { return std::min<int64_t>(cap_ub, ub[order[cursor]]); }
+    int64_t head_value() const { return value[order[cursor]]; }
+};
+void dev_ref(DevBlock* b) {
+    if (b) b->refs++;
+}
+void dev_unref(DevBlock* b) {
+    while (b && --b->refs == 0) {
+        DevBlock* p = b->parent;
+        delete b;
+        b = p;
+    }
+}
+struct LazyItem {
+    DevBlock* block;
+    int row;
+    int depth;
+    int64_t value, ub;
+};
+class LazyFringe {
+  public:
+    ~LazyFringe() { clear(); }
+    size_t len() const { return open_; }
+    bool empty() const { return heap_.empty(); }
+    /// rows with min(cap_ub, ub) > best_lb are ordered by (ub, value) descending with two counting sorts
+    void push_block(DevBlock* b, int64_t best_lb, int rank, int world) {
+        const int n = b->rows;
+        std::vector<uint32_t> tmp;
+        tmp.reserve(n);
+        int32_t vmin = INT32_MAX, vmax = INT32_MIN, umin = INT32_MAX, umax = INT32_MIN;
+        for (int j = 0; j < n; ++j) {
+            if (std::min<int64_t>(b->cap_ub, b->ub[j]) <= best_lb) continue;
+            tmp.push_back((uint32_t)j);
+            vmin = std::min(vmin, b->value[j]);
+            vmax = std::max(vmax, b->value[j]);
+            umin = std::min(umin, b->ub[j]);
+            umax = std::max(umax, b->ub[j]);
+        }
+        if (tmp.empty()) return;
+        auto counting = [&](const std::vector<int32_t>& key, int32_t lo, int32_t hi) {
+            const int64_t range = (int64_t)hi - lo + 1;
+            if (range > (1 << 22)) {   // huge key range: comparison sort
+                std::stable_sort(tmp.begin(), tmp.end(), [&](uint32_t x, uint32_t y) { return key[x] > key[y]; });
+                return;
+            }
+            std::vector<uint32_t> cnt((size_t)range + 1, 0), out(tmp.size());
+            for (uint32_t j : tmp) cnt[(size_t)(hi - key[j]) + 1]++;      // descending
+            for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+            for (uint32_t j : tmp) out[cnt[(size_t)(hi - key[j])]++] = j;
+            tmp.swap(out);
+        };
+        counting(b->value, vmin, vmax);   // LSD: secondary key first
+        counting(b->ub, umin, umax);
+        if (world > 1 && b->depth >= 0 && b->parent && b->parent->parent == nullptr && b->parent->off == NO_POOL_SRC) {
+            std::vector<uint32_t> mine;    // root cut-set: dealt round-robin over the ranks
+            for (size_t k = 0; k < tmp.size(); ++k)
+                if ((int)(k % (size_t)world) == rank) mine.push_back(tmp[k]);
+            tmp.swap(mine);
+            if (tmp.empty()) return;
+        }
+        b->order.swap(tmp);
+        b->cursor = 0;
+        b->id = next_id_++;
+        dev_ref(b);
+        open_ += b->order.size();
+        heap_.push_back(b);
+        sift_up(heap_.size() - 1);
+    }
+    /// best remaining node by (ub, value); false when nothing with ub > best_lb is left
+    bool pop(LazyItem& out, int64_t best_lb) {
+        while (!heap_.empty()) {
+            DevBlock* b = heap_[0];
+            if (b->head_ub() <= best_lb) {   // sorted by ub: the rest of the block is irrelevant too
+                if (b == heap_[0] && heap_.size() >= 1) {
+                    // the heap top carries the largest ub of the whole fringe: nothing relevant is left (parallel.rs:531-535)
+                    clear();
+                    return false;
+                }
+            }
+            const int j = (int)b->order[b->cursor];
+            out.block = b;
+            out.row = j;
+            out.depth = b->depth;
+            out.value = b->value[j];
+            out.ub = std::min<int64_t>(b->cap_ub, b->ub[j]);
+            dev_ref(b);   // the caller's reference
+            b->cursor++;
+            open_--;
+            if (b->cursor >= b->order.size()) {
+                heap_[0] = heap_.back();
+                heap_.pop_back();
+                if (!heap_.empty()) sift_down(0);
+                dev_unref(b);
+            } else {
+                sift_down(0);
+            }
+            return true;
+        }
+        return false;
+    }
+    int64_t best_ub() const { return heap_.empty() ? I64_MIN : heap_[0]->head_ub(); }
+    void clear() {
+        for (DevBlock* b : heap_) dev_unref(b);
+        heap_.clear();
+        open_ = 0;
+    }
+
+  private:
+    static bool less(const DevBlock* a, const DevBlock* b) {   // MaxUB (subproblem_ranking.rs:86-90) on the block heads
+        const int64_t ua = a->head_ub(), ub_ = b->head_ub();
+        if (ua != ub_) return ua < ub_;
+        const int64_t va = a->head_value(), vb = b->head_value();
+        if (va != vb) return va < vb;
+        return a->id > b->id;
+    }
+    void sift_up(size_t i) {
+        while (i > 0) {
+            size_t p = (i - 1) / 2;
+            if (!less(heap_[p], heap_[i])) break;
+            std::swap(heap_[p], heap_[i]);
+            i = p;
+        }
+    }
+    void sift_down(size_t i) {
+        const size_t n = heap_.size();
+        for (;;) {
+            size_t l = 2 * i + 1, r = l + 1, m = i;
+            if (l < n && less(heap_[m], heap_[l])) m = l;
+            if (r < n && less(heap_[m], heap_[r])) m = r;
+            if (m == i) break;
+            std::swap(heap_[m], heap_[i]);
+            i = m;
+        }
+    }
+    std::vector<DevBlock*> heap_;
+    size_t open_ = 0;
+    uint64_t next_id_ = 0;
+};
+
 }  // namespace
 
 struct ddo_solver {
@@ -254,6 +415,8 @@ struct ddo_solver {
     ddo_solver_config cfg{};
     std::shared_ptr<Engine> engine;
     NoDupFringe* fringe = nullptr;
+    LazyFringe* lazy = nullptr;          // DDO_FRINGE_LAZY
+    std::vector<LazyItem> litems;
     // Critical (parallel.rs:32-81)
     uint64_t explored = 0;
     int64_t best_lb = I64_MIN;
@@ -265,12 +428,40 @@ struct ddo_solver {
     bool finished = false;
     ddo_counters counters{};
     std::chrono::steady_clock::time_point t_start;
+    // optional statistics (DDO_HIP_STATS=1): per-DD layers / nodes / widest layer
+    std::vector<uint32_t> st_layers, st_maxw;
+    std::vector<uint64_t> st_nodes;
+    uint64_t st_clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st_push = 0, st_push_dup = 0;
+    double st_host_pop = 0, st_host_run = 0, st_host_post = 0;
+    bool want_stats = false;
     // scratch
     std::vector<DDInput> inputs;
     std::vector<Entry> items;
     std::vector<HostResult> results;
 
-    ~ddo_solver() { delete fringe; }
+    ~ddo_solver() {
+        if (want_stats && !st_layers.empty()) {
+            auto pct = [](std::vector<uint64_t> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+            std::vector<uint64_t> a(st_layers.begin(), st_layers.end()), b(st_maxw.begin(), st_maxw.end());
+            uint64_t tl = 0, tn = 0;
+            for (auto x : a) tl += x;
+            for (auto x : st_nodes) tn += x;
+            uint64_t tc = 0;
+            for (int q = 0; q < 8; ++q) tc += st_clk[q];
+            std::fprintf(stderr, "[ddo stats] device phase share: var %.1f%% select %.1f%% victims+merge %.1f%% worklist %.1f%% freelist %.1f%% expand %.1f%% final %.1f%% backward %.1f%% | host s: pop %.3f run %.3f post %.3f | pushes %llu\n",
+                         100.0 * st_clk[0] / std::max<uint64_t>(1, tc), 100.0 * st_clk[1] / std::max<uint64_t>(1, tc), 100.0 * st_clk[2] / std::max<uint64_t>(1, tc),
+                         100.0 * st_clk[3] / std::max<uint64_t>(1, tc), 100.0 * st_clk[4] / std::max<uint64_t>(1, tc), 100.0 * st_clk[5] / std::max<uint64_t>(1, tc),
+                         100.0 * st_clk[6] / std::max<uint64_t>(1, tc), 100.0 * st_clk[7] / std::max<uint64_t>(1, tc), st_host_pop, st_host_run, st_host_post,
+                         (unsigned long long)st_push);
+            std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
+                         a.size(), (double)tl / a.size(), (unsigned long long)pct(a, .5), (unsigned long long)pct(a, .9), (unsigned long long)pct(a, 1.0),
+                         (unsigned long long)pct(b, .1), (unsigned long long)pct(b, .5), (unsigned long long)pct(b, .75), (unsigned long long)pct(b, .9), (unsigned long long)pct(b, .99), (unsigned long long)pct(b, 1.0),
+                         (double)tn / a.size(), (unsigned long long)pct(st_nodes, .5), (unsigned long long)pct(st_nodes, .9), (unsigned long long)pct(st_nodes, 1.0), (double)tn / std::max<uint64_t>(1, tl));
+        }
+        delete fringe;
+        delete lazy;
+    }
 
     long engine_width() const {
         return cfg.width_policy == DDO_WIDTH_FIXED ? (long)cfg.width : (long)std::max(1, model->n);
@@ -349,13 +540,166 @@ struct ddo_solver {
             if (ub > best_lb) {                                   // :461
                 Entry e{b, j, b->depth, b->values[j], ub, hash_words(b->state(j), model->ws)};
                 fringe->push(e);
+                st_push += 1;
             }
         }
         block_unref(b);
     }
 
+    /// problem-root path of a pool node: decisions stored as bit strings + per-block variable lists in HBM
+    int materialize_pool_path(const DevBlock* b, int row, std::vector<ddo_decision>& out) {
+        std::vector<std::pair<const DevBlock*, int>> chain;
+        while (b) {
+            chain.push_back({b, row});
+            row = b->parent_row;
+            b = b->parent;
+        }
+        for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
+            const DevBlock* blk = it->first;
+            if (blk->off == NO_POOL_SRC || blk->lel == 0) continue;
+            PoolBlockHeader h;
+            int rc = engine->read_pool(blk->off, &h, sizeof(h));
+            if (rc != DDO_OK) return rc;
+            std::vector<uint32_t> lvar(h.lel);
+            if ((rc = engine->read_pool(blk->off + h.off_lvar, lvar.data(), (size_t)h.lel * 4)) != DDO_OK) return rc;
+            std::vector<uint64_t> bits(h.pw);
+            for (uint32_t k = 0; k < h.pw; ++k)
+                if ((rc = engine->read_pool(blk->off + h.off_paths + ((uint64_t)k * h.rows + (uint64_t)it->second) * 8, &bits[k], 8)) != DDO_OK) return rc;
+            for (uint32_t tr = 0; tr < h.lel; ++tr)   // root side first
+                out.push_back(ddo_decision{(int64_t)lvar[tr], (int64_t)((bits[tr >> 6] >> (tr & 63)) & 1ULL)});
+        }
+        return DDO_OK;
+    }
+
+    /// step() with the lazy block fringe: payload in the device node pool, (value, ub) keys on the host
+    int step_lazy() {
+        if (!initialized) {
+            initialized = true;
+            t_start = std::chrono::steady_clock::now();
+            engine->pool_reset();
+            DevBlock* root = new DevBlock();
+            root->rows = 1;
+            root->value.push_back(0);
+            root->ub.push_back(INT32_MAX);
+            lazy->push_block(root, I64_MIN, 0, 1);
+        }
+        if (finished) return 0;
+        if (aborted) return DDO_CUTOFF;
+        if (lazy->empty()) {
+            if (cfg.world_size <= 1) best_ub = best_lb;
+            finished = true;
+            return 0;
+        }
+        if (budget_exhausted()) {
+            aborted = true;
+            best_ub = lazy->best_ub();
+            lazy->clear();
+            return DDO_CUTOFF;
+        }
+        auto t_pop0 = std::chrono::steady_clock::now();
+        litems.clear();
+        const int B = std::max(1, cfg.nb_concurrent);
+        LazyItem it;
+        while ((int)litems.size() < B && lazy->pop(it, best_lb)) {
+            litems.push_back(it);
+            explored += 1;
+        }
+        if (litems.empty()) {
+            if (cfg.world_size <= 1) best_ub = best_lb;
+            finished = true;
+            return 0;
+        }
+        if (cfg.world_size <= 1) best_ub = litems[0].ub == INT32_MAX ? I64_MAX : litems[0].ub;
+        // longest-processing-time-first: shallow sub-problems with a lot of slack are the big DDs
+        if (litems.size() > 2)
+            std::stable_sort(litems.begin(), litems.end(), [](const LazyItem& a, const LazyItem& b) {
+                if (a.depth != b.depth) return a.depth < b.depth;
+                return (a.ub - a.value) > (b.ub - b.value);
+            });
+        inputs.resize(litems.size());
+        const int64_t lim = (int64_t)1 << 40;
+        for (size_t i = 0; i < litems.size(); ++i) {
+            DDInput& in = inputs[i];
+            std::memset(&in, 0, sizeof(in));
+            in.comp_type = CT_RESTRICTED;
+            in.flags = IN_FUSED | IN_FILTER_CUTSET | IN_POOL_OUT;
+            in.width = cfg.width_policy == DDO_WIDTH_FIXED ? (int)cfg.width : std::max(1, model->n - litems[i].depth);
+            in.value = (int32_t)litems[i].value;
+            in.depth = litems[i].depth;
+            in.best_lb = std::max(-lim, std::min(lim, best_lb));
+            in.src_off = litems[i].block->off;
+            in.src_row = (uint32_t)litems[i].row;
+            if (in.src_off == NO_POOL_SRC)
+                for (int v = 0; v < model->n; ++v) in.state[v / 64] |= 1ULL << (v % 64);
+        }
+        auto t_run0 = std::chrono::steady_clock::now();
+        st_host_pop += std::chrono::duration<double>(t_run0 - t_pop0).count();
+        int rc = engine->run_batch(inputs.data(), (int)inputs.size(), results);
+        auto t_run1 = std::chrono::steady_clock::now();
+        st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
+        if (rc != DDO_OK) {
+            for (LazyItem& e : litems) dev_unref(e.block);
+            return rc;
+        }
+        int err = DDO_OK;
+        for (size_t i = 0; i < litems.size() && err == DDO_OK; ++i) {
+            for (int k = 0; k < 2; ++k) {
+                HostResult* r = &results[2 * i + k];
+                if (r->hdr.status == ST_NOT_RUN) continue;
+                if (r->hdr.status != ST_OK) {
+                    set_error(r->hdr.status == ST_ERR_CAPACITY
+                                  ? "device node pool / output arena exhausted (raise DDO_HIP_POOL_GB or use DDO_FRINGE_NODUP)"
+                                  : "device compile failed with status " + std::to_string(r->hdr.status));
+                    err = r->hdr.status == ST_CUTOFF ? DDO_CUTOFF : (r->hdr.status == ST_ERR_CAPACITY ? DDO_ERR_CAPACITY : DDO_ERR_INTERNAL);
+                    break;
+                }
+                counters.nodes_expanded += r->hdr.nodes_expanded;
+                counters.arcs += r->hdr.arcs;
+                counters.layers += r->hdr.layers;
+                counters.compiles += 1;
+                if (want_stats) {
+                    st_layers.push_back((uint32_t)r->hdr.layers);
+                    st_maxw.push_back(r->hdr.max_width_seen);
+                    st_nodes.push_back(r->hdr.nodes_expanded);
+                    for (int q = 0; q < 8; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                }
+                if (r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
+                    best_lb = r->hdr.best_exact_value;
+                    best_sol.clear();
+                    if ((err = materialize_pool_path(litems[i].block, litems[i].row, best_sol)) != DDO_OK) break;
+                    const std::vector<uint32_t>& p = r->hdr.exact_same_as_best ? r->best_path : r->exact_path;
+                    for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)});
+                    has_sol = true;
+                }
+                const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;
+                if (k == 1 && !exact && r->n_cutset > 0 && r->pool_off != NO_POOL_SRC) {   // enqueue_cutset
+                    DevBlock* b = new DevBlock();
+                    b->parent = litems[i].block;
+                    b->parent_row = litems[i].row;
+                    dev_ref(litems[i].block);
+                    b->off = r->pool_off;
+                    b->rows = r->n_cutset;
+                    b->lel = r->cs_path_len;
+                    b->depth = litems[i].depth + r->cs_path_len;
+                    b->cap_ub = litems[i].ub;
+                    b->value = std::move(r->cs_value);
+                    b->ub = std::move(r->cs_ub);
+                    dev_ref(b);
+                    st_push += (uint64_t)b->rows;
+                    lazy->push_block(b, best_lb, cfg.rank, cfg.world_size);
+                    dev_unref(b);
+                }
+            }
+        }
+        for (LazyItem& e : litems) dev_unref(e.block);
+        st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
+        if (err != DDO_OK) return err;
+        return 1;
+    }
+
     /// One round of get_workload + process_one_node for up to nb_concurrent sub-problems.
     int step() {
+        if (lazy) return step_lazy();
         initialize();
         if (finished) return 0;
         if (aborted) return DDO_CUTOFF;
@@ -390,6 +734,12 @@ struct ddo_solver {
             return 0;
         }
         if (cfg.world_size <= 1) best_ub = items[0].ub;     // best-first: the first popped bounds the rest
+        // longest-processing-time-first: the device work queue hands items out in order, so put the
+        // sub-problems with the most remaining vertices (the biggest DDs) first to shorten the tail
+        if (items.size() > 2)
+            std::stable_sort(items.begin(), items.end(), [&](const Entry& a, const Entry& b) {
+                return model->popcount(a.block->state(a.row)) > model->popcount(b.block->state(b.row));
+            });
         // ---- process_one_node on the device (parallel.rs:391-437), restricted + relaxed fused
         inputs.resize(items.size());
         const int64_t lim = (int64_t)1 << 40;
@@ -402,9 +752,13 @@ struct ddo_solver {
             in.value = (int32_t)items[i].value;
             in.depth = items[i].depth;
             in.best_lb = std::max(-lim, std::min(lim, best_lb));
+            in.src_off = NO_POOL_SRC;
             std::memcpy(in.state, items[i].block->state(items[i].row), (size_t)model->ws * 8);
         }
+        auto t_run0 = std::chrono::steady_clock::now();
         int rc = engine->run_batch(inputs.data(), (int)inputs.size(), results);
+        auto t_run1 = std::chrono::steady_clock::now();
+        st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
         if (rc != DDO_OK) {
             for (Entry& e : items) block_unref(e.block);
             return rc;
@@ -435,12 +789,19 @@ struct ddo_solver {
                 counters.arcs += r->hdr.arcs;
                 counters.layers += r->hdr.layers;
                 counters.compiles += 1;
+                if (want_stats) {
+                    st_layers.push_back((uint32_t)r->hdr.layers);
+                    st_maxw.push_back(r->hdr.max_width_seen);
+                    st_nodes.push_back(r->hdr.nodes_expanded);
+                    for (int q = 0; q < 8; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                }
                 maybe_update_best(items[i], *r);
                 const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;
                 if (k == 1 && !exact) enqueue_cutset(items[i], *r);
             }
         }
         for (Entry& e : items) block_unref(e.block);
+        st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
         if (err != DDO_OK) return err;
         return 1;
     }
@@ -468,6 +829,15 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
         return nullptr;
     }
     s->fringe = new NoDupFringe(s->model);
+    if (s->cfg.fringe == DDO_FRINGE_LAZY) {
+        if (s->engine->engine_kind() != 2 || !s->engine->has_pool()) {
+            set_error("DDO_FRINGE_LAZY needs the in-place device engine and its node pool");
+            delete s;
+            return nullptr;
+        }
+        s->lazy = new LazyFringe();
+    }
+    s->want_stats = std::getenv("DDO_HIP_STATS") != nullptr;
     return s;
 }
 void ddo_solver_destroy(ddo_solver* s) { delete s; }
@@ -546,9 +916,11 @@ int ddo_solver_import_lower_bound(ddo_solver* s, int64_t best_lb) {
 uint64_t ddo_solver_fringe_len(const ddo_solver* s) {
     if (!s) return 0;
     if (!s->initialized) return 1;
+    if (s->lazy) return s->lazy->len();
     return s->fringe->len();
 }
 int64_t ddo_solver_fringe_best_ub(const ddo_solver* s) {
+    if (s->lazy) return s->lazy->best_ub();
     const Entry* top = s->fringe->peek();
     return top ? top->ub : I64_MIN;
 }

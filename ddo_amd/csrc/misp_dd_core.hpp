@@ -122,6 +122,7 @@ struct DDShared {
     int32_t ncut, ncut2;
     int32_t xbest;       // recycled merge: candidate re-added to the layer (clean.rs:868-872)
     uint32_t recycled_merges;
+    int32_t maxn;
     uint64_t k1and, k1or;
     uint64_t pivK1;
     uint64_t pivLex[MAX_WS];
@@ -508,6 +509,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         sh->nodes = 0;
         sh->arcs = 0;
         sh->recycled_merges = 0;
+        sh->maxn = 0;
         sh->cutoff = 0;
         for (int k = 0; k < WS; ++k) c.cstate[0][(size_t)k * capC1] = in.state[k];
         int pop = 0;
@@ -862,7 +864,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         if (myarcs) LDS_ADD_U64(&sh->arcs, (uint64_t)myarcs);
         if (myuniq) LDS_ADD_I32(&sh->nU, myuniq);
-        if (tid == 0) sh->nodes += (uint64_t)n;
+        if (tid == 0) {
+            sh->nodes += (uint64_t)n;
+            if (n > sh->maxn) sh->maxn = n;
+        }
         PAR_END
 #if defined(DDO_HOST_EMULATION)
         if (getenv("DD_TRACE")) std::printf("E1 L=%d var=%d n=%d arcs=%llu nU_next=%d squash=%d\n", L, var, n, (unsigned long long)sh->arcs, sh->nU, (int)squash);
@@ -1188,7 +1193,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         r.exact_len = arena_ok ? (same ? best_len : exact_len) : 0;
         r.exact_same_as_best = same ? 1 : 0;
         r.recycled_merges = sh->recycled_merges;
-        r.pad = 0;
+        r.max_width_seen = (uint32_t)sh->maxn;
         r.arena_off = sh->arena_off;
         r.arena_bytes = total;
         r.nodes_expanded = sh->nodes;
@@ -1200,6 +1205,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         r.cs_value_off = cs_value_off;
         r.cs_ub_off = cs_ub_off;
         r.cs_path_off = cs_path_off;
+        for (int k = 0; k < 8; ++k) r.phase_clk[k] = 0;
+        r.pool_off = NO_POOL_SRC;
         *res = r;
     }
     PAR_END

@@ -48,6 +48,14 @@ constexpr uint32_t KEY_POP_MASK = (1u << KEY_POP_BITS) - 1;
 #define GLB_ST_U32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
+#if defined(DDO_HOST_EMULATION)
+DDO_DEV uint64_t dd_clock() { return 0; }
+#else
+DDO_DEV uint64_t dd_clock() { return (uint64_t)__builtin_readcyclecounter(); }
+#endif
+// phase ids of DDResult::phase_clk
+constexpr int PH_VAR = 0, PH_SELECT = 1, PH_VICTIMS = 2, PH_WORKLIST = 3, PH_FREELIST = 4, PH_EXPAND = 5, PH_FINAL = 6, PH_BACKWARD = 7;
+
 struct DD2Shared {
     int32_t work, status, cutoff;
     uint32_t varkey;
@@ -60,6 +68,7 @@ struct DD2Shared {
     int32_t merged_slot, recycled, xslot, free_slot;
     int32_t ncut, ncut2;
     uint32_t recycled_merges;
+    int32_t maxn;
     uint32_t kand, kor, pivKey;
     uint32_t gs[64];
     uint64_t pivLex[MAX_WS];
@@ -69,6 +78,8 @@ struct DD2Shared {
     uint64_t nodes, arcs;
     uint64_t arena_off;
     uint64_t ev_pos;
+    uint64_t clk[8];
+    uint64_t clk_last;
     int32_t xcand[64];
 };
 
@@ -112,6 +123,9 @@ struct DD2Ctx {
     uint64_t arena_cap;
     unsigned long long* arena_head;
     const int32_t* cutoff_flag;
+    uint8_t* pool;
+    uint64_t pool_cap;
+    unsigned long long* pool_head;
     int vbase_off;
     int NT;
 #if !defined(DDO_HOST_EMULATION)
@@ -407,6 +421,15 @@ DDO_DEV void tab2_rebuild(DD2Ctx<WS>& c) {
 constexpr uint32_t EV_RAISED = 0x40000000u;
 constexpr uint32_t EV_SLOT_MASK = 0x000FFFFFu;
 
+#define DD2_TICK(ph)                                        \
+    PAR_BEGIN                                               \
+    if (tid == 0) {                                         \
+        const uint64_t _t = dd_clock();                     \
+        sh->clk[ph] += _t - sh->clk_last;                   \
+        sh->clk_last = _t;                                  \
+    }                                                       \
+    PAR_END
+
 template <int WS>
 DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
     DD_TID_SETUP(c)
@@ -432,24 +455,37 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         sh->nodes = 0;
         sh->arcs = 0;
         sh->recycled_merges = 0;
+        sh->maxn = 0;
         sh->cutoff = 0;
         sh->nlive = 1;
         sh->hiw = 1;
         sh->tab_used = 1;
         sh->ev_pos = 0;
+        for (int k = 0; k < 8; ++k) sh->clk[k] = 0;
+        sh->clk_last = dd_clock();
         int pop = 0;
+        uint64_t root[WS];
+        if (in.src_off != NO_POOL_SRC) {   // the residual state is a row of a cut-set block kept in the device pool
+            const PoolBlockHeader* h = (const PoolBlockHeader*)(c.pool + in.src_off);
+            const uint64_t* rows = (const uint64_t*)(c.pool + in.src_off + h->off_states);
+            for (int k = 0; k < WS; ++k) root[k] = k < (int)h->ws ? rows[(size_t)k * h->rows + in.src_row] : 0;
+        } else {
+            for (int k = 0; k < WS; ++k) root[k] = in.state[k];
+        }
         for (int k = 0; k < WS; ++k) {
-            c.st[(size_t)k * capS] = in.state[k];
+            c.st[(size_t)k * capS] = root[k];
             c.pb[(size_t)k * capS] = 0;
-            pop += dd_popc(in.state[k]);
+            pop += dd_popc(root[k]);
         }
         c.key32[0] = ((uint32_t)(in.value - vbase) << KEY_POP_BITS) | (uint32_t)pop;
-        c.hsh[0] = hash2_state<WS>(in.state);
+        c.hsh[0] = hash2_state<WS>(root);
     }
     PAR_END
     PAR_BEGIN
     if (tid == 0) {
-        add_bits<WS>(c.cnt, in.state, +1);
+        uint64_t root[WS];
+        for (int k = 0; k < WS; ++k) root[k] = c.st[(size_t)k * capS];
+        add_bits<WS>(c.cnt, root, +1);
         c.live[0] = 1u;
         c.okb[0] = 1u;
         c.fresh[0] = 1u;
@@ -489,6 +525,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             break;
         }
         if (L >= c.max_layers - 1 || sh->status != ST_OK) { failed = true; break; }
+        DD2_TICK(PH_VAR)
         const int nU = sh->nlive;
 
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
@@ -509,6 +546,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
             const int K = restricted ? W : W - 1;
             if (K > 0) select_pivot2<WS>(c, K);
+            DD2_TICK(PH_SELECT)
             PAR_BEGIN
             if (tid == 0) {
                 sh->nvict = 0;
@@ -664,6 +702,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
         }
+        DD2_TICK(PH_VICTIMS)
         const int n = sh->nlive;   // |layer L| after squash
         const int naff_bound = c.cnt[var] > 0 ? c.cnt[var] : 0;   // live states containing the variable
 
@@ -732,6 +771,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             failed = true;
             break;
         }
+        DD2_TICK(PH_WORKLIST)
         // ------------------------------------------------------------ free slots for the YES-children
         PAR_BEGIN
         {
@@ -774,6 +814,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
         }
 
+        DD2_TICK(PH_FREELIST)
         // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
         const uint64_t aff_off = sh->ev_pos;
         PAR_BEGIN
@@ -924,12 +965,14 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             eo[2] = (uint32_t)nrec;
             sh->ev_pos += 4ull * (uint64_t)nrec;
             sh->nodes += (uint64_t)n;
+            if (n > sh->maxn) sh->maxn = n;
             sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
 #if defined(DDO_HOST_EMULATION)
             if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
 #endif
         }
         PAR_END
+        DD2_TICK(PH_EXPAND)
         L += 1;
     }
 
@@ -984,6 +1027,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
     }
 
+    DD2_TICK(PH_FINAL)
     // ---------------------------------------------------------------- local bounds (clean.rs:448-475)
     const bool want_cutset = relaxed && !failed && lel >= 0 && has_best;
     int32_t* vb = (int32_t*)c.key32;       // the ranking keys are dead now: reuse their LDS
@@ -1048,6 +1092,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
     }
 
+    DD2_TICK(PH_BACKWARD)
     // ---------------------------------------------------------------- cut-set (clean.rs:417-445)
     const int ncs_layer = want_cutset ? ncs : 0;
     const bool filter = (in.flags & IN_FILTER_CUTSET) != 0;
@@ -1090,6 +1135,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     const int best_len = emit_best ? path_len : 0;
     const int exact_len = (emit_exact && !same) ? path_len : 0;
     const int cs_path_len = lel > 0 ? lel : 0;
+    const bool pool_out = (in.flags & IN_POOL_OUT) != 0 && c.pool != nullptr;
 
     uint64_t off = 0;
     const uint64_t path_off = off;
@@ -1097,22 +1143,38 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     const uint64_t exact_off = off;
     off += ((uint64_t)exact_len * 4 + 7) & ~7ULL;
     const uint64_t cs_state_off = off;
-    off += (uint64_t)ncut * WS * 8;
+    if (!pool_out) off += (uint64_t)ncut * WS * 8;
     const uint64_t cs_value_off = off;
     off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
     const uint64_t cs_ub_off = off;
     off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
     const uint64_t cs_path_off = off;
-    off += ((uint64_t)ncut * cs_path_len * 4 + 7) & ~7ULL;
+    if (!pool_out) off += ((uint64_t)ncut * cs_path_len * 4 + 7) & ~7ULL;
     const uint64_t total = off;
+    const uint32_t pw = (uint32_t)((cs_path_len + 63) / 64);
+    const uint64_t pool_bytes = (pool_out && ncut) ? pool_block_bytes((uint32_t)ncut, (uint32_t)WS, (uint32_t)cs_path_len) : 0;
 
     PAR_BEGIN
     if (tid == 0) {
         unsigned long long a = total ? GLB_ADD_U64(c.arena_head, (unsigned long long)total) : 0ULL;
         sh->arena_off = a;
         if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY;
+        sh->ev_pos = 0;   // reused: pool offset of this DD's cut-set block
+        if (pool_bytes) {
+            unsigned long long pa = GLB_ADD_U64(c.pool_head, (unsigned long long)pool_bytes);
+            sh->ev_pos = pa;
+            if (pa + pool_bytes > c.pool_cap) sh->status = ST_ERR_CAPACITY;
+        }
     }
     PAR_END
+    const uint64_t pool_off = sh->ev_pos;
+    uint8_t* pblock = pool_bytes ? c.pool + pool_off : nullptr;
+    // block-relative offsets (PoolBlockHeader)
+    const uint64_t b_lvar = 64;
+    const uint64_t b_states = b_lvar + (((uint64_t)cs_path_len * 4 + 7) & ~7ULL);
+    const uint64_t b_paths = b_states + (uint64_t)WS * (uint64_t)ncut * 8;
+    const uint64_t b_values = b_paths + (uint64_t)pw * (uint64_t)ncut * 8;
+    const uint64_t b_ubs = b_values + (((uint64_t)ncut * 4 + 7) & ~7ULL);
     const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;
     uint8_t* base = c.arena + sh->arena_off;
 
@@ -1135,7 +1197,52 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
             }
         }
-        if (want_cutset && ncut) {
+        if (want_cutset && ncut && pblock) {
+            // ---- cut-set kept in the device node pool: the host only receives (value, ub) per node
+            if (tid == 0) {
+                PoolBlockHeader* h = (PoolBlockHeader*)pblock;
+                h->rows = (uint32_t)ncut;
+                h->ws = (uint32_t)WS;
+                h->lel = (uint32_t)cs_path_len;
+                h->depth = (uint32_t)(in.depth + cs_path_len);
+                h->parent_off = in.src_off;
+                h->parent_row = in.src_row;
+                h->pw = pw;
+                h->off_lvar = b_lvar;
+                h->off_states = b_states;
+                h->off_paths = b_paths;
+                h->off_values = b_values;
+                h->off_ubs = b_ubs;
+            }
+            uint32_t* p_lvar = (uint32_t*)(pblock + b_lvar);
+            for (int j = tid; j < cs_path_len; j += NT) p_lvar[j] = (uint32_t)c.lvar[j];
+            uint64_t* p_state = (uint64_t*)(pblock + b_states);
+            uint64_t* p_path = (uint64_t*)(pblock + b_paths);
+            int32_t* p_value = (int32_t*)(pblock + b_values);
+            int32_t* p_ub = (int32_t*)(pblock + b_ubs);
+            int32_t* o_value = (int32_t*)(base + cs_value_off);
+            int32_t* o_ub = (int32_t*)(base + cs_ub_off);
+            for (int i = tid; i < ncs_layer; i += NT) {
+                const int32_t vbv = vb[c.cs_slot[i]];
+                if (vbv == VB_UNMARKED) continue;
+                uint64_t s[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) s[k] = c.cs_state[(size_t)k * c.capW + i];
+                const int64_t v = c.cs_value[i];
+                int64_t ub = v + (c.unit_weights ? (int64_t)c.cs_pop[i] : (int64_t)rub2_of<WS>(c, s));
+                if (v + vbv < ub) ub = v + vbv;
+                if (best_value < ub) ub = best_value;
+                if (filter && ub <= best_lb) continue;
+                const int idx = LDS_ADD_I32(&sh->ncut2, 1);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) p_state[(size_t)k * ncut + idx] = s[k];
+                for (uint32_t k = 0; k < pw; ++k) p_path[(size_t)k * ncut + idx] = c.cs_path[(size_t)k * c.capW + i];
+                p_value[idx] = (int32_t)v;
+                p_ub[idx] = (int32_t)ub;
+                o_value[idx] = (int32_t)v;
+                o_ub[idx] = (int32_t)ub;
+            }
+        } else if (want_cutset && ncut) {
             uint64_t* o_state = (uint64_t*)(base + cs_state_off);
             int32_t* o_value = (int32_t*)(base + cs_value_off);
             int32_t* o_ub = (int32_t*)(base + cs_ub_off);
@@ -1184,7 +1291,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         r.exact_len = arena_ok ? (same ? best_len : exact_len) : 0;
         r.exact_same_as_best = same ? 1 : 0;
         r.recycled_merges = sh->recycled_merges;
-        r.pad = 0;
+        r.max_width_seen = (uint32_t)sh->maxn;
         r.arena_off = sh->arena_off;
         r.arena_bytes = total;
         r.nodes_expanded = sh->nodes;
@@ -1196,6 +1303,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         r.cs_value_off = cs_value_off;
         r.cs_ub_off = cs_ub_off;
         r.cs_path_off = cs_path_off;
+        sh->clk[PH_FINAL] += dd_clock() - sh->clk_last;
+        for (int k = 0; k < 8; ++k) r.phase_clk[k] = sh->clk[k];
+        r.pool_off = pool_bytes ? pool_off : NO_POOL_SRC;
         *res = r;
     }
     PAR_END
@@ -1306,6 +1416,9 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.arena_cap = P.arena_cap;
     c.arena_head = P.arena_head;
     c.cutoff_flag = P.cutoff_flag;
+    c.pool = P.pool;
+    c.pool_cap = P.pool_cap;
+    c.pool_head = P.pool_head;
     c.vbase_off = P.vbase_off;
     c.NT = nthreads;
 }

@@ -151,6 +151,11 @@ int ddo_mdd_last_counters(const ddo_mdd* mdd, ddo_counters* out);
 #define DDO_WIDTH_FIXED 0         /* width.rs:166-171 FixedWidth(w)            */
 #define DDO_WIDTH_NB_UNASSIGNED 1 /* width.rs:397-402 NbUnassignedWidth(n)     */
 
+/* Fringe implementations (abstraction/fringe.rs:26-45) */
+#define DDO_FRINGE_NODUP 0 /* fringe/no_duplicate.rs:52-324: one entry per state, host resident (exact ddo order) */
+#define DDO_FRINGE_LAZY 1  /* fringe/simple.rs:35-62 semantics (MaxUB order, no de-duplication): cut-sets stay in the
+                              device node pool, the host orders whole cut-set blocks lazily by (ub, value)        */
+
 typedef struct ddo_solver_config {
     int device;            /* HIP device ordinal                                                   */
     int width_policy;      /* DDO_WIDTH_FIXED | DDO_WIDTH_NB_UNASSIGNED                             */
@@ -160,6 +165,7 @@ typedef struct ddo_solver_config {
     double time_budget_s;  /* <= 0: NoCutoff; else TimeBudget (cutoff.rs:302-323)                   */
     int rank;              /* fringe shard owned by this solver ...                                 */
     int world_size;        /* ... out of this many (1 = whole problem); see ddo_solver_step        */
+    int fringe;            /* DDO_FRINGE_NODUP | DDO_FRINGE_LAZY                                    */
 } ddo_solver_config;
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg);

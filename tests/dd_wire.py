@@ -12,7 +12,8 @@ ST_OK, ST_CUTOFF, ST_NOT_RUN = 0, 1, 77
 
 class DDInput(C.Structure):
     _fields_ = [("comp_type", C.c_int32), ("flags", C.c_uint32), ("width", C.c_int32), ("value", C.c_int32),
-                ("depth", C.c_int32), ("pad", C.c_int32), ("best_lb", C.c_int64), ("state", C.c_uint64 * MAX_WS)]
+                ("depth", C.c_int32), ("pad", C.c_int32), ("best_lb", C.c_int64), ("src_off", C.c_uint64), ("src_row", C.c_uint32),
+                ("pad2", C.c_uint32), ("state", C.c_uint64 * MAX_WS)]
 
 
 class DDResult(C.Structure):
@@ -20,11 +21,11 @@ class DDResult(C.Structure):
                 ("has_exact_best_path", C.c_int32), ("has_best", C.c_int32), ("has_best_exact", C.c_int32),
                 ("best_value", C.c_int32), ("best_exact_value", C.c_int32), ("n_layers", C.c_int32), ("lel", C.c_int32),
                 ("n_cutset", C.c_int32), ("best_len", C.c_int32), ("exact_len", C.c_int32),
-                ("exact_same_as_best", C.c_int32), ("recycled_merges", C.c_uint32), ("pad", C.c_uint32),
+                ("exact_same_as_best", C.c_int32), ("recycled_merges", C.c_uint32), ("max_width_seen", C.c_uint32),
                 ("arena_off", C.c_uint64), ("arena_bytes", C.c_uint64), ("nodes_expanded", C.c_uint64),
                 ("arcs", C.c_uint64), ("layers", C.c_uint64), ("path_off", C.c_uint64), ("exact_off", C.c_uint64),
                 ("cs_state_off", C.c_uint64), ("cs_value_off", C.c_uint64), ("cs_ub_off", C.c_uint64),
-                ("cs_path_off", C.c_uint64)]
+                ("cs_path_off", C.c_uint64), ("phase_clk", C.c_uint64 * 8), ("pool_off", C.c_uint64)]
 
 
 def parse_result(res, arena_ptr, ws, depth0):

@@ -60,6 +60,7 @@ class Emul:
         inp.value = int(value)
         inp.depth = int(depth)
         inp.best_lb = int(max(min(best_lb, (1 << 62)), -(1 << 62)))
+        inp.src_off = (1 << 64) - 1
         for k in range(MAX_WS):
             inp.state[k] = int(state[k]) if k < len(state) else 0
         res = (DDResult * 2)()

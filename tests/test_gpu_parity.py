@@ -99,6 +99,40 @@ def test_solver_known_optimum_concurrent(have_gpu, name, expected, width, thread
     assert len(chosen) == expected and is_independent_set(rows, model.ws, chosen)
 
 
+@pytest.mark.parametrize("name,expected,width,threads", [
+    ("brock200_2", 12, 1000, 64), ("brock200_2", 12, 0, 1), ("brock200_3", 15, 0, 256), ("keller4", 11, 50, 300),
+    ("johnson8-4-4", 14, 0, 7), ("MANN_a9", 16, 3, 32), ("p_hat300-1", 8, 0, 128), ("c-fat500-1", 14, 0, 8),
+])
+def test_solver_lazy_device_fringe(have_gpu, name, expected, width, threads):
+    """DDO_FRINGE_LAZY: cut-sets never leave HBM (device node pool), the host orders blocks by (ub, value) -- the
+    SimpleFringe/MaxUB configuration of the reference (fringe/simple.rs:35-62).  Same proved optimum, and the
+    incumbent's path (rebuilt from the pool's bit strings) is a feasible solution of that value."""
+    model = ddo_amd.Misp.read_instance(data_path("misp", name + ".clq"))
+    s = ParallelSolver(model, FixedWidth(width) if width else NbUnassignedWidth(model.n), nb_threads=threads, fringe="lazy")
+    c = s.maximize()
+    assert c.is_exact and c.best_value == expected
+    assert s.best_upper_bound() == expected and s.fringe_len() == 0
+    sol = s.best_solution()
+    assert sorted(d.variable for d in sol) == sorted(set(d.variable for d in sol))   # each variable decided once
+    chosen = [d.variable for d in sol if d.value == 1]
+    rows, w = model.export()
+    assert sum(int(w[v]) for v in chosen) == expected and is_independent_set(rows, model.ws, chosen)
+
+
+def test_sharded_lazy_fringe(have_gpu):
+    model = ddo_amd.Misp.read_instance(data_path("misp", "brock200_2.clq"))
+    ranks = [ParallelSolver(model, FixedWidth(100), nb_threads=32, rank=r, world_size=2, fringe="lazy") for r in range(2)]
+    live = [True, True]
+    while any(live):
+        for r, s in enumerate(ranks):
+            if live[r]:
+                live[r] = s.step() == 1
+        lb = max(s.best_lower_bound() for s in ranks)
+        for s in ranks:
+            s.import_lower_bound(lb)
+    assert max(s.best_lower_bound() for s in ranks) == 12
+
+
 # ---- (3) golden fixtures (generated by tests/golden/make_golden.py from the oracle) ----------------
 def _golden_cases():
     with open(GOLDEN) as f:
