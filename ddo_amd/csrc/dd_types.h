@@ -147,10 +147,9 @@ struct EngineParams {
     int32_t capW;              // work-list capacity (width + 4)
     int32_t tab2_cap;          // persistent dedup table slots (power of two, HBM)
     int32_t vbase_off;         // lowest reachable value relative to the residual value (sum of negative weights)
-    uint64_t* s_state;         // [slot][ws][capS]  node states, word major
-    uint64_t* s_path;          // [slot][ws][capS]  decisions of the best path to the node, one bit per layer
-    uint64_t* s_hash;          // [slot][capS]      cached state hash
-    uint64_t* s_wkey;          // [slot][capS]      (value ^ 2^31) << 32 | incoming-arc code of the current transition
+    uint64_t* s_state;         // [slot][ws][capS]  node states, word major (streaming scan copy)
+    uint64_t* s_rec;           // [slot][capS][RW]  node records: state words + cached hash, RW = 8*ceil((ws+1)/8) words
+    uint64_t* s_path;          // [slot][capS][PR]  best-path bit strings, one bit per layer, PR = 8*ceil(ws/8) words
     uint32_t* s_tab;           // [slot][tab2_cap]  open-addressing table: tag:12 | node slot:20, tombstones
     uint32_t* s_ev;            // [slot][ev_cap]    per-transition event records for the backward pass
     uint32_t* s_evoff;         // [slot][max_layers+1][4] offsets / counts per transition

@@ -209,7 +209,7 @@ int Engine::init(Model* model, int device, long max_width) {
     for (int i = 0; i < model->n; ++i)
         if (model->weight[i] < 0) neg += model->weight[i];
     P.vbase_off = (int32_t)neg;
-    P.ev_cap = (uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16);
+    P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 1) & ~1ull;
     engine_kind_ = 2;
     if (const char* env = std::getenv("DDO_HIP_ENGINE")) engine_kind_ = std::atoi(env) == 1 ? 1 : 2;
     const size_t lds2 = dd2_lds_bytes(P.capS, P.capW, P.npad, threads_);
@@ -229,8 +229,8 @@ int Engine::init(Model* model, int device, long max_width) {
                           ? 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
                                 ml * capN * 4 + ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
                                 (table_lds_ ? 0 : (size_t)P.table_cap * 4)
-                          : 2 * wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 + (size_t)P.tab2_cap * 4 + P.ev_cap * 4 + ml * 8 * 4 +
-                                ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
+                          : wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 * (((wsT + 8) / 8) * 8 + ((wsT + 7) / 8) * 8) +
+                                (size_t)P.tab2_cap * 4 + P.ev_cap * 4 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t arena_mb = 1024;
@@ -276,9 +276,10 @@ int Engine::init(Model* model, int device, long max_width) {
         if ((rc = dev_alloc(allocs_, P.arct, S * ml * 2 * capN))) return rc;
     } else {
         const size_t capS = P.capS, capW = P.capW;
+        const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
         if ((rc = dev_alloc(allocs_, P.s_state, S * wsT * capS))) return rc;
-        if ((rc = dev_alloc(allocs_, P.s_path, S * wsT * capS))) return rc;
-        if ((rc = dev_alloc(allocs_, P.s_hash, S * capS))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_rec, S * capS * RW))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_path, S * capS * PR))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_tab, S * (size_t)P.tab2_cap))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_ev, S * P.ev_cap))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_evoff, S * ml * 8))) return rc;
@@ -657,7 +658,7 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
         d->depth = inputs[i].residual.depth;
         d->path_to_root.assign(inputs[i].residual.path, inputs[i].residual.path + inputs[i].residual.path_len);
         int st = d->res.hdr.status;
-        int code = st == ST_OK ? DDO_OK : (st == ST_CUTOFF ? DDO_CUTOFF : st);
+        int code = st == ST_OK ? DDO_OK : (st == ST_CUTOFF ? DDO_CUTOFF : (st <= -100 ? DDO_ERR_CAPACITY : st));
         if (statuses) statuses[i] = code;
         if (code < 0 && worst >= 0) worst = code;
         if (code != DDO_OK) d->res.valid = false;

@@ -454,6 +454,10 @@ struct ddo_solver {
                          100.0 * st_clk[3] / std::max<uint64_t>(1, tc), 100.0 * st_clk[4] / std::max<uint64_t>(1, tc), 100.0 * st_clk[5] / std::max<uint64_t>(1, tc),
                          100.0 * st_clk[6] / std::max<uint64_t>(1, tc), 100.0 * st_clk[7] / std::max<uint64_t>(1, tc), st_host_pop, st_host_run, st_host_post,
                          (unsigned long long)st_push);
+            std::fprintf(stderr, "[ddo stats] device kcycles per layer: var %.1f select %.1f victims+merge %.1f worklist %.1f freelist %.1f expand %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
+                         st_clk[0] / 1e3 / std::max<uint64_t>(1, tl), st_clk[1] / 1e3 / std::max<uint64_t>(1, tl), st_clk[2] / 1e3 / std::max<uint64_t>(1, tl),
+                         st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
+                         tc / 1e3 / std::max<uint64_t>(1, tl), tc / 1e6 / a.size());
             std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
                          a.size(), (double)tl / a.size(), (unsigned long long)pct(a, .5), (unsigned long long)pct(a, .9), (unsigned long long)pct(a, 1.0),
                          (unsigned long long)pct(b, .1), (unsigned long long)pct(b, .5), (unsigned long long)pct(b, .75), (unsigned long long)pct(b, .9), (unsigned long long)pct(b, .99), (unsigned long long)pct(b, 1.0),
@@ -647,10 +651,11 @@ struct ddo_solver {
                 HostResult* r = &results[2 * i + k];
                 if (r->hdr.status == ST_NOT_RUN) continue;
                 if (r->hdr.status != ST_OK) {
-                    set_error(r->hdr.status == ST_ERR_CAPACITY
-                                  ? "device node pool / output arena exhausted (raise DDO_HIP_POOL_GB or use DDO_FRINGE_NODUP)"
-                                  : "device compile failed with status " + std::to_string(r->hdr.status));
-                    err = r->hdr.status == ST_CUTOFF ? DDO_CUTOFF : (r->hdr.status == ST_ERR_CAPACITY ? DDO_ERR_CAPACITY : DDO_ERR_INTERNAL);
+                    const bool capacity = r->hdr.status == ST_ERR_CAPACITY || r->hdr.status <= -100;
+                    set_error(capacity ? "device capacity exhausted (site " + std::to_string(r->hdr.status) + " dbg nodes=" + std::to_string(r->hdr.nodes_expanded) + " arcs=" + std::to_string(r->hdr.arcs) + " layers=" + std::to_string(r->hdr.layers) + " maxw=" + std::to_string(r->hdr.max_width_seen) + " k=" + std::to_string(k) +
+                                             "): node pool / output arena / workspace; raise DDO_HIP_POOL_GB or use DDO_FRINGE_NODUP"
+                                       : "device compile failed with status " + std::to_string(r->hdr.status));
+                    err = r->hdr.status == ST_CUTOFF ? DDO_CUTOFF : (capacity ? DDO_ERR_CAPACITY : DDO_ERR_INTERNAL);
                     break;
                 }
                 counters.nodes_expanded += r->hdr.nodes_expanded;
@@ -765,7 +770,8 @@ struct ddo_solver {
         }
         int err = DDO_OK;
         for (size_t i = 0; i < items.size() && err == DDO_OK; ++i) {
-            if (results[2 * i].hdr.status == ST_ERR_CAPACITY || results[2 * i + 1].hdr.status == ST_ERR_CAPACITY) {
+            if (results[2 * i].hdr.status == ST_ERR_CAPACITY || results[2 * i + 1].hdr.status == ST_ERR_CAPACITY ||
+                results[2 * i].hdr.status <= -100 || results[2 * i + 1].hdr.status <= -100) {
                 // the shared output arena overflowed: redo this sub-problem on its own
                 std::vector<HostResult> solo;
                 int rc2 = engine->run_batch(&inputs[i], 1, solo);

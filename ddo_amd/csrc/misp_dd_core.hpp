@@ -37,6 +37,7 @@
 #define DDO_DEV inline
 #define PAR_BEGIN for (int tid = 0; tid < NT; ++tid) {
 #define PAR_END }
+#define DD_SYNC()
 #define DDO_TID_DECL
 namespace ddo_hip {
 template <class T> inline T emu_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
@@ -77,6 +78,8 @@ inline uint64_t dd_brev(uint64_t x) {
 #define DDO_DEV __device__ __forceinline__
 #define PAR_BEGIN {
 #define PAR_END } __syncthreads();
+// explicit barrier: needed when workgroup-uniform code has read shared scalars that the very next phase rewrites
+#define DD_SYNC() __syncthreads()
 namespace ddo_hip {
 #define LDS_ADD_I32(p, v) atomicAdd((p), (v))
 #define LDS_ADD_U32(p, v) atomicAdd((p), (v))

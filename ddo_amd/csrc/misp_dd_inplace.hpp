@@ -70,6 +70,7 @@ struct DD2Shared {
     uint32_t recycled_merges;
     int32_t maxn;
     uint32_t kand, kor, pivKey;
+    uint64_t land, lor;
     uint32_t gs[64];
     uint64_t pivLex[MAX_WS];
     uint64_t merged[MAX_WS];
@@ -90,9 +91,10 @@ struct DD2Ctx {
     const int32_t* weight;
     int capS, capW, max_layers, nbw;
     // HBM, per engine slot
-    uint64_t* st;      // [ws][capS]
-    uint64_t* pb;      // [ws][capS]
-    uint64_t* hsh;     // [capS]
+    uint64_t* st;      // [ws][capS]   word-major copy of the states: only the streaming "who contains v" scan reads it
+    uint64_t* rec;     // [capS][RW]   node records, one (or two) 64-byte lines each: state words, then the cached hash
+    uint64_t* pbr;     // [capS][PR]   best-path bit strings, one line per node
+    int RW, PR;
     uint32_t* tab;
     int tab_cap;
     uint32_t* ev;
@@ -156,10 +158,46 @@ DDO_DEV uint64_t hash2_state(const uint64_t* s) {
     return h;
 }
 
+/// Node records are array-of-structures: a random access to a node costs one 64-byte line instead of one line
+/// per state word (rocprof showed the expand phase bound by random 8-byte requests, not by bytes).
 template <int WS>
 DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
+    const uint64_t* r = c.rec + (size_t)slot * c.RW;
 #pragma unroll
-    for (int k = 0; k < WS; ++k) s[k] = LD_U64(&c.st[(size_t)k * c.capS + slot]);
+    for (int k = 0; k < WS; ++k) s[k] = r[k];
+}
+template <int WS>
+DDO_DEV uint64_t ld_hash(const DD2Ctx<WS>& c, int slot) { return c.rec[(size_t)slot * c.RW + WS]; }
+template <int WS>
+DDO_DEV uint64_t ld_word(const DD2Ctx<WS>& c, int slot, int k) { return c.rec[(size_t)slot * c.RW + k]; }
+/// full (re)write of a node: record line + the word-major copy
+template <int WS>
+DDO_DEV void st_node(const DD2Ctx<WS>& c, int slot, const uint64_t* s, uint64_t h) {
+    uint64_t* r = c.rec + (size_t)slot * c.RW;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        r[k] = s[k];
+        c.st[(size_t)k * c.capS + slot] = s[k];
+    }
+    r[WS] = h;
+}
+/// one state word changes (NO-child in place)
+template <int WS>
+DDO_DEV void st_word(const DD2Ctx<WS>& c, int slot, int k, uint64_t w, uint64_t h) {
+    uint64_t* r = c.rec + (size_t)slot * c.RW;
+    r[k] = w;
+    r[WS] = h;
+    c.st[(size_t)k * c.capS + slot] = w;
+}
+template <int WS>
+DDO_DEV void copy_path(const DD2Ctx<WS>& c, int dst, int src) {
+    const uint64_t* a = c.pbr + (size_t)src * c.PR;
+    uint64_t* b = c.pbr + (size_t)dst * c.PR;
+    uint64_t tmp[WS];
+#pragma unroll
+    for (int k = 0; k < WS; ++k) tmp[k] = a[k];
+#pragma unroll
+    for (int k = 0; k < WS; ++k) b[k] = tmp[k];
 }
 
 /// insert node `x` (hash h, state in HBM) -> x when new, else the live node holding the same state
@@ -177,8 +215,11 @@ DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint64_t h, const uint64_t* 
         }
         if (e != T2_TOMB && (e >> 20) == tag) {
             const int w = (int)(e & 0xFFFFFu);
+            uint64_t o[WS];
+            ld_state<WS>(c, w, o);
             bool eq = true;
-            for (int k = 0; k < WS && eq; ++k) eq = LD_U64(&c.st[(size_t)k * c.capS + w]) == s[k];
+#pragma unroll
+            for (int k = 0; k < WS; ++k) eq &= o[k] == s[k];
             if (eq) return w;
         }
         slot = (slot + 1) & mask;
@@ -226,8 +267,11 @@ DDO_DEV int tab2_find(const DD2Ctx<WS>& c, uint64_t h, const uint64_t* s) {
         if (e == T2_EMPTY) return -1;
         if (e != T2_TOMB && (e >> 20) == tag) {
             const int w = (int)(e & 0xFFFFFu);
+            uint64_t o[WS];
+            ld_state<WS>(c, w, o);
             bool eq = true;
-            for (int k = 0; k < WS && eq; ++k) eq = LD_U64(&c.st[(size_t)k * c.capS + w]) == s[k];
+#pragma unroll
+            for (int k = 0; k < WS; ++k) eq &= o[k] == s[k];
             if (eq) return w;
         }
         slot = (slot + 1) & mask;
@@ -256,8 +300,8 @@ DDO_DEV bool ranks_above2(const DD2Ctx<WS>& c, int a, int b) {
     uint32_t ka = c.key32[a], kb = c.key32[b];
     if (ka != kb) return ka > kb;
     for (int k = 0; k < WS; ++k) {
-        uint64_t la = dd_brev(~c.st[(size_t)k * c.capS + a]);
-        uint64_t lb = dd_brev(~c.st[(size_t)k * c.capS + b]);
+        uint64_t la = dd_brev(~ld_word<WS>(c, a, k));
+        uint64_t lb = dd_brev(~ld_word<WS>(c, b, k));
         if (la != lb) return la > lb;
     }
     return false;
@@ -346,38 +390,112 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
     uint64_t pivLex[WS];
 #pragma unroll
     for (int k = 0; k < WS; ++k) pivLex[k] = 0;
-    for (int qd = 0; qd < 8 * WS && !done; ++qd) {
-        const int wj = qd >> 3;
-        const int shift = 8 * (7 - (qd & 7));
+    if (!done) {
+        // ---- tie-break inside the (value, popcount) bucket by member order (BitSet::cmp, main.rs:205-208):
+        // the bucket is compacted into a list once; per state word the lexicographic key brev(~word) of every
+        // listed node is fetched ONCE into a scratch row, digits that are constant over the list are skipped,
+        // and after each word the list shrinks to the nodes still tied with the pivot.
         PAR_BEGIN
-        if (tid < 256) c.hist[tid] = 0;
+        if (tid == 0) sh->nwl = 0;
         PAR_END
         PAR_BEGIN
-        for (int s = tid; s < hi; s += NT) {
-            if (!bm_test(c.live, s) || c.key32[s] != piv) continue;
-            bool active = true;
-            for (int k = 0; k < wj && active; ++k) active = dd_brev(~c.st[(size_t)k * c.capS + s]) == pivLex[k];
-            if (!active) continue;
-            uint64_t lw = dd_brev(~c.st[(size_t)wj * c.capS + s]);
-            if (shift + 8 < 64 && (lw >> (shift + 8)) != (pivLex[wj] >> (shift + 8))) continue;
-            LDS_ADD_U32(&c.hist[(lw >> shift) & 0xFF], 1u);
+        for (int s = tid; s < hi; s += NT)
+            if (bm_test(c.live, s) && c.key32[s] == piv) {
+                int i = LDS_ADD_I32(&sh->nwl, 1);
+                if (i < c.capW) c.wl[i] = (uint16_t)s;
+            }
+        PAR_END
+        int m = sh->nwl < c.capW ? sh->nwl : c.capW;
+        uint64_t* lwbuf = (uint64_t*)(c.ev + ((sh->ev_pos + 1) & ~1ULL));   // scratch behind the event records
+        const bool scratch_ok = ((sh->ev_pos + 1) & ~1ULL) + 2ull * (uint64_t)m + 2 <= c.ev_cap;
+        if (!scratch_ok) {
+            PAR_BEGIN
+            if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 1;
+            PAR_END
+            done = true;
         }
-        PAR_END
-        PAR_BEGIN
-        if (tid < 256) {
-            int above = 0;
-            for (int x = tid + 1; x < 256; ++x) above += (int)c.hist[x];
-            int mine = (int)c.hist[tid];
-            if (above < need && need <= above + mine) {
-                sh->sel_digit = tid;
-                sh->sel_above = above;
-                sh->sel_bucket = mine;
+        uint16_t* cur = c.wl;
+        uint16_t* nxt = c.fl;
+        for (int wj = 0; wj < WS && !done; ++wj) {
+            PAR_BEGIN
+            if (tid == 0) {
+                sh->land = ~0ULL;
+                sh->lor = 0;
+            }
+            PAR_END
+            PAR_BEGIN
+            uint64_t a = ~0ULL, o = 0;
+            for (int i = tid; i < m; i += NT) {
+                const uint64_t lw = dd_brev(~ld_word<WS>(c, cur[i], wj));
+                lwbuf[i] = lw;
+                a &= lw;
+                o |= lw;
+            }
+            if (tid < m) {
+                LDS_AND_U64(&sh->land, a);
+                LDS_OR_U64(&sh->lor, o);
+            }
+            PAR_END
+            const uint64_t land = sh->land;
+            const uint64_t ldiff = land ^ sh->lor;
+            DD_SYNC();   // every thread has its copy before thread 0 resets land/lor for the next word
+            if (ldiff == 0) {   // every tied node has the same word: nothing to decide here
+                pivLex[wj] = land;
+                continue;
+            }
+            uint64_t prefix = 0;
+            for (int b = 7; b >= 0 && !done; --b) {
+                const int shift = 8 * b;
+                if (((ldiff >> shift) & 0xFF) == 0) {
+                    prefix |= land & (0xFFULL << shift);
+                    continue;
+                }
+                PAR_BEGIN
+                if (tid < 256) c.hist[tid] = 0;
+                PAR_END
+                PAR_BEGIN
+                for (int i = tid; i < m; i += NT) {
+                    const uint64_t lw = lwbuf[i];
+                    if (shift + 8 < 64 && (lw >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+                    LDS_ADD_U32(&c.hist[(lw >> shift) & 0xFF], 1u);
+                }
+                PAR_END
+                PAR_BEGIN
+                if (tid < 256) {
+                    int above = 0;
+                    for (int x = tid + 1; x < 256; ++x) above += (int)c.hist[x];
+                    int mine = (int)c.hist[tid];
+                    if (above < need && need <= above + mine) {
+                        sh->sel_digit = tid;
+                        sh->sel_above = above;
+                        sh->sel_bucket = mine;
+                    }
+                }
+                PAR_END
+                prefix |= (uint64_t)sh->sel_digit << shift;
+                need -= sh->sel_above;
+                if (need == sh->sel_bucket) {
+                    done = true;   // everything still tied below this digit is kept
+                }
+            }
+            pivLex[wj] = prefix;
+            if (!done) {   // keep only the nodes still tied with the pivot on this word
+                PAR_BEGIN
+                if (tid == 0) sh->nwl = 0;
+                PAR_END
+                PAR_BEGIN
+                for (int i = tid; i < m; i += NT)
+                    if (lwbuf[i] == prefix) {
+                        int k = LDS_ADD_I32(&sh->nwl, 1);
+                        nxt[k] = cur[i];
+                    }
+                PAR_END
+                m = sh->nwl;
+                uint16_t* t = cur;
+                cur = nxt;
+                nxt = t;
             }
         }
-        PAR_END
-        pivLex[wj] |= (uint64_t)sh->sel_digit << shift;
-        need -= sh->sel_above;
-        if (need == sh->sel_bucket) done = true;
     }
     PAR_BEGIN
     if (tid == 0) {
@@ -392,7 +510,7 @@ DDO_DEV bool ge_pivot2(const DD2Ctx<WS>& c, int s, uint32_t key) {
     const DD2Shared* sh = c.sh;
     if (key != sh->pivKey) return key > sh->pivKey;
     for (int k = 0; k < WS; ++k) {
-        uint64_t lw = dd_brev(~c.st[(size_t)k * c.capS + s]);
+        uint64_t lw = dd_brev(~ld_word<WS>(c, s, k));
         if (lw != sh->pivLex[k]) return lw > sh->pivLex[k];
     }
     return true;
@@ -407,7 +525,7 @@ DDO_DEV void tab2_rebuild(DD2Ctx<WS>& c) {
     PAR_END
     PAR_BEGIN
     for (int s = tid; s < c.sh->hiw; s += NT)
-        if (bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, c.hsh[s]);
+        if (bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, ld_hash<WS>(c, s));
     if (tid == 0) c.sh->tab_used = c.sh->nlive;
     PAR_END
 }
@@ -473,23 +591,22 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             for (int k = 0; k < WS; ++k) root[k] = in.state[k];
         }
         for (int k = 0; k < WS; ++k) {
-            c.st[(size_t)k * capS] = root[k];
-            c.pb[(size_t)k * capS] = 0;
+            c.pbr[k] = 0;
             pop += dd_popc(root[k]);
         }
+        st_node<WS>(c, 0, root, hash2_state<WS>(root));
         c.key32[0] = ((uint32_t)(in.value - vbase) << KEY_POP_BITS) | (uint32_t)pop;
-        c.hsh[0] = hash2_state<WS>(root);
     }
     PAR_END
     PAR_BEGIN
     if (tid == 0) {
         uint64_t root[WS];
-        for (int k = 0; k < WS; ++k) root[k] = c.st[(size_t)k * capS];
+        ld_state<WS>(c, 0, root);
         add_bits<WS>(c.cnt, root, +1);
         c.live[0] = 1u;
         c.okb[0] = 1u;
         c.fresh[0] = 1u;
-        tab2_insert_unique<WS>(c, 0, c.hsh[0]);
+        tab2_insert_unique<WS>(c, 0, ld_hash<WS>(c, 0));
     }
     PAR_END
 
@@ -570,7 +687,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             const int nv = sh->nvict;
             if (nv > c.capW || sh->ev_pos + (uint64_t)nv + 8 > c.ev_cap) {
                 PAR_BEGIN
-                if (tid == 0) sh->status = ST_ERR_CAPACITY;
+                if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 2;
                 PAR_END
                 failed = true;
                 break;
@@ -581,7 +698,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 uint64_t st[WS];
                 ld_state<WS>(c, s, st);
                 add_bits<WS>(c.cnt, st, -1);
-                tab2_remove<WS>(c, s, c.hsh[s]);
+                tab2_remove<WS>(c, s, ld_hash<WS>(c, s));
                 bm_clr(c.live, s);
                 bm_clr(c.fresh, s);
                 if (relaxed) {
@@ -643,7 +760,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         const int bestv = (int)(uint32_t)sh->mergedKey;
                         if ((mkey >> KEY_POP_BITS) > (c.key32[r] >> KEY_POP_BITS)) {   // the best redirected arc wins
                             c.key32[r] = (mkey & ~KEY_POP_MASK) | (c.key32[r] & KEY_POP_MASK);
-                            for (int k = 0; k < WS; ++k) c.pb[(size_t)k * capS + r] = c.pb[(size_t)k * capS + bestv];
+                            copy_path<WS>(c, r, bestv);
                         }
                         bm_set(c.inex, r);
                         bm_clr(c.okb, r);       // F_RELAXED: best paths through r are not exact
@@ -652,7 +769,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         add_bits<WS>(c.cnt, xs, +1);
                         bm_set(c.live, best);
                         bm_set(c.fresh, best);   // its fresh mark was dropped with the victims: check it (again)
-                        tab2_insert_unique<WS>(c, best, c.hsh[best]);
+                        tab2_insert_unique<WS>(c, best, ld_hash<WS>(c, best));
                         sh->tab_used += 1;
                         sh->nlive += 1;
                         for (int i = 0; i < nv; ++i)
@@ -665,37 +782,48 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 } else {
                     if (sh->free_slot >= capS) {
                         PAR_BEGIN
-                        if (tid == 0) sh->status = ST_ERR_CAPACITY;
+                        if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 3;
                         PAR_END
                         failed = true;
                         break;
                     }
                     PAR_BEGIN
-                    if (tid == 0) {
+                    {
                         const int m = sh->free_slot;
                         const int bestv = (int)(uint32_t)sh->mergedKey;
-                        int pop = 0;
-                        uint64_t ms[WS];
-                        for (int k = 0; k < WS; ++k) {
-                            ms[k] = sh->merged[k];
-                            c.st[(size_t)k * capS + m] = ms[k];
-                            c.pb[(size_t)k * capS + m] = c.pb[(size_t)k * capS + bestv];
-                            pop += dd_popc(ms[k]);
+                        if (tid < WS) {   // one thread per state word: state, best path, vertex counters
+                            const uint64_t w = sh->merged[tid];
+                            c.st[(size_t)tid * capS + m] = w;
+                            c.rec[(size_t)m * c.RW + tid] = w;
+                            c.pbr[(size_t)m * c.PR + tid] = c.pbr[(size_t)bestv * c.PR + tid];
+                            uint64_t x = w;
+                            while (x) {
+                                int b = dd_ctz(x);
+                                LDS_ADD_I32(&c.cnt[tid * 64 + b], 1);
+                                x &= x - 1;
+                            }
                         }
-                        const uint32_t mkey = (uint32_t)(sh->mergedKey >> 32);
-                        c.key32[m] = (mkey & ~KEY_POP_MASK) | (uint32_t)pop;
-                        const uint64_t mh = hash2_state<WS>(ms);
-                        c.hsh[m] = mh;
-                        bm_set(c.live, m);
-                        bm_set(c.inex, m);
-                        bm_clr(c.okb, m);
-                        bm_set(c.fresh, m);
-                        add_bits<WS>(c.cnt, ms, +1);
-                        tab2_insert_unique<WS>(c, m, mh);
-                        sh->tab_used += 1;
-                        sh->nlive += 1;
-                        if (m >= sh->hiw) sh->hiw = m + 1;
-                        sh->merged_slot = m;
+                        if (tid == WS % NT) {
+                            int pop = 0;
+                            uint64_t ms[WS];
+                            for (int k = 0; k < WS; ++k) {
+                                ms[k] = sh->merged[k];
+                                pop += dd_popc(ms[k]);
+                            }
+                            const uint32_t mkey = (uint32_t)(sh->mergedKey >> 32);
+                            c.key32[m] = (mkey & ~KEY_POP_MASK) | (uint32_t)pop;
+                            const uint64_t mh = hash2_state<WS>(ms);
+                            c.rec[(size_t)m * c.RW + WS] = mh;
+                            bm_set(c.live, m);
+                            bm_set(c.inex, m);
+                            bm_clr(c.okb, m);
+                            bm_set(c.fresh, m);
+                            tab2_insert_unique<WS>(c, m, mh);
+                            sh->tab_used += 1;
+                            sh->nlive += 1;
+                            if (m >= sh->hiw) sh->hiw = m + 1;
+                            sh->merged_slot = m;
+                        }
                     }
                     PAR_END
                     merged_slot = sh->merged_slot;
@@ -720,8 +848,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 if (i >= c.capW) continue;
                 c.cs_slot[i] = (uint32_t)s;
                 for (int k = 0; k < WS; ++k) {
-                    c.cs_state[(size_t)k * c.capW + i] = c.st[(size_t)k * capS + s];
-                    c.cs_path[(size_t)k * c.capW + i] = c.pb[(size_t)k * capS + s];
+                    c.cs_state[(size_t)k * c.capW + i] = ld_word<WS>(c, s, k);
+                    c.cs_path[(size_t)k * c.capW + i] = c.pbr[(size_t)s * c.PR + k];
                 }
                 const uint32_t key = c.key32[s];
                 c.cs_value[i] = vbase + (int32_t)(key >> KEY_POP_BITS);
@@ -766,7 +894,12 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         const int nwl = sh->nwl;
         if (nwl > c.capW || n > c.capW || sh->ev_pos + 4ull * (uint64_t)nwl + 8 > c.ev_cap) {
             PAR_BEGIN
-            if (tid == 0) sh->status = ST_ERR_CAPACITY;
+            if (tid == 0) {
+                sh->status = ST_ERR_CAPACITY - 100 * (nwl > c.capW ? 41 : (n > c.capW ? 42 : 43));
+                sh->bestKey = ((uint64_t)(uint32_t)nwl << 32) | (uint32_t)n;   // debugging aid: reported as best_value fields
+                sh->nodes = sh->ev_pos;
+                sh->arcs = (uint64_t)L;
+            }
             PAR_END
             failed = true;
             break;
@@ -807,7 +940,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             tab2_rebuild<WS>(c);
             if (sh->tab_used + 2 * nwl + 2 > (c.tab_cap / 10) * 9) {
                 PAR_BEGIN
-                if (tid == 0) sh->status = ST_ERR_CAPACITY;
+                if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 5;
                 PAR_END
                 failed = true;
                 break;
@@ -833,7 +966,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             bm_clr(c.fresh, s);
             if ((int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365: no children
                 add_bits<WS>(c.cnt, st, -1);
-                tab2_remove<WS>(c, s, c.hsh[s]);
+                tab2_remove<WS>(c, s, ld_hash<WS>(c, s));
                 bm_clr(c.live, s);
                 LDS_ADD_I32(&sh->nlive, -1);
                 const int r = LDS_ADD_I32(&sh->nrec, 1);
@@ -851,7 +984,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 if (k == vw) hasv = (st[k] & vbit) != 0;
             if (!hasv) continue;   // fresh but unaffected: its NO-child is the node itself
             // ---- decision NO, in place (main.rs:77-85)
-            const uint64_t oldh = c.hsh[s];
+            const uint64_t oldh = ld_hash<WS>(c, s);
             tab2_remove<WS>(c, s, oldh);
             uint64_t oldw = 0, neww = 0;
 #pragma unroll
@@ -860,9 +993,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     oldw = st[k];
                     st[k] &= ~vbit;
                     neww = st[k];
-                    c.st[(size_t)k * capS + s] = neww;
                 }
-            c.hsh[s] = oldh ^ mixw(oldw, vw) ^ mixw(neww, vw);
+            st_word<WS>(c, s, vw, neww, oldh ^ mixw(oldw, vw) ^ mixw(neww, vw));
             c.key32[s] = key - 1;          // popcount - 1, same value (cost 0)
             LDS_ADD_I32(&c.cnt[var], -1);
             // ---- decision YES into a free slot (main.rs:95-102)
@@ -876,17 +1008,16 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 for (int k = 0; k < WS; ++k) {
                     y[k] = st[k] & adjv[k];
                     ypop += dd_popc(y[k]);
-                    c.st[(size_t)k * capS + ny] = y[k];
-                    uint64_t pw = c.pb[(size_t)k * capS + s];
+                    uint64_t pw = c.pbr[(size_t)s * c.PR + k];
                     if (k == (L >> 6)) pw |= 1ULL << (L & 63);
-                    c.pb[(size_t)k * capS + ny] = pw;
+                    c.pbr[(size_t)ny * c.PR + k] = pw;
                 }
-                c.hsh[ny] = hash2_state<WS>(y);
+                st_node<WS>(c, ny, y, hash2_state<WS>(y));
                 c.key32[ny] = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop;
                 bm_put(c.inex, ny, bm_test(c.inex, s));
                 bm_put(c.okb, ny, bm_test(c.okb, s));
             } else {
-                sh->status = ST_ERR_CAPACITY;
+                sh->status = ST_ERR_CAPACITY - 100 * 6;
             }
             const int r = LDS_ADD_I32(&sh->nrec, 1);
             uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
@@ -902,15 +1033,17 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 
         // ------------------------------------------------------------ expand, phase 2: dedup (clean.rs:738-775)
         PAR_BEGIN
-        for (int r = tid; r < nrec; r += NT) {
+        for (int idx = tid; idx < 2 * nrec; idx += NT) {   // one thread per arc: (record, NO | YES)
+            const int r = idx >> 1, which = idx & 1;
             uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
-            if (rec[1] == NONE32) continue;   // pruned parent
-            for (int which = 0; which < 2; ++which) {
-                const int x = (int)rec[1 + which];
-                if (which == 1 && rec[2] == NONE32) continue;
+            if (rec[3] == NONE32 && rec[1] == NONE32) continue;   // pruned parent
+            if (rec[1] == NONE32) continue;
+            {
+                const int x = which == 0 ? (int)rec[0] : (int)rec[3];
+                if (which == 1 && rec[3] == NONE32) continue;
                 uint64_t st[WS];
                 ld_state<WS>(c, x, st);
-                const int t = tab2_insert<WS>(c, x, c.hsh[x], st);
+                const int t = tab2_insert<WS>(c, x, ld_hash<WS>(c, x), st);
                 if (t == x) {
                     LDS_ADD_I32(&sh->tab_used, 1);
                     if (which == 0) {
@@ -952,7 +1085,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const int t = (int)(w & EV_SLOT_MASK);
                 const int x = which == 0 ? (int)rec[0] : (int)rec[3];
                 if (c.key32[t] == c.key32[x]) {
-                    for (int k = 0; k < WS; ++k) c.pb[(size_t)k * capS + t] = c.pb[(size_t)k * capS + x];
+                    copy_path<WS>(c, t, x);
                     bm_put(c.okb, t, bm_test(c.okb, x));
                 }
                 rec[1 + which] = w & ~EV_RAISED;
@@ -1158,12 +1291,12 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     if (tid == 0) {
         unsigned long long a = total ? GLB_ADD_U64(c.arena_head, (unsigned long long)total) : 0ULL;
         sh->arena_off = a;
-        if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY;
+        if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY - 100 * 7;
         sh->ev_pos = 0;   // reused: pool offset of this DD's cut-set block
         if (pool_bytes) {
             unsigned long long pa = GLB_ADD_U64(c.pool_head, (unsigned long long)pool_bytes);
             sh->ev_pos = pa;
-            if (pa + pool_bytes > c.pool_cap) sh->status = ST_ERR_CAPACITY;
+            if (pa + pool_bytes > c.pool_cap) sh->status = ST_ERR_CAPACITY - 100 * 8;
         }
     }
     PAR_END
@@ -1185,7 +1318,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             uint32_t* out = (uint32_t*)(base + path_off);
             for (int i = tid; i < best_len; i += NT) {
                 const int tr = path_len - 1 - i;
-                const uint64_t w = c.pb[(size_t)(tr >> 6) * capS + best_slot];
+                const uint64_t w = c.pbr[(size_t)best_slot * c.PR + (tr >> 6)];
                 out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
             }
         }
@@ -1193,7 +1326,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             uint32_t* out = (uint32_t*)(base + exact_off);
             for (int i = tid; i < exact_len; i += NT) {
                 const int tr = path_len - 1 - i;
-                const uint64_t w = c.pb[(size_t)(tr >> 6) * capS + exact_slot];
+                const uint64_t w = c.pbr[(size_t)exact_slot * c.PR + (tr >> 6)];
                 out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
             }
         }
@@ -1370,9 +1503,11 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.max_layers = P.max_layers;
     c.nbw = (P.capS + 31) / 32;
     const size_t capS = (size_t)P.capS, capW = (size_t)P.capW, ml = (size_t)P.max_layers, s = (size_t)slot;
+    c.RW = ((WS + 1 + 7) / 8) * 8;
+    c.PR = ((WS + 7) / 8) * 8;
     c.st = P.s_state + s * (size_t)WS * capS;
-    c.pb = P.s_path + s * (size_t)WS * capS;
-    c.hsh = P.s_hash + s * capS;
+    c.rec = P.s_rec + s * capS * (size_t)c.RW;
+    c.pbr = P.s_path + s * capS * (size_t)c.PR;
     c.tab = P.s_tab + s * (size_t)P.tab2_cap;
     c.tab_cap = P.tab2_cap;
     c.ev = P.s_ev + s * P.ev_cap;

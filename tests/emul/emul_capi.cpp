@@ -140,17 +140,17 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
     long long neg = 0;
     for (int i = 0; i < n; ++i) if (weights[i] < 0) neg += weights[i];
     P.vbase_off = (int32_t)neg;
-    P.ev_cap = (uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16);
+    P.ev_cap = (uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64;
     {
         const size_t capS = P.capS, capW = P.capW, mlz = P.max_layers;
-        size_t b2 = 2 * wsT * capS * 8 + capS * 8 * 2 + (size_t)P.tab2_cap * 4 + P.ev_cap * 4 + mlz * 8 * 4 + capW * 4 +
+        const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
+        size_t b2 = wsT * capS * 8 + capS * (RW + PR) * 8 + (size_t)P.tab2_cap * 4 + P.ev_cap * 4 + mlz * 8 * 4 + capW * 4 +
                     wsT * capW * 8 + 64 * 16;
         e->mem2.assign(b2, 0xCD);
         unsigned char* q = e->mem2.data();
         P.s_state = carve<uint64_t>(q, wsT * capS);
-        P.s_path = carve<uint64_t>(q, wsT * capS);
-        P.s_hash = carve<uint64_t>(q, capS);
-        P.s_wkey = carve<uint64_t>(q, capS);
+        P.s_rec = carve<uint64_t>(q, capS * RW);
+        P.s_path = carve<uint64_t>(q, capS * PR);
         P.s_tab = carve<uint32_t>(q, P.tab2_cap);
         P.s_ev = carve<uint32_t>(q, P.ev_cap);
         P.s_evoff = carve<uint32_t>(q, mlz * 8);

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout -s KILL 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -4
+DDO_HIP_STATS=1 timeout -s KILL 600 python bench.py --steps 4 --warmup 2 --no-cpu 2>&1 | grep -E "ddo stats|Error|error" | cut -c1-400
+DDO_HIP_STATS=1 timeout -s KILL 600 python bench.py --steps 1 --warmup 0 --no-cpu --concurrent 1 2>&1 | grep -E "ddo stats|ms_per_step|Error|error" | cut -c1-700
+DDO_HIP_SLOTS=64 DDO_HIP_STATS=1 timeout -s KILL 600 python bench.py --steps 3 --warmup 2 --no-cpu --concurrent 256 2>&1 | grep -E "ddo stats|Error|error" | cut -c1-400
