@@ -148,6 +148,7 @@ struct EngineParams {
     int32_t tab2_cap;          // persistent dedup table slots (power of two, HBM)
     int32_t vbase_off;         // lowest reachable value relative to the residual value (sum of negative weights)
     uint64_t* s_state;         // [slot][ws][capS]  node states, word major (streaming scan copy)
+    uint32_t* s_key;           // [slot][capS]      ranking keys when they do not live in LDS (else nullptr)
     uint64_t* s_rec;           // [slot][capS][RW]  node records: state words + cached hash, RW = 8*ceil((ws+1)/8) words
     uint64_t* s_path;          // [slot][capS][PR]  best-path bit strings, one bit per layer, PR = 8*ceil(ws/8) words
     uint32_t* s_tab;           // [slot][tab2_cap]  open-addressing table: tag:12 | node slot:20, tombstones

@@ -41,8 +41,8 @@ __global__ void __launch_bounds__(1024) misp_compile_kernel(EngineParams P) {
 }
 
 /// in-place engine (misp_dd_inplace.hpp)
-template <int WS>
-__global__ void __launch_bounds__(1024) misp_compile_kernel2(EngineParams P) {
+template <int WS, int MAXT>
+__global__ void __launch_bounds__(MAXT) misp_compile_kernel2(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     DD2Ctx<WS> c;
     dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
@@ -58,16 +58,21 @@ __global__ void __launch_bounds__(1024) misp_compile_kernel2(EngineParams P) {
 }
 
 typedef void (*kernel_fn)(EngineParams);
-static kernel_fn pick_kernel2(int wsT) {
+// MAXT = 512 lets the register allocator use 256 VGPRs (the 1024-thread variant is capped at 128 and spills)
+template <int MAXT>
+static kernel_fn pick_kernel2t(int wsT) {
     switch (wsT) {
-        case 1: return misp_compile_kernel2<1>;
-        case 2: return misp_compile_kernel2<2>;
-        case 4: return misp_compile_kernel2<4>;
-        case 7: return misp_compile_kernel2<7>;
-        case 8: return misp_compile_kernel2<8>;
-        case 16: return misp_compile_kernel2<16>;
+        case 1: return misp_compile_kernel2<1, MAXT>;
+        case 2: return misp_compile_kernel2<2, MAXT>;
+        case 4: return misp_compile_kernel2<4, MAXT>;
+        case 7: return misp_compile_kernel2<7, MAXT>;
+        case 8: return misp_compile_kernel2<8, MAXT>;
+        case 16: return misp_compile_kernel2<16, MAXT>;
         default: return nullptr;
     }
+}
+static kernel_fn pick_kernel2(int wsT, int threads) {
+    return threads <= 512 ? pick_kernel2t<512>(wsT) : pick_kernel2t<1024>(wsT);
 }
 template <bool TLDS>
 static kernel_fn pick_kernel(int wsT) {
@@ -212,7 +217,12 @@ int Engine::init(Model* model, int device, long max_width) {
     P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 1) & ~1ull;
     engine_kind_ = 2;
     if (const char* env = std::getenv("DDO_HIP_ENGINE")) engine_kind_ = std::atoi(env) == 1 ? 1 : 2;
-    const size_t lds2 = dd2_lds_bytes(P.capS, P.capW, P.npad, threads_);
+    size_t lds2 = dd2_lds_bytes(P.capS, P.capW, P.npad, threads_, true);
+    const size_t lds2g = dd2_lds_bytes(P.capS, P.capW, P.npad, threads_, false);
+    // ranking keys in HBM when that lets a second workgroup share the CU (latency-bound phases overlap)
+    keys_global_ = (lds2 > lds_max / 2 && lds2g <= lds_max / 2) || lds2 > lds_max;
+    if (const char* env = std::getenv("DDO_HIP_KEYS_GLOBAL")) keys_global_ = std::atoi(env) != 0;
+    if (keys_global_) lds2 = lds2g;
     if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
     if (engine_kind_ == 2) lds_bytes_ = lds2;
 
@@ -279,6 +289,9 @@ int Engine::init(Model* model, int device, long max_width) {
         const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
         if ((rc = dev_alloc(allocs_, P.s_state, S * wsT * capS))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_rec, S * capS * RW))) return rc;
+        if (keys_global_) {
+            if ((rc = dev_alloc(allocs_, P.s_key, S * capS))) return rc;
+        }
         if ((rc = dev_alloc(allocs_, P.s_path, S * capS * PR))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_tab, S * (size_t)P.tab2_cap))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_ev, S * P.ev_cap))) return rc;
@@ -331,7 +344,7 @@ int Engine::init(Model* model, int device, long max_width) {
     ev0_ = e0;
     ev1_ = e1;
 
-    kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model->wsT)
+    kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model->wsT, threads_)
                                      : (table_lds_ ? pick_kernel<true>(model->wsT) : pick_kernel<false>(model->wsT));
     if (!fn) {
         set_error("unsupported state width");
@@ -440,7 +453,7 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
     P.results = (DDResult*)d_results_;
     P.nbatch = count;
     const int grid = std::min(count, nslots_);
-    kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT)
+    kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT, threads_)
                                      : (table_lds_ ? pick_kernel<true>(model_->wsT) : pick_kernel<false>(model_->wsT));
     HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);

@@ -101,6 +101,7 @@ class Engine {
     int threads_ = 0;
     size_t lds_bytes_ = 0;
     bool table_lds_ = true;
+    bool keys_global_ = false;
     int engine_kind_ = 2;            // 1: per-layer rebuild (misp_dd_core.hpp), 2: in-place layers (misp_dd_inplace.hpp)
     EngineParams P_{};
     std::vector<void*> allocs_;

@@ -56,6 +56,18 @@ DDO_DEV uint64_t dd_clock() { return (uint64_t)__builtin_readcyclecounter(); }
 // phase ids of DDResult::phase_clk
 constexpr int PH_VAR = 0, PH_SELECT = 1, PH_VICTIMS = 2, PH_WORKLIST = 3, PH_FREELIST = 4, PH_EXPAND = 5, PH_FINAL = 6, PH_BACKWARD = 7;
 
+// ranking keys live in LDS, or -- to fit two workgroups per CU at large widths -- in HBM (L2-resident): all accesses
+// go through these wrappers (agent-scope loads/stores so that L2 atomics and plain accesses never mix in the L1)
+#if defined(DDO_HOST_EMULATION)
+#define K32(c, i) ((c).key32[(i)])
+#define K32_ST(c, i, v) ((c).key32[(i)] = (v))
+#define K32_MAX(c, i, v) emu_atomic_max<uint32_t>(&(c).key32[(i)], (v))
+#else
+#define K32(c, i) __hip_atomic_load(&(c).key32[(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define K32_ST(c, i, v) __hip_atomic_store(&(c).key32[(i)], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define K32_MAX(c, i, v) atomicMax(&(c).key32[(i)], (v))
+#endif
+
 struct DD2Shared {
     int32_t work, status, cutoff;
     uint32_t varkey;
@@ -297,7 +309,7 @@ DDO_DEV int32_t rub2_of(const DD2Ctx<WS>& c, const uint64_t* s) {
 /// full-order "node a ranks above node b": (key32, lexkey words)
 template <int WS>
 DDO_DEV bool ranks_above2(const DD2Ctx<WS>& c, int a, int b) {
-    uint32_t ka = c.key32[a], kb = c.key32[b];
+    uint32_t ka = K32(c, a), kb = K32(c, b);
     if (ka != kb) return ka > kb;
     for (int k = 0; k < WS; ++k) {
         uint64_t la = dd_brev(~ld_word<WS>(c, a, k));
@@ -324,7 +336,7 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
     uint32_t a = 0xFFFFFFFFu, o = 0;
     for (int s = tid; s < hi; s += NT)
         if (bm_test(c.live, s)) {
-            uint32_t k = c.key32[s];
+            uint32_t k = K32(c, s);
             a &= k;
             o |= k;
         }
@@ -355,7 +367,7 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
         const int up = shift + dbits[d];
         for (int s = tid; s < hi; s += NT)
             if (bm_test(c.live, s)) {
-                uint32_t k = c.key32[s];
+                uint32_t k = K32(c, s);
                 bool active = up >= 32 || (k >> up) == (piv >> up);
                 if (active) LDS_ADD_U32(&c.hist[(k >> shift) & dmask], 1u);
             }
@@ -400,7 +412,7 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
         PAR_END
         PAR_BEGIN
         for (int s = tid; s < hi; s += NT)
-            if (bm_test(c.live, s) && c.key32[s] == piv) {
+            if (bm_test(c.live, s) && K32(c, s) == piv) {
                 int i = LDS_ADD_I32(&sh->nwl, 1);
                 if (i < c.capW) c.wl[i] = (uint16_t)s;
             }
@@ -595,7 +607,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             pop += dd_popc(root[k]);
         }
         st_node<WS>(c, 0, root, hash2_state<WS>(root));
-        c.key32[0] = ((uint32_t)(in.value - vbase) << KEY_POP_BITS) | (uint32_t)pop;
+        K32_ST(c, 0, ((uint32_t)(in.value - vbase) << KEY_POP_BITS) | (uint32_t)pop);
     }
     PAR_END
     PAR_BEGIN
@@ -678,7 +690,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             PAR_BEGIN   // victims: live nodes ranked below the pivot (clean.rs:810-812 / :851-852)
             for (int s = tid; s < sh->hiw; s += NT) {
                 if (!bm_test(c.live, s)) continue;
-                const uint32_t key = c.key32[s];
+                const uint32_t key = K32(c, s);
                 if (K > 0 && ge_pivot2<WS>(c, s, key)) continue;
                 int i = LDS_ADD_I32(&sh->nvict, 1);
                 if (i < c.capW) c.wl[i] = (uint16_t)s;
@@ -705,7 +717,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #pragma unroll
                     for (int k = 0; k < WS; ++k)
                         if (st[k]) LDS_OR_U64(&sh->merged[k], st[k]);   // MispRelax::merge (main.rs:172-178)
-                    LDS_MAX_U64(&sh->mergedKey, ((uint64_t)c.key32[s] << 32) | (uint32_t)s);
+                    LDS_MAX_U64(&sh->mergedKey, ((uint64_t)K32(c, s) << 32) | (uint32_t)s);
                 }
                 c.ev[del_off + i] = (uint32_t)s;
             }
@@ -758,8 +770,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         const int r = sh->merged_slot;
                         const uint32_t mkey = (uint32_t)(sh->mergedKey >> 32);
                         const int bestv = (int)(uint32_t)sh->mergedKey;
-                        if ((mkey >> KEY_POP_BITS) > (c.key32[r] >> KEY_POP_BITS)) {   // the best redirected arc wins
-                            c.key32[r] = (mkey & ~KEY_POP_MASK) | (c.key32[r] & KEY_POP_MASK);
+                        if ((mkey >> KEY_POP_BITS) > (K32(c, r) >> KEY_POP_BITS)) {   // the best redirected arc wins
+                            K32_ST(c, r, (mkey & ~KEY_POP_MASK) | (K32(c, r) & KEY_POP_MASK));
                             copy_path<WS>(c, r, bestv);
                         }
                         bm_set(c.inex, r);
@@ -811,7 +823,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                                 pop += dd_popc(ms[k]);
                             }
                             const uint32_t mkey = (uint32_t)(sh->mergedKey >> 32);
-                            c.key32[m] = (mkey & ~KEY_POP_MASK) | (uint32_t)pop;
+                            K32_ST(c, m, (mkey & ~KEY_POP_MASK) | (uint32_t)pop);
                             const uint64_t mh = hash2_state<WS>(ms);
                             c.rec[(size_t)m * c.RW + WS] = mh;
                             bm_set(c.live, m);
@@ -851,7 +863,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     c.cs_state[(size_t)k * c.capW + i] = ld_word<WS>(c, s, k);
                     c.cs_path[(size_t)k * c.capW + i] = c.pbr[(size_t)s * c.PR + k];
                 }
-                const uint32_t key = c.key32[s];
+                const uint32_t key = K32(c, s);
                 c.cs_value[i] = vbase + (int32_t)(key >> KEY_POP_BITS);
                 c.cs_pop[i] = key & KEY_POP_MASK;
             }
@@ -957,7 +969,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         const int32_t wv = c.weight[var];
         for (int i = tid; i < nwl; i += NT) {
             const int s = c.wl[i];
-            const uint32_t key = c.key32[s];
+            const uint32_t key = K32(c, s);
             const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
             const int pop = (int)(key & KEY_POP_MASK);
             uint64_t st[WS];
@@ -995,7 +1007,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     neww = st[k];
                 }
             st_word<WS>(c, s, vw, neww, oldh ^ mixw(oldw, vw) ^ mixw(neww, vw));
-            c.key32[s] = key - 1;          // popcount - 1, same value (cost 0)
+            K32_ST(c, s, key - 1);         // popcount - 1, same value (cost 0)
             LDS_ADD_I32(&c.cnt[var], -1);
             // ---- decision YES into a free slot (main.rs:95-102)
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
@@ -1013,7 +1025,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     c.pbr[(size_t)ny * c.PR + k] = pw;
                 }
                 st_node<WS>(c, ny, y, hash2_state<WS>(y));
-                c.key32[ny] = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop;
+                K32_ST(c, ny, ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop);
                 bm_put(c.inex, ny, bm_test(c.inex, s));
                 bm_put(c.okb, ny, bm_test(c.okb, s));
             } else {
@@ -1059,8 +1071,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     continue;
                 }
                 // duplicate of node t: the arc enters t  (append_edge_to!, clean.rs:199-220)
-                const uint32_t kx = c.key32[x];
-                const uint32_t old = LDS_MAX_U32(&c.key32[t], kx);
+                const uint32_t kx = K32(c, x);
+                const uint32_t old = K32_MAX(c, t, kx);
                 rec[1 + which] = (uint32_t)t | (kx > old ? EV_RAISED : 0u);
                 if (bm_test(c.inex, x)) bm_set(c.inex, t);
                 if (which == 0) {               // the in-place NO-child dissolves into t
@@ -1084,7 +1096,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 if (w == NONE32 || !(w & EV_RAISED)) continue;
                 const int t = (int)(w & EV_SLOT_MASK);
                 const int x = which == 0 ? (int)rec[0] : (int)rec[3];
-                if (c.key32[t] == c.key32[x]) {
+                if (K32(c, t) == K32(c, x)) {
                     copy_path<WS>(c, t, x);
                     bm_put(c.okb, t, bm_test(c.okb, x));
                 }
@@ -1128,7 +1140,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_BEGIN   // _find_best_node (clean.rs:620-632)
         for (int s = tid; s < sh->hiw; s += NT) {
             if (!bm_test(c.live, s)) continue;
-            const uint64_t bk = (((uint64_t)c.key32[s] >> KEY_POP_BITS) << 32) | (uint32_t)s;
+            const uint64_t bk = (((uint64_t)K32(c, s) >> KEY_POP_BITS) << 32) | (uint32_t)s;
             LDS_MAX_U64(&sh->bestKey, bk + 1);
             if (!bm_test(c.inex, s)) LDS_MAX_U64(&sh->bestExactKey, bk + 1);
         }
@@ -1476,9 +1488,9 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
 }
 
 /// LDS bytes of one in-place workgroup
-inline size_t dd2_lds_bytes(int capS, int capW, int npad, int nthreads) {
+inline size_t dd2_lds_bytes(int capS, int capW, int npad, int nthreads, bool keys_in_lds = true) {
     const size_t nbw = ((size_t)capS + 31) / 32;
-    size_t b = (size_t)capS * 4;           // key32 / value_bot
+    size_t b = keys_in_lds ? (size_t)capS * 4 : 0;   // key32 / value_bot
     b = (b + 15) & ~(size_t)15;
     b += 4 * nbw * 4;                      // live, inex, okb, fresh
     b = (b + 15) & ~(size_t)15;
@@ -1522,8 +1534,12 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.cs_value = P.cs_value + s * (size_t)P.capN;
     c.cs_pop = P.cs_pop + s * (size_t)P.capN;
     unsigned char* p = lds;
-    c.key32 = (uint32_t*)p;
-    p += ((size_t)P.capS * 4 + 15) & ~(size_t)15;
+    if (P.s_key) {
+        c.key32 = P.s_key + s * capS;      // keys in HBM: the LDS footprint halves, two workgroups share a CU
+    } else {
+        c.key32 = (uint32_t*)p;
+        p += ((size_t)P.capS * 4 + 15) & ~(size_t)15;
+    }
     c.live = (uint32_t*)p;
     p += (size_t)c.nbw * 4;
     c.inex = (uint32_t*)p;

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+DDO_HIP_KEYS_GLOBAL=0 DDO_HIP_THREADS=512 DDO_HIP_STATS=1 timeout -s KILL 600 python bench.py --steps 4 --warmup 2 --no-cpu --concurrent 4096 2>&1 | grep -E "ddo stats|value|Error|error" | cut -c1-330
+DDO_HIP_KEYS_GLOBAL=1 DDO_HIP_THREADS=512 DDO_HIP_STATS=1 timeout -s KILL 600 python bench.py --steps 4 --warmup 2 --no-cpu --concurrent 4096 2>&1 | grep -E "ddo stats|value|Error|error" | cut -c1-330
