@@ -145,13 +145,14 @@ struct EngineParams {
     // ---- in-place engine (misp_dd_inplace.hpp): persistent node slots instead of per-layer candidate arrays
     int32_t capS;              // node slots per DD (2*width + 8)
     int32_t capW;              // work-list capacity (width + 4)
-    int32_t tab2_cap;          // persistent dedup table slots (power of two, HBM)
+    int32_t tab2_cap;          // dedup table slots (power of two, LDS)
     int32_t vbase_off;         // lowest reachable value relative to the residual value (sum of negative weights)
     uint64_t* s_state;         // [slot][ws][capS]  node states, word major (streaming scan copy)
     uint32_t* s_key;           // [slot][capS]      ranking keys when they do not live in LDS (else nullptr)
     uint64_t* s_rec;           // [slot][capS][RW]  node records: state words + cached hash, RW = 8*ceil((ws+1)/8) words
     uint64_t* s_path;          // [slot][capS][PR]  best-path bit strings, one bit per layer, PR = 8*ceil(ws/8) words
-    uint32_t* s_tab;           // [slot][tab2_cap]  open-addressing table: tag:12 | node slot:20, tombstones
+    uint64_t* s_hash;          // [slot][capS]      node hashes, contiguous (streamed by the per-layer table rebuild)
+    uint16_t* s_wl;            // [slot][2*capW]    work list + free list
     uint32_t* s_ev;            // [slot][ev_cap]    per-transition event records for the backward pass
     uint32_t* s_evoff;         // [slot][max_layers+1][4] offsets / counts per transition
     uint64_t ev_cap;

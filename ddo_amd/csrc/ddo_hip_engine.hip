@@ -208,7 +208,7 @@ int Engine::init(Model* model, int device, long max_width) {
     P.capS = 2 * (int)max_width + 8;
     P.capW = P.capN;
     int t2 = 1024;
-    while (t2 < 8 * P.capW) t2 <<= 1;
+    while (t2 < 3 * P.capW) t2 <<= 1;
     P.tab2_cap = t2;
     long long neg = 0;
     for (int i = 0; i < model->n; ++i)
@@ -217,10 +217,10 @@ int Engine::init(Model* model, int device, long max_width) {
     P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 1) & ~1ull;
     engine_kind_ = 2;
     if (const char* env = std::getenv("DDO_HIP_ENGINE")) engine_kind_ = std::atoi(env) == 1 ? 1 : 2;
-    size_t lds2 = dd2_lds_bytes(P.capS, P.capW, P.npad, threads_, true);
-    const size_t lds2g = dd2_lds_bytes(P.capS, P.capW, P.npad, threads_, false);
-    // ranking keys in HBM when that lets a second workgroup share the CU (latency-bound phases overlap)
-    keys_global_ = (lds2 > lds_max / 2 && lds2g <= lds_max / 2) || lds2 > lds_max;
+    size_t lds2 = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, true);
+    const size_t lds2g = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, false);
+    // the dedup table always lives in LDS; the ranking keys join it when both fit, else they stay in HBM (L2-hot)
+    keys_global_ = lds2 > lds_max;
     if (const char* env = std::getenv("DDO_HIP_KEYS_GLOBAL")) keys_global_ = std::atoi(env) != 0;
     if (keys_global_) lds2 = lds2g;
     if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
@@ -240,7 +240,7 @@ int Engine::init(Model* model, int device, long max_width) {
                                 ml * capN * 4 + ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
                                 (table_lds_ ? 0 : (size_t)P.table_cap * 4)
                           : wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 * (((wsT + 8) / 8) * 8 + ((wsT + 7) / 8) * 8) +
-                                (size_t)P.tab2_cap * 4 + P.ev_cap * 4 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
+                                (size_t)P.capS * 12 + capN * 4 + P.ev_cap * 4 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t arena_mb = 1024;
@@ -293,7 +293,8 @@ int Engine::init(Model* model, int device, long max_width) {
             if ((rc = dev_alloc(allocs_, P.s_key, S * capS))) return rc;
         }
         if ((rc = dev_alloc(allocs_, P.s_path, S * capS * PR))) return rc;
-        if ((rc = dev_alloc(allocs_, P.s_tab, S * (size_t)P.tab2_cap))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_hash, S * capS))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_wl, S * 2 * capW))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_ev, S * P.ev_cap))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_evoff, S * ml * 8))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_cs_slot, S * capW))) return rc;

@@ -106,6 +106,7 @@ struct DD2Ctx {
     uint64_t* st;      // [ws][capS]   word-major copy of the states: only the streaming "who contains v" scan reads it
     uint64_t* rec;     // [capS][RW]   node records, one (or two) 64-byte lines each: state words, then the cached hash
     uint64_t* pbr;     // [capS][PR]   best-path bit strings, one line per node
+    uint64_t* hsh;     // [capS]       hash of every node, contiguous: the per-layer table rebuild streams it
     int RW, PR;
     uint32_t* tab;
     int tab_cap;
@@ -192,6 +193,7 @@ DDO_DEV void st_node(const DD2Ctx<WS>& c, int slot, const uint64_t* s, uint64_t 
         c.st[(size_t)k * c.capS + slot] = s[k];
     }
     r[WS] = h;
+    c.hsh[slot] = h;
 }
 /// one state word changes (NO-child in place)
 template <int WS>
@@ -199,6 +201,7 @@ DDO_DEV void st_word(const DD2Ctx<WS>& c, int slot, int k, uint64_t w, uint64_t 
     uint64_t* r = c.rec + (size_t)slot * c.RW;
     r[k] = w;
     r[WS] = h;
+    c.hsh[slot] = h;
     c.st[(size_t)k * c.capS + slot] = w;
 }
 template <int WS>
@@ -212,7 +215,10 @@ DDO_DEV void copy_path(const DD2Ctx<WS>& c, int dst, int src) {
     for (int k = 0; k < WS; ++k) b[k] = tmp[k];
 }
 
-/// insert node `x` (hash h, state in HBM) -> x when new, else the live node holding the same state
+/// The dedup table lives in LDS and is rebuilt for every layer (clear, stream all unchanged live nodes in by their
+/// cached hash, then insert the changed / new nodes with duplicate detection): no tombstones, no removals, and no
+/// HBM round trip per probe (rocprof: the HBM-resident table accounted for about half of the L2 misses).
+/// insert node `x` (hash h, state s) -> x when new, else the node already holding the same state
 template <int WS>
 DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint64_t h, const uint64_t* s) {
     const uint32_t mask = (uint32_t)c.tab_cap - 1;
@@ -225,7 +231,7 @@ DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint64_t h, const uint64_t* 
             e = TAB_CAS(&c.tab[slot], T2_EMPTY, mine);
             if (e == T2_EMPTY) return x;
         }
-        if (e != T2_TOMB && (e >> 20) == tag) {
+        if ((e >> 20) == tag) {
             const int w = (int)(e & 0xFFFFFu);
             uint64_t o[WS];
             ld_state<WS>(c, w, o);
@@ -239,7 +245,7 @@ DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint64_t h, const uint64_t* 
     c.sh->status = ST_ERR_INTERNAL;
     return x;
 }
-/// insert without duplicate check (table rebuild: all live states are distinct)
+/// insert without duplicate check (all unchanged live states are distinct)
 template <int WS>
 DDO_DEV void tab2_insert_unique(const DD2Ctx<WS>& c, int x, uint64_t h) {
     const uint32_t mask = (uint32_t)c.tab_cap - 1;
@@ -247,23 +253,6 @@ DDO_DEV void tab2_insert_unique(const DD2Ctx<WS>& c, int x, uint64_t h) {
     uint32_t slot = (uint32_t)h & mask;
     for (uint32_t probes = 0; probes <= mask; ++probes) {
         if (LD_U32(&c.tab[slot]) == T2_EMPTY && TAB_CAS(&c.tab[slot], T2_EMPTY, mine) == T2_EMPTY) return;
-        slot = (slot + 1) & mask;
-    }
-    c.sh->status = ST_ERR_INTERNAL;
-}
-/// tombstone the entry of node x
-template <int WS>
-DDO_DEV void tab2_remove(const DD2Ctx<WS>& c, int x, uint64_t h) {
-    const uint32_t mask = (uint32_t)c.tab_cap - 1;
-    const uint32_t mine = ((uint32_t)(h >> 52) << 20) | (uint32_t)x;
-    uint32_t slot = (uint32_t)h & mask;
-    for (uint32_t probes = 0; probes <= mask; ++probes) {
-        uint32_t e = LD_U32(&c.tab[slot]);
-        if (e == mine) {
-            GLB_ST_U32(&c.tab[slot], T2_TOMB);
-            return;
-        }
-        if (e == T2_EMPTY) break;
         slot = (slot + 1) & mask;
     }
     c.sh->status = ST_ERR_INTERNAL;
@@ -277,7 +266,7 @@ DDO_DEV int tab2_find(const DD2Ctx<WS>& c, uint64_t h, const uint64_t* s) {
     for (uint32_t probes = 0; probes <= mask; ++probes) {
         uint32_t e = LD_U32(&c.tab[slot]);
         if (e == T2_EMPTY) return -1;
-        if (e != T2_TOMB && (e >> 20) == tag) {
+        if ((e >> 20) == tag) {
             const int w = (int)(e & 0xFFFFFu);
             uint64_t o[WS];
             ld_state<WS>(c, w, o);
@@ -528,20 +517,6 @@ DDO_DEV bool ge_pivot2(const DD2Ctx<WS>& c, int s, uint32_t key) {
     return true;
 }
 
-/// rebuilds the dedup table from the live nodes (drops all tombstones)
-template <int WS>
-DDO_DEV void tab2_rebuild(DD2Ctx<WS>& c) {
-    DD_TID_SETUP(c)
-    PAR_BEGIN
-    for (int i = tid; i < c.tab_cap; i += NT) GLB_ST_U32(&c.tab[i], T2_EMPTY);
-    PAR_END
-    PAR_BEGIN
-    for (int s = tid; s < c.sh->hiw; s += NT)
-        if (bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, ld_hash<WS>(c, s));
-    if (tid == 0) c.sh->tab_used = c.sh->nlive;
-    PAR_END
-}
-
 /// One compile() (clean.rs:345-381) with in-place layers.
 ///
 /// Event records (u32 stream `ev`, per transition L -> L+1, 4 words per affected or pruned parent):
@@ -579,7 +554,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         c.okb[i] = 0;
         c.fresh[i] = 0;
     }
-    for (int i = tid; i < c.tab_cap; i += NT) GLB_ST_U32(&c.tab[i], T2_EMPTY);
+    for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
     if (tid == 0) {
         sh->status = ST_OK;
         sh->nodes = 0;
@@ -589,7 +564,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         sh->cutoff = 0;
         sh->nlive = 1;
         sh->hiw = 1;
-        sh->tab_used = 1;
         sh->ev_pos = 0;
         for (int k = 0; k < 8; ++k) sh->clk[k] = 0;
         sh->clk_last = dd_clock();
@@ -618,7 +592,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         c.live[0] = 1u;
         c.okb[0] = 1u;
         c.fresh[0] = 1u;
-        tab2_insert_unique<WS>(c, 0, ld_hash<WS>(c, 0));
     }
     PAR_END
 
@@ -710,7 +683,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 uint64_t st[WS];
                 ld_state<WS>(c, s, st);
                 add_bits<WS>(c.cnt, st, -1);
-                tab2_remove<WS>(c, s, ld_hash<WS>(c, s));
                 bm_clr(c.live, s);
                 bm_clr(c.fresh, s);
                 if (relaxed) {
@@ -781,8 +753,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         add_bits<WS>(c.cnt, xs, +1);
                         bm_set(c.live, best);
                         bm_set(c.fresh, best);   // its fresh mark was dropped with the victims: check it (again)
-                        tab2_insert_unique<WS>(c, best, ld_hash<WS>(c, best));
-                        sh->tab_used += 1;
                         sh->nlive += 1;
                         for (int i = 0; i < nv; ++i)
                             if (c.ev[del_off + i] == (uint32_t)best) c.ev[del_off + i] = NONE32;
@@ -826,12 +796,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                             K32_ST(c, m, (mkey & ~KEY_POP_MASK) | (uint32_t)pop);
                             const uint64_t mh = hash2_state<WS>(ms);
                             c.rec[(size_t)m * c.RW + WS] = mh;
+                            c.hsh[m] = mh;
                             bm_set(c.live, m);
                             bm_set(c.inex, m);
                             bm_clr(c.okb, m);
                             bm_set(c.fresh, m);
-                            tab2_insert_unique<WS>(c, m, mh);
-                            sh->tab_used += 1;
                             sh->nlive += 1;
                             if (m >= sh->hiw) sh->hiw = m + 1;
                             sh->merged_slot = m;
@@ -947,18 +916,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
         if (tid == 0) sh->nfl = sh->scan_total < c.capW ? sh->scan_total : c.capW;
         PAR_END
-        // table pressure: drop the tombstones when the table fills up
-        if (sh->tab_used + 2 * nwl + 2 > (c.tab_cap / 10) * 7) {
-            tab2_rebuild<WS>(c);
-            if (sh->tab_used + 2 * nwl + 2 > (c.tab_cap / 10) * 9) {
-                PAR_BEGIN
-                if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 5;
-                PAR_END
-                failed = true;
-                break;
-            }
-        }
-
         DD2_TICK(PH_FREELIST)
         // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
         const uint64_t aff_off = sh->ev_pos;
@@ -978,7 +935,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             bm_clr(c.fresh, s);
             if ((int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365: no children
                 add_bits<WS>(c.cnt, st, -1);
-                tab2_remove<WS>(c, s, ld_hash<WS>(c, s));
                 bm_clr(c.live, s);
                 LDS_ADD_I32(&sh->nlive, -1);
                 const int r = LDS_ADD_I32(&sh->nrec, 1);
@@ -997,7 +953,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             if (!hasv) continue;   // fresh but unaffected: its NO-child is the node itself
             // ---- decision NO, in place (main.rs:77-85)
             const uint64_t oldh = ld_hash<WS>(c, s);
-            tab2_remove<WS>(c, s, oldh);
+            bm_clr(c.live, s);             // pending: it re-enters the layer (or dissolves into a twin) in phase 2
+            LDS_ADD_I32(&sh->nlive, -1);
             uint64_t oldw = 0, neww = 0;
 #pragma unroll
             for (int k = 0; k < WS; ++k)
@@ -1042,6 +999,14 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_END
         const int nrec = sh->nrec;
         if (sh->status != ST_OK) { failed = true; break; }
+        // ------------------------------------------------------------ dedup table of the unchanged nodes
+        PAR_BEGIN
+        for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
+        PAR_END
+        PAR_BEGIN
+        for (int s = tid; s < sh->hiw; s += NT)
+            if (bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, c.hsh[s]);
+        PAR_END
 
         // ------------------------------------------------------------ expand, phase 2: dedup (clean.rs:738-775)
         PAR_BEGIN
@@ -1057,9 +1022,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 ld_state<WS>(c, x, st);
                 const int t = tab2_insert<WS>(c, x, ld_hash<WS>(c, x), st);
                 if (t == x) {
-                    LDS_ADD_I32(&sh->tab_used, 1);
-                    if (which == 0) {
+                    if (which == 0) {           // the in-place NO-child stays in the layer
+                        bm_set(c.live, x);
                         bm_set(c.fresh, x);     // its rub shrank: check it again before it is expanded
+                        LDS_ADD_I32(&sh->nlive, 1);
                     } else {                    // a new node enters the layer
                         bm_set(c.live, x);
                         bm_set(c.fresh, x);
@@ -1075,11 +1041,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const uint32_t old = K32_MAX(c, t, kx);
                 rec[1 + which] = (uint32_t)t | (kx > old ? EV_RAISED : 0u);
                 if (bm_test(c.inex, x)) bm_set(c.inex, t);
-                if (which == 0) {               // the in-place NO-child dissolves into t
-                    add_bits<WS>(c.cnt, st, -1);
-                    bm_clr(c.live, x);
-                    LDS_ADD_I32(&sh->nlive, -1);
-                }
+                if (which == 0) add_bits<WS>(c.cnt, st, -1);   // the in-place NO-child dissolves into t
             }
         }
         PAR_END
@@ -1488,16 +1450,15 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
 }
 
 /// LDS bytes of one in-place workgroup
-inline size_t dd2_lds_bytes(int capS, int capW, int npad, int nthreads, bool keys_in_lds = true) {
+inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool keys_in_lds = true) {
     const size_t nbw = ((size_t)capS + 31) / 32;
     size_t b = keys_in_lds ? (size_t)capS * 4 : 0;   // key32 / value_bot
     b = (b + 15) & ~(size_t)15;
+    b += (size_t)tab_cap * 4;              // dedup table
     b += 4 * nbw * 4;                      // live, inex, okb, fresh
     b = (b + 15) & ~(size_t)15;
     b += (size_t)npad * 4;                 // cnt
     b += 2048 * 4;                         // hist
-    b += (size_t)capW * 2 * 2;             // wl + fl (== int32 tmp[capW])
-    b = (b + 15) & ~(size_t)15;
     b += (size_t)nthreads * 4 * 2;         // scan scratch
     b += (sizeof(DD2Shared) + 15) & ~(size_t)15;
     return (b + 15) & ~(size_t)15;
@@ -1520,8 +1481,8 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.st = P.s_state + s * (size_t)WS * capS;
     c.rec = P.s_rec + s * capS * (size_t)c.RW;
     c.pbr = P.s_path + s * capS * (size_t)c.PR;
-    c.tab = P.s_tab + s * (size_t)P.tab2_cap;
     c.tab_cap = P.tab2_cap;
+    c.hsh = P.s_hash + s * capS;
     c.ev = P.s_ev + s * P.ev_cap;
     c.ev_cap = P.ev_cap;
     c.evoff = P.s_evoff + s * ml * 8;
@@ -1540,6 +1501,8 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
         c.key32 = (uint32_t*)p;
         p += ((size_t)P.capS * 4 + 15) & ~(size_t)15;
     }
+    c.tab = (uint32_t*)p;
+    p += (size_t)P.tab2_cap * 4;
     c.live = (uint32_t*)p;
     p += (size_t)c.nbw * 4;
     c.inex = (uint32_t*)p;
@@ -1553,11 +1516,8 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     p += (size_t)P.npad * 4;
     c.hist = (uint32_t*)p;
     p += 2048 * 4;
-    c.wl = (uint16_t*)p;
-    p += (size_t)P.capW * 2;
-    c.fl = (uint16_t*)p;
-    p += (size_t)P.capW * 2;
-    p = (unsigned char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    c.wl = P.s_wl + s * 2 * capW;          // work lists live in HBM (written and read once per layer, coalesced)
+    c.fl = c.wl + capW;
     c.tcount = (int32_t*)p;
     p += (size_t)nthreads * 4;
     c.tcount2 = (int32_t*)p;

@@ -135,7 +135,7 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
     P.capS = 2 * max_width + 8;
     P.capW = P.capN;
     int t2 = 1024;
-    while (t2 < 8 * P.capW) t2 <<= 1;
+    while (t2 < 3 * P.capW) t2 <<= 1;
     P.tab2_cap = t2;
     long long neg = 0;
     for (int i = 0; i < n; ++i) if (weights[i] < 0) neg += weights[i];
@@ -144,14 +144,15 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
     {
         const size_t capS = P.capS, capW = P.capW, mlz = P.max_layers;
         const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
-        size_t b2 = wsT * capS * 8 + capS * (RW + PR) * 8 + (size_t)P.tab2_cap * 4 + P.ev_cap * 4 + mlz * 8 * 4 + capW * 4 +
+        size_t b2 = wsT * capS * 8 + capS * (RW + PR + 1) * 8 + capW * 4 + P.ev_cap * 4 + mlz * 8 * 4 + capW * 4 +
                     wsT * capW * 8 + 64 * 16;
         e->mem2.assign(b2, 0xCD);
         unsigned char* q = e->mem2.data();
         P.s_state = carve<uint64_t>(q, wsT * capS);
         P.s_rec = carve<uint64_t>(q, capS * RW);
         P.s_path = carve<uint64_t>(q, capS * PR);
-        P.s_tab = carve<uint32_t>(q, P.tab2_cap);
+        P.s_hash = carve<uint64_t>(q, capS);
+        P.s_wl = carve<uint16_t>(q, 2 * capW);
         P.s_ev = carve<uint32_t>(q, P.ev_cap);
         P.s_evoff = carve<uint32_t>(q, mlz * 8);
         P.s_cs_slot = carve<uint32_t>(q, capW);
@@ -160,7 +161,7 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
             std::fprintf(stderr, "emul: workspace2 overflow\n");
             std::abort();
         }
-        e->lds2.assign(dd2_lds_bytes(P.capS, P.capW, P.npad, nthreads), 0xEE);
+        e->lds2.assign(dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, nthreads), 0xEE);
     }
     return e;
 }
