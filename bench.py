@@ -77,6 +77,7 @@ def main():
                             fringe=args.fringe)
 
     def barrier():
+        solver.flush()   # the engine runs on its own HIP stream: wait for the launch in flight and absorb it
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

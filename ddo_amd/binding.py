@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "ddo_mdd_best_solution", "ddo_mdd_best_exact_solution", "ddo_mdd_drain_cutset", "ddo_mdd_last_counters",
     "ddo_solver_create", "ddo_solver_destroy", "ddo_solver_maximize", "ddo_solver_best_value",
     "ddo_solver_best_solution", "ddo_solver_best_lower_bound", "ddo_solver_best_upper_bound", "ddo_solver_set_primal",
-    "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step",
+    "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_flush",
     "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time",
 ]
 
@@ -122,6 +122,7 @@ def lib():
     L.ddo_solver_explored.argtypes = [C.c_void_p]
     L.ddo_solver_counters.argtypes = [C.c_void_p, C.POINTER(_Counters)]
     L.ddo_solver_step.argtypes = [C.c_void_p]
+    L.ddo_solver_flush.argtypes = [C.c_void_p]
     L.ddo_solver_import_lower_bound.argtypes = [C.c_void_p, C.c_int64]
     L.ddo_solver_fringe_len.restype = C.c_uint64
     L.ddo_solver_fringe_len.argtypes = [C.c_void_p]
@@ -396,6 +397,12 @@ class ParallelSolver:
         rc = lib().ddo_solver_step(self._h)
         if rc < 0:
             raise DdoError(f"ddo_solver_step rc={rc}: {_err()}")
+        return rc
+
+    def flush(self):
+        rc = lib().ddo_solver_flush(self._h)
+        if rc < 0:
+            raise DdoError(f"ddo_solver_flush rc={rc}: {_err()}")
         return rc
 
     def best_value(self):

@@ -142,8 +142,14 @@ std::shared_ptr<Engine> Engine::get(Model* model, int device, long max_width) {
         if (auto sp = it->second.lock()) return sp;
     }
     std::shared_ptr<Engine> e(new Engine());
-    if (e->init(model, device, max_width) != DDO_OK) return nullptr;
+    if (e->init(model, device, max_width, false) != DDO_OK) return nullptr;
     model->engines[key] = e;
+    return e;
+}
+
+std::shared_ptr<Engine> Engine::create_private(Model* model, int device, long max_width) {
+    std::shared_ptr<Engine> e(new Engine());
+    if (e->init(model, device, max_width, true) != DDO_OK) return nullptr;
     return e;
 }
 
@@ -161,7 +167,7 @@ static int dev_alloc(std::vector<void*>& allocs, T*& ptr, size_t count) {
     return DDO_OK;
 }
 
-int Engine::init(Model* model, int device, long max_width) {
+int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     model_ = model;
     device_ = device;
     max_width_ = max_width;
@@ -320,7 +326,7 @@ int Engine::init(Model* model, int device, long max_width) {
     P.arena_head = (unsigned long long*)(cnt + 8);
     P.cutoff_flag = (const int32_t*)(cnt + 16);
     P.pool_head = (unsigned long long*)(cnt + 32);
-    if (engine_kind_ == 2) {   // node pool: whatever HBM is left (capped), for cut-sets that stay on the device
+    if (engine_kind_ == 2 && want_pool) {   // node pool: whatever HBM is left (capped), for cut-sets that stay on the device
         size_t free2 = 0, total2 = 0;
         HIP_TRY(hipMemGetInfo(&free2, &total2));
         size_t want = (size_t)64 << 30;
@@ -427,8 +433,19 @@ void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) co
 }
 
 int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results) {
+    results.resize((size_t)std::max(count, 0) * 2);
+    if (count <= 0) return DDO_OK;
+    int rc = launch(inputs, count);
+    if (rc != DDO_OK) return rc;
+    return collect(results);
+}
+
+int Engine::launch(const DDInput* inputs, int count) {
     std::lock_guard<std::mutex> g(mtx_);
-    results.resize((size_t)count * 2);
+    if (pending_ > 0) {
+        set_error("Engine::launch: a batch is already in flight");
+        return DDO_ERR_INVALID;
+    }
     if (count <= 0) return DDO_OK;
     HIP_TRY(hipSetDevice(device_));
     hipStream_t st = (hipStream_t)stream_;
@@ -448,7 +465,7 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
         }
     }
     HIP_TRY(hipMemcpyAsync(d_inputs_, inputs, (size_t)count * sizeof(DDInput), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_counters_, 0, 16, st));  // work counter + arena head (the cutoff flag is kept)
+    HIP_TRY(hipMemsetAsync(d_counters_, 0, 16, st));  // work counter + arena head (cutoff flag and pool head are kept)
     EngineParams P = P_;
     P.inputs = (const DDInput*)d_inputs_;
     P.results = (DDResult*)d_results_;
@@ -462,15 +479,26 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
     HIP_TRY(hipEventRecord((hipEvent_t)ev1_, st));
     h_results_.resize((size_t)count * 2);
     HIP_TRY(hipMemcpyAsync(h_results_.data(), d_results_, (size_t)count * 2 * sizeof(DDResult), hipMemcpyDeviceToHost, st));
-    unsigned long long head = 0;
-    HIP_TRY(hipMemcpyAsync(&head, (uint8_t*)d_counters_ + 8, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&h_head_, (uint8_t*)d_counters_ + 8, 8, hipMemcpyDeviceToHost, st));
+    pending_ = count;
+    return DDO_OK;
+}
+
+int Engine::collect(std::vector<HostResult>& results) {
+    std::lock_guard<std::mutex> g(mtx_);
+    const int count = pending_;
+    results.resize((size_t)count * 2);
+    if (count <= 0) return DDO_OK;
+    pending_ = 0;
+    HIP_TRY(hipSetDevice(device_));
+    hipStream_t st = (hipStream_t)stream_;
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
     last_kernel_ms_ = ms;
     kernel_ms_ += ms;
     launches_ += 1;
-    size_t used = (size_t)std::min<unsigned long long>(head, arena_cap_);
+    size_t used = (size_t)std::min<unsigned long long>(h_head_, arena_cap_);
     if (h_arena_.size() < used) h_arena_.resize(used);
     if (used) HIP_TRY(hipMemcpy(h_arena_.data(), d_arena_, used, hipMemcpyDeviceToHost));
     for (int i = 0; i < count; ++i) {

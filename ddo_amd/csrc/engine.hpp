@@ -65,11 +65,18 @@ struct HostResult {
 class Engine {
   public:
     static std::shared_ptr<Engine> get(Model* model, int device, long max_width);
+    /// an engine of its own (not shared through the model): needed by owners of the device node pool
+    static std::shared_ptr<Engine> create_private(Model* model, int device, long max_width);
     ~Engine();
 
     /// Runs `count` work items in one launch.  results: 2 per item ([1] used by IN_FUSED).
     /// Returns DDO_OK or a negative error.  Thread-safe (serialised internally).
     int run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results);
+    /// The two halves of run_batch: launch() enqueues upload + kernel + download of the result headers and
+    /// returns at once; collect() waits, fetches the arena and decodes.  One launch may be in flight.
+    int launch(const DDInput* inputs, int count);
+    int collect(std::vector<HostResult>& results);
+    bool in_flight() const { return pending_ > 0; }
 
     int device() const { return device_; }
     long max_width() const { return max_width_; }
@@ -91,7 +98,7 @@ class Engine {
 
   private:
     Engine() = default;
-    int init(Model* model, int device, long max_width);
+    int init(Model* model, int device, long max_width, bool want_pool);
     void decode(const DDResult& r, const uint8_t* arena, HostResult& out) const;
 
     Model* model_ = nullptr;
@@ -116,6 +123,8 @@ class Engine {
     size_t arena_cap_ = 0;
     std::vector<uint8_t> h_arena_;
     std::vector<DDResult> h_results_;
+    int pending_ = 0;
+    unsigned long long h_head_ = 0;
     double kernel_ms_ = 0, last_kernel_ms_ = 0;
     uint64_t launches_ = 0;
     std::mutex mtx_;

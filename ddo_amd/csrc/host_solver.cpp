@@ -416,7 +416,7 @@ struct ddo_solver {
     std::shared_ptr<Engine> engine;
     NoDupFringe* fringe = nullptr;
     LazyFringe* lazy = nullptr;          // DDO_FRINGE_LAZY
-    std::vector<LazyItem> litems;
+    std::vector<LazyItem> litems, flight;   // flight: the batch currently on the device
     // Critical (parallel.rs:32-81)
     uint64_t explored = 0;
     int64_t best_lb = I64_MIN;
@@ -575,7 +575,85 @@ struct ddo_solver {
         return DDO_OK;
     }
 
-    /// step() with the lazy block fringe: payload in the device node pool, (value, ub) keys on the host
+    /// results of a finished lazy launch -> incumbent, counters, new cut-set blocks (parallel.rs:420-434)
+    int absorb_lazy(std::vector<LazyItem>& its, std::vector<HostResult>& res) {
+        int err = DDO_OK;
+        for (size_t i = 0; i < its.size() && err == DDO_OK; ++i) {
+            for (int k = 0; k < 2; ++k) {
+                HostResult* r = &res[2 * i + k];
+                if (r->hdr.status == ST_NOT_RUN) continue;
+                if (r->hdr.status != ST_OK) {
+                    const bool capacity = r->hdr.status == ST_ERR_CAPACITY || r->hdr.status <= -100;
+                    set_error(capacity ? "device capacity exhausted (site " + std::to_string(r->hdr.status) +
+                                             "): node pool / output arena / workspace; raise DDO_HIP_POOL_GB or use DDO_FRINGE_NODUP"
+                                       : "device compile failed with status " + std::to_string(r->hdr.status));
+                    err = r->hdr.status == ST_CUTOFF ? DDO_CUTOFF : (capacity ? DDO_ERR_CAPACITY : DDO_ERR_INTERNAL);
+                    break;
+                }
+                counters.nodes_expanded += r->hdr.nodes_expanded;
+                counters.arcs += r->hdr.arcs;
+                counters.layers += r->hdr.layers;
+                counters.compiles += 1;
+                if (want_stats) {
+                    st_layers.push_back((uint32_t)r->hdr.layers);
+                    st_maxw.push_back(r->hdr.max_width_seen);
+                    st_nodes.push_back(r->hdr.nodes_expanded);
+                    for (int q = 0; q < 8; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                }
+                if (r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
+                    best_lb = r->hdr.best_exact_value;
+                    best_sol.clear();
+                    if ((err = materialize_pool_path(its[i].block, its[i].row, best_sol)) != DDO_OK) break;
+                    const std::vector<uint32_t>& p = r->hdr.exact_same_as_best ? r->best_path : r->exact_path;
+                    for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)});
+                    has_sol = true;
+                }
+                const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;
+                if (k == 1 && !exact && r->n_cutset > 0 && r->pool_off != NO_POOL_SRC) {   // enqueue_cutset
+                    DevBlock* b = new DevBlock();
+                    b->parent = its[i].block;
+                    b->parent_row = its[i].row;
+                    dev_ref(its[i].block);
+                    b->off = r->pool_off;
+                    b->rows = r->n_cutset;
+                    b->lel = r->cs_path_len;
+                    b->depth = its[i].depth + r->cs_path_len;
+                    b->cap_ub = its[i].ub;
+                    b->value = std::move(r->cs_value);
+                    b->ub = std::move(r->cs_ub);
+                    dev_ref(b);
+                    st_push += (uint64_t)b->rows;
+                    lazy->push_block(b, best_lb, cfg.rank, cfg.world_size);
+                    dev_unref(b);
+                }
+            }
+        }
+        for (LazyItem& e : its) dev_unref(e.block);
+        its.clear();
+        return err;
+    }
+
+    /// waits for the launch in flight (if any) and absorbs its results
+    int flush_lazy() {
+        if (!lazy || flight.empty()) return DDO_OK;
+        auto t0 = std::chrono::steady_clock::now();
+        int rc = engine->collect(results);
+        auto t1 = std::chrono::steady_clock::now();
+        st_host_run += std::chrono::duration<double>(t1 - t0).count();
+        if (rc != DDO_OK) {
+            for (LazyItem& e : flight) dev_unref(e.block);
+            flight.clear();
+            return rc;
+        }
+        rc = absorb_lazy(flight, results);
+        st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        return rc;
+    }
+
+    /// step() with the lazy block fringe: payload in the device node pool, (value, ub) keys on the host.
+    /// Software pipeline: the batch popped in this call is launched BEFORE the results of the previous one are
+    /// turned into fringe blocks, so the host work overlaps the device (the sub-problems of a batch therefore do not
+    /// see the cut-sets of the batch right before them -- the same staleness as nb_concurrent racing threads).
     int step_lazy() {
         if (!initialized) {
             initialized = true;
@@ -589,12 +667,18 @@ struct ddo_solver {
         }
         if (finished) return 0;
         if (aborted) return DDO_CUTOFF;
-        if (lazy->empty()) {
+        if (lazy->empty() || (int)lazy->len() < std::max(1, cfg.nb_concurrent) / 2) {
+            // nothing (or too little) to overlap with: take the results of the launch in flight first
+            int rc = flush_lazy();
+            if (rc != DDO_OK) return rc;
+        }
+        if (lazy->empty() && flight.empty()) {
             if (cfg.world_size <= 1) best_ub = best_lb;
             finished = true;
             return 0;
         }
         if (budget_exhausted()) {
+            flush_lazy();
             aborted = true;
             best_ub = lazy->best_ub();
             lazy->clear();
@@ -609,9 +693,14 @@ struct ddo_solver {
             explored += 1;
         }
         if (litems.empty()) {
-            if (cfg.world_size <= 1) best_ub = best_lb;
-            finished = true;
-            return 0;
+            int rc = flush_lazy();
+            if (rc != DDO_OK) return rc;
+            if (lazy->empty()) {
+                if (cfg.world_size <= 1) best_ub = best_lb;
+                finished = true;
+                return 0;
+            }
+            return 1;
         }
         if (cfg.world_size <= 1) best_ub = litems[0].ub == INT32_MAX ? I64_MAX : litems[0].ub;
         // longest-processing-time-first: shallow sub-problems with a lot of slack are the big DDs
@@ -636,67 +725,32 @@ struct ddo_solver {
             if (in.src_off == NO_POOL_SRC)
                 for (int v = 0; v < model->n; ++v) in.state[v / 64] |= 1ULL << (v % 64);
         }
+        // the previous launch must have left the device before its buffers are reused
+        std::vector<HostResult> prev_results;
+        std::vector<LazyItem> prev_items;
         auto t_run0 = std::chrono::steady_clock::now();
         st_host_pop += std::chrono::duration<double>(t_run0 - t_pop0).count();
-        int rc = engine->run_batch(inputs.data(), (int)inputs.size(), results);
+        if (!flight.empty()) {
+            int rc = engine->collect(prev_results);
+            if (rc != DDO_OK) {
+                for (LazyItem& e : flight) dev_unref(e.block);
+                for (LazyItem& e : litems) dev_unref(e.block);
+                flight.clear();
+                return rc;
+            }
+            prev_items.swap(flight);
+        }
+        int rc = engine->launch(inputs.data(), (int)inputs.size());
         auto t_run1 = std::chrono::steady_clock::now();
         st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
         if (rc != DDO_OK) {
             for (LazyItem& e : litems) dev_unref(e.block);
+            for (LazyItem& e : prev_items) dev_unref(e.block);
             return rc;
         }
-        int err = DDO_OK;
-        for (size_t i = 0; i < litems.size() && err == DDO_OK; ++i) {
-            for (int k = 0; k < 2; ++k) {
-                HostResult* r = &results[2 * i + k];
-                if (r->hdr.status == ST_NOT_RUN) continue;
-                if (r->hdr.status != ST_OK) {
-                    const bool capacity = r->hdr.status == ST_ERR_CAPACITY || r->hdr.status <= -100;
-                    set_error(capacity ? "device capacity exhausted (site " + std::to_string(r->hdr.status) + " dbg nodes=" + std::to_string(r->hdr.nodes_expanded) + " arcs=" + std::to_string(r->hdr.arcs) + " layers=" + std::to_string(r->hdr.layers) + " maxw=" + std::to_string(r->hdr.max_width_seen) + " k=" + std::to_string(k) +
-                                             "): node pool / output arena / workspace; raise DDO_HIP_POOL_GB or use DDO_FRINGE_NODUP"
-                                       : "device compile failed with status " + std::to_string(r->hdr.status));
-                    err = r->hdr.status == ST_CUTOFF ? DDO_CUTOFF : (capacity ? DDO_ERR_CAPACITY : DDO_ERR_INTERNAL);
-                    break;
-                }
-                counters.nodes_expanded += r->hdr.nodes_expanded;
-                counters.arcs += r->hdr.arcs;
-                counters.layers += r->hdr.layers;
-                counters.compiles += 1;
-                if (want_stats) {
-                    st_layers.push_back((uint32_t)r->hdr.layers);
-                    st_maxw.push_back(r->hdr.max_width_seen);
-                    st_nodes.push_back(r->hdr.nodes_expanded);
-                    for (int q = 0; q < 8; ++q) st_clk[q] += r->hdr.phase_clk[q];
-                }
-                if (r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
-                    best_lb = r->hdr.best_exact_value;
-                    best_sol.clear();
-                    if ((err = materialize_pool_path(litems[i].block, litems[i].row, best_sol)) != DDO_OK) break;
-                    const std::vector<uint32_t>& p = r->hdr.exact_same_as_best ? r->best_path : r->exact_path;
-                    for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)});
-                    has_sol = true;
-                }
-                const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;
-                if (k == 1 && !exact && r->n_cutset > 0 && r->pool_off != NO_POOL_SRC) {   // enqueue_cutset
-                    DevBlock* b = new DevBlock();
-                    b->parent = litems[i].block;
-                    b->parent_row = litems[i].row;
-                    dev_ref(litems[i].block);
-                    b->off = r->pool_off;
-                    b->rows = r->n_cutset;
-                    b->lel = r->cs_path_len;
-                    b->depth = litems[i].depth + r->cs_path_len;
-                    b->cap_ub = litems[i].ub;
-                    b->value = std::move(r->cs_value);
-                    b->ub = std::move(r->cs_ub);
-                    dev_ref(b);
-                    st_push += (uint64_t)b->rows;
-                    lazy->push_block(b, best_lb, cfg.rank, cfg.world_size);
-                    dev_unref(b);
-                }
-            }
-        }
-        for (LazyItem& e : litems) dev_unref(e.block);
+        flight.swap(litems);
+        // ... and while the device works on it, fold the previous batch into the fringe
+        int err = prev_items.empty() ? DDO_OK : absorb_lazy(prev_items, prev_results);
         st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
         if (err != DDO_OK) return err;
         return 1;
@@ -829,7 +883,9 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
     s->cfg = *cfg;
     if (s->cfg.world_size < 1) s->cfg.world_size = 1;
     if (s->cfg.rank < 0 || s->cfg.rank >= s->cfg.world_size) s->cfg.rank = 0;
-    s->engine = Engine::get(s->model, cfg->device, s->engine_width());
+    // the lazy fringe keeps its nodes in the engine's device pool and leaves launches in flight: it owns its engine
+    s->engine = cfg->fringe == DDO_FRINGE_LAZY ? Engine::create_private(s->model, cfg->device, s->engine_width())
+                                               : Engine::get(s->model, cfg->device, s->engine_width());
     if (!s->engine) {
         delete s;
         return nullptr;
@@ -852,6 +908,10 @@ int ddo_solver_step(ddo_solver* s) {
     if (!s) return DDO_ERR_INVALID;
     return s->step();
 }
+int ddo_solver_flush(ddo_solver* s) {
+    if (!s) return DDO_ERR_INVALID;
+    return s->flush_lazy();
+}
 
 int ddo_solver_maximize(ddo_solver* s, ddo_completion* out) {
     if (!s) return DDO_ERR_INVALID;
@@ -859,6 +919,7 @@ int ddo_solver_maximize(ddo_solver* s, ddo_completion* out) {
     while ((rc = s->step()) == 1) {
     }
     if (rc < 0) return rc;
+    s->flush_lazy();
     if (out) {   // parallel.rs:604-606
         out->is_exact = s->aborted ? 0 : 1;
         out->has_best_value = s->has_sol ? 1 : 0;

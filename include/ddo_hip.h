@@ -187,6 +187,9 @@ int ddo_solver_counters(const ddo_solver* s, ddo_counters* out);
  *  Returns 1 while work remains on this shard, 0 when its fringe is exhausted, DDO_CUTOFF on
  *  cutoff, <0 on error. */
 int ddo_solver_step(ddo_solver* s);
+/** With DDO_FRINGE_LAZY a step leaves its launch in flight and folds the results in during the next step;
+ *  flush waits for it and absorbs the results (counters, incumbent and fringe are then up to date). */
+int ddo_solver_flush(ddo_solver* s);
 /** Lower bound seen by the next step (max-reduced across ranks by the caller, parallel.rs:439-453). */
 int ddo_solver_import_lower_bound(ddo_solver* s, int64_t best_lb);
 /** Open sub-problems on this shard (fringe length), for termination detection (parallel.rs:512). */
