@@ -454,9 +454,10 @@ struct ddo_solver {
                          100.0 * st_clk[3] / std::max<uint64_t>(1, tc), 100.0 * st_clk[4] / std::max<uint64_t>(1, tc), 100.0 * st_clk[5] / std::max<uint64_t>(1, tc),
                          100.0 * st_clk[6] / std::max<uint64_t>(1, tc), 100.0 * st_clk[7] / std::max<uint64_t>(1, tc), st_host_pop, st_host_run, st_host_post,
                          (unsigned long long)st_push);
-            std::fprintf(stderr, "[ddo stats] device kcycles per layer: var %.1f select %.1f victims+merge %.1f worklist %.1f freelist %.1f expand %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
+            std::fprintf(stderr, "[ddo stats] device kcycles per layer: misc(var,worklist,freelist,final) %.1f selK1 %.1f selLex %.1f victims+merge %.1f exp1 %.1f table %.1f | exp2 %.1f exp3 %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
                          st_clk[0] / 1e3 / std::max<uint64_t>(1, tl), st_clk[1] / 1e3 / std::max<uint64_t>(1, tl), st_clk[2] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
+                         st_clk[6] / 1e3 / std::max<uint64_t>(1, tl), st_clk[7] / 1e3 / std::max<uint64_t>(1, tl),
                          tc / 1e3 / std::max<uint64_t>(1, tl), tc / 1e6 / a.size());
             std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
                          a.size(), (double)tl / a.size(), (unsigned long long)pct(a, .5), (unsigned long long)pct(a, .9), (unsigned long long)pct(a, 1.0),

@@ -54,7 +54,8 @@ DDO_DEV uint64_t dd_clock() { return 0; }
 DDO_DEV uint64_t dd_clock() { return (uint64_t)__builtin_readcyclecounter(); }
 #endif
 // phase ids of DDResult::phase_clk
-constexpr int PH_VAR = 0, PH_SELECT = 1, PH_VICTIMS = 2, PH_WORKLIST = 3, PH_FREELIST = 4, PH_EXPAND = 5, PH_FINAL = 6, PH_BACKWARD = 7;
+constexpr int PH_VAR = 0, PH_SELECT = 1, PH_VICTIMS = 3, PH_WORKLIST = 0, PH_FREELIST = 0, PH_EXPAND = 7, PH_FINAL = 0, PH_BACKWARD = 0;
+constexpr int PH_SELLEX = 2, PH_EXP1 = 4, PH_TABLE = 5, PH_EXP2 = 6;
 
 // ranking keys live in LDS, or -- to fit two workgroups per CU at large widths -- in HBM (L2-resident): all accesses
 // go through these wrappers (agent-scope loads/stores so that L2 atomics and plain accesses never mix in the L1)
@@ -95,6 +96,15 @@ struct DD2Shared {
     uint64_t clk_last;
     int32_t xcand[64];
 };
+
+#define DD2_TICK(ph)                                        \
+    PAR_BEGIN                                               \
+    if (tid == 0) {                                         \
+        const uint64_t _t = dd_clock();                     \
+        sh->clk[ph] += _t - sh->clk_last;                   \
+        sh->clk_last = _t;                                  \
+    }                                                       \
+    PAR_END
 
 template <int WS>
 struct DD2Ctx {
@@ -183,16 +193,27 @@ template <int WS>
 DDO_DEV uint64_t ld_hash(const DD2Ctx<WS>& c, int slot) { return c.rec[(size_t)slot * c.RW + WS]; }
 template <int WS>
 DDO_DEV uint64_t ld_word(const DD2Ctx<WS>& c, int slot, int k) { return c.rec[(size_t)slot * c.RW + k]; }
-/// full (re)write of a node: record line + the word-major copy
+struct alignas(16) U64x2 {
+    uint64_t a, b;
+};
+struct alignas(16) U32x4 {
+    uint32_t x, y, z, w;
+};
+/// full (re)write of a node: record line (16-byte stores: every store instruction of a lane is its own write
+/// request at the L2, so fewer, wider stores matter) + the word-major copy
 template <int WS>
 DDO_DEV void st_node(const DD2Ctx<WS>& c, int slot, const uint64_t* s, uint64_t h) {
-    uint64_t* r = c.rec + (size_t)slot * c.RW;
+    U64x2* r2 = (U64x2*)(c.rec + (size_t)slot * c.RW);
+    constexpr int NP = (WS + 2) / 2;   // pairs covering the WS state words and the hash
 #pragma unroll
-    for (int k = 0; k < WS; ++k) {
-        r[k] = s[k];
-        c.st[(size_t)k * c.capS + slot] = s[k];
+    for (int q = 0; q < NP; ++q) {
+        U64x2 v;
+        v.a = 2 * q < WS ? s[2 * q] : (2 * q == WS ? h : 0);
+        v.b = 2 * q + 1 < WS ? s[2 * q + 1] : (2 * q + 1 == WS ? h : 0);
+        r2[q] = v;
     }
-    r[WS] = h;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) c.st[(size_t)k * c.capS + slot] = s[k];
     c.hsh[slot] = h;
 }
 /// one state word changes (NO-child in place)
@@ -204,15 +225,17 @@ DDO_DEV void st_word(const DD2Ctx<WS>& c, int slot, int k, uint64_t w, uint64_t 
     c.hsh[slot] = h;
     c.st[(size_t)k * c.capS + slot] = w;
 }
+/// copies the first `nw` words of a path (the words that can hold decisions up to the current layer)
 template <int WS>
-DDO_DEV void copy_path(const DD2Ctx<WS>& c, int dst, int src) {
+DDO_DEV void copy_path(const DD2Ctx<WS>& c, int dst, int src, int nw) {
     const uint64_t* a = c.pbr + (size_t)src * c.PR;
     uint64_t* b = c.pbr + (size_t)dst * c.PR;
     uint64_t tmp[WS];
 #pragma unroll
-    for (int k = 0; k < WS; ++k) tmp[k] = a[k];
+    for (int k = 0; k < WS; ++k) tmp[k] = k < nw ? a[k] : 0;
 #pragma unroll
-    for (int k = 0; k < WS; ++k) b[k] = tmp[k];
+    for (int k = 0; k < WS; ++k)
+        if (k < nw) b[k] = tmp[k];
 }
 
 /// The dedup table lives in LDS and is rebuilt for every layer (clear, stream all unchanged live nodes in by their
@@ -388,6 +411,7 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
         need -= sh->sel_above;
         if (need == sh->sel_bucket) done = true;
     }
+    DD2_TICK(PH_SELECT)
     uint64_t pivLex[WS];
 #pragma unroll
     for (int k = 0; k < WS; ++k) pivLex[k] = 0;
@@ -526,14 +550,6 @@ DDO_DEV bool ge_pivot2(const DD2Ctx<WS>& c, int s, uint32_t key) {
 constexpr uint32_t EV_RAISED = 0x40000000u;
 constexpr uint32_t EV_SLOT_MASK = 0x000FFFFFu;
 
-#define DD2_TICK(ph)                                        \
-    PAR_BEGIN                                               \
-    if (tid == 0) {                                         \
-        const uint64_t _t = dd_clock();                     \
-        sh->clk[ph] += _t - sh->clk_last;                   \
-        sh->clk_last = _t;                                  \
-    }                                                       \
-    PAR_END
 
 template <int WS>
 DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
@@ -595,6 +611,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     }
     PAR_END
 
+    // every transition branches on a vertex of the root state, so a DD has at most popcount(root) layers: the best
+    // paths need that many bits, not n
+    const int root_pop = (int)(K32(c, 0) & KEY_POP_MASK);
+    const int npw = root_pop == 0 ? 1 : ((root_pop + 63) / 64 < WS ? (root_pop + 63) / 64 : WS);
+
     int lel = -1;
     int snapL = -1;  // layer whose snapshot sits in the cut-set buffers
     int ncs = 0;
@@ -648,7 +669,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
             const int K = restricted ? W : W - 1;
             if (K > 0) select_pivot2<WS>(c, K);
-            DD2_TICK(PH_SELECT)
+            DD2_TICK(PH_SELLEX)
             PAR_BEGIN
             if (tid == 0) {
                 sh->nvict = 0;
@@ -744,7 +765,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         const int bestv = (int)(uint32_t)sh->mergedKey;
                         if ((mkey >> KEY_POP_BITS) > (K32(c, r) >> KEY_POP_BITS)) {   // the best redirected arc wins
                             K32_ST(c, r, (mkey & ~KEY_POP_MASK) | (K32(c, r) & KEY_POP_MASK));
-                            copy_path<WS>(c, r, bestv);
+                            copy_path<WS>(c, r, bestv, npw);
                         }
                         bm_set(c.inex, r);
                         bm_clr(c.okb, r);       // F_RELAXED: best paths through r are not exact
@@ -777,7 +798,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                             const uint64_t w = sh->merged[tid];
                             c.st[(size_t)tid * capS + m] = w;
                             c.rec[(size_t)m * c.RW + tid] = w;
-                            c.pbr[(size_t)m * c.PR + tid] = c.pbr[(size_t)bestv * c.PR + tid];
+                            if (tid < npw) c.pbr[(size_t)m * c.PR + tid] = c.pbr[(size_t)bestv * c.PR + tid];
                             uint64_t x = w;
                             while (x) {
                                 int b = dd_ctz(x);
@@ -873,7 +894,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
         PAR_END
         const int nwl = sh->nwl;
-        if (nwl > c.capW || n > c.capW || sh->ev_pos + 4ull * (uint64_t)nwl + 8 > c.ev_cap) {
+        if (nwl > c.capW || n > c.capW || sh->ev_pos + 4ull * (uint64_t)nwl + 12 > c.ev_cap) {
             PAR_BEGIN
             if (tid == 0) {
                 sh->status = ST_ERR_CAPACITY - 100 * (nwl > c.capW ? 41 : (n > c.capW ? 42 : 43));
@@ -887,38 +908,30 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
         DD2_TICK(PH_WORKLIST)
         // ------------------------------------------------------------ free slots for the YES-children
+        // Each thread claims room in the list for the free bits of its bitmap words with one LDS atomic; only as
+        // many slots as this transition can consume are listed (at most one YES-child per work item).
+        const int need_free = nwl + 1 < c.capW ? nwl + 1 : c.capW;
         PAR_BEGIN
-        {
-            int cntf = 0;
-            for (int ww = tid; ww < c.nbw; ww += NT) {
-                uint32_t freebits = ~c.live[ww];
-                const int base = ww * 32;
-                if (base + 32 > capS) freebits &= ((1u << (capS - base)) - 1u);
-                cntf += dd_popc((uint64_t)freebits);
+        for (int ww = tid; ww < c.nbw; ww += NT) {
+            if (sh->nfl >= need_free) break;
+            uint32_t freebits = ~c.live[ww];
+            const int base = ww * 32;
+            if (base + 32 > capS) freebits &= ((1u << (capS - base)) - 1u);
+            if (!freebits) continue;
+            int pos = LDS_ADD_I32(&sh->nfl, dd_popc((uint64_t)freebits));
+            while (freebits && pos < need_free) {
+                int b = dd_ctz((uint64_t)freebits);
+                c.fl[pos++] = (uint16_t)(base + b);
+                freebits &= freebits - 1;
             }
-            c.tcount[tid] = cntf;
         }
         PAR_END
-        block_exclusive_scan_any(c, c.tcount, c.tcount2, &sh->scan_total);
         PAR_BEGIN
-        {
-            int pos = c.tcount[tid];
-            for (int ww = tid; ww < c.nbw && pos < c.capW; ww += NT) {
-                uint32_t freebits = ~c.live[ww];
-                const int base = ww * 32;
-                if (base + 32 > capS) freebits &= ((1u << (capS - base)) - 1u);
-                while (freebits && pos < c.capW) {
-                    int b = dd_ctz((uint64_t)freebits);
-                    c.fl[pos++] = (uint16_t)(base + b);
-                    freebits &= freebits - 1;
-                }
-            }
-        }
-        if (tid == 0) sh->nfl = sh->scan_total < c.capW ? sh->scan_total : c.capW;
+        if (tid == 0 && sh->nfl > need_free) sh->nfl = need_free;
         PAR_END
         DD2_TICK(PH_FREELIST)
         // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
-        const uint64_t aff_off = sh->ev_pos;
+        const uint64_t aff_off = (sh->ev_pos + 3) & ~3ULL;   // 16-byte aligned records
         PAR_BEGIN
         uint64_t adjv[WS];
 #pragma unroll
@@ -938,11 +951,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 bm_clr(c.live, s);
                 LDS_ADD_I32(&sh->nlive, -1);
                 const int r = LDS_ADD_I32(&sh->nrec, 1);
-                uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
-                rec[0] = (uint32_t)s;
-                rec[1] = NONE32;
-                rec[2] = NONE32;
-                rec[3] = NONE32;
+                U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
+                *rec4 = U32x4{(uint32_t)s, NONE32, NONE32, NONE32};
                 LDS_ADD_I32(&sh->npruned, 1);
                 continue;
             }
@@ -977,9 +987,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 for (int k = 0; k < WS; ++k) {
                     y[k] = st[k] & adjv[k];
                     ypop += dd_popc(y[k]);
-                    uint64_t pw = c.pbr[(size_t)s * c.PR + k];
-                    if (k == (L >> 6)) pw |= 1ULL << (L & 63);
-                    c.pbr[(size_t)ny * c.PR + k] = pw;
+                    if (k < npw) {   // a DD has at most popcount(root state) layers: only these path words exist
+                        uint64_t pw = c.pbr[(size_t)s * c.PR + k];
+                        if (k == (L >> 6)) pw |= 1ULL << (L & 63);
+                        c.pbr[(size_t)ny * c.PR + k] = pw;
+                    }
                 }
                 st_node<WS>(c, ny, y, hash2_state<WS>(y));
                 K32_ST(c, ny, ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop);
@@ -989,16 +1001,15 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 sh->status = ST_ERR_CAPACITY - 100 * 6;
             }
             const int r = LDS_ADD_I32(&sh->nrec, 1);
-            uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
-            rec[0] = (uint32_t)s;
-            rec[1] = (uint32_t)s;                       // NO target, provisional: the node itself
-            rec[2] = ny >= 0 ? (uint32_t)ny : NONE32;   // YES target, provisional: the new slot
-            rec[3] = ny >= 0 ? (uint32_t)ny : NONE32;
+            U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
+            // parent | NO target (provisional: the node itself) | YES target (provisional: the new slot) | YES slot
+            *rec4 = U32x4{(uint32_t)s, (uint32_t)s, ny >= 0 ? (uint32_t)ny : NONE32, ny >= 0 ? (uint32_t)ny : NONE32};
             LDS_ADD_I32(&sh->nyes, 1);
         }
         PAR_END
         const int nrec = sh->nrec;
         if (sh->status != ST_OK) { failed = true; break; }
+        DD2_TICK(PH_EXP1)
         // ------------------------------------------------------------ dedup table of the unchanged nodes
         PAR_BEGIN
         for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
@@ -1007,6 +1018,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         for (int s = tid; s < sh->hiw; s += NT)
             if (bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, c.hsh[s]);
         PAR_END
+        DD2_TICK(PH_TABLE)
 
         // ------------------------------------------------------------ expand, phase 2: dedup (clean.rs:738-775)
         PAR_BEGIN
@@ -1045,6 +1057,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
         }
         PAR_END
+        DD2_TICK(PH_EXP2)
         // ------------------------------------------------------------ expand, phase 3: new best parents
         // The arc that RAISED its target's key and still equals the target's final key is the one that set
         // the maximum (`value >= value_top`, clean.rs:215-218): the target inherits the loser's path.  Losers
@@ -1059,7 +1072,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const int t = (int)(w & EV_SLOT_MASK);
                 const int x = which == 0 ? (int)rec[0] : (int)rec[3];
                 if (K32(c, t) == K32(c, x)) {
-                    copy_path<WS>(c, t, x);
+                    copy_path<WS>(c, t, x, npw);
                     bm_put(c.okb, t, bm_test(c.okb, x));
                 }
                 rec[1 + which] = w & ~EV_RAISED;
@@ -1070,7 +1083,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             eo[0] = (uint32_t)aff_off;
             eo[1] = (uint32_t)(aff_off >> 32);
             eo[2] = (uint32_t)nrec;
-            sh->ev_pos += 4ull * (uint64_t)nrec;
+            sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
             sh->nodes += (uint64_t)n;
             if (n > sh->maxn) sh->maxn = n;
             sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
