@@ -315,15 +315,16 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     if (engine_kind_ == 1 && !table_lds_) {
         if ((rc = dev_alloc(allocs_, P.gtable, S * (size_t)P.table_cap))) return rc;
     }
-    if ((rc = dev_alloc(allocs_, d_arena_, arena_cap_))) return rc;
-    P.arena = d_arena_;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = dev_alloc(allocs_, io_[k].d_arena, arena_cap_))) return rc;
+        if ((rc = dev_alloc(allocs_, io_[k].d_cnt, 64))) return rc;
+        HIP_TRY(hipMemset(io_[k].d_cnt, 0, 64));
+    }
     P.arena_cap = arena_cap_;
     uint8_t* cnt = nullptr;
     if ((rc = dev_alloc(allocs_, cnt, 64))) return rc;
     d_counters_ = cnt;
     HIP_TRY(hipMemset(cnt, 0, 64));
-    P.work_counter = (int32_t*)cnt;
-    P.arena_head = (unsigned long long*)(cnt + 8);
     P.cutoff_flag = (const int32_t*)(cnt + 16);
     P.pool_head = (unsigned long long*)(cnt + 32);
     if (engine_kind_ == 2 && want_pool) {   // node pool: whatever HBM is left (capped), for cut-sets that stay on the device
@@ -342,9 +343,11 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
         }
     }
 
-    hipStream_t st;
+    hipStream_t st, st2;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     stream_ = st;
+    HIP_TRY(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    copy_stream_ = st2;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -365,8 +368,12 @@ Engine::~Engine() {
     if (device_ >= 0) (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize((hipStream_t)stream_);
     for (void* p : allocs_) (void)hipFree(p);
-    if (d_inputs_) (void)hipFree(d_inputs_);
-    if (d_results_) (void)hipFree(d_results_);
+    for (int k = 0; k < 2; ++k) {
+        if (io_[k].d_inputs) (void)hipFree(io_[k].d_inputs);
+        if (io_[k].d_results) (void)hipFree(io_[k].d_results);
+        if (io_[k].h_arena) (void)hipHostFree(io_[k].h_arena);
+    }
+    if (copy_stream_) (void)hipStreamDestroy((hipStream_t)copy_stream_);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
     if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
@@ -381,7 +388,7 @@ void Engine::set_cutoff(bool on) {
 int Engine::pool_reset() {
     std::lock_guard<std::mutex> g(mtx_);
     HIP_TRY(hipSetDevice(device_));
-    HIP_TRY(hipMemset((uint8_t*)d_counters_ + 32, 0, 8));
+    HIP_TRY(hipMemset((uint8_t*)d_counters_ + 32, 0, 8));   // pool head
     return DDO_OK;
 }
 int Engine::read_pool(uint64_t off, void* dst, size_t bytes) {
@@ -447,16 +454,21 @@ int Engine::launch(const DDInput* inputs, int count) {
         return DDO_ERR_INVALID;
     }
     if (count <= 0) return DDO_OK;
+    if (fetch_set_ == next_set_) {
+        set_error("Engine::launch: the previous results of this buffer set were not fetched");
+        return DDO_ERR_INVALID;
+    }
     HIP_TRY(hipSetDevice(device_));
     hipStream_t st = (hipStream_t)stream_;
-    if (count > in_cap_) {
-        if (d_inputs_) HIP_TRY(hipFree(d_inputs_));
-        if (d_results_) HIP_TRY(hipFree(d_results_));
-        d_inputs_ = d_results_ = nullptr;
+    IoSet& io = io_[next_set_];
+    if (count > io.in_cap) {
+        if (io.d_inputs) HIP_TRY(hipFree(io.d_inputs));
+        if (io.d_results) HIP_TRY(hipFree(io.d_results));
+        io.d_inputs = io.d_results = nullptr;
         int cap = std::max(count, 256);
-        HIP_TRY(hipMalloc(&d_inputs_, (size_t)cap * sizeof(DDInput)));
-        HIP_TRY(hipMalloc(&d_results_, (size_t)cap * 2 * sizeof(DDResult)));
-        in_cap_ = cap;
+        HIP_TRY(hipMalloc(&io.d_inputs, (size_t)cap * sizeof(DDInput)));
+        HIP_TRY(hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)));
+        io.in_cap = cap;
     }
     for (int i = 0; i < count; ++i) {
         if (inputs[i].width + 2 > P_.capN || inputs[i].width < 1) {
@@ -464,12 +476,15 @@ int Engine::launch(const DDInput* inputs, int count) {
             return DDO_ERR_CAPACITY;
         }
     }
-    HIP_TRY(hipMemcpyAsync(d_inputs_, inputs, (size_t)count * sizeof(DDInput), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_counters_, 0, 16, st));  // work counter + arena head (cutoff flag and pool head are kept)
+    HIP_TRY(hipMemcpyAsync(io.d_inputs, inputs, (size_t)count * sizeof(DDInput), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(io.d_cnt, 0, 16, st));  // work counter + arena head of this buffer set
     EngineParams P = P_;
-    P.inputs = (const DDInput*)d_inputs_;
-    P.results = (DDResult*)d_results_;
+    P.inputs = (const DDInput*)io.d_inputs;
+    P.results = (DDResult*)io.d_results;
     P.nbatch = count;
+    P.work_counter = (int32_t*)io.d_cnt;
+    P.arena_head = (unsigned long long*)(io.d_cnt + 8);
+    P.arena = io.d_arena;
     const int grid = std::min(count, nslots_);
     kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT, threads_)
                                      : (table_lds_ ? pick_kernel<true>(model_->wsT) : pick_kernel<false>(model_->wsT));
@@ -477,33 +492,62 @@ int Engine::launch(const DDInput* inputs, int count) {
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)ev1_, st));
-    h_results_.resize((size_t)count * 2);
-    HIP_TRY(hipMemcpyAsync(h_results_.data(), d_results_, (size_t)count * 2 * sizeof(DDResult), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&h_head_, (uint8_t*)d_counters_ + 8, 8, hipMemcpyDeviceToHost, st));
+    io.h_results.resize((size_t)count * 2);
+    HIP_TRY(hipMemcpyAsync(io.h_results.data(), io.d_results, (size_t)count * 2 * sizeof(DDResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&io.h_head, io.d_cnt + 8, 8, hipMemcpyDeviceToHost, st));
+    io.count = count;
     pending_ = count;
+    pending_set_ = next_set_;
+    next_set_ ^= 1;
     return DDO_OK;
 }
 
-int Engine::collect(std::vector<HostResult>& results) {
+int Engine::wait() {
     std::lock_guard<std::mutex> g(mtx_);
-    const int count = pending_;
-    results.resize((size_t)count * 2);
-    if (count <= 0) return DDO_OK;
-    pending_ = 0;
+    if (pending_ <= 0) return DDO_OK;
     HIP_TRY(hipSetDevice(device_));
-    hipStream_t st = (hipStream_t)stream_;
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
     last_kernel_ms_ = ms;
     kernel_ms_ += ms;
     launches_ += 1;
-    size_t used = (size_t)std::min<unsigned long long>(h_head_, arena_cap_);
-    if (h_arena_.size() < used) h_arena_.resize(used);
-    if (used) HIP_TRY(hipMemcpy(h_arena_.data(), d_arena_, used, hipMemcpyDeviceToHost));
+    fetch_set_ = pending_set_;
+    pending_set_ = -1;
+    pending_ = 0;
+    return DDO_OK;
+}
+
+int Engine::fetch(std::vector<HostResult>& results) {
+    std::lock_guard<std::mutex> g(mtx_);
+    if (fetch_set_ < 0) {
+        results.clear();
+        return DDO_OK;
+    }
+    IoSet& io = io_[fetch_set_];
+    fetch_set_ = -1;
+    const int count = io.count;
+    results.resize((size_t)count * 2);
+    HIP_TRY(hipSetDevice(device_));
+    size_t used = (size_t)std::min<unsigned long long>(io.h_head, arena_cap_);
+    if (used > io.h_arena_cap) {
+        if (io.h_arena) HIP_TRY(hipHostFree(io.h_arena));
+        io.h_arena = nullptr;
+        size_t cap = std::max<size_t>(used + used / 2, (size_t)64 << 20);
+        cap = std::min(cap, arena_cap_);
+        void* hp = nullptr;
+        HIP_TRY(hipHostMalloc(&hp, cap, hipHostMallocDefault));   // pinned: the download runs at PCIe speed
+        io.h_arena = (uint8_t*)hp;
+        io.h_arena_cap = cap;
+    }
+    if (used) {
+        hipStream_t cs = (hipStream_t)copy_stream_;   // second stream: overlaps the kernel of the next batch
+        HIP_TRY(hipMemcpyAsync(io.h_arena, io.d_arena, used, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipStreamSynchronize(cs));
+    }
     for (int i = 0; i < count; ++i) {
         for (int k = 0; k < 2; ++k) {
-            const DDResult& r = h_results_[(size_t)i * 2 + k];
+            const DDResult& r = io.h_results[(size_t)i * 2 + k];
             HostResult& out = results[(size_t)i * 2 + k];
             if (r.status == ST_NOT_RUN) {
                 out.clear();
@@ -517,10 +561,16 @@ int Engine::collect(std::vector<HostResult>& results) {
                 out.valid = true;
                 continue;
             }
-            decode(r, h_arena_.data(), out);
+            decode(r, io.h_arena, out);
         }
     }
     return DDO_OK;
+}
+
+int Engine::collect(std::vector<HostResult>& results) {
+    int rc = wait();
+    if (rc != DDO_OK) return rc;
+    return fetch(results);
 }
 
 }  // namespace ddo_hip

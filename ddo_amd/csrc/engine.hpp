@@ -75,7 +75,12 @@ class Engine {
     /// The two halves of run_batch: launch() enqueues upload + kernel + download of the result headers and
     /// returns at once; collect() waits, fetches the arena and decodes.  One launch may be in flight.
     int launch(const DDInput* inputs, int count);
-    int collect(std::vector<HostResult>& results);
+    int collect(std::vector<HostResult>& results);   // == wait() + fetch()
+    /// wait(): the launch in flight has left the device (its result headers are on the host).  After it a new
+    /// launch() may be issued at once -- it uses the other buffer set -- and fetch() then downloads and decodes
+    /// the finished batch's output arena on a second stream while the new kernel runs.
+    int wait();
+    int fetch(std::vector<HostResult>& results);
     bool in_flight() const { return pending_ > 0; }
 
     int device() const { return device_; }
@@ -115,16 +120,27 @@ class Engine {
     void* stream_ = nullptr;
     void* ev0_ = nullptr;
     void* ev1_ = nullptr;
-    void* d_inputs_ = nullptr;
-    void* d_results_ = nullptr;
-    int in_cap_ = 0;
-    void* d_counters_ = nullptr;   // [0] work counter (i32), [8..16) arena head (u64), [16] cutoff flag
-    uint8_t* d_arena_ = nullptr;
+    /// ping-pong I/O buffers: batch k+1 is uploaded and launched while batch k's arena is still being downloaded
+    struct IoSet {
+        void* d_inputs = nullptr;
+        void* d_results = nullptr;
+        int in_cap = 0;
+        uint8_t* d_arena = nullptr;
+        uint8_t* d_cnt = nullptr;      // [0] work counter (i32), [8..16) arena head (u64)
+        uint8_t* h_arena = nullptr;    // pinned
+        size_t h_arena_cap = 0;
+        std::vector<DDResult> h_results;
+        unsigned long long h_head = 0;
+        int count = 0;
+    };
+    IoSet io_[2];
+    int next_set_ = 0;       // set the next launch() uses
+    int pending_set_ = -1;   // set of the launch in flight
+    int fetch_set_ = -1;     // set whose kernel finished (wait() done) but whose arena is not fetched yet
+    void* copy_stream_ = nullptr;
+    void* d_counters_ = nullptr;   // [16] cutoff flag, [32..40) pool head
     size_t arena_cap_ = 0;
-    std::vector<uint8_t> h_arena_;
-    std::vector<DDResult> h_results_;
     int pending_ = 0;
-    unsigned long long h_head_ = 0;
     double kernel_ms_ = 0, last_kernel_ms_ = 0;
     uint64_t launches_ = 0;
     std::mutex mtx_;

@@ -732,7 +732,7 @@ struct ddo_solver {
         auto t_run0 = std::chrono::steady_clock::now();
         st_host_pop += std::chrono::duration<double>(t_run0 - t_pop0).count();
         if (!flight.empty()) {
-            int rc = engine->collect(prev_results);
+            int rc = engine->wait();   // the previous kernel has finished; its arena stays on the device for now
             if (rc != DDO_OK) {
                 for (LazyItem& e : flight) dev_unref(e.block);
                 for (LazyItem& e : litems) dev_unref(e.block);
@@ -745,6 +745,11 @@ struct ddo_solver {
         auto t_run1 = std::chrono::steady_clock::now();
         st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
         if (rc != DDO_OK) {
+            for (LazyItem& e : litems) dev_unref(e.block);
+            for (LazyItem& e : prev_items) dev_unref(e.block);
+            return rc;
+        }
+        if (!prev_items.empty() && (rc = engine->fetch(prev_results)) != DDO_OK) {   // overlaps the new kernel
             for (LazyItem& e : litems) dev_unref(e.block);
             for (LazyItem& e : prev_items) dev_unref(e.block);
             return rc;
