@@ -120,7 +120,23 @@ def main():
         bytes_per_node = (ws_bytes + 8) + c_mean * (ws_bytes + 16)
         launches = max(1, l1 - l0)
         kernel_s = (k1 - k0) / 1e3
+        ws_t = next(w for w in (1, 2, 4, 7, 8, 16) if w >= (model.n + 63) // 64)
         achieved = my_nodes * bytes_per_node / max(kernel_s, 1e-12) / 1e9   # GB/s over the kernel's own time
+        # HBM traffic: PMC counters cannot be read from inside this process; the committed rocprofv3 passes of this
+        # very command (tools/profile_round.sh -> profiles/<round>/pmc_summary.json) give bytes per expanded node,
+        # scaled here by the nodes one launch of THIS run processed.
+        traffic, traffic_src = None, None
+        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            pj = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
+            if os.path.exists(pj):
+                try:
+                    tj = json.load(open(pj)).get("traffic")
+                    if tj and tj.get("hbm_bytes_per_node"):
+                        traffic = tj["hbm_bytes_per_node"] * my_nodes / launches
+                        traffic_src = f"profiles/{rnd}/pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per node) x nodes of this run's launches"
+                        break
+                except (ValueError, OSError):
+                    pass
         out = {
             "metric": "MDD nodes expanded/sec, MISP brock400_1 w=10k (restricted+relaxed DD compilation inside B&B)",
             "value": nodes / elapsed,
@@ -143,8 +159,8 @@ def main():
             "fringe_len_rank0": solver.fringe_len(),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "misp_compile_kernel<7,true>", "kernel_ms_avg": 1e3 * kernel_s / launches, "launches": launches,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "kernel": f"ddo_hip::misp_compile_kernel2<{ws_t}, 1024>", "kernel_ms_avg": 1e3 * kernel_s / launches, "launches": launches,
                 "bytes_per_node": bytes_per_node, "children_per_node": c_mean, "nodes_per_launch": my_nodes / launches,
                 "kernel_nodes_per_s": my_nodes / max(kernel_s, 1e-12),
             },

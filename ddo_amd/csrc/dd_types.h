@@ -94,7 +94,7 @@ struct DDResult {
     uint64_t arcs;
     uint64_t layers;
     uint64_t path_off, exact_off, cs_state_off, cs_value_off, cs_ub_off, cs_path_off;  // byte offsets from arena_off
-    uint64_t phase_clk[8];         // shader-clock ticks per phase (profiling aid; engine 2 only)
+    uint64_t phase_clk[24];        // shader-clock ticks per phase [0..8) and per wave-0 code mark [8..24) (profiling aid; engine 2)
     uint64_t pool_off;             // IN_POOL_OUT: byte offset of the cut-set block in the node pool
 };
 
@@ -136,7 +136,7 @@ struct EngineParams {
     const DDInput* inputs;
     DDResult* results;         // [nbatch][2]  (index 1 only used by IN_FUSED)
     int32_t nbatch;
-    int32_t pad0;
+    int32_t phase_clocks;      // 1: engine 2 accounts shader-clock ticks per phase (one extra barrier per phase)
     int32_t* work_counter;
     unsigned long long* arena_head;
     uint8_t* arena;

@@ -125,12 +125,12 @@ class Engine {
         void* d_inputs = nullptr;
         void* d_results = nullptr;
         int in_cap = 0;
-        uint8_t* d_arena = nullptr;
         uint8_t* d_cnt = nullptr;      // [0] work counter (i32), [8..16) arena head (u64)
-        uint8_t* h_arena = nullptr;    // pinned
+        uint8_t* h_arena = nullptr;    // pinned host memory, written directly by the kernel (zero-copy output)
         size_t h_arena_cap = 0;
-        std::vector<DDResult> h_results;
-        unsigned long long h_head = 0;
+        DDResult* h_results = nullptr; // pinned: a pageable destination would make the "async" download block launch()
+        unsigned long long* h_head = nullptr;   // pinned (same allocation)
+        DDInput* h_inputs = nullptr;            // pinned staging copy of the batch (same allocation)
         int count = 0;
     };
     IoSet io_[2];

@@ -431,9 +431,9 @@ struct ddo_solver {
     // optional statistics (DDO_HIP_STATS=1): per-DD layers / nodes / widest layer
     std::vector<uint32_t> st_layers, st_maxw;
     std::vector<uint64_t> st_nodes;
-    uint64_t st_clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st_clk[24] = {0};
     uint64_t st_push = 0, st_push_dup = 0;
-    double st_host_pop = 0, st_host_run = 0, st_host_post = 0;
+    double st_host_pop = 0, st_host_run = 0, st_host_post = 0, st_host_fetch = 0;
     bool want_stats = false;
     // scratch
     std::vector<DDInput> inputs;
@@ -449,16 +449,19 @@ struct ddo_solver {
             for (auto x : st_nodes) tn += x;
             uint64_t tc = 0;
             for (int q = 0; q < 8; ++q) tc += st_clk[q];
-            std::fprintf(stderr, "[ddo stats] device phase share: var %.1f%% select %.1f%% victims+merge %.1f%% worklist %.1f%% freelist %.1f%% expand %.1f%% final %.1f%% backward %.1f%% | host s: pop %.3f run %.3f post %.3f | pushes %llu\n",
+            std::fprintf(stderr, "[ddo stats] device phase share: var %.1f%% select %.1f%% victims+merge %.1f%% worklist %.1f%% freelist %.1f%% expand %.1f%% final %.1f%% backward %.1f%% | host s: pop %.3f run %.3f post %.3f (of which fetch %.3f) | pushes %llu\n",
                          100.0 * st_clk[0] / std::max<uint64_t>(1, tc), 100.0 * st_clk[1] / std::max<uint64_t>(1, tc), 100.0 * st_clk[2] / std::max<uint64_t>(1, tc),
                          100.0 * st_clk[3] / std::max<uint64_t>(1, tc), 100.0 * st_clk[4] / std::max<uint64_t>(1, tc), 100.0 * st_clk[5] / std::max<uint64_t>(1, tc),
-                         100.0 * st_clk[6] / std::max<uint64_t>(1, tc), 100.0 * st_clk[7] / std::max<uint64_t>(1, tc), st_host_pop, st_host_run, st_host_post,
+                         100.0 * st_clk[6] / std::max<uint64_t>(1, tc), 100.0 * st_clk[7] / std::max<uint64_t>(1, tc), st_host_pop, st_host_run, st_host_post, st_host_fetch,
                          (unsigned long long)st_push);
             std::fprintf(stderr, "[ddo stats] device kcycles per layer: misc(var,worklist,freelist,final) %.1f selK1 %.1f selLex %.1f victims+merge %.1f exp1 %.1f table %.1f | exp2 %.1f exp3 %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
                          st_clk[0] / 1e3 / std::max<uint64_t>(1, tl), st_clk[1] / 1e3 / std::max<uint64_t>(1, tl), st_clk[2] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[6] / 1e3 / std::max<uint64_t>(1, tl), st_clk[7] / 1e3 / std::max<uint64_t>(1, tl),
                          tc / 1e3 / std::max<uint64_t>(1, tl), tc / 1e6 / a.size());
+            std::fprintf(stderr, "[ddo stats] wave-0 marks, kcycles per layer:");
+            for (int q = 8; q < 24; ++q) std::fprintf(stderr, " m%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
+            std::fprintf(stderr, "\n");
             std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
                          a.size(), (double)tl / a.size(), (unsigned long long)pct(a, .5), (unsigned long long)pct(a, .9), (unsigned long long)pct(a, 1.0),
                          (unsigned long long)pct(b, .1), (unsigned long long)pct(b, .5), (unsigned long long)pct(b, .75), (unsigned long long)pct(b, .9), (unsigned long long)pct(b, .99), (unsigned long long)pct(b, 1.0),
@@ -599,7 +602,7 @@ struct ddo_solver {
                     st_layers.push_back((uint32_t)r->hdr.layers);
                     st_maxw.push_back(r->hdr.max_width_seen);
                     st_nodes.push_back(r->hdr.nodes_expanded);
-                    for (int q = 0; q < 8; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                    for (int q = 0; q < 24; ++q) st_clk[q] += r->hdr.phase_clk[q];
                 }
                 if (r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
                     best_lb = r->hdr.best_exact_value;
@@ -755,6 +758,7 @@ struct ddo_solver {
             return rc;
         }
         flight.swap(litems);
+        st_host_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
         // ... and while the device works on it, fold the previous batch into the fringe
         int err = prev_items.empty() ? DDO_OK : absorb_lazy(prev_items, prev_results);
         st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
@@ -859,7 +863,7 @@ struct ddo_solver {
                     st_layers.push_back((uint32_t)r->hdr.layers);
                     st_maxw.push_back(r->hdr.max_width_seen);
                     st_nodes.push_back(r->hdr.nodes_expanded);
-                    for (int q = 0; q < 8; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                    for (int q = 0; q < 24; ++q) st_clk[q] += r->hdr.phase_clk[q];
                 }
                 maybe_update_best(items[i], *r);
                 const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;

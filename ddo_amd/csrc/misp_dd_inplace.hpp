@@ -94,17 +94,37 @@ struct DD2Shared {
     uint64_t ev_pos;
     uint64_t clk[8];
     uint64_t clk_last;
+    uint64_t mk[16];        // wave-0 code marks (DD2_MARK)
+    uint64_t mk_last;
     int32_t xcand[64];
 };
 
 #define DD2_TICK(ph)                                        \
-    PAR_BEGIN                                               \
-    if (tid == 0) {                                         \
-        const uint64_t _t = dd_clock();                     \
-        sh->clk[ph] += _t - sh->clk_last;                   \
-        sh->clk_last = _t;                                  \
-    }                                                       \
-    PAR_END
+    if (c.clocks) {                                         \
+        PAR_BEGIN                                           \
+        if (tid == 0) {                                     \
+            const uint64_t _t = dd_clock();                 \
+            sh->clk[ph] += _t - sh->clk_last;               \
+            sh->clk_last = _t;                              \
+        }                                                   \
+        PAR_END                                             \
+    }
+
+// DD2_MARK(k): wave 0 drains its memory counters and charges the cycles since its previous mark to mk[k]
+#if defined(DDO_HOST_EMULATION)
+#define DD2_MARK(k)
+#else
+#define DD2_MARK(k)                                                             \
+    if (c.clocks && tid < 64) {                                                 \
+        __builtin_amdgcn_s_waitcnt(0);                                          \
+        const uint64_t _em = __builtin_amdgcn_ballot_w64(true);                 \
+        if (tid == __builtin_ctzll(_em)) {                                      \
+            const uint64_t _t = dd_clock();                                     \
+            sh->mk[k] += _t - sh->mk_last;                                      \
+            sh->mk_last = _t;                                                   \
+        }                                                                       \
+    }
+#endif
 
 template <int WS>
 struct DD2Ctx {
@@ -153,6 +173,7 @@ struct DD2Ctx {
     unsigned long long* pool_head;
     int vbase_off;
     int NT;
+    int clocks;        // per-phase shader-clock accounting (DDO_HIP_STATS): costs one barrier per phase
 #if !defined(DDO_HOST_EMULATION)
     int tid_;
 #endif
@@ -582,6 +603,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         sh->hiw = 1;
         sh->ev_pos = 0;
         for (int k = 0; k < 8; ++k) sh->clk[k] = 0;
+        for (int k = 0; k < 16; ++k) sh->mk[k] = 0;
         sh->clk_last = dd_clock();
         int pop = 0;
         uint64_t root[WS];
@@ -937,6 +959,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #pragma unroll
         for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
         const int32_t wv = c.weight[var];
+        DD2_MARK(15)
         for (int i = tid; i < nwl; i += NT) {
             const int s = c.wl[i];
             const uint32_t key = K32(c, s);
@@ -944,6 +967,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             const int pop = (int)(key & KEY_POP_MASK);
             uint64_t st[WS];
             ld_state<WS>(c, s, st);
+            DD2_MARK(0)
             const int32_t rub = c.unit_weights ? pop : rub2_of<WS>(c, st);   // main.rs:191-193
             bm_clr(c.fresh, s);
             if ((int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365: no children
@@ -954,6 +978,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
                 *rec4 = U32x4{(uint32_t)s, NONE32, NONE32, NONE32};
                 LDS_ADD_I32(&sh->npruned, 1);
+                DD2_MARK(1)
                 continue;
             }
             bool hasv = false;
@@ -962,6 +987,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 if (k == vw) hasv = (st[k] & vbit) != 0;
             if (!hasv) continue;   // fresh but unaffected: its NO-child is the node itself
             // ---- decision NO, in place (main.rs:77-85)
+            DD2_MARK(2)
             const uint64_t oldh = ld_hash<WS>(c, s);
             bm_clr(c.live, s);             // pending: it re-enters the layer (or dissolves into a twin) in phase 2
             LDS_ADD_I32(&sh->nlive, -1);
@@ -976,6 +1002,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             st_word<WS>(c, s, vw, neww, oldh ^ mixw(oldw, vw) ^ mixw(neww, vw));
             K32_ST(c, s, key - 1);         // popcount - 1, same value (cost 0)
             LDS_ADD_I32(&c.cnt[var], -1);
+            DD2_MARK(3)
             // ---- decision YES into a free slot (main.rs:95-102)
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
             int ny = -1;
@@ -993,6 +1020,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         c.pbr[(size_t)ny * c.PR + k] = pw;
                     }
                 }
+                DD2_MARK(4)
                 st_node<WS>(c, ny, y, hash2_state<WS>(y));
                 K32_ST(c, ny, ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop);
                 bm_put(c.inex, ny, bm_test(c.inex, s));
@@ -1005,7 +1033,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             // parent | NO target (provisional: the node itself) | YES target (provisional: the new slot) | YES slot
             *rec4 = U32x4{(uint32_t)s, (uint32_t)s, ny >= 0 ? (uint32_t)ny : NONE32, ny >= 0 ? (uint32_t)ny : NONE32};
             LDS_ADD_I32(&sh->nyes, 1);
+            DD2_MARK(5)
         }
+        DD2_MARK(6)
         PAR_END
         const int nrec = sh->nrec;
         if (sh->status != ST_OK) { failed = true; break; }
@@ -1022,6 +1052,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 
         // ------------------------------------------------------------ expand, phase 2: dedup (clean.rs:738-775)
         PAR_BEGIN
+        DD2_MARK(15)
         for (int idx = tid; idx < 2 * nrec; idx += NT) {   // one thread per arc: (record, NO | YES)
             const int r = idx >> 1, which = idx & 1;
             uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
@@ -1032,7 +1063,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 if (which == 1 && rec[3] == NONE32) continue;
                 uint64_t st[WS];
                 ld_state<WS>(c, x, st);
+                DD2_MARK(8)
                 const int t = tab2_insert<WS>(c, x, ld_hash<WS>(c, x), st);
+                DD2_MARK(9)
                 if (t == x) {
                     if (which == 0) {           // the in-place NO-child stays in the layer
                         bm_set(c.live, x);
@@ -1046,6 +1079,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         LDS_MAX_I32(&sh->hiw, x + 1);
                         rec[2] = (uint32_t)x | EV_CREATED;
                     }
+                    DD2_MARK(10)
                     continue;
                 }
                 // duplicate of node t: the arc enters t  (append_edge_to!, clean.rs:199-220)
@@ -1054,8 +1088,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 rec[1 + which] = (uint32_t)t | (kx > old ? EV_RAISED : 0u);
                 if (bm_test(c.inex, x)) bm_set(c.inex, t);
                 if (which == 0) add_bits<WS>(c.cnt, st, -1);   // the in-place NO-child dissolves into t
+                DD2_MARK(11)
             }
         }
+        DD2_MARK(12)
         PAR_END
         DD2_TICK(PH_EXP2)
         // ------------------------------------------------------------ expand, phase 3: new best parents
@@ -1425,6 +1461,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         r.cs_path_off = cs_path_off;
         sh->clk[PH_FINAL] += dd_clock() - sh->clk_last;
         for (int k = 0; k < 8; ++k) r.phase_clk[k] = sh->clk[k];
+        for (int k = 0; k < 16; ++k) r.phase_clk[8 + k] = sh->mk[k];
         r.pool_off = pool_bytes ? pool_off : NO_POOL_SRC;
         *res = r;
     }
@@ -1544,6 +1581,7 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.pool_cap = P.pool_cap;
     c.pool_head = P.pool_head;
     c.vbase_off = P.vbase_off;
+    c.clocks = P.phase_clocks;
     c.NT = nthreads;
 }
 

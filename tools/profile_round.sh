@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): collects the rocprofv3 evidence of the default bench command into
+# gpurun_out/prof_round/.  tools/summarize_profiles.py turns it into profiles/rNN/ (tracked).
+# PMC passes are separate from each other and use --kernel-trace only (no sys/hip/hsa trace domains).
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_round
+rm -rf $OUT; mkdir -p $OUT
+B="python bench.py --no-cpu"
+timeout -s KILL 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -c 600 $OUT/bench.json
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r --output-format csv -- $B > $OUT/trace.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o r --output-format csv -- $B > $OUT/fetch.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o r --output-format csv -- $B > $OUT/write.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum --kernel-trace -d $OUT/tcp -o r --output-format csv -- $B > $OUT/tcp.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/sq -o r --output-format csv -- $B > $OUT/sq.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_ATOMIC_RETURN SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS --kernel-trace -d $OUT/sq2 -o r --output-format csv -- $B > $OUT/sq2.log 2>&1
+find $OUT -name "*.csv" | head -30
+du -sh $OUT

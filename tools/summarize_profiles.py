@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_round (tools/profile_round.sh) into profiles/<round>/: the rocprofv3 kernel statistics, the
+per-dispatch PMC counters of the compile kernel and pmc_summary.json (what bench.py reports as roofline.traffic)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_round"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01"
+os.makedirs(dst, exist_ok=True)
+KERNEL = "misp_compile_kernel"
+
+
+def find(sub, suffix):
+    for root, _, files in os.walk(os.path.join(src, sub)):
+        for f in files:
+            if f.endswith(suffix):
+                return os.path.join(root, f)
+    return None
+
+
+def kernel_dispatches(sub):
+    """dispatch id -> (kernel name, duration ns) for the compile kernel, in launch order"""
+    out = collections.OrderedDict()
+    p = find(sub, "kernel_trace.csv")
+    for r in csv.DictReader(open(p)):
+        if KERNEL in r["Kernel_Name"]:
+            out[r["Dispatch_Id"]] = (r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return out
+
+
+def counters(sub):
+    p = find(sub, "counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(p)):
+        if KERNEL in r["Kernel_Name"]:
+            agg[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+    return agg
+
+
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+steps, warm = bench["steps"], bench["warmup"]
+summary = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "steps", "warmup")}, "roofline": bench["roofline"]}
+
+for name in ("kernel_stats.csv", "kernel_trace.csv"):
+    p = find("trace", name)
+    if p:
+        shutil.copy(p, os.path.join(dst, name))
+disp = kernel_dispatches("trace")
+durs = [d for _, d in disp.values()]
+timed = durs[-steps:]
+summary["kernel_trace"] = {"launches_ms": [d / 1e6 for d in durs], "timed_avg_ms": sum(timed) / len(timed) / 1e6,
+                           "note": "root sub-problem (1 workgroup), warm-up launches, then the timed launches"}
+
+rows = []
+for sub in ("fetch", "write", "tcp", "sq", "sq2"):
+    if not find(sub, "counter_collection.csv"):
+        continue
+    d = kernel_dispatches(sub)
+    c = counters(sub)
+    ids = list(d.keys())
+    for i, k in enumerate(ids):
+        for cn, v in sorted(c[k].items()):
+            rows.append({"pass": sub, "launch": i, "duration_ms": d[k][1] / 1e6, "counter": cn, "value": v})
+    tids = ids[-steps:]
+    for cn in sorted({cn for k in tids for cn in c[k]}):
+        summary.setdefault("pmc_timed_avg", {})[cn] = sum(c[k][cn] for k in tids) / len(tids)
+    summary.setdefault("pmc_timed_ms", {})[sub] = sum(d[k][1] for k in tids) / len(tids) / 1e6
+with open(os.path.join(dst, "pmc_counters.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=["pass", "launch", "duration_ms", "counter", "value"])
+    w.writeheader()
+    w.writerows(rows)
+
+pa = summary.get("pmc_timed_avg", {})
+if "FETCH_SIZE" in pa and "WRITE_SIZE" in pa:
+    # FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB; gfx950 reports half of a wide read stream
+    # (MI355X_MICROARCH.md, HBM section): FETCH is doubled.  This kernel's reads are mostly 8-64 B gathers, for
+    # which the guide calls the counter uncalibrated, so both the raw and the doubled figure are kept.
+    fetch = pa["FETCH_SIZE"] * 1024.0
+    write = pa["WRITE_SIZE"] * 1024.0
+    summary["traffic"] = {"fetch_bytes_raw": fetch, "fetch_bytes_x2": 2 * fetch, "write_bytes": write,
+                          "hbm_bytes_per_launch": 2 * fetch + write,
+                          "hbm_bytes_per_node": (2 * fetch + write) / bench["roofline"]["nodes_per_launch"],
+                          "algorithmic_bytes_per_launch": bench["roofline"]["nodes_per_launch"] * bench["roofline"]["bytes_per_node"]}
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:3000])
