@@ -147,6 +147,8 @@ struct EngineParams {
     int32_t capW;              // work-list capacity (width + 4)
     int32_t tab2_cap;          // dedup table slots (power of two, LDS)
     int32_t vbase_off;         // lowest reachable value relative to the residual value (sum of negative weights)
+    int32_t lex_cap;           // tie lists up to this size (<= 1024) are split by rank counting in LDS, longer ones by radix rounds
+    int32_t pad1;
     uint64_t* s_state;         // [slot][ws][capS]  node states, word major (streaming scan copy)
     uint32_t* s_key;           // [slot][capS]      ranking keys when they do not live in LDS (else nullptr)
     uint64_t* s_rec;           // [slot][capS][RW]  node records: state words + cached hash, RW = 8*ceil((ws+1)/8) words

@@ -222,7 +222,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
         if (model->weight[i] < 0) neg += model->weight[i];
     P.vbase_off = (int32_t)neg;
     P.phase_clocks = std::getenv("DDO_HIP_STATS") ? 1 : 0;
-    P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 1) & ~1ull;
+    P.lex_cap = 1024;
+    if (const char* env = std::getenv("DDO_HIP_LEX_CAP")) P.lex_cap = std::max(1, std::min(1024, std::atoi(env)));   // tests: force the radix path
+    P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 3) & ~3ull;   // 16-byte event records stay aligned per slot
     engine_kind_ = 2;
     if (const char* env = std::getenv("DDO_HIP_ENGINE")) engine_kind_ = std::atoi(env) == 1 ? 1 : 2;
     size_t lds2 = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, true);

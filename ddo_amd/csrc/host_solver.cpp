@@ -459,8 +459,10 @@ struct ddo_solver {
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[6] / 1e3 / std::max<uint64_t>(1, tl), st_clk[7] / 1e3 / std::max<uint64_t>(1, tl),
                          tc / 1e3 / std::max<uint64_t>(1, tl), tc / 1e6 / a.size());
-            std::fprintf(stderr, "[ddo stats] wave-0 marks, kcycles per layer:");
-            for (int q = 8; q < 24; ++q) std::fprintf(stderr, " m%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
+            std::fprintf(stderr, "[ddo stats] per layer: lex-ties %.1f lex-selects %.3f digit-rounds %.2f lex-words %.2f (tied at word start %.1f) | worklist %.1f (contain var %.1f) records %.1f victims %.1f squashes %.3f |",
+                         (double)st_clk[8] / tl, (double)st_clk[9] / tl, (double)st_clk[10] / tl, (double)st_clk[11] / tl, (double)st_clk[16] / tl,
+                         (double)st_clk[12] / tl, (double)st_clk[15] / tl, (double)st_clk[13] / tl, (double)st_clk[14] / tl, (double)st_clk[17] / tl);
+            for (int q = 18; q < 24; ++q) std::fprintf(stderr, " m%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
             std::fprintf(stderr, "\n");
             std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
                          a.size(), (double)tl / a.size(), (unsigned long long)pct(a, .5), (unsigned long long)pct(a, .9), (unsigned long long)pct(a, 1.0),

@@ -75,7 +75,7 @@ struct DD2Shared {
     int32_t nlive;
     int32_t nwl, nrec, nnew, nvict, nfl;
     int32_t npruned, nyes, ndup;
-    int32_t scan_total, sel_digit, sel_above, sel_bucket;
+    int32_t scan_total, sel_digit, sel_above, sel_bucket, sel_need;
     int32_t tab_used;
     int32_t hiw;            // slots [0, hiw) have been used at least once
     int32_t merged_slot, recycled, xslot, free_slot;
@@ -99,6 +99,13 @@ struct DD2Shared {
     int32_t xcand[64];
 };
 
+// DD2_STAT(k, v): profiling statistics (DDO_HIP_STATS) accumulated next to the code marks; workgroup-uniform context
+#define DD2_STAT(k, v)                                      \
+    if (c.clocks) {                                         \
+        PAR_BEGIN                                           \
+        if (tid == 0) sh->mk[k] += (uint64_t)(v);           \
+        PAR_END                                             \
+    }
 #define DD2_TICK(ph)                                        \
     if (c.clocks) {                                         \
         PAR_BEGIN                                           \
@@ -173,6 +180,7 @@ struct DD2Ctx {
     unsigned long long* pool_head;
     int vbase_off;
     int NT;
+    int lex_cap;
     int clocks;        // per-phase shader-clock accounting (DDO_HIP_STATS): costs one barrier per phase
 #if !defined(DDO_HOST_EMULATION)
     int tid_;
@@ -204,22 +212,36 @@ DDO_DEV uint64_t hash2_state(const uint64_t* s) {
 
 /// Node records are array-of-structures: a random access to a node costs one 64-byte line instead of one line
 /// per state word (rocprof showed the expand phase bound by random 8-byte requests, not by bytes).
-template <int WS>
-DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
-    const uint64_t* r = c.rec + (size_t)slot * c.RW;
-#pragma unroll
-    for (int k = 0; k < WS; ++k) s[k] = r[k];
-}
-template <int WS>
-DDO_DEV uint64_t ld_hash(const DD2Ctx<WS>& c, int slot) { return c.rec[(size_t)slot * c.RW + WS]; }
-template <int WS>
-DDO_DEV uint64_t ld_word(const DD2Ctx<WS>& c, int slot, int k) { return c.rec[(size_t)slot * c.RW + k]; }
 struct alignas(16) U64x2 {
     uint64_t a, b;
 };
 struct alignas(16) U32x4 {
     uint32_t x, y, z, w;
 };
+/// state words (+ the cached hash) of a node with 16-byte loads: records are 64-byte aligned, and one thread reading
+/// its record with 8-byte loads costs 2.5x more than with 16-byte ones (tools/micro/recload.hip: 22.5 vs 8.9 kcycles
+/// per 1024 records)
+template <int WS>
+DDO_DEV void ld_state_h(const DD2Ctx<WS>& c, int slot, uint64_t* s, uint64_t& h) {
+    const U64x2* r2 = (const U64x2*)(c.rec + (size_t)slot * c.RW);
+    constexpr int NP = (WS + 2) / 2;   // pairs covering the WS state words and the hash
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const U64x2 v = r2[q];
+        if (2 * q < WS) s[2 * q] = v.a; else if (2 * q == WS) h = v.a;
+        if (2 * q + 1 < WS) s[2 * q + 1] = v.b; else if (2 * q + 1 == WS) h = v.b;
+    }
+}
+template <int WS>
+DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
+    uint64_t h;
+    ld_state_h<WS>(c, slot, s, h);
+    (void)h;
+}
+template <int WS>
+DDO_DEV uint64_t ld_hash(const DD2Ctx<WS>& c, int slot) { return c.rec[(size_t)slot * c.RW + WS]; }
+template <int WS>
+DDO_DEV uint64_t ld_word(const DD2Ctx<WS>& c, int slot, int k) { return c.rec[(size_t)slot * c.RW + k]; }
 /// full (re)write of a node: record line (16-byte stores: every store instruction of a lane is its own write
 /// request at the L2, so fewer, wider stores matter) + the word-major copy
 template <int WS>
@@ -352,10 +374,14 @@ DDO_DEV bool ranks_above2(const DD2Ctx<WS>& c, int a, int b) {
     return false;
 }
 
-/// Exact K-th largest among the live nodes by (value, popcount, member order); result in
-/// sh->pivKey / sh->pivLex (unresolved low digits zero): node kept <=> key >= pivot.
+/// (value, popcount) part of the exact top-K selection (clean.rs:802-824 with main.rs:205-208): MSD radix select over
+/// key32.  Result: sh->pivKey, and sh->sel_need = how many nodes with key == pivKey stay in the layer, or -1 when all of
+/// them stay (then the unresolved low digits of pivKey are zero and "kept <=> key >= pivKey").
+/// Keys may live in HBM (L2) at large widths: every sweep fetches KB keys per thread before it touches them, so the
+/// sweep costs hi / (NT * KB) dependent round trips instead of hi / NT.
+constexpr int KB = 4;
 template <int WS>
-DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
+DDO_DEV void select_key2(DD2Ctx<WS>& c, int K) {
     DD_TID_SETUP(c)
     DD2Shared* sh = c.sh;
     const int hi = sh->hiw;
@@ -367,12 +393,22 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
     PAR_END
     PAR_BEGIN
     uint32_t a = 0xFFFFFFFFu, o = 0;
-    for (int s = tid; s < hi; s += NT)
-        if (bm_test(c.live, s)) {
-            uint32_t k = K32(c, s);
-            a &= k;
-            o |= k;
+    for (int base = 0; base < hi; base += NT * KB) {
+        uint32_t kk[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const int s = base + b * NT + tid;
+            kk[b] = s < hi ? K32(c, s) : 0u;
         }
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const int s = base + b * NT + tid;
+            if (s < hi && bm_test(c.live, s)) {
+                a &= kk[b];
+                o |= kk[b];
+            }
+        }
+    }
     if (a != 0xFFFFFFFFu || o != 0) {
         LDS_AND_U32(&sh->kand, a);
         LDS_OR_U32(&sh->kor, o);
@@ -398,12 +434,23 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
         PAR_END
         PAR_BEGIN
         const int up = shift + dbits[d];
-        for (int s = tid; s < hi; s += NT)
-            if (bm_test(c.live, s)) {
-                uint32_t k = K32(c, s);
-                bool active = up >= 32 || (k >> up) == (piv >> up);
-                if (active) LDS_ADD_U32(&c.hist[(k >> shift) & dmask], 1u);
+        for (int base = 0; base < hi; base += NT * KB) {
+            uint32_t kk[KB];
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const int s = base + b * NT + tid;
+                kk[b] = s < hi ? K32(c, s) : 0u;
             }
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const int s = base + b * NT + tid;
+                if (s < hi && bm_test(c.live, s)) {
+                    const uint32_t k = kk[b];
+                    const bool active = up >= 32 || (k >> up) == (piv >> up);
+                    if (active) LDS_ADD_U32(&c.hist[(k >> shift) & dmask], 1u);
+                }
+            }
+        }
         PAR_END
         PAR_BEGIN  // group sums: 64 groups of nb/64 bins
         if (tid < 64) {
@@ -416,11 +463,12 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
         PAR_BEGIN
         const int g = nb >> 6;
         for (int b = tid; b < nb; b += NT) {
+            const int mine = (int)c.hist[b];
+            if (mine == 0) continue;   // an empty bin never holds the K-th node
             const int grp = b / g;
             int above = 0;
             for (int x = grp + 1; x < 64; ++x) above += (int)sh->gs[x];
             for (int x = b + 1; x < (grp + 1) * g; ++x) above += (int)c.hist[x];
-            const int mine = (int)c.hist[b];
             if (above < need && need <= above + mine) {
                 sh->sel_digit = b;
                 sh->sel_above = above;
@@ -432,86 +480,115 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
         need -= sh->sel_above;
         if (need == sh->sel_bucket) done = true;
     }
-    DD2_TICK(PH_SELECT)
-    uint64_t pivLex[WS];
-#pragma unroll
-    for (int k = 0; k < WS; ++k) pivLex[k] = 0;
-    if (!done) {
-        // ---- tie-break inside the (value, popcount) bucket by member order (BitSet::cmp, main.rs:205-208):
-        // the bucket is compacted into a list once; per state word the lexicographic key brev(~word) of every
-        // listed node is fetched ONCE into a scratch row, digits that are constant over the list are skipped,
-        // and after each word the list shrinks to the nodes still tied with the pivot.
+    const int bucket = sh->sel_bucket;
+    DD_SYNC();
+    PAR_BEGIN
+    if (tid == 0) {
+        sh->pivKey = piv;
+        sh->sel_need = done ? -1 : need;   // not done after the last digit: `bucket` nodes tie on key32, `need` of them stay
+        sh->sel_bucket = bucket;
+    }
+    PAR_END
+}
+
+/// Member-order tie-break (BitSet::cmp, main.rs:205-208) among the `m` nodes of the list `tie` that share the pivot
+/// (value, popcount): the `need` largest stay, the others are appended to the victim list c.wl (sh->nvict).
+/// Per state word the lexicographic keys brev(~word) of the tied nodes are fetched once; the need-th largest key is
+/// found by rank counting out of LDS when the list is short (every thread compares its key with all others: one
+/// pass, no digit rounds), by 8-bit radix rounds otherwise; then the list shrinks to the nodes still tied.
+template <int WS>
+DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
+    DD_TID_SETUP(c)
+    DD2Shared* sh = c.sh;
+    const int LCAP = c.lex_cap;                      // lexicographic keys that fit the histogram area of LDS (<= 1024)
+    uint64_t* lwl = (uint64_t*)c.hist;
+    const uint64_t sbase = (sh->ev_pos + 3) & ~3ULL;   // scratch behind the event records
+    if (sbase + 2ull * (uint64_t)m + (uint64_t)(m + 1) / 2 + 8 > c.ev_cap) {
         PAR_BEGIN
-        if (tid == 0) sh->nwl = 0;
+        if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 1;
         PAR_END
+        return false;
+    }
+    uint64_t* lwg = (uint64_t*)(c.ev + sbase);
+    uint16_t* cur = tie;
+    uint16_t* nxt = (uint16_t*)(lwg + m);   // second list: the tie list ping-pongs between the caller's and this one
+    for (int wj = 0; wj < WS; ++wj) {
+        if (need <= 0 || need >= m) break;
+        uint64_t* lw = m <= LCAP ? lwl : lwg;
+        DD2_STAT(3, 1)
+        DD2_STAT(8, m)
         PAR_BEGIN
-        for (int s = tid; s < hi; s += NT)
-            if (bm_test(c.live, s) && K32(c, s) == piv) {
-                int i = LDS_ADD_I32(&sh->nwl, 1);
-                if (i < c.capW) c.wl[i] = (uint16_t)s;
-            }
-        PAR_END
-        int m = sh->nwl < c.capW ? sh->nwl : c.capW;
-        uint64_t* lwbuf = (uint64_t*)(c.ev + ((sh->ev_pos + 1) & ~1ULL));   // scratch behind the event records
-        const bool scratch_ok = ((sh->ev_pos + 1) & ~1ULL) + 2ull * (uint64_t)m + 2 <= c.ev_cap;
-        if (!scratch_ok) {
-            PAR_BEGIN
-            if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 1;
-            PAR_END
-            done = true;
+        if (tid == 0) {
+            sh->land = ~0ULL;
+            sh->lor = 0;
+            sh->sel_digit = -1;
+            sh->nwl = 0;
         }
-        uint16_t* cur = c.wl;
-        uint16_t* nxt = c.fl;
-        for (int wj = 0; wj < WS && !done; ++wj) {
+        PAR_END
+        PAR_BEGIN
+        uint64_t a = ~0ULL, o = 0;
+        for (int i = tid; i < m; i += NT) {
+            const uint64_t v = dd_brev(~ld_word<WS>(c, cur[i], wj));
+            lw[i] = v;
+            a &= v;
+            o |= v;
+        }
+        if (tid < m) {
+            LDS_AND_U64(&sh->land, a);
+            LDS_OR_U64(&sh->lor, o);
+        }
+        PAR_END
+        const uint64_t land = sh->land;
+        const uint64_t ldiff = land ^ sh->lor;
+        DD_SYNC();   // every thread has its copy before thread 0 resets land/lor for the next word
+        if (ldiff == 0) continue;   // every tied node has the same word: nothing to decide here
+        uint64_t pivw = 0;
+        bool all_ge_kept = false;   // radix path only: the whole digit bucket stays, pivw's low bytes are unresolved (zero)
+        if (m <= LCAP) {
             PAR_BEGIN
-            if (tid == 0) {
-                sh->land = ~0ULL;
-                sh->lor = 0;
-            }
-            PAR_END
-            PAR_BEGIN
-            uint64_t a = ~0ULL, o = 0;
             for (int i = tid; i < m; i += NT) {
-                const uint64_t lw = dd_brev(~ld_word<WS>(c, cur[i], wj));
-                lwbuf[i] = lw;
-                a &= lw;
-                o |= lw;
-            }
-            if (tid < m) {
-                LDS_AND_U64(&sh->land, a);
-                LDS_OR_U64(&sh->lor, o);
+                const uint64_t v = lw[i];
+                int gt = 0, ge = 0;
+                for (int j = 0; j < m; ++j) {
+                    const uint64_t u = lw[j];
+                    gt += u > v ? 1 : 0;
+                    ge += u >= v ? 1 : 0;
+                }
+                if (gt < need && need <= ge) {   // v is the need-th largest word (every node holding it agrees)
+                    sh->pivLex[0] = v;
+                    sh->sel_above = gt;
+                    sh->sel_bucket = ge - gt;
+                }
             }
             PAR_END
-            const uint64_t land = sh->land;
-            const uint64_t ldiff = land ^ sh->lor;
-            DD_SYNC();   // every thread has its copy before thread 0 resets land/lor for the next word
-            if (ldiff == 0) {   // every tied node has the same word: nothing to decide here
-                pivLex[wj] = land;
-                continue;
-            }
+            pivw = sh->pivLex[0];
+        } else {
             uint64_t prefix = 0;
-            for (int b = 7; b >= 0 && !done; --b) {
+            int nd = need;
+            bool rdone = false;
+            for (int b = 7; b >= 0 && !rdone; --b) {
                 const int shift = 8 * b;
                 if (((ldiff >> shift) & 0xFF) == 0) {
                     prefix |= land & (0xFFULL << shift);
                     continue;
                 }
+                DD2_STAT(2, 1)
                 PAR_BEGIN
                 if (tid < 256) c.hist[tid] = 0;
                 PAR_END
                 PAR_BEGIN
                 for (int i = tid; i < m; i += NT) {
-                    const uint64_t lw = lwbuf[i];
-                    if (shift + 8 < 64 && (lw >> (shift + 8)) != (prefix >> (shift + 8))) continue;
-                    LDS_ADD_U32(&c.hist[(lw >> shift) & 0xFF], 1u);
+                    const uint64_t v = lw[i];
+                    if (shift + 8 < 64 && (v >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+                    LDS_ADD_U32(&c.hist[(v >> shift) & 0xFF], 1u);
                 }
                 PAR_END
                 PAR_BEGIN
                 if (tid < 256) {
                     int above = 0;
                     for (int x = tid + 1; x < 256; ++x) above += (int)c.hist[x];
-                    int mine = (int)c.hist[tid];
-                    if (above < need && need <= above + mine) {
+                    const int mine = (int)c.hist[tid];
+                    if (above < nd && nd <= above + mine) {
                         sh->sel_digit = tid;
                         sh->sel_above = above;
                         sh->sel_bucket = mine;
@@ -519,45 +596,55 @@ DDO_DEV void select_pivot2(DD2Ctx<WS>& c, int K) {
                 }
                 PAR_END
                 prefix |= (uint64_t)sh->sel_digit << shift;
-                need -= sh->sel_above;
-                if (need == sh->sel_bucket) {
-                    done = true;   // everything still tied below this digit is kept
-                }
+                nd -= sh->sel_above;
+                if (nd == sh->sel_bucket) rdone = true;   // everything still tied below this digit stays
+                DD_SYNC();
             }
-            pivLex[wj] = prefix;
-            if (!done) {   // keep only the nodes still tied with the pivot on this word
-                PAR_BEGIN
-                if (tid == 0) sh->nwl = 0;
-                PAR_END
-                PAR_BEGIN
-                for (int i = tid; i < m; i += NT)
-                    if (lwbuf[i] == prefix) {
-                        int k = LDS_ADD_I32(&sh->nwl, 1);
-                        nxt[k] = cur[i];
-                    }
-                PAR_END
-                m = sh->nwl;
-                uint16_t* t = cur;
-                cur = nxt;
-                nxt = t;
+            pivw = prefix;
+            all_ge_kept = rdone;
+        }
+        // ---- partition: larger words stay, smaller ones are victims, equal ones remain tied
+        PAR_BEGIN
+        if (tid == 0) {
+            sh->nrec = 0;   // kept
+            sh->nnew = 0;   // still tied
+        }
+        PAR_END
+        PAR_BEGIN
+        for (int i = tid; i < m; i += NT) {
+            const uint64_t v = lw[i];
+            const int s = cur[i];
+            if (v > pivw || (all_ge_kept && v >= pivw)) {
+                LDS_ADD_I32(&sh->nrec, 1);
+            } else if (v == pivw) {
+                const int k = LDS_ADD_I32(&sh->nnew, 1);
+                nxt[k] = (uint16_t)s;
+            } else {
+                const int k = LDS_ADD_I32(&sh->nvict, 1);
+                if (k < c.capW) c.wl[k] = (uint16_t)s;
             }
         }
+        PAR_END
+        need -= sh->nrec;
+        m = sh->nnew;
+        DD_SYNC();
+        uint16_t* t = cur;
+        cur = nxt;
+        nxt = t;
     }
-    PAR_BEGIN
-    if (tid == 0) {
-        sh->pivKey = piv;
-        for (int k = 0; k < WS; ++k) sh->pivLex[k] = pivLex[k];
+    if (need > 0 && need < m) {   // cannot happen: two live nodes never hold the same state
+        PAR_BEGIN
+        if (tid == 0) sh->status = ST_ERR_INTERNAL;
+        PAR_END
+        return false;
     }
-    PAR_END
-}
-
-template <int WS>
-DDO_DEV bool ge_pivot2(const DD2Ctx<WS>& c, int s, uint32_t key) {
-    const DD2Shared* sh = c.sh;
-    if (key != sh->pivKey) return key > sh->pivKey;
-    for (int k = 0; k < WS; ++k) {
-        uint64_t lw = dd_brev(~ld_word<WS>(c, s, k));
-        if (lw != sh->pivLex[k]) return lw > sh->pivLex[k];
+    if (need <= 0 && m > 0) {   // nothing more to keep: the remaining tied nodes are victims
+        PAR_BEGIN
+        for (int i = tid; i < m; i += NT) {
+            const int k = LDS_ADD_I32(&sh->nvict, 1);
+            if (k < c.capW) c.wl[k] = cur[i];
+        }
+        PAR_END
     }
     return true;
 }
@@ -690,11 +777,12 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
             const int K = restricted ? W : W - 1;
-            if (K > 0) select_pivot2<WS>(c, K);
-            DD2_TICK(PH_SELLEX)
+            if (K > 0) select_key2<WS>(c, K);
+            DD2_TICK(PH_SELECT)
             PAR_BEGIN
             if (tid == 0) {
                 sh->nvict = 0;
+                sh->nfl = 0;      // nodes tied with the pivot on (value, popcount)
                 sh->mergedKey = 0;
                 for (int k = 0; k < WS; ++k) sh->merged[k] = 0;
                 sh->recycled = 0;
@@ -703,15 +791,48 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 sh->free_slot = 0x7FFFFFFF;
             }
             PAR_END
-            PAR_BEGIN   // victims: live nodes ranked below the pivot (clean.rs:810-812 / :851-852)
-            for (int s = tid; s < sh->hiw; s += NT) {
-                if (!bm_test(c.live, s)) continue;
-                const uint32_t key = K32(c, s);
-                if (K > 0 && ge_pivot2<WS>(c, s, key)) continue;
-                int i = LDS_ADD_I32(&sh->nvict, 1);
-                if (i < c.capW) c.wl[i] = (uint16_t)s;
+            const uint32_t pivKey = sh->pivKey;
+            const int tie_need = K > 0 ? sh->sel_need : -1;
+            PAR_BEGIN   // victims: live nodes ranked below the pivot (clean.rs:810-812 / :851-852); ties are listed apart
+            for (int base = 0; base < sh->hiw; base += NT * KB) {
+                uint32_t kk[KB];
+#pragma unroll
+                for (int b = 0; b < KB; ++b) {
+                    const int s = base + b * NT + tid;
+                    kk[b] = s < sh->hiw ? K32(c, s) : 0u;
+                }
+#pragma unroll
+                for (int b = 0; b < KB; ++b) {
+                    const int s = base + b * NT + tid;
+                    if (s >= sh->hiw || !bm_test(c.live, s)) continue;
+                    const uint32_t key = kk[b];
+                    if (K > 0 && key > pivKey) continue;
+                    if (K > 0 && key == pivKey) {
+                        if (tie_need < 0) continue;
+                        const int i = LDS_ADD_I32(&sh->nfl, 1);
+                        if (i < c.capW) c.fl[i] = (uint16_t)s;
+                        continue;
+                    }
+                    const int i = LDS_ADD_I32(&sh->nvict, 1);
+                    if (i < c.capW) c.wl[i] = (uint16_t)s;
+                }
             }
             PAR_END
+            if (K > 0 && tie_need >= 0) {
+                const int m = sh->nfl;
+                DD2_STAT(0, m)
+                DD2_STAT(1, 1)
+                if (m > c.capW || !lex_split2<WS>(c, c.fl, m, tie_need)) {
+                    if (m > c.capW) {
+                        PAR_BEGIN
+                        if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 2;
+                        PAR_END
+                    }
+                    failed = true;
+                    break;
+                }
+            }
+            DD2_TICK(PH_SELLEX)
             const int nv = sh->nvict;
             if (nv > c.capW || sh->ev_pos + (uint64_t)nv + 8 > c.ev_cap) {
                 PAR_BEGIN
@@ -742,6 +863,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
             PAR_END
             n_del = nv;
+            DD2_STAT(6, nv)
+            DD2_STAT(9, 1)
             if (relaxed) {
                 // ---------------------------------------------------- merged node (clean.rs:826-875)
                 PAR_BEGIN
@@ -928,6 +1051,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             failed = true;
             break;
         }
+        DD2_STAT(4, nwl)
+        DD2_STAT(7, naff_bound)
         DD2_TICK(PH_WORKLIST)
         // ------------------------------------------------------------ free slots for the YES-children
         // Each thread claims room in the list for the free bits of its bitmap words with one LDS atomic; only as
@@ -959,15 +1084,14 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #pragma unroll
         for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
         const int32_t wv = c.weight[var];
-        DD2_MARK(15)
         for (int i = tid; i < nwl; i += NT) {
             const int s = c.wl[i];
             const uint32_t key = K32(c, s);
             const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
             const int pop = (int)(key & KEY_POP_MASK);
             uint64_t st[WS];
-            ld_state<WS>(c, s, st);
-            DD2_MARK(0)
+            uint64_t oldh = 0;
+            ld_state_h<WS>(c, s, st, oldh);
             const int32_t rub = c.unit_weights ? pop : rub2_of<WS>(c, st);   // main.rs:191-193
             bm_clr(c.fresh, s);
             if ((int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365: no children
@@ -978,7 +1102,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
                 *rec4 = U32x4{(uint32_t)s, NONE32, NONE32, NONE32};
                 LDS_ADD_I32(&sh->npruned, 1);
-                DD2_MARK(1)
                 continue;
             }
             bool hasv = false;
@@ -987,8 +1110,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 if (k == vw) hasv = (st[k] & vbit) != 0;
             if (!hasv) continue;   // fresh but unaffected: its NO-child is the node itself
             // ---- decision NO, in place (main.rs:77-85)
-            DD2_MARK(2)
-            const uint64_t oldh = ld_hash<WS>(c, s);
             bm_clr(c.live, s);             // pending: it re-enters the layer (or dissolves into a twin) in phase 2
             LDS_ADD_I32(&sh->nlive, -1);
             uint64_t oldw = 0, neww = 0;
@@ -1002,7 +1123,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             st_word<WS>(c, s, vw, neww, oldh ^ mixw(oldw, vw) ^ mixw(neww, vw));
             K32_ST(c, s, key - 1);         // popcount - 1, same value (cost 0)
             LDS_ADD_I32(&c.cnt[var], -1);
-            DD2_MARK(3)
             // ---- decision YES into a free slot (main.rs:95-102)
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
             int ny = -1;
@@ -1020,7 +1140,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         c.pbr[(size_t)ny * c.PR + k] = pw;
                     }
                 }
-                DD2_MARK(4)
                 st_node<WS>(c, ny, y, hash2_state<WS>(y));
                 K32_ST(c, ny, ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop);
                 bm_put(c.inex, ny, bm_test(c.inex, s));
@@ -1033,12 +1152,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             // parent | NO target (provisional: the node itself) | YES target (provisional: the new slot) | YES slot
             *rec4 = U32x4{(uint32_t)s, (uint32_t)s, ny >= 0 ? (uint32_t)ny : NONE32, ny >= 0 ? (uint32_t)ny : NONE32};
             LDS_ADD_I32(&sh->nyes, 1);
-            DD2_MARK(5)
         }
-        DD2_MARK(6)
         PAR_END
         const int nrec = sh->nrec;
         if (sh->status != ST_OK) { failed = true; break; }
+        DD2_STAT(5, nrec)
         DD2_TICK(PH_EXP1)
         // ------------------------------------------------------------ dedup table of the unchanged nodes
         PAR_BEGIN
@@ -1052,7 +1170,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 
         // ------------------------------------------------------------ expand, phase 2: dedup (clean.rs:738-775)
         PAR_BEGIN
-        DD2_MARK(15)
         for (int idx = tid; idx < 2 * nrec; idx += NT) {   // one thread per arc: (record, NO | YES)
             const int r = idx >> 1, which = idx & 1;
             uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
@@ -1062,10 +1179,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const int x = which == 0 ? (int)rec[0] : (int)rec[3];
                 if (which == 1 && rec[3] == NONE32) continue;
                 uint64_t st[WS];
-                ld_state<WS>(c, x, st);
-                DD2_MARK(8)
-                const int t = tab2_insert<WS>(c, x, ld_hash<WS>(c, x), st);
-                DD2_MARK(9)
+                uint64_t xh = 0;
+                ld_state_h<WS>(c, x, st, xh);
+                const int t = tab2_insert<WS>(c, x, xh, st);
                 if (t == x) {
                     if (which == 0) {           // the in-place NO-child stays in the layer
                         bm_set(c.live, x);
@@ -1079,7 +1195,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         LDS_MAX_I32(&sh->hiw, x + 1);
                         rec[2] = (uint32_t)x | EV_CREATED;
                     }
-                    DD2_MARK(10)
                     continue;
                 }
                 // duplicate of node t: the arc enters t  (append_edge_to!, clean.rs:199-220)
@@ -1088,10 +1203,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 rec[1 + which] = (uint32_t)t | (kx > old ? EV_RAISED : 0u);
                 if (bm_test(c.inex, x)) bm_set(c.inex, t);
                 if (which == 0) add_bits<WS>(c.cnt, st, -1);   // the in-place NO-child dissolves into t
-                DD2_MARK(11)
             }
         }
-        DD2_MARK(12)
         PAR_END
         DD2_TICK(PH_EXP2)
         // ------------------------------------------------------------ expand, phase 3: new best parents
@@ -1582,6 +1695,7 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.pool_head = P.pool_head;
     c.vbase_off = P.vbase_off;
     c.clocks = P.phase_clocks;
+    c.lex_cap = P.lex_cap > 0 && P.lex_cap <= 1024 ? P.lex_cap : 1024;
     c.NT = nthreads;
 }
 

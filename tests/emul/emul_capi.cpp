@@ -140,7 +140,9 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
     long long neg = 0;
     for (int i = 0; i < n; ++i) if (weights[i] < 0) neg += weights[i];
     P.vbase_off = (int32_t)neg;
-    P.ev_cap = (uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64;
+    P.lex_cap = 1024;
+    if (const char* env = std::getenv("DDO_EMUL_LEX_CAP")) P.lex_cap = std::max(1, std::min(1024, std::atoi(env)));
+    P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 3) & ~3ull;
     {
         const size_t capS = P.capS, capW = P.capW, mlz = P.max_layers;
         const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
