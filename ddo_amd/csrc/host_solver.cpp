@@ -433,6 +433,7 @@ struct ddo_solver {
     std::vector<uint64_t> st_nodes;
     uint64_t st_clk[24] = {0};
     uint64_t st_push = 0, st_push_dup = 0;
+    uint64_t st_recycled = 0;
     double st_host_pop = 0, st_host_run = 0, st_host_post = 0, st_host_fetch = 0;
     bool want_stats = false;
     // scratch
@@ -463,6 +464,7 @@ struct ddo_solver {
                          (double)st_clk[8] / tl, (double)st_clk[9] / tl, (double)st_clk[10] / tl, (double)st_clk[11] / tl, (double)st_clk[16] / tl,
                          (double)st_clk[12] / tl, (double)st_clk[15] / tl, (double)st_clk[13] / tl, (double)st_clk[14] / tl, (double)st_clk[17] / tl);
             for (int q = 18; q < 24; ++q) std::fprintf(stderr, " m%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
+            std::fprintf(stderr, " | recycled merges per layer %.4f", (double)st_recycled / tl);
             std::fprintf(stderr, "\n");
             std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
                          a.size(), (double)tl / a.size(), (unsigned long long)pct(a, .5), (unsigned long long)pct(a, .9), (unsigned long long)pct(a, 1.0),
@@ -605,6 +607,7 @@ struct ddo_solver {
                     st_maxw.push_back(r->hdr.max_width_seen);
                     st_nodes.push_back(r->hdr.nodes_expanded);
                     for (int q = 0; q < 24; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                    st_recycled += r->hdr.recycled_merges;
                 }
                 if (r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
                     best_lb = r->hdr.best_exact_value;
@@ -866,6 +869,7 @@ struct ddo_solver {
                     st_maxw.push_back(r->hdr.max_width_seen);
                     st_nodes.push_back(r->hdr.nodes_expanded);
                     for (int q = 0; q < 24; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                    st_recycled += r->hdr.recycled_merges;
                 }
                 maybe_update_best(items[i], *r);
                 const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;

@@ -106,6 +106,18 @@ struct DD2Shared {
         if (tid == 0) sh->mk[k] += (uint64_t)(v);           \
         PAR_END                                             \
     }
+// DD2_TICK2(k): like DD2_TICK but the elapsed ticks are ALSO charged to the auxiliary slot mk[k] (finer breakdown)
+#define DD2_TICK2(ph, k)                                    \
+    if (c.clocks) {                                         \
+        PAR_BEGIN                                           \
+        if (tid == 0) {                                     \
+            const uint64_t _t = dd_clock();                 \
+            sh->clk[ph] += _t - sh->clk_last;               \
+            sh->mk[k] += _t - sh->clk_last;                 \
+            sh->clk_last = _t;                              \
+        }                                                   \
+        PAR_END                                             \
+    }
 #define DD2_TICK(ph)                                        \
     if (c.clocks) {                                         \
         PAR_BEGIN                                           \
@@ -346,6 +358,29 @@ DDO_DEV int tab2_find(const DD2Ctx<WS>& c, uint64_t h, const uint64_t* s) {
     return -1;
 }
 
+
+/// OR / MAX over the lanes of a wave (every lane of the wave must call; lanes without a value pass 0)
+#if defined(DDO_HOST_EMULATION)
+DDO_DEV uint64_t wave_or_u64(uint64_t x) { return x; }
+DDO_DEV uint64_t wave_max_u64(uint64_t x) { return x; }
+DDO_DEV bool wave_leader(int) { return true; }
+#else
+DDO_DEV uint64_t wave_or_u64(uint64_t x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x |= (uint64_t)__shfl_xor((unsigned long long)x, off, 64);
+    return x;
+}
+DDO_DEV uint64_t wave_max_u64(uint64_t x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)x, off, 64);
+        x = y > x ? y : x;
+    }
+    return x;
+}
+DDO_DEV bool wave_leader(int tid) { return (tid & 63) == 0; }
+#endif
+
 template <int WS>
 DDO_DEV int32_t rub2_of(const DD2Ctx<WS>& c, const uint64_t* s) {
     int32_t sum = 0;
@@ -545,22 +580,51 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
         uint64_t pivw = 0;
         bool all_ge_kept = false;   // radix path only: the whole digit bucket stays, pivw's low bytes are unresolved (zero)
         if (m <= LCAP) {
-            PAR_BEGIN
-            for (int i = tid; i < m; i += NT) {
-                const uint64_t v = lw[i];
-                int gt = 0, ge = 0;
-                for (int j = 0; j < m; ++j) {
-                    const uint64_t u = lw[j];
-                    gt += u > v ? 1 : 0;
-                    ge += u >= v ? 1 : 0;
+            // rank counting: node i holds the need-th largest word iff #greater < need <= #greater-or-equal.  With a
+            // short list the inner loop is split over P threads per node (partial counts meet in LDS).
+            const int P = 2 * m <= NT ? NT / m : 1;
+            if (P > 1) {
+                PAR_BEGIN
+                for (int i = tid; i < m; i += NT) {
+                    c.tcount[i] = 0;
+                    c.tcount2[i] = 0;
                 }
-                if (gt < need && need <= ge) {   // v is the need-th largest word (every node holding it agrees)
-                    sh->pivLex[0] = v;
-                    sh->sel_above = gt;
-                    sh->sel_bucket = ge - gt;
+                PAR_END
+                PAR_BEGIN
+                if (tid < m * P) {
+                    const int i = tid % m, part = tid / m;
+                    const int j0 = (int)((long long)part * m / P), j1 = (int)((long long)(part + 1) * m / P);
+                    const uint64_t v = lw[i];
+                    int gt = 0, ge = 0;
+                    for (int j = j0; j < j1; ++j) {
+                        const uint64_t u = lw[j];
+                        gt += u > v ? 1 : 0;
+                        ge += u >= v ? 1 : 0;
+                    }
+                    if (gt) LDS_ADD_I32(&c.tcount[i], gt);
+                    if (ge) LDS_ADD_I32(&c.tcount2[i], ge);
                 }
+                PAR_END
+                PAR_BEGIN
+                for (int i = tid; i < m; i += NT) {
+                    const int gt = c.tcount[i], ge = c.tcount2[i];
+                    if (gt < need && need <= ge) sh->pivLex[0] = lw[i];
+                }
+                PAR_END
+            } else {
+                PAR_BEGIN
+                for (int i = tid; i < m; i += NT) {
+                    const uint64_t v = lw[i];
+                    int gt = 0, ge = 0;
+                    for (int j = 0; j < m; ++j) {
+                        const uint64_t u = lw[j];
+                        gt += u > v ? 1 : 0;
+                        ge += u >= v ? 1 : 0;
+                    }
+                    if (gt < need && need <= ge) sh->pivLex[0] = v;   // every node holding this word agrees
+                }
+                PAR_END
             }
-            PAR_END
             pivw = sh->pivLex[0];
         } else {
             uint64_t prefix = 0;
@@ -757,7 +821,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             break;
         }
         if (L >= c.max_layers - 1 || sh->status != ST_OK) { failed = true; break; }
-        DD2_TICK(PH_VAR)
+        DD2_TICK2(PH_VAR, 15)
         const int nU = sh->nlive;
 
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
@@ -842,20 +906,28 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 break;
             }
             PAR_BEGIN
-            for (int i = tid; i < nv; i += NT) {
-                const int s = c.wl[i];
+            for (int i = tid; (i & ~63) < nv; i += NT) {   // whole waves: the merged state is OR-reduced per wave first
+                const bool valid = i < nv;
+                const int s = valid ? (int)c.wl[i] : 0;
                 uint64_t st[WS];
                 ld_state<WS>(c, s, st);
-                add_bits<WS>(c.cnt, st, -1);
-                bm_clr(c.live, s);
-                bm_clr(c.fresh, s);
-                if (relaxed) {
-#pragma unroll
-                    for (int k = 0; k < WS; ++k)
-                        if (st[k]) LDS_OR_U64(&sh->merged[k], st[k]);   // MispRelax::merge (main.rs:172-178)
-                    LDS_MAX_U64(&sh->mergedKey, ((uint64_t)K32(c, s) << 32) | (uint32_t)s);
+                if (valid) {
+                    add_bits<WS>(c.cnt, st, -1);
+                    bm_clr(c.live, s);
+                    bm_clr(c.fresh, s);
+                    c.ev[del_off + i] = (uint32_t)s;
                 }
-                c.ev[del_off + i] = (uint32_t)s;
+                if (relaxed) {
+                    // MispRelax::merge (main.rs:172-178): union of the merged states; one LDS atomic per wave and
+                    // word instead of one per victim (they all hit the same seven addresses)
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) {
+                        const uint64_t u = wave_or_u64(valid ? st[k] : 0ULL);
+                        if (wave_leader(tid) && u) LDS_OR_U64(&sh->merged[k], u);
+                    }
+                    const uint64_t mk = wave_max_u64(valid ? (((uint64_t)K32(c, s) << 32) | (uint32_t)s) : 0ULL);
+                    if (wave_leader(tid) && mk) LDS_MAX_U64(&sh->mergedKey, mk);
+                }
             }
             if (tid == 0) {
                 sh->nlive -= nv;
@@ -865,6 +937,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             n_del = nv;
             DD2_STAT(6, nv)
             DD2_STAT(9, 1)
+            DD2_TICK2(PH_VICTIMS, 10)
             if (relaxed) {
                 // ---------------------------------------------------- merged node (clean.rs:826-875)
                 PAR_BEGIN
@@ -884,25 +957,67 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     }
                 }
                 PAR_END
+                DD2_TICK2(PH_VICTIMS, 12)
                 if (sh->recycled) {
-                    // clean.rs:868-872: the best-ranked node of the merged set stays in the layer
+                    // clean.rs:868-872: the best-ranked node X of the merged set stays in the layer.  X = the victim with
+                    // the largest (value, popcount) key and, among those, the largest member order: the candidates are
+                    // filtered word by word against the maximum lexicographic key (one gather per word).
+                    const uint32_t topk = (uint32_t)(sh->mergedKey >> 32);
                     PAR_BEGIN
-                    if (tid < 64) {
-                        int best = -1;
-                        for (int i = tid; i < nv; i += 64) {
-                            int s = c.wl[i];
-                            if (best < 0 || ranks_above2<WS>(c, s, best)) best = s;
-                        }
-                        sh->xcand[tid] = best;
-                    }
+                    if (tid == 0) sh->nfl = 0;
                     PAR_END
                     PAR_BEGIN
-                    if (tid == 0) {
-                        int best = -1;
-                        for (int l = 0; l < 64; ++l) {
-                            int s = sh->xcand[l];
-                            if (s >= 0 && (best < 0 || ranks_above2<WS>(c, s, best))) best = s;
+                    for (int i = tid; i < nv; i += NT) {
+                        const int s = c.wl[i];
+                        if (K32(c, s) == topk) {
+                            const int k = LDS_ADD_I32(&sh->nfl, 1);
+                            c.fl[k] = (uint16_t)s;
                         }
+                    }
+                    PAR_END
+                    int m = sh->nfl;
+                    const uint64_t sbase = (sh->ev_pos + 3) & ~3ULL;   // scratch behind the event records
+                    if (sbase + 2ull * (uint64_t)m + (uint64_t)(m + 1) / 2 + 8 > c.ev_cap) {
+                        PAR_BEGIN
+                        if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 9;
+                        PAR_END
+                        failed = true;
+                        break;
+                    }
+                    uint64_t* lwg = (uint64_t*)(c.ev + sbase);
+                    uint16_t* cur = c.fl;
+                    uint16_t* nxt = (uint16_t*)(lwg + m);
+                    for (int wj = 0; wj < WS && m > 1; ++wj) {
+                        uint64_t* lw = m <= c.lex_cap ? (uint64_t*)c.hist : lwg;
+                        PAR_BEGIN
+                        if (tid == 0) {
+                            sh->lor = 0;
+                            sh->nnew = 0;
+                        }
+                        PAR_END
+                        PAR_BEGIN
+                        uint64_t mx = 0;
+                        for (int i = tid; i < m; i += NT) {
+                            const uint64_t v = dd_brev(~ld_word<WS>(c, cur[i], wj));
+                            lw[i] = v;
+                            mx = v > mx ? v : mx;
+                        }
+                        if (mx) LDS_MAX_U64(&sh->lor, mx);
+                        PAR_END
+                        const uint64_t top = sh->lor;
+                        PAR_BEGIN
+                        for (int i = tid; i < m; i += NT)
+                            if (lw[i] == top) nxt[LDS_ADD_I32(&sh->nnew, 1)] = cur[i];
+                        PAR_END
+                        m = sh->nnew;
+                        DD_SYNC();
+                        uint16_t* t = cur;
+                        cur = nxt;
+                        nxt = t;
+                    }
+                    PAR_BEGIN
+                    if (tid == 0) {
+                        const int best = cur[0];
                         sh->xslot = best;
                         sh->recycled_merges += 1;
                         const int r = sh->merged_slot;
@@ -920,8 +1035,13 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         bm_set(c.live, best);
                         bm_set(c.fresh, best);   // its fresh mark was dropped with the victims: check it (again)
                         sh->nlive += 1;
-                        for (int i = 0; i < nv; ++i)
-                            if (c.ev[del_off + i] == (uint32_t)best) c.ev[del_off + i] = NONE32;
+                    }
+                    PAR_END
+                    PAR_BEGIN
+                    {
+                        const uint32_t best = (uint32_t)sh->xslot;   // X is not deleted after all
+                        for (int i = tid; i < nv; i += NT)
+                            if (c.ev[del_off + i] == best) c.ev[del_off + i] = NONE32;
                     }
                     PAR_END
                     merged_slot = sh->merged_slot;
@@ -977,7 +1097,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
         }
-        DD2_TICK(PH_VICTIMS)
+        DD2_TICK2(PH_VICTIMS, 11)
         const int n = sh->nlive;   // |layer L| after squash
         const int naff_bound = c.cnt[var] > 0 ? c.cnt[var] : 0;   // live states containing the variable
 
@@ -1029,12 +1149,25 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         const int vw = var >> 6;
         const uint64_t vbit = 1ULL << (var & 63);
         PAR_BEGIN
-        for (int s = tid; s < sh->hiw; s += NT) {
-            if (!bm_test(c.live, s)) continue;
-            const bool hasv = (c.st[(size_t)vw * capS + s] & vbit) != 0;
-            if (hasv || bm_test(c.fresh, s)) {
-                int i = LDS_ADD_I32(&sh->nwl, 1);
-                if (i < c.capW) c.wl[i] = (uint16_t)s;
+        {
+            const uint64_t* row = c.st + (size_t)vw * capS;   // word `vw` of every slot: a coalesced stream
+            const int hi = sh->hiw;
+            for (int base = 0; base < hi; base += NT * KB) {
+                uint64_t ww[KB];
+#pragma unroll
+                for (int b = 0; b < KB; ++b) {   // all loads of the batch are in flight before the first is used
+                    const int s = base + b * NT + tid;
+                    ww[b] = s < hi ? row[s] : 0;
+                }
+#pragma unroll
+                for (int b = 0; b < KB; ++b) {
+                    const int s = base + b * NT + tid;
+                    if (s >= hi || !bm_test(c.live, s)) continue;
+                    if ((ww[b] & vbit) != 0 || bm_test(c.fresh, s)) {
+                        const int i = LDS_ADD_I32(&sh->nwl, 1);
+                        if (i < c.capW) c.wl[i] = (uint16_t)s;
+                    }
+                }
             }
         }
         PAR_END
@@ -1053,7 +1186,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
         DD2_STAT(4, nwl)
         DD2_STAT(7, naff_bound)
-        DD2_TICK(PH_WORKLIST)
+        DD2_TICK2(PH_WORKLIST, 13)
         // ------------------------------------------------------------ free slots for the YES-children
         // Each thread claims room in the list for the free bits of its bitmap words with one LDS atomic; only as
         // many slots as this transition can consume are listed (at most one YES-child per work item).
@@ -1076,7 +1209,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_BEGIN
         if (tid == 0 && sh->nfl > need_free) sh->nfl = need_free;
         PAR_END
-        DD2_TICK(PH_FREELIST)
+        DD2_TICK2(PH_FREELIST, 14)
         // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
         const uint64_t aff_off = (sh->ev_pos + 3) & ~3ULL;   // 16-byte aligned records
         PAR_BEGIN
@@ -1163,8 +1296,22 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
         PAR_END
         PAR_BEGIN
-        for (int s = tid; s < sh->hiw; s += NT)
-            if (bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, c.hsh[s]);
+        {
+            const int hi = sh->hiw;
+            for (int base = 0; base < hi; base += NT * KB) {
+                uint64_t hh[KB];
+#pragma unroll
+                for (int b = 0; b < KB; ++b) {
+                    const int s = base + b * NT + tid;
+                    hh[b] = s < hi ? c.hsh[s] : 0;
+                }
+#pragma unroll
+                for (int b = 0; b < KB; ++b) {
+                    const int s = base + b * NT + tid;
+                    if (s < hi && bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, hh[b]);
+                }
+            }
+        }
         PAR_END
         DD2_TICK(PH_TABLE)
 
