@@ -65,6 +65,7 @@ inline uint32_t emu_atomic_cas(uint32_t* p, uint32_t cmp, uint32_t v) { uint32_t
 #define FENCE_BLOCK()
 inline int dd_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
+inline int dd_clz32(uint32_t x) { return __builtin_clz(x); }
 inline uint64_t dd_brev(uint64_t x) {
     x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
     x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
@@ -103,6 +104,7 @@ namespace ddo_hip {
 #define FENCE_BLOCK() __threadfence_block()
 __device__ __forceinline__ int dd_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
+__device__ __forceinline__ int dd_clz32(uint32_t x) { return __builtin_clz(x); }
 __device__ __forceinline__ uint64_t dd_brev(uint64_t x) { return __brevll(x); }
 }  // namespace ddo_hip
 #endif

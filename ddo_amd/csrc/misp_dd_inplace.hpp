@@ -77,7 +77,8 @@ struct DD2Shared {
     int32_t npruned, nyes, ndup;
     int32_t scan_total, sel_digit, sel_above, sel_bucket, sel_need;
     int32_t tab_used;
-    int32_t hiw;            // slots [0, hiw) have been used at least once
+    int32_t hiw;            // every live node sits in a slot below hiw (recomputed per layer: the sweeps stop there)
+    int32_t hiw2;
     int32_t merged_slot, recycled, xslot, free_slot;
     int32_t ncut, ncut2;
     uint32_t recycled_merges;
@@ -282,15 +283,22 @@ DDO_DEV void st_word(const DD2Ctx<WS>& c, int slot, int k, uint64_t w, uint64_t 
 }
 /// copies the first `nw` words of a path (the words that can hold decisions up to the current layer)
 template <int WS>
-DDO_DEV void copy_path(const DD2Ctx<WS>& c, int dst, int src, int nw) {
-    const uint64_t* a = c.pbr + (size_t)src * c.PR;
-    uint64_t* b = c.pbr + (size_t)dst * c.PR;
-    uint64_t tmp[WS];
+DDO_DEV void copy_path(const DD2Ctx<WS>& c, int dst, int src, int nw, int setbit = -1) {
+    // 16-byte accesses (path lines are 64-byte aligned): half the memory requests of word-wise copies; the word
+    // behind an odd nw is copied along (it is never read)
+    const U64x2* a = (const U64x2*)(c.pbr + (size_t)src * c.PR);
+    U64x2* b = (U64x2*)(c.pbr + (size_t)dst * c.PR);
+    constexpr int NP = (WS + 1) / 2;
+    U64x2 tmp[NP];
 #pragma unroll
-    for (int k = 0; k < WS; ++k) tmp[k] = k < nw ? a[k] : 0;
+    for (int q = 0; q < NP; ++q) tmp[q] = 2 * q < nw ? a[q] : U64x2{0, 0};
 #pragma unroll
-    for (int k = 0; k < WS; ++k)
-        if (k < nw) b[k] = tmp[k];
+    for (int q = 0; q < NP; ++q)
+        if (2 * q < nw) {
+            if (setbit >= 0 && (setbit >> 6) == 2 * q) tmp[q].a |= 1ULL << (setbit & 63);
+            if (setbit >= 0 && (setbit >> 6) == 2 * q + 1) tmp[q].b |= 1ULL << (setbit & 63);
+            b[q] = tmp[q];
+        }
 }
 
 /// The dedup table lives in LDS and is rebuilt for every layer (clear, stream all unchanged live nodes in by their
@@ -414,7 +422,7 @@ DDO_DEV bool ranks_above2(const DD2Ctx<WS>& c, int a, int b) {
 /// them stay (then the unresolved low digits of pivKey are zero and "kept <=> key >= pivKey").
 /// Keys may live in HBM (L2) at large widths: every sweep fetches KB keys per thread before it touches them, so the
 /// sweep costs hi / (NT * KB) dependent round trips instead of hi / NT.
-constexpr int KB = 4;
+constexpr int KB = 8;
 template <int WS>
 DDO_DEV void select_key2(DD2Ctx<WS>& c, int K) {
     DD_TID_SETUP(c)
@@ -801,6 +809,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_BEGIN
         if (tid == 0) {
             sh->varkey = 0xFFFFFFFFu;
+            sh->hiw2 = 0;
             if (c.cutoff_flag) sh->cutoff = LD_I32(c.cutoff_flag);
         }
         PAR_END
@@ -810,6 +819,13 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             if (cv > 0) LDS_MIN_U32(&sh->varkey, ((uint32_t)cv << 12) | (uint32_t)i);
             else if (cv < 0) sh->status = ST_ERR_INTERNAL;
         }
+        for (int w = tid; w < c.nbw; w += NT) {   // highest live slot: dead slots above it need not be swept
+            const uint32_t lv = c.live[w];
+            if (lv) LDS_MAX_I32(&sh->hiw2, w * 32 + 32 - dd_clz32(lv));
+        }
+        PAR_END
+        PAR_BEGIN
+        if (tid == 0) sh->hiw = sh->hiw2 > 0 ? sh->hiw2 : 1;
         PAR_END
         var = sh->varkey == 0xFFFFFFFFu ? -1 : (int)(sh->varkey & 0xFFFu);
         if (var < 0) break;
@@ -1267,12 +1283,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 for (int k = 0; k < WS; ++k) {
                     y[k] = st[k] & adjv[k];
                     ypop += dd_popc(y[k]);
-                    if (k < npw) {   // a DD has at most popcount(root state) layers: only these path words exist
-                        uint64_t pw = c.pbr[(size_t)s * c.PR + k];
-                        if (k == (L >> 6)) pw |= 1ULL << (L & 63);
-                        c.pbr[(size_t)ny * c.PR + k] = pw;
-                    }
                 }
+                // a DD has at most popcount(root state) layers: only npw path words exist; the child's path is the
+                // parent's plus decision bit L
+                copy_path<WS>(c, ny, s, npw, L);
                 st_node<WS>(c, ny, y, hash2_state<WS>(y));
                 K32_ST(c, ny, ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop);
                 bm_put(c.inex, ny, bm_test(c.inex, s));
