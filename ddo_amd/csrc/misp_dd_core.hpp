@@ -46,6 +46,7 @@ template <class T> inline T emu_atomic_min(T* p, T v) { T o = *p; if (v < o) *p 
 template <class T> inline T emu_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> inline T emu_atomic_and(T* p, T v) { T o = *p; *p = o & v; return o; }
 inline uint32_t emu_atomic_cas(uint32_t* p, uint32_t cmp, uint32_t v) { uint32_t o = *p; if (o == cmp) *p = v; return o; }
+#define LDS_PTR(T) T*
 #define LDS_ADD_I32(p, v) emu_atomic_add<int32_t>((p), (v))
 #define LDS_ADD_U32(p, v) emu_atomic_add<uint32_t>((p), (v))
 #define LDS_MIN_U32(p, v) emu_atomic_min<uint32_t>((p), (v))
@@ -82,15 +83,25 @@ inline uint64_t dd_brev(uint64_t x) {
 // explicit barrier: needed when workgroup-uniform code has read shared scalars that the very next phase rewrites
 #define DD_SYNC() __syncthreads()
 namespace ddo_hip {
-#define LDS_ADD_I32(p, v) atomicAdd((p), (v))
-#define LDS_ADD_U32(p, v) atomicAdd((p), (v))
-#define LDS_MIN_U32(p, v) atomicMin((p), (v))
-#define LDS_MAX_I32(p, v) atomicMax((p), (v))
-#define LDS_OR_U64(p, v) atomicOr((unsigned long long*)(p), (unsigned long long)(v))
-#define LDS_AND_U64(p, v) atomicAnd((unsigned long long*)(p), (unsigned long long)(v))
-#define LDS_MAX_U64(p, v) atomicMax((unsigned long long*)(p), (unsigned long long)(v))
-#define LDS_ADD_U64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(v))
-#define TAB_CAS(p, c, v) atomicCAS((p), (c), (v))
+// Pointers into LDS carry the address space: through a generic pointer every access becomes a FLAT instruction,
+// which travels the vector-memory path and ties LDS traffic to vmcnt (an LDS atomic would then wait behind
+// outstanding global stores).  The __hip_atomic builtins accept any address space: ds_* for LDS pointers, the usual
+// flat/global atomics for generic ones (agent scope = what atomicAdd & co. use).
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+#define LDS_ADD_I32(p, v) __hip_atomic_fetch_add((p), (int32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_ADD_U32(p, v) __hip_atomic_fetch_add((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_MIN_U32(p, v) __hip_atomic_fetch_min((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_MAX_I32(p, v) __hip_atomic_fetch_max((p), (int32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_OR_U64(p, v) __hip_atomic_fetch_or((p), (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_AND_U64(p, v) __hip_atomic_fetch_and((p), (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_MAX_U64(p, v) __hip_atomic_fetch_max((p), (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_ADD_U64(p, v) __hip_atomic_fetch_add((p), (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+template <class P>
+__device__ __forceinline__ uint32_t dd_tab_cas(P p, uint32_t cmp, uint32_t v) {
+    __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return cmp;
+}
+#define TAB_CAS(p, c, v) dd_tab_cas((p), (c), (v))
 #define GLB_MAX_U64(p, v) atomicMax((unsigned long long*)(p), (unsigned long long)(v))
 #define GLB_OR_U32(p, v) atomicOr((p), (v))
 #define GLB_ADD_U64(p, v) atomicAdd((p), (v))
@@ -210,8 +221,8 @@ DDO_DEV uint64_t hash_state(const uint64_t* s) {
 
 /// cnt[i] += delta for every member i of the state (delta maintenance of the
 /// next_variable counters, main.rs:130-135).
-template <int WS>
-DDO_DEV void add_bits(int32_t* cnt, const uint64_t* s, int delta) {
+template <int WS, class CP>
+DDO_DEV void add_bits(CP cnt, const uint64_t* s, int delta) {
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
         uint64_t x = s[k];

@@ -42,16 +42,26 @@ constexpr uint32_t KEY_POP_MASK = (1u << KEY_POP_BITS) - 1;
 #define LDS_MAX_U32(p, v) emu_atomic_max<uint32_t>((p), (v))
 #define GLB_ST_U32(p, v) (*(p) = (v))
 #else
-#define LDS_OR_U32(p, v) atomicOr((p), (v))
-#define LDS_AND_U32(p, v) atomicAnd((p), (v))
-#define LDS_MAX_U32(p, v) atomicMax((p), (v))
+#define LDS_OR_U32(p, v) __hip_atomic_fetch_or((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_AND_U32(p, v) __hip_atomic_fetch_and((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LDS_MAX_U32(p, v) __hip_atomic_fetch_max((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GLB_ST_U32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 #if defined(DDO_HOST_EMULATION)
 DDO_DEV uint64_t dd_clock() { return 0; }
+#define DD_UNIFORM(x) (x)
+#define DD_UNIFORM64(x) (x)
 #else
 DDO_DEV uint64_t dd_clock() { return (uint64_t)__builtin_readcyclecounter(); }
+// Workgroup-uniform scalars read from LDS land in VGPRs; at the 128-VGPR cap of 1024-thread workgroups every
+// long-lived one costs a spill somewhere.  readfirstlane moves them to SGPRs (and makes the loads they index scalar).
+#define DD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+DDO_DEV uint64_t dd_uniform64(uint64_t x) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
+#define DD_UNIFORM64(x) dd_uniform64(x)
 #endif
 // phase ids of DDResult::phase_clk
 constexpr int PH_VAR = 0, PH_SELECT = 1, PH_VICTIMS = 3, PH_WORKLIST = 0, PH_FREELIST = 0, PH_EXPAND = 7, PH_FINAL = 0, PH_BACKWARD = 0;
@@ -73,7 +83,7 @@ struct DD2Shared {
     int32_t work, status, cutoff;
     uint32_t varkey;
     int32_t nlive;
-    int32_t nwl, nrec, nnew, nvict, nfl;
+    int32_t nwl, nwl2, nrec, nnew, nvict, nfl;
     int32_t npruned, nyes, ndup;
     int32_t scan_total, sel_digit, sel_above, sel_bucket, sel_need;
     int32_t tab_used;
@@ -158,7 +168,7 @@ struct DD2Ctx {
     uint64_t* pbr;     // [capS][PR]   best-path bit strings, one line per node
     uint64_t* hsh;     // [capS]       hash of every node, contiguous: the per-layer table rebuild streams it
     int RW, PR;
-    uint32_t* tab;
+    LDS_PTR(uint32_t) tab;
     int tab_cap;
     uint32_t* ev;
     uint64_t ev_cap;
@@ -173,17 +183,17 @@ struct DD2Ctx {
     uint32_t* cs_pop;
     // LDS
     uint32_t* key32;   // capS   (aliased by the value_bot array of the backward pass)
-    uint32_t* live;    // nbw
-    uint32_t* inex;    // nbw
-    uint32_t* okb;     // nbw
-    uint32_t* fresh;   // nbw
-    int32_t* cnt;      // npad
-    uint32_t* hist;    // 2048
+    LDS_PTR(uint32_t) live;    // nbw
+    LDS_PTR(uint32_t) inex;    // nbw
+    LDS_PTR(uint32_t) okb;     // nbw
+    LDS_PTR(uint32_t) fresh;   // nbw
+    LDS_PTR(int32_t) cnt;      // npad
+    LDS_PTR(uint32_t) hist;    // 2048
     uint16_t* wl;      // capW
     uint16_t* fl;      // capW   (wl+fl together are reused as int32 tmp[capW] in the backward pass)
-    int32_t* tcount;   // NT
-    int32_t* tcount2;  // NT
-    DD2Shared* sh;
+    LDS_PTR(int32_t) tcount;   // NT
+    LDS_PTR(int32_t) tcount2;  // NT
+    LDS_PTR(DD2Shared) sh;
     uint8_t* arena;
     uint64_t arena_cap;
     unsigned long long* arena_head;
@@ -200,10 +210,10 @@ struct DD2Ctx {
 #endif
 };
 
-DDO_DEV bool bm_test(const uint32_t* bm, int s) { return (bm[s >> 5] >> (s & 31)) & 1u; }
-DDO_DEV void bm_set(uint32_t* bm, int s) { LDS_OR_U32(&bm[s >> 5], 1u << (s & 31)); }
-DDO_DEV void bm_clr(uint32_t* bm, int s) { LDS_AND_U32(&bm[s >> 5], ~(1u << (s & 31))); }
-DDO_DEV void bm_put(uint32_t* bm, int s, bool v) { if (v) bm_set(bm, s); else bm_clr(bm, s); }
+template <class BP> DDO_DEV bool bm_test(BP bm, int s) { return (bm[s >> 5] >> (s & 31)) & 1u; }
+template <class BP> DDO_DEV void bm_set(BP bm, int s) { LDS_OR_U32(&bm[s >> 5], 1u << (s & 31)); }
+template <class BP> DDO_DEV void bm_clr(BP bm, int s) { LDS_AND_U32(&bm[s >> 5], ~(1u << (s & 31))); }
+template <class BP> DDO_DEV void bm_put(BP bm, int s, bool v) { if (v) bm_set(bm, s); else bm_clr(bm, s); }
 
 /// per-word mix of the incremental state hash: H(state) = XOR_k mixw(word_k, k)
 DDO_DEV uint64_t mixw(uint64_t w, int k) {
@@ -338,7 +348,7 @@ DDO_DEV void tab2_insert_unique(const DD2Ctx<WS>& c, int x, uint64_t h) {
     const uint32_t mine = ((uint32_t)(h >> 52) << 20) | (uint32_t)x;
     uint32_t slot = (uint32_t)h & mask;
     for (uint32_t probes = 0; probes <= mask; ++probes) {
-        if (LD_U32(&c.tab[slot]) == T2_EMPTY && TAB_CAS(&c.tab[slot], T2_EMPTY, mine) == T2_EMPTY) return;
+        if (TAB_CAS(&c.tab[slot], T2_EMPTY, mine) == T2_EMPTY) return;
         slot = (slot + 1) & mask;
     }
     c.sh->status = ST_ERR_INTERNAL;
@@ -426,8 +436,8 @@ constexpr int KB = 8;
 template <int WS>
 DDO_DEV void select_key2(DD2Ctx<WS>& c, int K) {
     DD_TID_SETUP(c)
-    DD2Shared* sh = c.sh;
-    const int hi = sh->hiw;
+    LDS_PTR(DD2Shared) sh = c.sh;
+    const int hi = DD_UNIFORM(sh->hiw);
     PAR_BEGIN
     if (tid == 0) {
         sh->kand = 0xFFFFFFFFu;
@@ -542,9 +552,9 @@ DDO_DEV void select_key2(DD2Ctx<WS>& c, int K) {
 template <int WS>
 DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
     DD_TID_SETUP(c)
-    DD2Shared* sh = c.sh;
+    LDS_PTR(DD2Shared) sh = c.sh;
     const int LCAP = c.lex_cap;                      // lexicographic keys that fit the histogram area of LDS (<= 1024)
-    uint64_t* lwl = (uint64_t*)c.hist;
+    LDS_PTR(uint64_t) lwl = (LDS_PTR(uint64_t))c.hist;
     const uint64_t sbase = (sh->ev_pos + 3) & ~3ULL;   // scratch behind the event records
     if (sbase + 2ull * (uint64_t)m + (uint64_t)(m + 1) / 2 + 8 > c.ev_cap) {
         PAR_BEGIN
@@ -557,7 +567,7 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
     uint16_t* nxt = (uint16_t*)(lwg + m);   // second list: the tie list ping-pongs between the caller's and this one
     for (int wj = 0; wj < WS; ++wj) {
         if (need <= 0 || need >= m) break;
-        uint64_t* lw = m <= LCAP ? lwl : lwg;
+        const bool in_lds = m <= LCAP;
         DD2_STAT(3, 1)
         DD2_STAT(8, m)
         PAR_BEGIN
@@ -572,7 +582,7 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
         uint64_t a = ~0ULL, o = 0;
         for (int i = tid; i < m; i += NT) {
             const uint64_t v = dd_brev(~ld_word<WS>(c, cur[i], wj));
-            lw[i] = v;
+            if (in_lds) lwl[i] = v; else lwg[i] = v;
             a &= v;
             o |= v;
         }
@@ -602,10 +612,10 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
                 if (tid < m * P) {
                     const int i = tid % m, part = tid / m;
                     const int j0 = (int)((long long)part * m / P), j1 = (int)((long long)(part + 1) * m / P);
-                    const uint64_t v = lw[i];
+                    const uint64_t v = lwl[i];
                     int gt = 0, ge = 0;
                     for (int j = j0; j < j1; ++j) {
-                        const uint64_t u = lw[j];
+                        const uint64_t u = lwl[j];
                         gt += u > v ? 1 : 0;
                         ge += u >= v ? 1 : 0;
                     }
@@ -616,16 +626,16 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
                 PAR_BEGIN
                 for (int i = tid; i < m; i += NT) {
                     const int gt = c.tcount[i], ge = c.tcount2[i];
-                    if (gt < need && need <= ge) sh->pivLex[0] = lw[i];
+                    if (gt < need && need <= ge) sh->pivLex[0] = lwl[i];
                 }
                 PAR_END
             } else {
                 PAR_BEGIN
                 for (int i = tid; i < m; i += NT) {
-                    const uint64_t v = lw[i];
+                    const uint64_t v = lwl[i];
                     int gt = 0, ge = 0;
                     for (int j = 0; j < m; ++j) {
-                        const uint64_t u = lw[j];
+                        const uint64_t u = lwl[j];
                         gt += u > v ? 1 : 0;
                         ge += u >= v ? 1 : 0;
                     }
@@ -650,7 +660,7 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
                 PAR_END
                 PAR_BEGIN
                 for (int i = tid; i < m; i += NT) {
-                    const uint64_t v = lw[i];
+                    const uint64_t v = lwg[i];
                     if (shift + 8 < 64 && (v >> (shift + 8)) != (prefix >> (shift + 8))) continue;
                     LDS_ADD_U32(&c.hist[(v >> shift) & 0xFF], 1u);
                 }
@@ -684,7 +694,7 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
         PAR_END
         PAR_BEGIN
         for (int i = tid; i < m; i += NT) {
-            const uint64_t v = lw[i];
+            const uint64_t v = in_lds ? lwl[i] : lwg[i];
             const int s = cur[i];
             if (v > pivw || (all_ge_kept && v >= pivw)) {
                 LDS_ADD_I32(&sh->nrec, 1);
@@ -734,7 +744,7 @@ constexpr uint32_t EV_SLOT_MASK = 0x000FFFFFu;
 template <int WS>
 DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
     DD_TID_SETUP(c)
-    DD2Shared* sh = c.sh;
+    LDS_PTR(DD2Shared) sh = c.sh;
     const int capS = c.capS;
     const int W = in.width;
     const bool relaxed = comp_type == CT_RELAXED;
@@ -794,7 +804,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 
     // every transition branches on a vertex of the root state, so a DD has at most popcount(root) layers: the best
     // paths need that many bits, not n
-    const int root_pop = (int)(K32(c, 0) & KEY_POP_MASK);
+    const int root_pop = DD_UNIFORM((int)(K32(c, 0) & KEY_POP_MASK));
     const int npw = root_pop == 0 ? 1 : ((root_pop + 63) / 64 < WS ? (root_pop + 63) / 64 : WS);
 
     int lel = -1;
@@ -827,7 +837,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_BEGIN
         if (tid == 0) sh->hiw = sh->hiw2 > 0 ? sh->hiw2 : 1;
         PAR_END
-        var = sh->varkey == 0xFFFFFFFFu ? -1 : (int)(sh->varkey & 0xFFFu);
+        var = DD_UNIFORM(sh->varkey == 0xFFFFFFFFu ? -1 : (int)(sh->varkey & 0xFFFu));
         if (var < 0) break;
         if (sh->cutoff) {
             PAR_BEGIN
@@ -838,12 +848,12 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
         if (L >= c.max_layers - 1 || sh->status != ST_OK) { failed = true; break; }
         DD2_TICK2(PH_VAR, 15)
-        const int nU = sh->nlive;
+        const int nU = DD_UNIFORM(sh->nlive);
 
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
         const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
         int merged_slot = -1, dup_from = -1, dup_to = -1;
-        const uint64_t del_off = sh->ev_pos;
+        const uint64_t del_off = DD_UNIFORM64(sh->ev_pos);
         int n_del = 0;
         if (squash) {
             if (lel < 0) {
@@ -871,8 +881,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 sh->free_slot = 0x7FFFFFFF;
             }
             PAR_END
-            const uint32_t pivKey = sh->pivKey;
-            const int tie_need = K > 0 ? sh->sel_need : -1;
+            const uint32_t pivKey = (uint32_t)DD_UNIFORM((int)sh->pivKey);
+            const int tie_need = DD_UNIFORM(K > 0 ? sh->sel_need : -1);
             PAR_BEGIN   // victims: live nodes ranked below the pivot (clean.rs:810-812 / :851-852); ties are listed apart
             for (int base = 0; base < sh->hiw; base += NT * KB) {
                 uint32_t kk[KB];
@@ -899,7 +909,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
             PAR_END
             if (K > 0 && tie_need >= 0) {
-                const int m = sh->nfl;
+                const int m = DD_UNIFORM(sh->nfl);
                 DD2_STAT(0, m)
                 DD2_STAT(1, 1)
                 if (m > c.capW || !lex_split2<WS>(c, c.fl, m, tie_need)) {
@@ -913,7 +923,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
             DD2_TICK(PH_SELLEX)
-            const int nv = sh->nvict;
+            const int nv = DD_UNIFORM(sh->nvict);
             if (nv > c.capW || sh->ev_pos + (uint64_t)nv + 8 > c.ev_cap) {
                 PAR_BEGIN
                 if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 2;
@@ -969,7 +979,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     uint32_t freebits = ~c.live[w];
                     if (freebits) {
                         int s = w * 32 + dd_ctz((uint64_t)freebits);
-                        if (s < capS) LDS_MIN_U32((uint32_t*)&sh->free_slot, (uint32_t)s);
+                        if (s < capS) LDS_MIN_U32((LDS_PTR(uint32_t))&sh->free_slot, (uint32_t)s);
                     }
                 }
                 PAR_END
@@ -1004,7 +1014,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     uint16_t* cur = c.fl;
                     uint16_t* nxt = (uint16_t*)(lwg + m);
                     for (int wj = 0; wj < WS && m > 1; ++wj) {
-                        uint64_t* lw = m <= c.lex_cap ? (uint64_t*)c.hist : lwg;
+                        LDS_PTR(uint64_t) lwl = (LDS_PTR(uint64_t))c.hist;
+                        const bool in_lds = m <= c.lex_cap;
                         PAR_BEGIN
                         if (tid == 0) {
                             sh->lor = 0;
@@ -1015,7 +1026,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         uint64_t mx = 0;
                         for (int i = tid; i < m; i += NT) {
                             const uint64_t v = dd_brev(~ld_word<WS>(c, cur[i], wj));
-                            lw[i] = v;
+                            if (in_lds) lwl[i] = v; else lwg[i] = v;
                             mx = v > mx ? v : mx;
                         }
                         if (mx) LDS_MAX_U64(&sh->lor, mx);
@@ -1023,7 +1034,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         const uint64_t top = sh->lor;
                         PAR_BEGIN
                         for (int i = tid; i < m; i += NT)
-                            if (lw[i] == top) nxt[LDS_ADD_I32(&sh->nnew, 1)] = cur[i];
+                            if ((in_lds ? lwl[i] : lwg[i]) == top) nxt[LDS_ADD_I32(&sh->nnew, 1)] = cur[i];
                         PAR_END
                         m = sh->nnew;
                         DD_SYNC();
@@ -1114,7 +1125,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
         }
         DD2_TICK2(PH_VICTIMS, 11)
-        const int n = sh->nlive;   // |layer L| after squash
+        const int n = DD_UNIFORM(sh->nlive);   // |layer L| after squash
         const int naff_bound = c.cnt[var] > 0 ? c.cnt[var] : 0;   // live states containing the variable
 
         // ------------------------------------------------------------ candidate last exact layer: snapshot
@@ -1145,8 +1156,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 
         // ------------------------------------------------------------ work list: affected or fresh nodes
         PAR_BEGIN
+        for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;   // dedup table of the next layer (see the sweep)
         if (tid == 0) {
             sh->nwl = 0;
+            sh->nwl2 = 0;
             sh->nrec = 0;
             sh->nnew = 0;
             sh->nfl = 0;
@@ -1164,34 +1177,71 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_END
         const int vw = var >> 6;
         const uint64_t vbit = 1ULL << (var & 63);
+        // One sweep over the live slots does two jobs: (1) the work list -- nodes that contain the variable go to the
+        // front of `wl`, fresh nodes that do not (their rough upper bound was never checked) to its back; (2) every
+        // other node stays unchanged in the next layer and enters the dedup table right away with its cached hash
+        // (fresh survivors follow in expand 1, changed / new nodes in expand 2).  Word `var/64` of every slot and
+        // the hashes are contiguous streams; the loads of a batch are in flight before the first is used.
+        constexpr int KS = 4;
         PAR_BEGIN
         {
-            const uint64_t* row = c.st + (size_t)vw * capS;   // word `vw` of every slot: a coalesced stream
-            const int hi = sh->hiw;
-            for (int base = 0; base < hi; base += NT * KB) {
-                uint64_t ww[KB];
+            const uint64_t* row = c.st + (size_t)vw * capS;
+            const int hi = DD_UNIFORM(sh->hiw);
+            for (int base = 0; base < hi; base += NT * KS) {
+                uint64_t ww[KS], hh[KS];
 #pragma unroll
-                for (int b = 0; b < KB; ++b) {   // all loads of the batch are in flight before the first is used
+                for (int b = 0; b < KS; ++b) {
                     const int s = base + b * NT + tid;
                     ww[b] = s < hi ? row[s] : 0;
+                    hh[b] = s < hi ? c.hsh[s] : 0;
                 }
+                uint32_t pslot[KS], pmine[KS];
+                bool pend[KS];
 #pragma unroll
-                for (int b = 0; b < KB; ++b) {
+                for (int b = 0; b < KS; ++b) {
                     const int s = base + b * NT + tid;
+                    pend[b] = false;
+                    pslot[b] = (uint32_t)hh[b] & ((uint32_t)c.tab_cap - 1);
+                    pmine[b] = ((uint32_t)(hh[b] >> 52) << 20) | (uint32_t)s;
                     if (s >= hi || !bm_test(c.live, s)) continue;
-                    if ((ww[b] & vbit) != 0 || bm_test(c.fresh, s)) {
+                    if ((ww[b] & vbit) != 0) {
                         const int i = LDS_ADD_I32(&sh->nwl, 1);
                         if (i < c.capW) c.wl[i] = (uint16_t)s;
+                    } else if (bm_test(c.fresh, s)) {
+                        const int i = LDS_ADD_I32(&sh->nwl2, 1);
+                        if (i < c.capW) c.wl[c.capW - 1 - i] = (uint16_t)s;
+                    } else {
+                        pend[b] = true;   // unchanged node: into the table (all such states are distinct)
                     }
+                }
+                // the KS inserts of the batch probe together: their compare-and-swaps are in flight at the same time
+                for (int round = 0; round <= c.tab_cap; ++round) {
+                    uint32_t got[KS];
+                    bool any = false;
+#pragma unroll
+                    for (int b = 0; b < KS; ++b)
+                        if (pend[b]) got[b] = TAB_CAS(&c.tab[pslot[b]], T2_EMPTY, pmine[b]);
+#pragma unroll
+                    for (int b = 0; b < KS; ++b)
+                        if (pend[b]) {
+                            if (got[b] == T2_EMPTY) pend[b] = false;
+                            else {
+                                pslot[b] = (pslot[b] + 1) & ((uint32_t)c.tab_cap - 1);
+                                any = true;
+                            }
+                        }
+                    if (!any) break;
+                    if (round == c.tab_cap) sh->status = ST_ERR_INTERNAL;
                 }
             }
         }
         PAR_END
-        const int nwl = sh->nwl;
-        if (nwl > c.capW || n > c.capW || sh->ev_pos + 4ull * (uint64_t)nwl + 12 > c.ev_cap) {
+        const int nwl = DD_UNIFORM(sh->nwl);      // nodes containing the variable
+        const int nwl2 = DD_UNIFORM(sh->nwl2);    // fresh nodes that do not
+        if (nwl + nwl2 > c.capW || n > c.capW || sh->ev_pos + 4ull * (uint64_t)(nwl + nwl2) + 12 > c.ev_cap) {
             PAR_BEGIN
             if (tid == 0) {
-                sh->status = ST_ERR_CAPACITY - 100 * (nwl > c.capW ? 41 : (n > c.capW ? 42 : 43));
+                sh->status = ST_ERR_CAPACITY - 100 * (nwl + nwl2 > c.capW ? 41 : (n > c.capW ? 42 : 43));
                 sh->bestKey = ((uint64_t)(uint32_t)nwl << 32) | (uint32_t)n;   // debugging aid: reported as best_value fields
                 sh->nodes = sh->ev_pos;
                 sh->arcs = (uint64_t)L;
@@ -1200,7 +1250,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             failed = true;
             break;
         }
-        DD2_STAT(4, nwl)
+        DD2_STAT(4, nwl + nwl2)
         DD2_STAT(7, naff_bound)
         DD2_TICK2(PH_WORKLIST, 13)
         // ------------------------------------------------------------ free slots for the YES-children
@@ -1227,12 +1277,44 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_END
         DD2_TICK2(PH_FREELIST, 14)
         // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
-        const uint64_t aff_off = (sh->ev_pos + 3) & ~3ULL;   // 16-byte aligned records
+        const uint64_t aff_off = DD_UNIFORM64((sh->ev_pos + 3) & ~3ULL);   // 16-byte aligned records
         PAR_BEGIN
         uint64_t adjv[WS];
 #pragma unroll
         for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
         const int32_t wv = c.weight[var];
+        // ---- fresh nodes without the variable: bound check only (clean.rs:362-365); a survivor's only child is the
+        // node itself, it joins the dedup table with its cached hash.  With unit weights the rough upper bound is the
+        // popcount held in the key, so the record is not even read.
+        for (int j = tid; j < nwl2; j += NT) {
+            const int s = c.wl[c.capW - 1 - j];
+            const uint32_t key = K32(c, s);
+            const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
+            bm_clr(c.fresh, s);
+            bool pruned;
+            uint64_t st[WS];
+            uint64_t hs = 0;
+            if (c.unit_weights) {
+                pruned = (int64_t)(key & KEY_POP_MASK) + (int64_t)val <= best_lb;
+                if (pruned) ld_state_h<WS>(c, s, st, hs);
+                else hs = c.hsh[s];
+            } else {
+                ld_state_h<WS>(c, s, st, hs);
+                pruned = (int64_t)rub2_of<WS>(c, st) + (int64_t)val <= best_lb;
+            }
+            if (pruned) {
+                add_bits<WS>(c.cnt, st, -1);
+                bm_clr(c.live, s);
+                LDS_ADD_I32(&sh->nlive, -1);
+                const int r = LDS_ADD_I32(&sh->nrec, 1);
+                U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
+                *rec4 = U32x4{(uint32_t)s, NONE32, NONE32, NONE32};
+                LDS_ADD_I32(&sh->npruned, 1);
+            } else {
+                tab2_insert_unique<WS>(c, s, hs);
+            }
+        }
+        // ---- nodes containing the variable
         for (int i = tid; i < nwl; i += NT) {
             const int s = c.wl[i];
             const uint32_t key = K32(c, s);
@@ -1301,32 +1383,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             LDS_ADD_I32(&sh->nyes, 1);
         }
         PAR_END
-        const int nrec = sh->nrec;
+        const int nrec = DD_UNIFORM(sh->nrec);
         if (sh->status != ST_OK) { failed = true; break; }
         DD2_STAT(5, nrec)
         DD2_TICK(PH_EXP1)
-        // ------------------------------------------------------------ dedup table of the unchanged nodes
-        PAR_BEGIN
-        for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
-        PAR_END
-        PAR_BEGIN
-        {
-            const int hi = sh->hiw;
-            for (int base = 0; base < hi; base += NT * KB) {
-                uint64_t hh[KB];
-#pragma unroll
-                for (int b = 0; b < KB; ++b) {
-                    const int s = base + b * NT + tid;
-                    hh[b] = s < hi ? c.hsh[s] : 0;
-                }
-#pragma unroll
-                for (int b = 0; b < KB; ++b) {
-                    const int s = base + b * NT + tid;
-                    if (s < hi && bm_test(c.live, s)) tab2_insert_unique<WS>(c, s, hh[b]);
-                }
-            }
-        }
-        PAR_END
+        // (the dedup table of the unchanged nodes was filled by the work-list sweep and by the fresh survivors above)
         DD2_TICK(PH_TABLE)
 
         // ------------------------------------------------------------ expand, phase 2: dedup (clean.rs:738-775)
@@ -1825,28 +1886,28 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
         c.key32 = (uint32_t*)p;
         p += ((size_t)P.capS * 4 + 15) & ~(size_t)15;
     }
-    c.tab = (uint32_t*)p;
+    c.tab = (LDS_PTR(uint32_t))p;
     p += (size_t)P.tab2_cap * 4;
-    c.live = (uint32_t*)p;
+    c.live = (LDS_PTR(uint32_t))p;
     p += (size_t)c.nbw * 4;
-    c.inex = (uint32_t*)p;
+    c.inex = (LDS_PTR(uint32_t))p;
     p += (size_t)c.nbw * 4;
-    c.okb = (uint32_t*)p;
+    c.okb = (LDS_PTR(uint32_t))p;
     p += (size_t)c.nbw * 4;
-    c.fresh = (uint32_t*)p;
+    c.fresh = (LDS_PTR(uint32_t))p;
     p += (size_t)c.nbw * 4;
     p = (unsigned char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-    c.cnt = (int32_t*)p;
+    c.cnt = (LDS_PTR(int32_t))p;
     p += (size_t)P.npad * 4;
-    c.hist = (uint32_t*)p;
+    c.hist = (LDS_PTR(uint32_t))p;
     p += 2048 * 4;
     c.wl = P.s_wl + s * 2 * capW;          // work lists live in HBM (written and read once per layer, coalesced)
     c.fl = c.wl + capW;
-    c.tcount = (int32_t*)p;
+    c.tcount = (LDS_PTR(int32_t))p;
     p += (size_t)nthreads * 4;
-    c.tcount2 = (int32_t*)p;
+    c.tcount2 = (LDS_PTR(int32_t))p;
     p += (size_t)nthreads * 4;
-    c.sh = (DD2Shared*)p;
+    c.sh = (LDS_PTR(DD2Shared))p;
     c.arena = P.arena;
     c.arena_cap = P.arena_cap;
     c.arena_head = P.arena_head;
