@@ -61,12 +61,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    # test hook (single-GPU boxes): DDO_BENCH_ONE_GPU=1 puts every rank on cuda:0 and rendezvous over gloo, so the
+    # multi-process path (sharded root cut-set, incumbent all-reduce, max-over-ranks timing) can be exercised there
+    one_gpu = os.environ.get("DDO_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    comm_device = "cpu" if one_gpu else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import ddo_amd
     from ddo_amd import FixedWidth, ParallelSolver
@@ -88,7 +97,7 @@ def main():
     def one_step():
         rc = solver.step()
         if dist is not None:   # parallel.rs:439-453: the incumbent is the only datum shared between workers
-            solver.import_lower_bound(exchange_incumbent(dist, solver.best_lower_bound(), "cuda"))
+            solver.import_lower_bound(exchange_incumbent(dist, solver.best_lower_bound(), comm_device))
         return rc
 
     for _ in range(args.warmup):
@@ -110,7 +119,7 @@ def main():
 
     elapsed, (nodes, arcs, subs, compiles) = reduce_stats(
         dist, t1 - t0, [c1["nodes_expanded"] - c0["nodes_expanded"], c1["arcs"] - c0["arcs"], e1 - e0,
-                        c1["compiles"] - c0["compiles"]], "cuda")
+                        c1["compiles"] - c0["compiles"]], comm_device)
 
     if rank == 0:
         ws_bytes = 8 * ((model.n + 63) // 64)                    # S: state bytes
