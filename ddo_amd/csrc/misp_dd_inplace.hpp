@@ -329,11 +329,12 @@ DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint64_t h, const uint64_t* 
         }
         if ((e >> 20) == tag) {
             const int w = (int)(e & 0xFFFFFu);
-            uint64_t o[WS];
-            ld_state<WS>(c, w, o);
+            // the holder may have been written by another wave a moment ago (expand publishes a node right after
+            // storing it): agent-scope loads bypass this CU's vector L1, which other waves' stores do not refresh
+            const uint64_t* o = c.rec + (size_t)w * c.RW;
             bool eq = true;
 #pragma unroll
-            for (int k = 0; k < WS; ++k) eq &= o[k] == s[k];
+            for (int k = 0; k < WS; ++k) eq &= LD_U64(&o[k]) == s[k];
             if (eq) return w;
         }
         slot = (slot + 1) & mask;
@@ -1279,10 +1280,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
         const uint64_t aff_off = DD_UNIFORM64((sh->ev_pos + 3) & ~3ULL);   // 16-byte aligned records
         PAR_BEGIN
-        uint64_t adjv[WS];
-#pragma unroll
-        for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
-        const int32_t wv = c.weight[var];
         // ---- fresh nodes without the variable: bound check only (clean.rs:362-365); a survivor's only child is the
         // node itself, it joins the dedup table with its cached hash.  With unit weights the rough upper bound is the
         // popcount held in the key, so the record is not even read.
@@ -1314,7 +1311,15 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 tab2_insert_unique<WS>(c, s, hs);
             }
         }
-        // ---- nodes containing the variable
+        PAR_END
+        // ---- nodes containing the variable: expansion AND dedup (clean.rs:738-775) in one pass.  The table holds every
+        // unchanged node of the next layer now, so a thread writes its two children, makes the stores visible to the
+        // workgroup and inserts them right away -- the records never have to be read back.
+        PAR_BEGIN
+        uint64_t adjv[WS];
+#pragma unroll
+        for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
+        const int32_t wv = c.weight[var];
         for (int i = tid; i < nwl; i += NT) {
             const int s = c.wl[i];
             const uint32_t key = K32(c, s);
@@ -1341,8 +1346,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 if (k == vw) hasv = (st[k] & vbit) != 0;
             if (!hasv) continue;   // fresh but unaffected: its NO-child is the node itself
             // ---- decision NO, in place (main.rs:77-85)
-            bm_clr(c.live, s);             // pending: it re-enters the layer (or dissolves into a twin) in phase 2
-            LDS_ADD_I32(&sh->nlive, -1);
             uint64_t oldw = 0, neww = 0;
 #pragma unroll
             for (int k = 0; k < WS; ++k)
@@ -1351,15 +1354,21 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     st[k] &= ~vbit;
                     neww = st[k];
                 }
-            st_word<WS>(c, s, vw, neww, oldh ^ mixw(oldw, vw) ^ mixw(neww, vw));
-            K32_ST(c, s, key - 1);         // popcount - 1, same value (cost 0)
+            const uint64_t newh = oldh ^ mixw(oldw, vw) ^ mixw(neww, vw);
+            st_word<WS>(c, s, vw, neww, newh);
+            const uint32_t kno = key - 1;  // popcount - 1, same value (cost 0)
+            K32_ST(c, s, kno);
             LDS_ADD_I32(&c.cnt[var], -1);
             // ---- decision YES into a free slot (main.rs:95-102)
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
             int ny = -1;
+            uint64_t y[WS];
+            uint64_t yh = 0;
+            uint32_t kyes = 0;
+#pragma unroll
+            for (int k = 0; k < WS; ++k) y[k] = 0;
             if (fi < sh->nfl) {
                 ny = c.fl[fi];
-                uint64_t y[WS];
                 int ypop = 0;
 #pragma unroll
                 for (int k = 0; k < WS; ++k) {
@@ -1369,17 +1378,49 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 // a DD has at most popcount(root state) layers: only npw path words exist; the child's path is the
                 // parent's plus decision bit L
                 copy_path<WS>(c, ny, s, npw, L);
-                st_node<WS>(c, ny, y, hash2_state<WS>(y));
-                K32_ST(c, ny, ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop);
+                yh = hash2_state<WS>(y);
+                st_node<WS>(c, ny, y, yh);
+                kyes = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop;
+                K32_ST(c, ny, kyes);
                 bm_put(c.inex, ny, bm_test(c.inex, s));
                 bm_put(c.okb, ny, bm_test(c.okb, s));
             } else {
                 sh->status = ST_ERR_CAPACITY - 100 * 6;
             }
+            FENCE_BLOCK();   // both records are visible to the workgroup before the table publishes their slots
+            // ---- dedup: NO-child (append_edge_to!, clean.rs:199-220)
+            uint32_t e_no = (uint32_t)s, e_yes = NONE32;
+            const int t0 = tab2_insert<WS>(c, s, newh, st);
+            if (t0 == s) {
+                bm_set(c.fresh, s);          // it stays in the layer; its rub shrank: check it again before it is expanded
+            } else {                         // the in-place NO-child dissolves into its twin t0
+                const uint32_t old = K32_MAX(c, t0, kno);
+                e_no = (uint32_t)t0 | (kno > old ? EV_RAISED : 0u);
+                if (bm_test(c.inex, s)) bm_set(c.inex, t0);
+                add_bits<WS>(c.cnt, st, -1);
+                bm_clr(c.live, s);
+                LDS_ADD_I32(&sh->nlive, -1);
+            }
+            // ---- dedup: YES-child
+            if (ny >= 0) {
+                const int t1 = tab2_insert<WS>(c, ny, yh, y);
+                if (t1 == ny) {              // a new node enters the layer
+                    bm_set(c.live, ny);
+                    bm_set(c.fresh, ny);
+                    add_bits<WS>(c.cnt, y, +1);
+                    LDS_ADD_I32(&sh->nlive, 1);
+                    LDS_MAX_I32(&sh->hiw, ny + 1);
+                    e_yes = (uint32_t)ny | EV_CREATED;
+                } else {
+                    const uint32_t old = K32_MAX(c, t1, kyes);
+                    e_yes = (uint32_t)t1 | (kyes > old ? EV_RAISED : 0u);
+                    if (bm_test(c.inex, ny)) bm_set(c.inex, t1);
+                }
+            }
             const int r = LDS_ADD_I32(&sh->nrec, 1);
             U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
-            // parent | NO target (provisional: the node itself) | YES target (provisional: the new slot) | YES slot
-            *rec4 = U32x4{(uint32_t)s, (uint32_t)s, ny >= 0 ? (uint32_t)ny : NONE32, ny >= 0 ? (uint32_t)ny : NONE32};
+            // parent | NO target | YES target | slot allocated for the YES-child
+            *rec4 = U32x4{(uint32_t)s, e_no, e_yes, ny >= 0 ? (uint32_t)ny : NONE32};
             LDS_ADD_I32(&sh->nyes, 1);
         }
         PAR_END
@@ -1390,44 +1431,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // (the dedup table of the unchanged nodes was filled by the work-list sweep and by the fresh survivors above)
         DD2_TICK(PH_TABLE)
 
-        // ------------------------------------------------------------ expand, phase 2: dedup (clean.rs:738-775)
-        PAR_BEGIN
-        for (int idx = tid; idx < 2 * nrec; idx += NT) {   // one thread per arc: (record, NO | YES)
-            const int r = idx >> 1, which = idx & 1;
-            uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
-            if (rec[3] == NONE32 && rec[1] == NONE32) continue;   // pruned parent
-            if (rec[1] == NONE32) continue;
-            {
-                const int x = which == 0 ? (int)rec[0] : (int)rec[3];
-                if (which == 1 && rec[3] == NONE32) continue;
-                uint64_t st[WS];
-                uint64_t xh = 0;
-                ld_state_h<WS>(c, x, st, xh);
-                const int t = tab2_insert<WS>(c, x, xh, st);
-                if (t == x) {
-                    if (which == 0) {           // the in-place NO-child stays in the layer
-                        bm_set(c.live, x);
-                        bm_set(c.fresh, x);     // its rub shrank: check it again before it is expanded
-                        LDS_ADD_I32(&sh->nlive, 1);
-                    } else {                    // a new node enters the layer
-                        bm_set(c.live, x);
-                        bm_set(c.fresh, x);
-                        add_bits<WS>(c.cnt, st, +1);
-                        LDS_ADD_I32(&sh->nlive, 1);
-                        LDS_MAX_I32(&sh->hiw, x + 1);
-                        rec[2] = (uint32_t)x | EV_CREATED;
-                    }
-                    continue;
-                }
-                // duplicate of node t: the arc enters t  (append_edge_to!, clean.rs:199-220)
-                const uint32_t kx = K32(c, x);
-                const uint32_t old = K32_MAX(c, t, kx);
-                rec[1 + which] = (uint32_t)t | (kx > old ? EV_RAISED : 0u);
-                if (bm_test(c.inex, x)) bm_set(c.inex, t);
-                if (which == 0) add_bits<WS>(c.cnt, st, -1);   // the in-place NO-child dissolves into t
-            }
-        }
-        PAR_END
+        // (expand phase 2, the dedup, is part of phase 1 now)
         DD2_TICK(PH_EXP2)
         // ------------------------------------------------------------ expand, phase 3: new best parents
         // The arc that RAISED its target's key and still equals the target's final key is the one that set
