@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 #include "../../include/ddo_hip.h"
 #include "engine.hpp"
@@ -295,6 +296,10 @@ class LazyFringe {
     bool empty() const { return heap_.empty(); }
     /// rows with min(cap_ub, ub) > best_lb are ordered by (ub, value) descending with two counting sorts
     void push_block(DevBlock* b, int64_t best_lb, int rank, int world) {
+        if (prepare_block(b, best_lb, rank, world)) commit_block(b);
+    }
+    /// Thread-safe half of push_block: filters and orders the rows of `b` (b->order).  False: nothing to enqueue.
+    static bool prepare_block(DevBlock* b, int64_t best_lb, int rank, int world) {
         const int n = b->rows;
         std::vector<uint32_t> tmp;
         tmp.reserve(n);
@@ -307,7 +312,7 @@ class LazyFringe {
             umin = std::min(umin, b->ub[j]);
             umax = std::max(umax, b->ub[j]);
         }
-        if (tmp.empty()) return;
+        if (tmp.empty()) return false;
         auto counting = [&](const std::vector<int32_t>& key, int32_t lo, int32_t hi) {
             const int64_t range = (int64_t)hi - lo + 1;
             if (range > (1 << 22)) {   // huge key range: comparison sort
@@ -327,10 +332,14 @@ class LazyFringe {
             for (size_t k = 0; k < tmp.size(); ++k)
                 if ((int)(k % (size_t)world) == rank) mine.push_back(tmp[k]);
             tmp.swap(mine);
-            if (tmp.empty()) return;
+            if (tmp.empty()) return false;
         }
         b->order.swap(tmp);
         b->cursor = 0;
+        return true;
+    }
+    /// Sequential half: the prepared block enters the heap.
+    void commit_block(DevBlock* b) {
         b->id = next_id_++;
         dev_ref(b);
         open_ += b->order.size();
@@ -586,6 +595,7 @@ struct ddo_solver {
     /// results of a finished lazy launch -> incumbent, counters, new cut-set blocks (parallel.rs:420-434)
     int absorb_lazy(std::vector<LazyItem>& its, std::vector<HostResult>& res) {
         int err = DDO_OK;
+        std::vector<DevBlock*> fresh_blocks;
         for (size_t i = 0; i < its.size() && err == DDO_OK; ++i) {
             for (int k = 0; k < 2; ++k) {
                 HostResult* r = &res[2 * i + k];
@@ -632,9 +642,31 @@ struct ddo_solver {
                     b->ub = std::move(r->cs_ub);
                     dev_ref(b);
                     st_push += (uint64_t)b->rows;
-                    lazy->push_block(b, best_lb, cfg.rank, cfg.world_size);
-                    dev_unref(b);
+                    fresh_blocks.push_back(b);
                 }
+            }
+        }
+        // The cut-set blocks are filtered against the final incumbent and ordered (two counting sorts each) by a few
+        // host threads, then enter the heap in submission order: this is the only host work of a step that is
+        // proportional to the number of cut-set nodes, and it runs behind the next launch.
+        if (!fresh_blocks.empty()) {
+            std::vector<char> keep(fresh_blocks.size(), 0);
+            const int nthreads = (int)std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 4)), fresh_blocks.size());
+            auto work = [&](int t) {
+                for (size_t q = (size_t)t; q < fresh_blocks.size(); q += (size_t)nthreads)
+                    keep[q] = LazyFringe::prepare_block(fresh_blocks[q], best_lb, cfg.rank, cfg.world_size) ? 1 : 0;
+            };
+            if (nthreads > 1) {
+                std::vector<std::thread> pool;
+                for (int t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
+                work(0);
+                for (std::thread& th : pool) th.join();
+            } else {
+                work(0);
+            }
+            for (size_t q = 0; q < fresh_blocks.size(); ++q) {
+                if (keep[q]) lazy->commit_block(fresh_blocks[q]);
+                dev_unref(fresh_blocks[q]);
             }
         }
         for (LazyItem& e : its) dev_unref(e.block);
