@@ -19,6 +19,9 @@ constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 // comp_type values follow include/ddo_hip.h (== mdd.rs:41-48 order)
 constexpr int CT_EXACT = 0, CT_RELAXED = 1, CT_RESTRICTED = 2;
 
+// EngineParams.model_kind
+constexpr int MODEL_MISP = 0, MODEL_KNAPSACK = 1;
+
 // DDInput.flags
 constexpr uint32_t IN_FUSED = 1u;          // restricted, then (if inexact) relaxed: parallel.rs:391-437 on device
 constexpr uint32_t IN_FILTER_CUTSET = 2u;  // emit only cut-set nodes with ub > best_lb (parallel.rs:461)
@@ -147,6 +150,10 @@ struct EngineParams {
     int32_t capW;              // work-list capacity (width + 4)
     int32_t tab2_cap;          // dedup table slots (power of two, LDS)
     int32_t vbase_off;         // lowest reachable value relative to the residual value (sum of negative weights)
+    int32_t model_kind;        // MODEL_MISP | MODEL_KNAPSACK
+    int32_t pad2;
+    const int32_t* kp_weight;  // knapsack: item weights [n]   (`weight` holds the profits)
+    const int32_t* kp_order;   // knapsack: items by decreasing profit / weight [n]
     int32_t lex_cap;           // tie lists up to this size (<= 1024) are split by rank counting in LDS, longer ones by radix rounds
     int32_t pad1;
     uint64_t* s_state;         // [slot][ws][capS]  node states, word major (streaming scan copy)

@@ -118,7 +118,13 @@ int Model::popcount(const uint64_t* a) const {
     for (int k = 0; k < ws; ++k) c += __builtin_popcountll(a[k]);
     return c;
 }
+void Model::initial_state(uint64_t* out) const {
+    for (int k = 0; k < ws; ++k) out[k] = 0;
+    if (kind == MODEL_KNAPSACK) out[0] = (uint64_t)kp_capacity;                 // knapsack/main.rs:100-102
+    else for (int i = 0; i < n; ++i) out[i / 64] |= 1ULL << (i % 64);           // misp/main.rs:69-71
+}
 int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
+    if (kind == MODEL_KNAPSACK) return a[0] < b[0] ? -1 : (a[0] > b[0] ? 1 : 0);   // KPRanking (knapsack/main.rs:187-194)
     int pa = popcount(a), pb = popcount(b);
     if (pa != pb) return pa < pb ? -1 : 1;
     // equal popcounts: at the lowest differing member, the set owning it is the smaller one
@@ -195,7 +201,8 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     P.ws = model->wsT;
     P.unit_weights = model->unit_weights ? 1 : 0;
     P.npad = (model->n + 63) / 64 * 64;
-    P.capN = (int)max_width + 2;
+    // the terminal layer is never squashed (clean.rs:608-618): MISP ends in at most one node, a knapsack DD in up to 2W
+    P.capN = model->kind == MODEL_KNAPSACK ? 2 * (int)max_width + 3 : (int)max_width + 2;
     P.capC1 = 2 * P.capN + 1;
     P.max_layers = model->n + 2;
     int tc = 1024;
@@ -234,6 +241,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     if (const char* env = std::getenv("DDO_HIP_KEYS_GLOBAL")) keys_global_ = std::atoi(env) != 0;
     if (keys_global_) lds2 = lds2g;
     if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
+    if (model->kind != MODEL_MISP) engine_kind_ = 1;   // scalar-state models run on the layer-rebuilding engine
     if (engine_kind_ == 2) lds_bytes_ = lds2;
 
     // ---- how many DDs in flight: residency of the kernel, then HBM
@@ -269,8 +277,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
 
     // ---- model tables
     std::vector<uint64_t> adjT((size_t)model->n * wsT, 0);
-    for (int i = 0; i < model->n; ++i)
-        for (int k = 0; k < model->ws; ++k) adjT[(size_t)i * wsT + k] = model->adj[(size_t)i * model->ws + k];
+    if (model->kind == MODEL_MISP)
+        for (int i = 0; i < model->n; ++i)
+            for (int k = 0; k < model->ws; ++k) adjT[(size_t)i * wsT + k] = model->adj[(size_t)i * model->ws + k];
     std::vector<int32_t> w32(model->n);
     for (int i = 0; i < model->n; ++i) w32[i] = (int32_t)model->weight[i];
     uint64_t* d_adj = nullptr;
@@ -282,6 +291,18 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     HIP_TRY(hipMemcpy(d_w, w32.data(), w32.size() * 4, hipMemcpyHostToDevice));
     P.adj = d_adj;
     P.weight = d_w;
+    P.model_kind = model->kind;
+    if (model->kind == MODEL_KNAPSACK) {
+        std::vector<int32_t> kw(model->n);
+        for (int i = 0; i < model->n; ++i) kw[i] = (int32_t)model->kp_weight[i];
+        int32_t *d_kw = nullptr, *d_ko = nullptr;
+        if ((rc = dev_alloc(allocs_, d_kw, kw.size()))) return rc;
+        if ((rc = dev_alloc(allocs_, d_ko, kw.size()))) return rc;
+        HIP_TRY(hipMemcpy(d_kw, kw.data(), kw.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_ko, model->kp_order.data(), kw.size() * 4, hipMemcpyHostToDevice));
+        P.kp_weight = d_kw;
+        P.kp_order = d_ko;
+    }
 
     // ---- workspace
     if (engine_kind_ == 1) {
@@ -642,6 +663,50 @@ ddo_model* ddo_model_create_misp(int n, const uint64_t* rows, const int64_t* wei
     return m;
 }
 
+ddo_model* ddo_model_create_knapsack(int n, int64_t capacity, const int64_t* profit, const int64_t* weight) {
+    if (n < 1 || n > 4095 || capacity < 0 || !profit || !weight) {
+        set_error("ddo_model_create_knapsack: invalid arguments (1 <= n <= 4095, capacity >= 0)");
+        return nullptr;
+    }
+    int64_t psum = 0;
+    for (int i = 0; i < n; ++i) {
+        if (profit[i] < 0 || weight[i] < 1 || weight[i] >= (1LL << 31)) {
+            set_error("ddo_model_create_knapsack: profits must be >= 0 and weights in [1, 2^31)");
+            return nullptr;
+        }
+        psum += profit[i];
+    }
+    if (psum >= (1LL << 30) || capacity >= (1LL << 62)) {
+        set_error("ddo_model_create_knapsack: sum of profits must stay below 2^30 (device values are int32)");
+        return nullptr;
+    }
+    ddo_model* m = new ddo_model();
+    m->m.kind = MODEL_KNAPSACK;
+    m->m.n = n;
+    m->m.ws = 2;      // KnapsackState { capacity, depth } (main.rs:44-50): the depth keeps equal capacities of
+    m->m.wsT = 2;     // different levels apart in the fringe; on the device it is constant over a layer
+    m->m.kp_capacity = capacity;
+    m->m.weight.assign(profit, profit + n);
+    m->m.kp_weight.assign(weight, weight + n);
+    m->m.unit_weights = false;
+    m->m.weight_abs_sum = psum;
+    // main.rs:66-70: items by increasing -profit/weight; ties keep index order (the reference's unstable sort leaves
+    // them unspecified: documented deviation shared with the oracle)
+    m->m.kp_order.resize(n);
+    for (int i = 0; i < n; ++i) m->m.kp_order[i] = i;
+    std::stable_sort(m->m.kp_order.begin(), m->m.kp_order.end(), [&](int32_t a, int32_t b) {
+        return -(double)profit[a] / (double)weight[a] < -(double)profit[b] / (double)weight[b];
+    });
+    return m;
+}
+
+ddo_model* ddo_model_read_knapsack(const char* path) {
+    int64_t capacity = 0;
+    std::vector<int64_t> profit, weight;
+    if (!path || !read_knapsack(path, capacity, profit, weight)) return nullptr;
+    return ddo_model_create_knapsack((int)profit.size(), capacity, profit.data(), weight.data());
+}
+
 ddo_model* ddo_model_read_misp(const char* path) {
     int n = 0;
     std::vector<uint64_t> rows;
@@ -656,9 +721,7 @@ int ddo_model_state_words(const ddo_model* model) { return model ? model->m.ws :
 
 int ddo_model_initial_state(const ddo_model* model, uint64_t* out) {
     if (!model || !out) return DDO_ERR_INVALID;
-    const Model& m = model->m;
-    for (int k = 0; k < m.ws; ++k) out[k] = 0;
-    for (int i = 0; i < m.n; ++i) out[i / 64] |= 1ULL << (i % 64);  // main.rs:69-71
+    model->m.initial_state(out);
     return DDO_OK;
 }
 int64_t ddo_model_initial_value(const ddo_model*) { return 0; }  // main.rs:73-75

@@ -24,9 +24,16 @@ struct Model {
     int ws = 0;                      // ceil(n / 64): words per state at the ABI
     int wsT = 0;                     // words per state in the device kernel (template instance)
     std::vector<uint64_t> adj;       // [n][ws]   complement adjacency rows
-    std::vector<int64_t> weight;     // [n]
+    std::vector<int64_t> weight;     // [n]   MISP: vertex weights; knapsack: item profits
     bool unit_weights = true;
     int64_t weight_abs_sum = 0;
+    // knapsack (examples/knapsack/main.rs:53-72): `Knapsack` + `KPRelax` + `KPRanking`; the state is one word, the
+    // remaining capacity (all nodes of a layer share their depth)
+    int kind = MODEL_MISP;
+    int64_t kp_capacity = 0;
+    std::vector<int64_t> kp_weight;  // [n]
+    std::vector<int32_t> kp_order;   // [n]   items by decreasing profit / weight (main.rs:66-70)
+    void initial_state(uint64_t* out) const;   // Problem::initial_state
 
     std::mutex mtx;
     std::map<std::pair<int, long>, std::weak_ptr<class Engine>> engines;  // (device, max_width)
@@ -149,6 +156,9 @@ class Engine {
 /// Reads a DIMACS-like .clq file the way examples/misp/main.rs:258-317 does.
 /// Returns false (and sets the error text) on IO / format errors.
 bool read_misp_clq(const std::string& path, int& n, std::vector<uint64_t>& rows, std::vector<int64_t>& weights);
+/// Reads a knapsack instance the way examples/knapsack/main.rs:267-303 does ("n capacity", then n lines "profit weight";
+/// lines starting with 'c' are comments).
+bool read_knapsack(const std::string& path, int64_t& capacity, std::vector<int64_t>& profit, std::vector<int64_t>& weight);
 
 }  // namespace ddo_hip
 

@@ -506,7 +506,7 @@ struct ddo_solver {
         CutsetBlock* root = new CutsetBlock();
         root->ws = model->ws;
         root->states.assign(model->ws, 0);
-        for (int i = 0; i < model->n; ++i) root->states[i / 64] |= 1ULL << (i % 64);
+        model->initial_state(root->states.data());   // Problem::initial_state
         root->values.push_back(0);
         Entry e{root, 0, 0, 0, I64_MAX, hash_words(root->states.data(), model->ws)};
         block_ref(root);   // keep alive while pushing

@@ -66,6 +66,7 @@ inline uint32_t emu_atomic_cas(uint32_t* p, uint32_t cmp, uint32_t v) { uint32_t
 #define FENCE_BLOCK()
 inline int dd_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
+inline double dd_floor(double x) { return __builtin_floor(x); }
 inline int dd_clz32(uint32_t x) { return __builtin_clz(x); }
 inline uint64_t dd_brev(uint64_t x) {
     x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
@@ -115,6 +116,7 @@ __device__ __forceinline__ uint32_t dd_tab_cas(P p, uint32_t cmp, uint32_t v) {
 #define FENCE_BLOCK() __threadfence_block()
 __device__ __forceinline__ int dd_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
+__device__ __forceinline__ double dd_floor(double x) { return __builtin_floor(x); }
 __device__ __forceinline__ int dd_clz32(uint32_t x) { return __builtin_clz(x); }
 __device__ __forceinline__ uint64_t dd_brev(uint64_t x) { return __brevll(x); }
 }  // namespace ddo_hip
@@ -156,7 +158,12 @@ struct DDCtx {
     // model
     int n, npad, unit_weights;
     const uint64_t* adj;
-    const int32_t* weight;
+    const int32_t* weight;      // MISP: vertex weights; knapsack: item profits (the cost of a TAKE arc)
+    // knapsack (examples/knapsack/main.rs:53-72): kind == MODEL_KNAPSACK, the state is one word = remaining capacity
+    int kind;
+    int depth0;                 // depth of the residual sub-problem (static variable order: main.rs:118-125)
+    const int32_t* kp_weight;   // item weights
+    const int32_t* kp_order;    // items by decreasing profit/weight
     // capacity
     int capN, capC1, max_layers;
     // slot workspace
@@ -234,9 +241,33 @@ DDO_DEV void add_bits(CP cnt, const uint64_t* s, int delta) {
     }
 }
 
-/// MispRelax::fast_upper_bound (main.rs:191-193)
+/// lexicographic ranking word: MISP orders states by member lists (BitSet::cmp) = brev(~word) descending;
+/// knapsack ranks by remaining capacity (examples/knapsack/main.rs:187-194)
+template <class Ctx>
+DDO_DEV uint64_t lexkey(const Ctx& c, uint64_t w) { return c.kind == MODEL_KNAPSACK ? w : dd_brev(~w); }
+
+/// Relaxation::fast_upper_bound: MISP main.rs:191-193; knapsack main.rs:158-184 (fractional bound over the remaining
+/// items in ratio order; the only floating point on the path: cap/weight * profit, floored)
 template <int WS>
-DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop) {
+DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth) {
+    if (c.kind == MODEL_KNAPSACK) {
+        int64_t cap = (int64_t)s[0];
+        int64_t max_profit = 0;
+        for (int d = depth; cap > 0 && d < c.n; ++d) {
+            const int item = c.kp_order[d];
+            const int64_t w = c.kp_weight[item];
+            if (cap >= w) {
+                max_profit += c.weight[item];
+                cap -= w;
+            } else {
+                const double ratio = (double)cap / (double)w;
+                const double pr = ratio * (double)c.weight[item];
+                max_profit += (int64_t)dd_floor(pr);
+                cap = 0;
+            }
+        }
+        return (int32_t)max_profit;
+    }
     if (c.unit_weights) return pop;
     int32_t sum = 0;
 #pragma unroll
@@ -389,9 +420,9 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
             if (k1_of(LD_U64(&key[cd]), pop[cd]) != pivK1) continue;
             bool active = true;
             for (int k = 0; k < wj && active; ++k)
-                active = dd_brev(~st[(size_t)k * capC1 + cd]) == pivLex[k];
+                active = lexkey(c, st[(size_t)k * capC1 + cd]) == pivLex[k];
             if (!active) continue;
-            uint64_t lw = dd_brev(~st[(size_t)wj * capC1 + cd]);
+            uint64_t lw = lexkey(c, st[(size_t)wj * capC1 + cd]);
             if (shift + 8 < 64 && (lw >> (shift + 8)) != (pivLex[wj] >> (shift + 8))) continue;
             LDS_ADD_U32(&c.hist[(lw >> shift) & 0xFF], 1u);
         }
@@ -427,7 +458,7 @@ DDO_DEV bool ge_pivot(const DDCtx<WS>& c, int cur, int cd, uint64_t k1) {
     if (k1 != sh->pivK1) return k1 > sh->pivK1;
     const uint64_t* st = c.cstate[cur];
     for (int k = 0; k < WS; ++k) {
-        uint64_t lw = dd_brev(~st[(size_t)k * c.capC1 + cd]);
+        uint64_t lw = lexkey(c, st[(size_t)k * c.capC1 + cd]);
         if (lw != sh->pivLex[k]) return lw > sh->pivLex[k];
     }
     return true;
@@ -441,8 +472,8 @@ DDO_DEV bool ranks_above(const DDCtx<WS>& c, int cur, int a, int b) {
     if (ka != kb) return ka > kb;
     const uint64_t* st = c.cstate[cur];
     for (int k = 0; k < WS; ++k) {
-        uint64_t la = dd_brev(~st[(size_t)k * c.capC1 + a]);
-        uint64_t lb = dd_brev(~st[(size_t)k * c.capC1 + b]);
+        uint64_t la = lexkey(c, st[(size_t)k * c.capC1 + a]);
+        uint64_t lb = lexkey(c, st[(size_t)k * c.capC1 + b]);
         if (la != lb) return la > lb;
     }
     return false;
@@ -529,7 +560,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         sh->cutoff = 0;
         for (int k = 0; k < WS; ++k) c.cstate[0][(size_t)k * capC1] = in.state[k];
         int pop = 0;
-        for (int k = 0; k < WS; ++k) pop += dd_popc(in.state[k]);
+        if (c.kind == MODEL_MISP)
+            for (int k = 0; k < WS; ++k) pop += dd_popc(in.state[k]);
         c.ckey[0][0] = ((uint64_t)bias32(in.value) << 32) | NONE32;
         c.cpop[0][0] = (uint32_t)pop;
         c.cflags[0][0] = 0;
@@ -538,7 +570,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     }
     PAR_END
     PAR_BEGIN
-    if (tid == 0) add_bits<WS>(c.cnt, in.state, +1);
+    if (tid == 0) if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, in.state, +1);
     // the table must describe the current unique layer (needed by recycled-merge probes)
     for (int i = tid; i < hsize; i += NT) c.table[i] = TAB_EMPTY;
     PAR_END
@@ -558,10 +590,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         PAR_END
         PAR_BEGIN
-        for (int i = tid; i < c.n; i += NT) {
-            int cv = c.cnt[i];
-            if (cv > 0) LDS_MIN_U32(&sh->varkey, ((uint32_t)cv << 12) | (uint32_t)i);
-            else if (cv < 0) sh->status = ST_ERR_INTERNAL;
+        if (c.kind == MODEL_KNAPSACK) {   // static order (knapsack/main.rs:118-125); an empty layer ends the DD
+            if (tid == 0 && c.depth0 + L < c.n && sh->nU > 0) sh->varkey = (uint32_t)c.kp_order[c.depth0 + L];
+        } else {
+            for (int i = tid; i < c.n; i += NT) {
+                int cv = c.cnt[i];
+                if (cv > 0) LDS_MIN_U32(&sh->varkey, ((uint32_t)cv << 12) | (uint32_t)i);
+                else if (cv < 0) sh->status = ST_ERR_INTERNAL;
+            }
         }
         PAR_END
         var = sh->varkey == 0xFFFFFFFFu ? -1 : (int)(sh->varkey & 0xFFFu);
@@ -640,10 +676,16 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                         uint64_t s[WS];
 #pragma unroll
                         for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + cd];
-                        add_bits<WS>(c.cnt, s, -1);  // it leaves the layer
+                        if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);  // it leaves the layer
                         if (relaxed) {
+                            if (c.kind == MODEL_KNAPSACK) {   // KPRelax::merge: the largest capacity (main.rs:150-152)
 #pragma unroll
-                            for (int k = 0; k < WS; ++k) mor[k] |= s[k];
+                                for (int k = 0; k < WS; ++k)
+                                    if (s[k] > mor[k]) mor[k] = s[k];   // word 1 is the depth, equal over the layer
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < WS; ++k) mor[k] |= s[k];
+                            }
                             if (key > mkey) mkey = key;
                             anydel = true;
                         }
@@ -655,9 +697,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         c.tcount[tid] = kept;
         if (anydel) {
+            if (c.kind == MODEL_KNAPSACK) {
 #pragma unroll
-            for (int k = 0; k < WS; ++k)
-                if (mor[k]) LDS_OR_U64(&sh->merged[k], mor[k]);   // MispRelax::merge (main.rs:172-178)
+                for (int k = 0; k < WS; ++k) LDS_MAX_U64(&sh->merged[k], mor[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < WS; ++k)
+                    if (mor[k]) LDS_OR_U64(&sh->merged[k], mor[k]);   // MispRelax::merge (main.rs:172-178)
+            }
             LDS_MAX_U64(&sh->mergedKey, mkey);
         }
         PAR_END
@@ -698,7 +745,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     int pop = 0;
                     for (int k = 0; k < WS; ++k) {
                         c.cstate[cur][(size_t)k * capC1 + MERGED] = ms[k];
-                        pop += dd_popc(ms[k]);
+                        if (c.kind == MODEL_MISP) pop += dd_popc(ms[k]);
                     }
                     c.ckey[cur][MERGED] = sh->mergedKey;
                     c.cpop[cur][MERGED] = (uint32_t)pop;
@@ -707,7 +754,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     c.posmap[MERGED] = (uint32_t)nkept;
                     c.cls[MERGED] = 1;
                     sh->merged_pos = nkept;
-                    add_bits<WS>(c.cnt, ms, +1);
+                    if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, ms, +1);
                 }
             }
             PAR_END
@@ -737,7 +784,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     sh->xbest = best;
                     uint64_t s[WS];
                     for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + best];
-                    add_bits<WS>(c.cnt, s, +1);
+                    if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, +1);
                     c.cls[best] = 1;
                     c.keep[nkept] = (uint32_t)best;
                     c.posmap[best] = (uint32_t)nkept;
@@ -793,12 +840,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (tid == 0) sh->nU = 0;
         PAR_END
         PAR_BEGIN
+        const bool kp = c.kind == MODEL_KNAPSACK;
         uint64_t adjv[WS];
 #pragma unroll
-        for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
+        for (int k = 0; k < WS; ++k) adjv[k] = kp ? 0 : c.adj[(size_t)var * WS + k];
         const int vw = var >> 6;
         const uint64_t vbit = 1ULL << (var & 63);
         const int32_t wv = c.weight[var];
+        const uint64_t kpw = kp ? (uint64_t)c.kp_weight[var] : 0;
         int myarcs = 0, myuniq = 0;
         for (int pos = tid; pos < n; pos += NT) {
             const uint32_t p = c.keep[pos];
@@ -810,23 +859,31 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             const int pop = (int)c.cpop[cur][p];
             const uint32_t pfl = LD_U32(&c.cflags[cur][p]);
             const uint32_t inexact = (pfl & (NF_INEXACT | NF_RELAXED)) ? NF_INEXACT : 0u;
-            const int32_t rub = rub_of<WS>(c, s, pop);
+            const int32_t rub = rub_of<WS>(c, s, pop, c.depth0 + L);
             if ((int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded
-                add_bits<WS>(c.cnt, s, -1);
+                if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);
                 c.ctarget[pos] = NONE32;
                 c.ctarget[capN + pos] = NONE32;
                 continue;
             }
-            bool hasv = false;
+            bool hasv = false;   // MISP: the vertex is in the state; knapsack: the item fits (main.rs:93-99)
+            if (kp) hasv = s[0] >= kpw;
+            else {
 #pragma unroll
-            for (int k = 0; k < WS; ++k)
-                if (k == vw) hasv = (s[k] & vbit) != 0;
-            // ---- decision NO (main.rs:77-85 with value == NO): state minus the variable
-            if (hasv) {
+                for (int k = 0; k < WS; ++k)
+                    if (k == vw) hasv = (s[k] & vbit) != 0;
+            }
+            // ---- decision NO (main.rs:77-85 with value == NO): state minus the variable; knapsack LEAVE_IT_OUT: same state
+            if (hasv && !kp) {
 #pragma unroll
                 for (int k = 0; k < WS; ++k)
                     if (k == vw) s[k] &= ~vbit;
                 LDS_ADD_I32(&c.cnt[var], -1);
+            }
+            if (kp) {   // KnapsackState = (capacity, depth) (main.rs:44-50): both children are one level deeper
+#pragma unroll
+                for (int k = 0; k < WS; ++k)
+                    if (k == 1) s[k] += 1;
             }
             {
                 const uint32_t cd = (uint32_t)pos;
@@ -834,7 +891,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = s[k];
                 const uint64_t mykey = ((uint64_t)bias32(val) << 32) | cd;
                 c.ckey[nxt][cd] = mykey;
-                c.cpop[nxt][cd] = (uint32_t)(pop - (hasv ? 1 : 0));
+                c.cpop[nxt][cd] = (uint32_t)(pop - ((hasv && !kp) ? 1 : 0));
                 c.cflags[nxt][cd] = inexact;
                 FENCE_BLOCK();
                 const uint32_t w = dedup_insert<WS>(c, nxt, cd, s, hmask);
@@ -844,7 +901,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 else {
                     GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
                     if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
-                    add_bits<WS>(c.cnt, s, -1);                      // duplicate: not a new member of next_l
+                    if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);                      // duplicate: not a new member of next_l
                 }
             }
             // ---- decision YES (only when the variable is in the state, main.rs:95-102)
@@ -855,6 +912,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int k = 0; k < WS; ++k) {
                     y[k] = s[k] & adjv[k];
                     ypop += dd_popc(y[k]);
+                }
+                if (kp) {   // TAKE_IT (main.rs:106-113): the capacity shrinks by the item's weight
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) y[k] = k == 0 ? s[0] - kpw : s[k];
+                    ypop = 0;
                 }
                 const uint32_t cd = (uint32_t)(capN + pos);
 #pragma unroll
@@ -869,7 +931,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 ++myarcs;
                 if (w == cd) {
                     ++myuniq;
-                    add_bits<WS>(c.cnt, y, +1);
+                    if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, y, +1);
                 } else {
                     GLB_MAX_U64(&c.ckey[nxt][w], mykey);
                     if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
@@ -1088,7 +1150,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 #pragma unroll
                 for (int k = 0; k < WS; ++k) s[k] = c.cs_state[(size_t)k * capN + pos];
                 int64_t v = c.cs_value[pos];
-                int64_t ub = v + rub_of<WS>(c, s, (int)c.cs_pop[pos]);
+                int64_t ub = v + rub_of<WS>(c, s, (int)c.cs_pop[pos], c.depth0 + lel);
                 if (v + vb < ub) ub = v + vb;
                 if (best_value < ub) ub = best_value;
                 if (ub <= best_lb) continue;
@@ -1170,7 +1232,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 #pragma unroll
                 for (int k = 0; k < WS; ++k) s[k] = c.cs_state[(size_t)k * capN + pos];
                 int64_t v = c.cs_value[pos];
-                int64_t ub = v + rub_of<WS>(c, s, (int)c.cs_pop[pos]);
+                int64_t ub = v + rub_of<WS>(c, s, (int)c.cs_pop[pos], c.depth0 + lel);
                 if (v + vb < ub) ub = v + vb;
                 if (best_value < ub) ub = best_value;
                 if (filter && ub <= best_lb) continue;
@@ -1234,6 +1296,7 @@ template <int WS>
 DDO_DEV void run_work_item(DDCtx<WS>& c, const DDInput& in, DDResult* res2) {
     DD_TID_SETUP(c)
     (void)NT;
+    c.depth0 = in.depth;
     if (in.flags & IN_FUSED) {
         run_dd<WS>(c, in, CT_RESTRICTED, in.best_lb, &res2[0]);
         // all threads read the restricted result through shared memory state written by thread 0
@@ -1280,6 +1343,10 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.unit_weights = P.unit_weights;
     c.adj = P.adj;
     c.weight = P.weight;
+    c.kind = P.model_kind;
+    c.depth0 = 0;   // set per work item
+    c.kp_weight = P.kp_weight;
+    c.kp_order = P.kp_order;
     c.capN = P.capN;
     c.capC1 = P.capC1;
     c.max_layers = P.max_layers;

@@ -12,6 +12,7 @@
 #include <cctype>
 #include <cstdio>
 #include <fstream>
+#include <sstream>
 #include <string>
 
 #include "engine.hpp"
@@ -133,6 +134,40 @@ bool read_misp_clq(const std::string& path, int& n, std::vector<uint64_t>& rows,
     }
     if (n <= 0) {
         set_error("ill formed instance: no `p edge` line");
+        return false;
+    }
+    return true;
+}
+
+bool read_knapsack(const std::string& path, int64_t& capacity, std::vector<int64_t>& profit, std::vector<int64_t>& weight) {
+    std::ifstream f(path);
+    if (!f) {
+        set_error("cannot open " + path);
+        return false;
+    }
+    profit.clear();
+    weight.clear();
+    std::string line;
+    bool header = true;
+    long long n = 0;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line[0] == 'c') continue;   // main.rs:281-283
+        std::istringstream is(line);
+        long long a = 0, b = 0;
+        if (header) {
+            if (!(is >> a >> b)) continue;               // blank lines before the header
+            n = a;
+            capacity = b;
+            header = false;
+        } else {
+            if ((long long)profit.size() >= n) break;   // main.rs:292: only the first n items count
+            if (!(is >> a >> b)) continue;
+            profit.push_back(a);
+            weight.push_back(b);
+        }
+    }
+    if (header || n < 1 || (long long)profit.size() != n) {
+        set_error("malformed knapsack instance " + path);
         return false;
     }
     return true;

@@ -107,6 +107,13 @@ int ddo_device_count(void);
 ddo_model* ddo_model_create_misp(int n, const uint64_t* compl_adj_rows, const int64_t* weights);
 /** Reads a DIMACS-like .clq file exactly as examples/misp/main.rs:258-317 does. */
 ddo_model* ddo_model_read_misp(const char* path);
+/** Knapsack (examples/knapsack/main.rs:53-194: `Knapsack`, `KPRelax`, `KPRanking`).  The state is two words,
+ *  `KnapsackState { capacity, depth }` (main.rs:44-50); variables are branched in decreasing
+ *  profit/weight order (main.rs:66-70, 118-125); decision 1 = TAKE_IT, 0 = LEAVE_IT_OUT; merge = largest capacity;
+ *  fast_upper_bound = fractional bound over the remaining items (main.rs:158-184). */
+ddo_model* ddo_model_create_knapsack(int n, int64_t capacity, const int64_t* profit, const int64_t* weight);
+/** Reads an instance exactly as examples/knapsack/main.rs:267-303 does ("n capacity", then n x "profit weight"). */
+ddo_model* ddo_model_read_knapsack(const char* path);
 void ddo_model_destroy(ddo_model* model);
 int ddo_model_nb_variables(const ddo_model* model);
 int ddo_model_state_words(const ddo_model* model);
