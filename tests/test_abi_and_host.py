@@ -101,3 +101,41 @@ def test_wire_structs_match_the_device_header():
     L.emul_sizeof_input.restype = ctypes.c_uint64
     L.emul_sizeof_result.restype = ctypes.c_uint64
     assert L.emul_sizeof_input() == ctypes.sizeof(DDInput) and L.emul_sizeof_result() == ctypes.sizeof(DDResult)
+
+
+# ---- knapsack model descriptor (examples/knapsack/main.rs:53-194), host side only ------------------------------
+def test_knapsack_model_host_side(tmp_path):
+    m = ddo_amd.Knapsack.from_items(50, [60, 100, 120], [10, 20, 30])
+    assert m.n == 3 and m.ws == 2
+    assert [int(x) for x in m.initial_state()] == [50, 0] and m.initial_value() == 0
+    # KPRanking (main.rs:187-194): the remaining capacity alone, whatever the depth word says
+    a, b = np.array([7, 3], dtype=np.uint64), np.array([9, 1], dtype=np.uint64)
+    assert m.compare(a, b) < 0 and m.compare(b, a) > 0 and m.compare(a, np.array([7, 5], dtype=np.uint64)) == 0
+    # reader (main.rs:267-303): comment lines, "n capacity", n x "profit weight", anything after the n items ignored
+    p = tmp_path / "kp.txt"
+    p.write_text("c a comment\n3 50\n60 10\nc another\n100 20\n120 30\n999 1\n")
+    r = ddo_amd.Knapsack.read_instance(p)
+    assert r.n == 3 and int(r.initial_state()[0]) == 50
+    for bad in ("3 50\n60 10\n", "", "c only comments\n"):
+        q = tmp_path / "bad.txt"
+        q.write_text(bad)
+        with pytest.raises(ddo_amd.DdoError):
+            ddo_amd.Knapsack.read_instance(q)
+    with pytest.raises(ddo_amd.DdoError):
+        ddo_amd.Knapsack.from_items(10, [1, 2], [0, 3])       # weights must be >= 1
+    with pytest.raises(ddo_amd.DdoError):
+        ddo_amd.Knapsack.from_items(-1, [1], [1])
+
+
+@pytest.mark.parametrize("name", ["f1_l-d_kp_10_269", "f8_l-d_kp_23_10000", "knapPI_1_100_1000_1"])
+def test_knapsack_reader_agrees_with_the_oracle(oracle, name):
+    """same optimum from the oracle whether it parses the file itself or gets the product reader's arrays"""
+    path = data_path("knapsack", name)
+    rows = [l.split() for l in open(path) if l.strip() and not l.startswith("c")]
+    n, cap = int(rows[0][0]), int(rows[0][1])
+    m = ddo_amd.Knapsack.read_instance(path)
+    assert m.n == n and int(m.initial_state()[0]) == cap
+    if n <= 23:
+        v_file, _ = oracle.knapsack_file(path, 10, 0)
+        v_arr, _ = oracle.knapsack([int(r[0]) for r in rows[1:1 + n]], [int(r[1]) for r in rows[1:1 + n]], cap, 10, 0)
+        assert v_file == v_arr
