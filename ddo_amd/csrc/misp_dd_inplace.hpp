@@ -13,9 +13,11 @@
 //   * an unaffected node is not touched at all: it simply stays alive;
 //   * an affected node s is updated in place (NO-child = s minus the vertex: one word
 //     rewritten, hash patched incrementally) and spawns its YES-child into a free slot;
-//   * only changed / new states go through the (persistent, HBM) dedup table;
-//   * the ranking keys (value, popcount) of all slots live in LDS, so the exact top-K
-//     selection of _restrict/_relax never leaves the CU except for lexicographic ties;
+//   * the dedup table lives in LDS and is refilled per layer by the same sweep that builds
+//     the work list; children are de-duplicated right where they are created;
+//   * the ranking keys (value, popcount) are one u32 per slot (LDS, or L2 at width 10 000
+//     where the table needs the LDS); the exact top-K selection of _restrict/_relax is a
+//     radix select over them plus a rank-counting tie-break on member order;
 //   * the best path to a node is a bit string (one decision bit per layer) stored with
 //     the node, copied only when a node is created or its best parent changes -- no
 //     per-layer parent arrays, no path walks;
@@ -105,8 +107,7 @@ struct DD2Shared {
     uint64_t ev_pos;
     uint64_t clk[8];
     uint64_t clk_last;
-    uint64_t mk[16];        // wave-0 code marks (DD2_MARK)
-    uint64_t mk_last;
+    uint64_t mk[16];        // statistics and auxiliary tick slots (DD2_STAT, DD2_TICK2)
     int32_t xcand[64];
 };
 
@@ -139,22 +140,6 @@ struct DD2Shared {
         }                                                   \
         PAR_END                                             \
     }
-
-// DD2_MARK(k): wave 0 drains its memory counters and charges the cycles since its previous mark to mk[k]
-#if defined(DDO_HOST_EMULATION)
-#define DD2_MARK(k)
-#else
-#define DD2_MARK(k)                                                             \
-    if (c.clocks && tid < 64) {                                                 \
-        __builtin_amdgcn_s_waitcnt(0);                                          \
-        const uint64_t _em = __builtin_amdgcn_ballot_w64(true);                 \
-        if (tid == __builtin_ctzll(_em)) {                                      \
-            const uint64_t _t = dd_clock();                                     \
-            sh->mk[k] += _t - sh->mk_last;                                      \
-            sh->mk_last = _t;                                                   \
-        }                                                                       \
-    }
-#endif
 
 template <int WS>
 struct DD2Ctx {
@@ -261,8 +246,6 @@ DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
     ld_state_h<WS>(c, slot, s, h);
     (void)h;
 }
-template <int WS>
-DDO_DEV uint64_t ld_hash(const DD2Ctx<WS>& c, int slot) { return c.rec[(size_t)slot * c.RW + WS]; }
 template <int WS>
 DDO_DEV uint64_t ld_word(const DD2Ctx<WS>& c, int slot, int k) { return c.rec[(size_t)slot * c.RW + k]; }
 /// full (re)write of a node: record line (16-byte stores: every store instruction of a lane is its own write
@@ -413,19 +396,6 @@ DDO_DEV int32_t rub2_of(const DD2Ctx<WS>& c, const uint64_t* s) {
         }
     }
     return sum;
-}
-
-/// full-order "node a ranks above node b": (key32, lexkey words)
-template <int WS>
-DDO_DEV bool ranks_above2(const DD2Ctx<WS>& c, int a, int b) {
-    uint32_t ka = K32(c, a), kb = K32(c, b);
-    if (ka != kb) return ka > kb;
-    for (int k = 0; k < WS; ++k) {
-        uint64_t la = dd_brev(~ld_word<WS>(c, a, k));
-        uint64_t lb = dd_brev(~ld_word<WS>(c, b, k));
-        if (la != lb) return la > lb;
-    }
-    return false;
 }
 
 /// (value, popcount) part of the exact top-K selection (clean.rs:802-824 with main.rs:205-208): MSD radix select over
