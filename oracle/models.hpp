@@ -383,4 +383,264 @@ inline Knapsack read_knapsack_instance(const std::string& fname) {
     return Knapsack(capa, std::move(profit), std::move(weight));
 }
 
+// ===========================================================================
+// MAX2SAT  (examples/max2sat/{data.rs, model.rs, relax.rs, heuristics.rs})
+// ===========================================================================
+/// model.rs:55-60: the marginal benefit of setting each variable to true, plus the depth
+struct Max2SatState {
+    size_t depth = 0;
+    std::vector<isize> substates;
+    bool operator==(const Max2SatState& o) const { return depth == o.depth && substates == o.substates; }
+    /// model.rs:76-79
+    isize rank() const {
+        isize r = 0;
+        for (isize x : substates) r += x < 0 ? -x : x;
+        return r;
+    }
+};
+template <>
+struct StateHash<Max2SatState> {
+    size_t operator()(const Max2SatState& s) const {
+        uint64_t h = 0;
+        auto mix = [&](uint64_t w) { h = (((h << 5) | (h >> 59)) ^ w) * 0x517cc1b727220a95ULL; };
+        mix((uint64_t)s.depth);
+        mix((uint64_t)s.substates.size());
+        for (isize x : s.substates) mix((uint64_t)x);
+        return (size_t)h;
+    }
+};
+
+/// data.rs:31-53: a clause over literals (+-(1 + variable)), smaller literal first
+struct BinaryClause {
+    isize a, b;
+    BinaryClause(isize x, isize y) : a(std::min(x, y)), b(std::max(x, y)) {}
+    bool is_tautology() const { return a == -b; }
+    bool is_unit() const { return a == b; }
+};
+/// data.rs:58-62.  `insert` semantics: a clause listed twice keeps its LAST weight.
+struct Weighed2Sat {
+    size_t nb_vars = 0;
+    std::vector<std::pair<BinaryClause, isize>> weights;   // unique clauses, in order of first appearance
+    void insert(BinaryClause c, isize w) {
+        for (auto& e : weights)
+            if (e.first.a == c.a && e.first.b == c.b) {
+                e.second = w;
+                return;
+            }
+        weights.emplace_back(c, w);
+    }
+};
+
+/// data.rs:67-116.  The four line patterns of the reference, tried in its order on the trimmed line:
+///   comment  ^c\s.*$            problem  ^p\s+wcnf\s+(\d+)\s+(\d+)
+///   binary   ^(-?\d+)\s+(-?\d+)\s+(-?\d+)\s+0      unit  ^(-?\d+)\s+(-?\d+)-?\s+0
+inline Weighed2Sat read_max2sat_instance(const std::string& fname) {
+    std::ifstream f(fname);
+    if (!f) throw std::runtime_error("io error: cannot open " + fname);
+    static const std::regex comment(R"(^c\s.*$)");
+    static const std::regex pb_decl(R"(^p\s+wcnf\s+(\d+)\s+(\d+))");
+    static const std::regex bin_decl(R"(^(-?\d+)\s+(-?\d+)\s+(-?\d+)\s+0)");
+    static const std::regex unit_decl(R"(^(-?\d+)\s+(-?\d+)-?\s+0)");
+    Weighed2Sat inst;
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t b = line.find_first_not_of(" \t\r\n"), e = line.find_last_not_of(" \t\r\n");
+        if (b == std::string::npos) continue;
+        line = line.substr(b, e - b + 1);
+        std::smatch m;
+        if (std::regex_search(line, m, comment)) continue;
+        if (std::regex_search(line, m, pb_decl)) {
+            inst.nb_vars = (size_t)std::stoull(m[1].str());
+            continue;
+        }
+        if (std::regex_search(line, m, bin_decl)) {
+            inst.insert(BinaryClause((isize)std::stoll(m[2].str()), (isize)std::stoll(m[3].str())), (isize)std::stoll(m[1].str()));
+            continue;
+        }
+        if (std::regex_search(line, m, unit_decl)) {
+            isize x = (isize)std::stoll(m[2].str());
+            inst.insert(BinaryClause(x, x), (isize)std::stoll(m[1].str()));
+            continue;
+        }
+    }
+    return inst;
+}
+
+/// model.rs:91-346.  DP model of Bergman, Cire, van Hoeve (INFORMS J. Comp. 2016).
+struct Max2Sat : Problem<Max2SatState> {
+    static constexpr isize T = 1, F = -1;                       // model.rs:29-31
+    size_t nb_vars = 0;
+    isize initial = 0;
+    std::vector<isize> weights;                                   // (2n)^2, indexed by offset(x, y)
+    std::vector<isize> sum_of_clause_weights;
+    std::vector<size_t> order;                                    // vars_by_sum_of_clause_weights (worst first)
+    std::vector<isize> nk, estimates;
+
+    static isize lit_t(size_t v) { return 1 + (isize)v; }         // model.rs:34-46
+    static isize lit_f(size_t v) { return -(1 + (isize)v); }
+    static isize pos(isize x) { return x > 0 ? x : 0; }           // model.rs:49-51
+    static size_t var_of(isize lit) { return (size_t)((lit < 0 ? -lit : lit) - 1); }   // idx, model.rs:105-107
+    static size_t mk_lit(isize x) {                               // model.rs:108-113
+        size_t a = var_of(x);
+        return a + a + (x > 0 ? 1 : 0);
+    }
+    size_t offset(isize x, isize y) const {                       // model.rs:154-159
+        isize a = std::min(x, y), b = std::max(x, y);
+        return mk_lit(a) * 2 * nb_vars + mk_lit(b);
+    }
+    isize weight(isize x, isize y) const { return weights[offset(x, y)]; }   // model.rs:150-152
+
+    explicit Max2Sat(const Weighed2Sat& inst) {                   // model.rs:115-148
+        nb_vars = inst.nb_vars;
+        const size_t n = nb_vars;
+        weights.assign((2 * n) * (2 * n), 0);
+        sum_of_clause_weights.assign(n, 0);
+        for (const auto& e : inst.weights) {
+            const BinaryClause& c = e.first;
+            weights[offset(c.a, c.b)] = e.second;
+            sum_of_clause_weights[var_of(c.a)] += e.second;
+            if (!c.is_unit()) sum_of_clause_weights[var_of(c.b)] += e.second;
+            if (c.is_tautology()) initial += e.second;
+        }
+        // sort_unstable_by_key(sum_of_clause_weights): ties keep index order here (documented deviation: the
+        // reference's unstable sort leaves them unspecified)
+        order.resize(n);
+        for (size_t i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](size_t a, size_t b) { return sum_of_clause_weights[a] < sum_of_clause_weights[b]; });
+        estimates.assign(n, 0);
+        for (size_t k = 0; k < n; ++k) estimates[k] = precompute_estimate(k);
+        nk.assign(n, 0);
+        for (size_t k = 0; k < n; ++k) {                          // model.rs:178-185
+            isize sum = 0;
+            for (size_t i = 0; i < k; ++i) sum += weight(lit_t(order[i]), lit_f(order[i]));
+            nk[k] = sum;
+        }
+    }
+    /// model.rs:193-229
+    isize precompute_estimate(size_t k) const {
+        const size_t n = nb_vars;
+        isize sum = 0;
+        for (size_t i = k; i < n; ++i) {
+            const size_t vi = order[i];
+            for (size_t j = i + 1; j < n; ++j) {
+                const size_t vj = order[j];
+                const isize tt = weight(lit_t(vi), lit_t(vj)), tf = weight(lit_t(vi), lit_f(vj));
+                const isize ft = weight(lit_f(vi), lit_t(vj)), ff = weight(lit_f(vi), lit_f(vj));
+                const isize wtt = tt + tf + ft, wtf = tt + tf + ff, wft = tt + ft + ff, wff = tf + ft + ff;
+                sum += std::max(std::max(wtt, wtf), std::max(wft, wff));
+            }
+            sum += weight(lit_t(vi), lit_f(vi)) + std::max(weight(lit_t(vi), lit_t(vi)), weight(lit_f(vi), lit_f(vi)));
+        }
+        return sum;
+    }
+    /// model.rs:231-240
+    isize fast_upper_bound(const Max2SatState& s) const {
+        return s.rank() + estimates[s.depth] - initial + nk[s.depth];
+    }
+
+    size_t nb_variables() const override { return nb_vars; }
+    Max2SatState initial_state() const override {
+        Max2SatState s;
+        s.substates.assign(nb_vars, 0);
+        return s;
+    }
+    isize initial_value() const override { return initial; }      // sum of all tautologies
+    void for_each_in_domain(Variable var, const Max2SatState&, DecisionCallback& f) const override {
+        f.apply(Decision{var.id, T});
+        f.apply(Decision{var.id, F});
+    }
+    /// model.rs:275-293.  varset(state) = the first n - (depth + 1) variables of the order (model.rs:161-170)
+    Max2SatState transition(const Max2SatState& s, Decision d) const override {
+        const size_t k = d.variable;
+        Max2SatState r = s;
+        r.depth += 1;
+        r.substates[k] = 0;
+        const size_t nfree = nb_vars - (s.depth + 1);
+        for (size_t i = 0; i < nfree; ++i) {
+            const size_t l = order[i];
+            if (d.value == F) r.substates[l] += weight(lit_t(k), lit_t(l)) - weight(lit_t(k), lit_f(l));
+            else r.substates[l] += weight(lit_f(k), lit_t(l)) - weight(lit_f(k), lit_f(l));
+        }
+        return r;
+    }
+    /// model.rs:294-329
+    isize transition_cost(const Max2SatState& s, const Max2SatState&, Decision d) const override {
+        const size_t k = d.variable;
+        const size_t nfree = nb_vars - (s.depth + 1);
+        if (d.value == F) {
+            isize sum = weight(lit_f(k), lit_f(k));
+            for (size_t i = 0; i < nfree; ++i) {
+                const size_t l = order[i];
+                const isize wff = weight(lit_f(k), lit_f(l)), wft = weight(lit_f(k), lit_t(l));
+                const isize wtt = weight(lit_t(k), lit_t(l)), wtf = weight(lit_t(k), lit_f(l));
+                sum += (wff + wft) + std::min(pos(s.substates[l]) + wtt, pos(-s.substates[l]) + wtf);
+            }
+            return pos(-s.substates[k]) + sum;
+        }
+        isize sum = weight(lit_t(k), lit_t(k));
+        for (size_t i = 0; i < nfree; ++i) {
+            const size_t l = order[i];
+            const isize wtt = weight(lit_t(k), lit_t(l)), wtf = weight(lit_t(k), lit_f(l));
+            const isize wff = weight(lit_f(k), lit_f(l)), wft = weight(lit_f(k), lit_t(l));
+            sum += (wtf + wtt) + std::min(pos(s.substates[l]) + wft, pos(-s.substates[l]) + wff);
+        }
+        return pos(s.substates[k]) + sum;
+    }
+    /// model.rs:330-346: the depth of the first state of the next layer decides; none when the layer is empty
+    std::optional<Variable> next_variable(size_t, StateIter<Max2SatState>& next_layer) const override {
+        const Max2SatState* s = next_layer.next();
+        if (!s) return std::nullopt;
+        if (s->depth < nb_vars) return Variable{order[nb_vars - s->depth - 1]};
+        return std::nullopt;
+    }
+};
+
+/// relax.rs:42-90
+struct Max2SatRelax : Relaxation<Max2SatState> {
+    const Max2Sat& pb;
+    explicit Max2SatRelax(const Max2Sat& p) : pb(p) {}
+    /// relax.rs:46-77: per variable, the smallest |benefit| with the common sign; 0 when the signs disagree
+    Max2SatState merge(StateIter<Max2SatState>& it) const override {
+        std::vector<const Max2SatState*> states;
+        while (const Max2SatState* s = it.next()) states.push_back(s);
+        Max2SatState out;
+        out.depth = states[0]->depth;
+        out.substates.assign(pb.nb_vars, 0);
+        for (size_t v = 0; v < pb.nb_vars; ++v) {
+            isize sign = 0, min_benef = ISIZE_MAX;
+            bool same = true;
+            for (const Max2SatState* s : states) {
+                const isize sub = s->substates[v];
+                min_benef = std::min(min_benef, sub < 0 ? -sub : sub);
+                if (sign == 0 && sub != 0) sign = sub < 0 ? -1 : 1;
+                else if (sign * sub < 0) {
+                    same = false;
+                    break;
+                }
+            }
+            if (same) out.substates[v] = sign * min_benef;
+        }
+        return out;
+    }
+    /// relax.rs:78-84
+    isize relax(const Max2SatState&, const Max2SatState& dst, const Max2SatState& merged, Decision, isize cost) const override {
+        isize c = cost;
+        for (size_t v = 0; v < pb.nb_vars; ++v) {
+            const isize a = dst.substates[v], b = merged.substates[v];
+            c += (a < 0 ? -a : a) - (b < 0 ? -b : b);
+        }
+        return c;
+    }
+    isize fast_upper_bound(const Max2SatState& s) const override { return pb.fast_upper_bound(s); }
+};
+
+/// heuristics.rs:30-37
+struct Max2SatRanking : StateRanking<Max2SatState> {
+    int compare(const Max2SatState& a, const Max2SatState& b) const override {
+        const isize x = a.rank(), y = b.rank();
+        return x < y ? -1 : (x > y ? 1 : 0);
+    }
+};
+
 }  // namespace ddo

@@ -415,4 +415,85 @@ int64_t oracle_knapsack_solve_file(const char* path, uint64_t width, int nthread
     }
 }
 
+/// MAX2SAT (examples/max2sat): solves a .wcnf file the way examples/max2sat/tests.rs:42-63 does (NoDupFringe, MaxUB,
+/// EmptyDominanceChecker, NoCutoff; width 0 = NbUnassignedWidth).  nthreads <= 0: SequentialSolver.
+/// sol_values (n entries, may be null) receives +1 / -1 per variable.  Returns the optimum, -1 when there is none.
+int64_t oracle_max2sat_solve_file(const char* path, uint64_t width, int nthreads, double time_budget_s, int64_t* sol_values,
+                                  oracle_solve_out* out) {
+    try {
+        Weighed2Sat inst = read_max2sat_instance(path);
+        Max2Sat pb(inst);
+        Max2SatRelax relax(pb);
+        Max2SatRanking rank;
+        FixedWidth<Max2SatState> fixed(width);
+        NbUnassignedWidth<Max2SatState> unassigned(pb.nb_variables());
+        const WidthHeuristic<Max2SatState>& w = width ? (const WidthHeuristic<Max2SatState>&)fixed : unassigned;
+        EmptyDominanceChecker<Max2SatState> dom;
+        NoCutoff nocut;
+        TimeBudget budget(time_budget_s > 0 ? time_budget_s : 1e9);
+        const Cutoff& cut = time_budget_s > 0 ? (const Cutoff&)budget : (const Cutoff&)nocut;
+        MaxUB<Max2SatState> mx(rank);
+        NoDupFringe<Max2SatState> fringe(mx);
+        Completion c;
+        std::optional<Solution> sol;
+        auto t0 = std::chrono::steady_clock::now();
+        auto fill = [&](auto& s) {
+            c = s.maximize();
+            sol = s.best_solution();
+            if (out) {
+                out->explored = s.explored();
+                out->best_lb = s.best_lower_bound();
+                out->best_ub = s.best_upper_bound();
+                out->nodes_expanded = s.counters().nodes_expanded;
+                out->arcs = s.counters().arcs;
+                out->layers = s.counters().layers;
+                out->compiles = s.counters().compiles;
+            }
+        };
+        if (nthreads <= 0) {
+            SequentialSolver<Max2SatState> s(pb, relax, rank, w, dom, cut, fringe);
+            fill(s);
+        } else {
+            ParallelSolver<Max2SatState> s(pb, relax, rank, w, dom, cut, fringe, (size_t)nthreads);
+            fill(s);
+        }
+        if (out) {
+            out->has_value = c.best_value.has_value() ? 1 : 0;
+            out->is_exact = c.is_exact ? 1 : 0;
+            out->best_value = c.best_value.value_or(-1);
+            out->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            out->n_solution = sol ? (int)sol->size() : 0;
+        }
+        if (sol && sol_values) {
+            for (size_t i = 0; i < pb.nb_variables(); ++i) sol_values[i] = 0;
+            for (const Decision& d : *sol) sol_values[d.variable] = d.value;
+        }
+        return c.best_value.value_or(-1);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "oracle_max2sat_solve_file: %s\n", e.what());
+        return -2;
+    }
+}
+/// nb_vars and number of distinct clauses of a .wcnf file (data.rs:119-126 checks 3 and 4 on debug2.wcnf)
+int oracle_max2sat_instance_info(const char* path, uint64_t* nb_vars, uint64_t* nb_clauses) {
+    try {
+        Weighed2Sat inst = read_max2sat_instance(path);
+        *nb_vars = inst.nb_vars;
+        *nb_clauses = inst.weights.size();
+        return 0;
+    } catch (const std::exception&) {
+        return -2;
+    }
+}
+/// total weight of the clauses satisfied by an assignment (+1 / -1 per variable): independent check of a solution
+int64_t oracle_max2sat_evaluate(const char* path, const int64_t* values) {
+    Weighed2Sat inst = read_max2sat_instance(path);
+    int64_t total = 0;
+    for (const auto& e : inst.weights) {
+        auto sat = [&](isize lit) { return (lit > 0) == (values[(lit < 0 ? -lit : lit) - 1] > 0); };
+        if (sat(e.first.a) || sat(e.first.b)) total += e.second;
+    }
+    return total;
+}
+
 }  // extern "C"

@@ -140,7 +140,26 @@ class Oracle:
                                             C.c_void_p, C.POINTER(SolveOut)]
         L.oracle_knapsack_solve_file.restype = C.c_int64
         L.oracle_knapsack_solve_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(SolveOut)]
+        L.oracle_max2sat_solve_file.restype = C.c_int64
+        L.oracle_max2sat_solve_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_double, C.c_void_p, C.POINTER(SolveOut)]
+        L.oracle_max2sat_instance_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.oracle_max2sat_evaluate.restype = C.c_int64
+        L.oracle_max2sat_evaluate.argtypes = [C.c_char_p, C.c_void_p]
         self.L = L
+
+    def max2sat_file(self, path, width=0, nthreads=0, time_budget_s=0.0):
+        nv, nc = C.c_uint64(0), C.c_uint64(0)
+        assert self.L.oracle_max2sat_instance_info(path.encode(), C.byref(nv), C.byref(nc)) == 0
+        sol = np.zeros(max(1, nv.value), dtype=np.int64)
+        out = SolveOut()
+        v = self.L.oracle_max2sat_solve_file(path.encode(), width, nthreads, time_budget_s, sol.ctypes.data_as(C.c_void_p),
+                                             C.byref(out))
+        d = out.asdict()
+        d["solution"] = [int(x) for x in sol[:nv.value]]
+        d["nb_vars"], d["nb_clauses"] = int(nv.value), int(nc.value)
+        if d["n_solution"]:
+            d["solution_weight"] = int(self.L.oracle_max2sat_evaluate(path.encode(), sol.ctypes.data_as(C.c_void_p)))
+        return int(v), d
 
     def misp(self, path):
         return MispInstance(self, path)

@@ -90,3 +90,32 @@ def test_knapsack_n50_width100_against_dp(oracle):
     assert v == int(best[cap]) and info["is_exact"]
     taken = [i for i, x in enumerate(info["solution"]) if x == 1]
     assert sum(weight[i] for i in taken) <= cap and sum(profit[i] for i in taken) == v
+
+
+# ---- MAX2SAT (the next model family): oracle pinned on examples/max2sat/tests.rs:65-105 and data.rs:119-126 ---------
+MAX2SAT_KAT = [("debug", 24), ("debug2", 13), ("pass", 54), ("tautology", 7), ("unit", 6), ("negative_wt", 4258)]
+
+
+@pytest.mark.parametrize("name,expected", MAX2SAT_KAT)
+@pytest.mark.parametrize("width,threads", [(0, 0), (1, 0), (3, 2)])
+def test_max2sat_small_known_optima(oracle, name, expected, width, threads):
+    v, info = oracle.max2sat_file(data_path("max2sat", name + ".wcnf"), width, threads)
+    assert v == expected and info["is_exact"]
+    assert info["best_lb"] == expected and info["best_ub"] == expected
+    assert info["solution_weight"] == expected      # the decisions really satisfy clauses worth the optimum
+
+
+def test_max2sat_reader(oracle):
+    """data.rs:119-126: debug2.wcnf has 3 variables and 4 clauses (a unit clause written `w x x 0` included)"""
+    _, info = oracle.max2sat_file(data_path("max2sat", "debug2.wcnf"))
+    assert (info["nb_vars"], info["nb_clauses"]) == (3, 4)
+    _, info = oracle.max2sat_file(data_path("max2sat", "frb10-6-1.wcnf"), 2, 0, 0.2)
+    assert info["nb_vars"] == 60
+
+
+@pytest.mark.parametrize("name,expected", [("frb10-6-1", 37037), ("frb10-6-2", 38196), ("frb10-6-3", 36671),
+                                           ("frb10-6-4", 38928)])
+def test_max2sat_frb10_known_optima(oracle, name, expected):
+    """examples/max2sat/tests.rs:89-104 (n = 60, BASELINE config C3's parity instance family)"""
+    v, info = oracle.max2sat_file(data_path("max2sat", name + ".wcnf"), 0, 16)
+    assert v == expected and info["is_exact"] and info["solution_weight"] == expected
