@@ -1,6 +1,7 @@
 // =============================================================================
 // models.hpp -- CPU restatement of the ddo example models that sit on the hot
-// path: MISP (examples/misp/main.rs) and 0/1 knapsack (examples/knapsack/main.rs).
+// path: MISP (examples/misp/main.rs), 0/1 knapsack (examples/knapsack/main.rs) and
+// MAX2SAT (examples/max2sat/{data,model,relax,heuristics}.rs).
 //
 // *** TEST INFRASTRUCTURE (parity oracle + CPU baseline), see ddo_oracle.hpp ***
 //
