@@ -469,6 +469,9 @@ struct ddo_solver {
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[6] / 1e3 / std::max<uint64_t>(1, tl), st_clk[7] / 1e3 / std::max<uint64_t>(1, tl),
                          tc / 1e3 / std::max<uint64_t>(1, tl), tc / 1e6 / a.size());
+            if (engine && engine->kernel_ms() > 0)   // busy share of the slots: sum of per-DD shader clocks vs slots x kernel time
+                std::fprintf(stderr, "[ddo stats] slot utilisation: %.1f %% (sum of DD cycles %.3g over %d slots x %.1f ms of kernels at 2.4 GHz)\n",
+                             100.0 * (double)tc / (2.4e6 * engine->kernel_ms() * engine->nslots()), (double)tc, engine->nslots(), engine->kernel_ms());
             std::fprintf(stderr, "[ddo stats] per layer: lex-ties %.1f lex-selects %.3f digit-rounds %.2f lex-words %.2f (tied at word start %.1f) | worklist %.1f (contain var %.1f) records %.1f victims %.1f squashes %.3f |",
                          (double)st_clk[8] / tl, (double)st_clk[9] / tl, (double)st_clk[10] / tl, (double)st_clk[11] / tl, (double)st_clk[16] / tl,
                          (double)st_clk[12] / tl, (double)st_clk[15] / tl, (double)st_clk[13] / tl, (double)st_clk[14] / tl, (double)st_clk[17] / tl);
