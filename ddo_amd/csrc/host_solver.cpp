@@ -459,12 +459,9 @@ struct ddo_solver {
             for (auto x : st_nodes) tn += x;
             uint64_t tc = 0;
             for (int q = 0; q < 8; ++q) tc += st_clk[q];
-            std::fprintf(stderr, "[ddo stats] device phase share: var %.1f%% select %.1f%% victims+merge %.1f%% worklist %.1f%% freelist %.1f%% expand %.1f%% final %.1f%% backward %.1f%% | host s: pop %.3f run %.3f post %.3f (of which fetch %.3f) | pushes %llu\n",
-                         100.0 * st_clk[0] / std::max<uint64_t>(1, tc), 100.0 * st_clk[1] / std::max<uint64_t>(1, tc), 100.0 * st_clk[2] / std::max<uint64_t>(1, tc),
-                         100.0 * st_clk[3] / std::max<uint64_t>(1, tc), 100.0 * st_clk[4] / std::max<uint64_t>(1, tc), 100.0 * st_clk[5] / std::max<uint64_t>(1, tc),
-                         100.0 * st_clk[6] / std::max<uint64_t>(1, tc), 100.0 * st_clk[7] / std::max<uint64_t>(1, tc), st_host_pop, st_host_run, st_host_post, st_host_fetch,
-                         (unsigned long long)st_push);
-            std::fprintf(stderr, "[ddo stats] device kcycles per layer: misc(var,worklist,freelist,final) %.1f selK1 %.1f selLex %.1f victims+merge %.1f exp1 %.1f table %.1f | exp2 %.1f exp3 %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
+            std::fprintf(stderr, "[ddo stats] host s: pop %.3f run %.3f post %.3f (of which fetch %.3f) | pushes %llu\n", st_host_pop, st_host_run,
+                         st_host_post, st_host_fetch, (unsigned long long)st_push);
+            std::fprintf(stderr, "[ddo stats] device kcycles per layer: misc(var,sweep,freelist,final,backward) %.1f select %.1f classify+tie-break %.1f victims+merge %.1f expand+dedup %.1f (unused %.1f %.1f) hand-over %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
                          st_clk[0] / 1e3 / std::max<uint64_t>(1, tl), st_clk[1] / 1e3 / std::max<uint64_t>(1, tl), st_clk[2] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[6] / 1e3 / std::max<uint64_t>(1, tl), st_clk[7] / 1e3 / std::max<uint64_t>(1, tl),
@@ -475,7 +472,7 @@ struct ddo_solver {
             std::fprintf(stderr, "[ddo stats] per layer: lex-ties %.1f lex-selects %.3f digit-rounds %.2f lex-words %.2f (tied at word start %.1f) | worklist %.1f (contain var %.1f) records %.1f victims %.1f squashes %.3f |",
                          (double)st_clk[8] / tl, (double)st_clk[9] / tl, (double)st_clk[10] / tl, (double)st_clk[11] / tl, (double)st_clk[16] / tl,
                          (double)st_clk[12] / tl, (double)st_clk[15] / tl, (double)st_clk[13] / tl, (double)st_clk[14] / tl, (double)st_clk[17] / tl);
-            for (int q = 18; q < 24; ++q) std::fprintf(stderr, " m%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
+            for (int q = 18; q < 24; ++q) std::fprintf(stderr, " aux%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
             std::fprintf(stderr, " | recycled merges per layer %.4f", (double)st_recycled / tl);
             std::fprintf(stderr, "\n");
             std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
