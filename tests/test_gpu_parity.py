@@ -297,3 +297,40 @@ def test_sharded_search_covers_the_problem(have_gpu):
             s.import_lower_bound(lb)
     assert max(s.best_lower_bound() for s in ranks) == 12
     assert any(s.best_value() == 12 for s in ranks)
+
+
+# ---- (6) maximum sizes: the 16-word state template (n = 600 pads 10 words to 16; n = 1024 is the largest model) ------
+def _write_random_clq(path, n, p_edge, seed, weights=None):
+    rng = np.random.RandomState(seed)
+    with open(path, "w") as f:
+        edges = []
+        for a in range(n):
+            nb = np.nonzero(rng.rand(n - a - 1) < p_edge)[0]
+            edges.extend((a, a + 1 + int(b)) for b in nb)
+        f.write(f"p edge {n} {len(edges)}\n")
+        if weights is not None:
+            for i, wv in enumerate(weights):
+                f.write(f"n {i + 1} {int(wv)}\n")
+        for a, b in edges:
+            f.write(f"e {a + 1} {b + 1}\n")
+
+
+@pytest.mark.parametrize("n,p_edge,width,max_compiles,weighted", [
+    (600, 0.05, 40, 12, False),      # sparse complement graph: dense conflict structure, deep DDs
+    (1024, 0.5, 64, 10, False),      # the largest model the ABI accepts (MAX_WS = 16 words)
+    (1024, 0.9, 300, 6, True),       # weighted: values, rough upper bounds and ranking use the weights
+])
+def test_replay_at_maximum_state_sizes(have_gpu, oracle, tmp_path, n, p_edge, width, max_compiles, weighted):
+    p = tmp_path / f"rand{n}.clq"
+    weights = np.random.RandomState(n).randint(1, 50, size=n) if weighted else None
+    _write_random_clq(p, n, p_edge, seed=n + width, weights=weights)
+    inst = oracle.misp(str(p))
+    model = ddo_amd.Misp.read_instance(str(p))
+    assert model.n == n and model.ws == (n + 63) // 64
+    rows, w = model.export()
+    assert np.array_equal(rows, inst.rows) and np.array_equal(w, inst.weights)
+    _, recs = inst.trace_solve(width, max_compiles)
+    assert recs
+    for i, r, got in replay_records(model, recs):
+        d = diff(r, got)
+        assert d is None, f"n={n} W={width} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
