@@ -58,7 +58,8 @@ class _Counters(C.Structure):
 
 class _SolverConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("width_policy", C.c_int), ("width", C.c_size_t), ("nb_concurrent", C.c_int),
-                ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int), ("fringe", C.c_int)]
+                ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int), ("fringe", C.c_int),
+                ("sequential", C.c_int)]
 
 
 _CUTSET_CB = C.CFUNCTYPE(None, C.POINTER(_SubProblem), C.c_void_p)
@@ -388,7 +389,8 @@ class ParallelSolver:
     (parallel.rs:320-358); relaxation / ranking are carried by the model, dominance is the empty checker,
     the fringe is the NoDupFringe<MaxUB>.  `nb_threads` = sub-problems compiled concurrently on the GPU."""
 
-    def __init__(self, problem, width, cutoff=None, nb_threads=256, device=0, rank=0, world_size=1, fringe="nodup"):
+    def __init__(self, problem, width, cutoff=None, nb_threads=256, device=0, rank=0, world_size=1, fringe="nodup",
+                 sequential=False):
         self.problem = problem
         cfg = _SolverConfig()
         cfg.device = device
@@ -402,6 +404,7 @@ class ParallelSolver:
         cfg.time_budget_s = float(getattr(cutoff, "seconds", 0.0) or 0.0)
         cfg.rank, cfg.world_size = int(rank), int(world_size)
         cfg.fringe = {"nodup": 0, "lazy": 1}[fringe]  # NoDupFringe (exact ddo order) | lazy block SimpleFringe on device
+        cfg.sequential = 1 if sequential else 0
         self._h = lib().ddo_solver_create(problem._h, C.byref(cfg))
         if not self._h:
             raise DdoError("ddo_solver_create failed: " + _err())
@@ -486,4 +489,12 @@ class ParallelSolver:
         return ms.value, n.value
 
 
-DefaultSolver = ParallelSolver  # solver/mod.rs:28
+DefaultSolver = ParallelSolver
+
+
+class SequentialSolver(ParallelSolver):
+    """SequentialSolver (sequential.rs:202-527): one sub-problem at a time, NoDupFringe, and its `explored` bookkeeping."""
+
+    def __init__(self, problem, width, cutoff=None, device=0):
+        super().__init__(problem, width, cutoff=cutoff, nb_threads=1, device=device, fringe="nodup", sequential=True)
+  # solver/mod.rs:28

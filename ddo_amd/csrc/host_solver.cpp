@@ -827,6 +827,9 @@ struct ddo_solver {
         Entry nn;
         while ((int)items.size() < B && fringe->pop(nn)) {
             if (nn.ub <= best_lb) {                          // :531-535 nothing relevant is left
+                // SequentialSolver pops (and counts) every remaining node, each one skipped by
+                // process_one_node (sequential.rs:452-456, 398-400): same outcome, different `explored`
+                if (cfg.sequential) explored += 1 + fringe->len();
                 block_unref(nn.block);
                 fringe->clear();
                 break;

@@ -168,11 +168,14 @@ typedef struct ddo_solver_config {
     int width_policy;      /* DDO_WIDTH_FIXED | DDO_WIDTH_NB_UNASSIGNED                             */
     size_t width;          /* FixedWidth value (ignored for NB_UNASSIGNED)                          */
     int nb_concurrent;     /* sub-problems compiled concurrently on the device == the reference's
-                              nb_threads (parallel.rs:328); 1 reproduces SequentialSolver exactly   */
+                              nb_threads (parallel.rs:328); 1 = the one-thread ParallelSolver         */
     double time_budget_s;  /* <= 0: NoCutoff; else TimeBudget (cutoff.rs:302-323)                   */
     int rank;              /* fringe shard owned by this solver ...                                 */
     int world_size;        /* ... out of this many (1 = whole problem); see ddo_solver_step        */
     int fringe;            /* DDO_FRINGE_NODUP | DDO_FRINGE_LAZY                                    */
+    int sequential;        /* 1 (with nb_concurrent 1, DDO_FRINGE_NODUP): SequentialSolver's bookkeeping
+                              (sequential.rs:433-461: `explored` counts every popped node, also the ones
+                              skipped because ub <= best_lb) instead of ParallelSolver's (parallel.rs:531-553) */
 } ddo_solver_config;
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg);

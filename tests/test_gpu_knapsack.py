@@ -123,3 +123,30 @@ def test_knapsack_n100(have_gpu, oracle, name):
     c = s.maximize()
     assert c.is_exact and c.best_value == opt
     check_solution(s, cap, profit, weight, opt)
+
+
+@pytest.mark.parametrize("name,width", [("f7_l-d_kp_7_50", 1), ("f1_l-d_kp_10_269", 3), ("f10_l-d_kp_20_879", 0)])
+def test_sequential_solver_bookkeeping(have_gpu, oracle, name, width):
+    """BASELINE config C1 runs the reference's SequentialSolver: same counters AND its own `explored` bookkeeping
+    (sequential.rs:433-461 counts every popped node, parallel.rs:531-553 stops counting once ub <= best_lb)."""
+    path = data_path("knapsack", name)
+    model = ddo_amd.Knapsack.read_instance(path)
+    s = ddo_amd.SequentialSolver(model, FixedWidth(width) if width else NbUnassignedWidth(model.n))
+    c = s.maximize()
+    v, ref = oracle.knapsack_file(path, width, 0)        # nthreads = 0: the oracle's SequentialSolver
+    assert c.is_exact and c.best_value == v
+    cnt = s.counters()
+    assert (s.explored(), cnt["nodes_expanded"], cnt["arcs"], cnt["layers"], cnt["compiles"]) == \
+           (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
+
+
+def test_config_c1_sequential(have_gpu, oracle):
+    cap, profit, weight = lcg_instance()
+    model = ddo_amd.Knapsack.from_items(cap, profit, weight)
+    s = ddo_amd.SequentialSolver(model, FixedWidth(100))
+    c = s.maximize()
+    v, ref = oracle.knapsack(profit, weight, cap, 100, 0)
+    assert c.is_exact and c.best_value == v == dp_optimum(cap, profit, weight)
+    cnt = s.counters()
+    assert (s.explored(), cnt["nodes_expanded"], cnt["arcs"], cnt["layers"], cnt["compiles"]) == \
+           (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
