@@ -782,6 +782,8 @@ struct ddo_solver {
             prev_items.swap(flight);
         }
         int rc = engine->launch(inputs.data(), (int)inputs.size());
+        if (want_stats) std::fprintf(stderr, "[ddo stats] launch of %zu sub-problems (fringe %zu open, best_lb %lld, top ub %lld)\n", inputs.size(),
+                                     lazy->len(), (long long)best_lb, (long long)litems[0].ub);
         auto t_run1 = std::chrono::steady_clock::now();
         st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
         if (rc != DDO_OK) {
