@@ -1,7 +1,7 @@
 // =============================================================================
 // models.hpp -- CPU restatement of the ddo example models that sit on the hot
 // path: MISP (examples/misp/main.rs), 0/1 knapsack (examples/knapsack/main.rs) and
-// MAX2SAT (examples/max2sat/{data,model,relax,heuristics}.rs).
+// MAX2SAT (examples/max2sat/{data,model,relax,heuristics}.rs) and MCP (examples/mcp/{graph,model,relax}.rs).
 //
 // *** TEST INFRASTRUCTURE (parity oracle + CPU baseline), see ddo_oracle.hpp ***
 //
@@ -641,6 +641,196 @@ struct Max2SatRanking : StateRanking<Max2SatState> {
     int compare(const Max2SatState& a, const Max2SatState& b) const override {
         const isize x = a.rank(), y = b.rank();
         return x < y ? -1 : (x > y ? 1 : 0);
+    }
+};
+
+// ===========================================================================
+// MCP -- maximum cut  (examples/mcp/{graph.rs, model.rs, relax.rs})
+// ===========================================================================
+/// graph.rs:30-85: adjacency matrix of a weighted undirected graph
+struct McpGraph {
+    size_t nb_vertices = 0;
+    std::vector<isize> adj;
+    explicit McpGraph(size_t n = 0) : nb_vertices(n), adj(n * n, 0) {}
+    isize at(size_t x, size_t y) const { return adj[x * nb_vertices + y]; }
+    void add_bidir_edge(size_t x, size_t y, isize w) {
+        adj[x * nb_vertices + y] = w;
+        adj[y * nb_vertices + x] = w;
+    }
+    /// graph.rs:37-42: halved because every edge sits twice in the matrix
+    isize sum_of_negative_edges() const {
+        isize s = 0;
+        for (isize w : adj)
+            if (w < 0) s += w;
+        return s / 2;
+    }
+};
+/// graph.rs:48-79: "c " comment lines, "<vars> <edges>" (re)creates the graph, "<src> <dst> <w>" adds an edge (1-based)
+inline McpGraph read_mcp_instance(const std::string& fname) {
+    std::ifstream f(fname);
+    if (!f) throw std::runtime_error("io error: cannot open " + fname);
+    static const std::regex graph_decl(R"(^(\d+)\s+(\d+)$)");
+    static const std::regex edge_decl(R"(^(\d+)\s+(\d+)\s+(-?\d+)$)");
+    McpGraph g(0);
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t b = line.find_first_not_of(" \t\r\n"), e = line.find_last_not_of(" \t\r\n");
+        if (b == std::string::npos) continue;
+        line = line.substr(b, e - b + 1);
+        if (line.rfind("c ", 0) == 0) continue;
+        std::smatch m;
+        if (std::regex_match(line, m, graph_decl)) {
+            g = McpGraph((size_t)std::stoull(m[1].str()));
+            continue;
+        }
+        if (std::regex_match(line, m, edge_decl))
+            g.add_bidir_edge((size_t)std::stoull(m[1].str()) - 1, (size_t)std::stoull(m[2].str()) - 1, (isize)std::stoll(m[3].str()));
+    }
+    return g;
+}
+
+/// model.rs:27-31
+struct McpState {
+    std::vector<isize> benef;
+    uint16_t depth = 0;
+    bool operator==(const McpState& o) const { return depth == o.depth && benef == o.benef; }
+};
+template <>
+struct StateHash<McpState> {
+    size_t operator()(const McpState& s) const {
+        uint64_t h = 0;
+        auto mix = [&](uint64_t w) { h = (((h << 5) | (h >> 59)) ^ w) * 0x517cc1b727220a95ULL; };
+        mix((uint64_t)s.benef.size());
+        for (isize x : s.benef) mix((uint64_t)x);
+        mix((uint64_t)s.depth);
+        return (size_t)h;
+    }
+};
+
+/// model.rs:37-130: vertices are assigned to side S (+1) or T (-1) in natural order; the first one is fixed to S
+struct Mcp : Problem<McpState> {
+    static constexpr isize SIDE_S = 1, SIDE_T = -1;
+    McpGraph graph;
+    explicit Mcp(McpGraph g) : graph(std::move(g)) {}
+    size_t nb_variables() const override { return graph.nb_vertices; }
+    McpState initial_state() const override {
+        McpState s;
+        s.benef.assign(nb_variables(), 0);
+        return s;
+    }
+    isize initial_value() const override { return graph.sum_of_negative_edges(); }
+    void for_each_in_domain(Variable var, const McpState& s, DecisionCallback& f) const override {   // model.rs:60-67
+        f.apply(Decision{var.id, SIDE_S});
+        if (s.depth != 0) f.apply(Decision{var.id, SIDE_T});
+    }
+    /// model.rs:69-78: benefits of the variables before the branching one are dropped to 0
+    McpState transition(const McpState& s, Decision d) const override {
+        const size_t n = nb_variables(), x = d.variable;
+        McpState r;
+        r.benef.assign(n, 0);
+        for (size_t v = x; v < n; ++v) r.benef[v] = s.benef[v] + d.value * graph.at(x, v);
+        r.depth = (uint16_t)(1 + s.depth);
+        return r;
+    }
+    /// model.rs:80-86, 99-130
+    isize transition_cost(const McpState& s, const McpState&, Decision d) const override {
+        if (s.depth == 0) return 0;
+        const size_t n = nb_variables(), x = d.variable;
+        auto iabs = [](isize a) { return a < 0 ? -a : a; };
+        isize sum = 0;
+        if (d.value == SIDE_S) {
+            for (size_t v = x; v < n; ++v) {
+                const isize skl = s.benef[v], wkl = graph.at(x, v);
+                if (skl * wkl <= 0) sum += std::min(iabs(skl), iabs(wkl));
+            }
+            return std::max<isize>(0, -s.benef[x]) + sum;
+        }
+        for (size_t v = x; v < n; ++v) {
+            const isize skl = s.benef[v], wkl = graph.at(x, v);
+            if (skl * wkl >= 0) sum += std::min(iabs(skl), iabs(wkl));
+        }
+        return std::max<isize>(0, s.benef[x]) + sum;
+    }
+    std::optional<Variable> next_variable(size_t depth, StateIter<McpState>&) const override {   // model.rs:88-96
+        if (depth < nb_variables()) return Variable{depth};
+        return std::nullopt;
+    }
+};
+
+/// relax.rs:27-184
+struct McpRelax : Relaxation<McpState> {
+    const Mcp& pb;
+    isize vr;
+    std::vector<isize> nk, estimates;
+    explicit McpRelax(const Mcp& p) : pb(p), vr(p.initial_value()) {
+        const size_t n = pb.nb_variables();
+        estimates.assign(n + 1, 0);                    // relax.rs:58-80: positive edges among vertices >= depth
+        for (size_t d = 0; d <= n; ++d) {
+            isize v = 0;
+            for (size_t a = d; a < n; ++a)
+                for (size_t b = a + 1; b < n; ++b)
+                    if (pb.graph.at(a, b) > 0) v += pb.graph.at(a, b);
+            estimates[d] = v;
+        }
+        nk.assign(n + 1, 0);                           // relax.rs:83-106: negative edges among vertices < depth
+        for (size_t d = 0; d <= n; ++d) {
+            isize v = 0;
+            for (size_t j = 0; j < d; ++j)
+                for (size_t i = 0; i < j; ++i)
+                    if (pb.graph.at(i, j) < 0) v += pb.graph.at(i, j);
+            nk[d] = v;
+        }
+    }
+    /// relax.rs:141-176: same sign everywhere -> the value closest to zero; mixed signs -> 0
+    McpState merge(StateIter<McpState>& it) const override {
+        std::vector<const McpState*> nodes;
+        while (const McpState* s = it.next()) nodes.push_back(s);
+        McpState out;
+        out.depth = nodes[0]->depth;
+        out.benef.assign(pb.nb_variables(), 0);
+        for (size_t v = 0; v < pb.nb_variables(); ++v) {
+            bool posi = false, nega = false;
+            for (const McpState* s : nodes) {
+                if (s->benef[v] < 0) nega = true;
+                else if (s->benef[v] > 0) posi = true;
+                if (posi && nega) break;
+            }
+            if (posi && !nega) {
+                isize m = ISIZE_MAX;
+                for (const McpState* s : nodes) m = std::min(m, s->benef[v]);
+                out.benef[v] = m;
+            } else if (nega && !posi) {
+                isize m = ISIZE_MAX;
+                for (const McpState* s : nodes) m = std::min(m, s->benef[v] < 0 ? -s->benef[v] : s->benef[v]);
+                out.benef[v] = -m;
+            }
+        }
+        return out;
+    }
+    /// relax.rs:115-121
+    isize relax(const McpState&, const McpState& dst, const McpState& mrg, Decision, isize c) const override {
+        for (size_t v = 0; v < pb.nb_variables(); ++v) {
+            const isize a = dst.benef[v], b = mrg.benef[v];
+            c += (a < 0 ? -a : a) - (b < 0 ? -b : b);
+        }
+        return c;
+    }
+    /// relax.rs:123-130
+    isize fast_upper_bound(const McpState& s) const override {
+        const size_t k = s.depth;
+        isize marginal = 0;
+        for (size_t v = k; v < s.benef.size(); ++v) marginal += s.benef[v] < 0 ? -s.benef[v] : s.benef[v];
+        return marginal + estimates[k] - vr + nk[k];
+    }
+};
+
+/// model.rs:154-163
+struct McpRanking : StateRanking<McpState> {
+    int compare(const McpState& a, const McpState& b) const override {
+        isize xa = 0, xb = 0;
+        for (isize v : a.benef) xa += v < 0 ? -v : v;
+        for (isize v : b.benef) xb += v < 0 ? -v : v;
+        return xa < xb ? -1 : (xa > xb ? 1 : 0);
     }
 };
 

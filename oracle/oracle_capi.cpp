@@ -496,4 +496,70 @@ int64_t oracle_max2sat_evaluate(const char* path, const int64_t* values) {
     return total;
 }
 
+/// MCP (examples/mcp): solves a .mcp file the way examples/mcp/tests.rs:36-62 does; sol_values receives +1 (side S) /
+/// -1 (side T) per vertex.  Returns the optimum (-1: none, -2: io error).
+int64_t oracle_mcp_solve_file(const char* path, uint64_t width, int nthreads, int64_t* sol_values, oracle_solve_out* out) {
+    try {
+        Mcp pb(read_mcp_instance(path));
+        McpRelax relax(pb);
+        McpRanking rank;
+        FixedWidth<McpState> fixed(width);
+        NbUnassignedWidth<McpState> unassigned(pb.nb_variables());
+        const WidthHeuristic<McpState>& w = width ? (const WidthHeuristic<McpState>&)fixed : unassigned;
+        EmptyDominanceChecker<McpState> dom;
+        NoCutoff cut;
+        MaxUB<McpState> mx(rank);
+        NoDupFringe<McpState> fringe(mx);
+        Completion c;
+        std::optional<Solution> sol;
+        auto t0 = std::chrono::steady_clock::now();
+        auto fill = [&](auto& s) {
+            c = s.maximize();
+            sol = s.best_solution();
+            if (out) {
+                out->explored = s.explored();
+                out->best_lb = s.best_lower_bound();
+                out->best_ub = s.best_upper_bound();
+                out->nodes_expanded = s.counters().nodes_expanded;
+                out->arcs = s.counters().arcs;
+                out->layers = s.counters().layers;
+                out->compiles = s.counters().compiles;
+            }
+        };
+        if (nthreads <= 0) {
+            SequentialSolver<McpState> s(pb, relax, rank, w, dom, cut, fringe);
+            fill(s);
+        } else {
+            ParallelSolver<McpState> s(pb, relax, rank, w, dom, cut, fringe, (size_t)nthreads);
+            fill(s);
+        }
+        if (out) {
+            out->has_value = c.best_value.has_value() ? 1 : 0;
+            out->is_exact = c.is_exact ? 1 : 0;
+            out->best_value = c.best_value.value_or(-1);
+            out->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            out->n_solution = sol ? (int)sol->size() : 0;
+        }
+        if (sol && sol_values) {
+            for (size_t i = 0; i < pb.nb_variables(); ++i) sol_values[i] = 0;
+            for (const Decision& d : *sol) sol_values[d.variable] = d.value;
+        }
+        return c.best_value.value_or(-1);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "oracle_mcp_solve_file: %s\n", e.what());
+        return -2;
+    }
+}
+/// number of vertices of a .mcp file and the weight of the cut defined by `sides` (+1 / -1 per vertex): independent check
+int64_t oracle_mcp_cut_weight(const char* path, const int64_t* sides, uint64_t* nb_vertices) {
+    McpGraph g = read_mcp_instance(path);
+    if (nb_vertices) *nb_vertices = g.nb_vertices;
+    int64_t total = 0;
+    if (sides)
+        for (size_t a = 0; a < g.nb_vertices; ++a)
+            for (size_t b = a + 1; b < g.nb_vertices; ++b)
+                if (sides[a] * sides[b] < 0) total += g.at(a, b);
+    return total;
+}
+
 }  // extern "C"

@@ -145,7 +145,24 @@ class Oracle:
         L.oracle_max2sat_instance_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.oracle_max2sat_evaluate.restype = C.c_int64
         L.oracle_max2sat_evaluate.argtypes = [C.c_char_p, C.c_void_p]
+        L.oracle_mcp_solve_file.restype = C.c_int64
+        L.oracle_mcp_solve_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(SolveOut)]
+        L.oracle_mcp_cut_weight.restype = C.c_int64
+        L.oracle_mcp_cut_weight.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_uint64)]
         self.L = L
+
+    def mcp_file(self, path, width=0, nthreads=0):
+        nv = C.c_uint64(0)
+        self.L.oracle_mcp_cut_weight(path.encode(), None, C.byref(nv))
+        sol = np.zeros(max(1, nv.value), dtype=np.int64)
+        out = SolveOut()
+        v = self.L.oracle_mcp_solve_file(path.encode(), width, nthreads, sol.ctypes.data_as(C.c_void_p), C.byref(out))
+        d = out.asdict()
+        d["solution"] = [int(x) for x in sol[:nv.value]]
+        d["nb_vertices"] = int(nv.value)
+        if d["n_solution"]:
+            d["cut_weight"] = int(self.L.oracle_mcp_cut_weight(path.encode(), sol.ctypes.data_as(C.c_void_p), None))
+        return int(v), d
 
     def max2sat_file(self, path, width=0, nthreads=0, time_budget_s=0.0):
         nv, nc = C.c_uint64(0), C.c_uint64(0)

@@ -119,3 +119,22 @@ def test_max2sat_frb10_known_optima(oracle, name, expected):
     """examples/max2sat/tests.rs:89-104 (n = 60, BASELINE config C3's parity instance family)"""
     v, info = oracle.max2sat_file(data_path("max2sat", name + ".wcnf"), 0, 16)
     assert v == expected and info["is_exact"] and info["solution_weight"] == expected
+
+
+# ---- MCP (maximum cut): oracle pinned on examples/mcp/tests.rs:64-103 ----------------------------------------------
+MCP_KAT = [("000", 13), ("001", 18), ("002", 15), ("003", 19), ("004", 16), ("005", 19), ("006", 12), ("007", 18),
+           ("008", 20), ("009", 22)]
+
+
+@pytest.mark.parametrize("idx,expected", MCP_KAT)
+def test_mcp_known_optima(oracle, idx, expected):
+    v, info = oracle.mcp_file(data_path("mcp", f"mcp_n30_p0.1_{idx}.mcp"), 0, 8)
+    assert info["nb_vertices"] == 30
+    assert v == expected and info["is_exact"]
+    assert info["cut_weight"] == expected and info["solution"][0] == 1     # the first vertex is fixed on side S
+
+
+def test_mcp_sequential_and_fixed_width(oracle):
+    for width, threads in ((0, 0), (5, 0), (50, 2)):
+        v, info = oracle.mcp_file(data_path("mcp", "mcp_n30_p0.1_006.mcp"), width, threads)
+        assert v == 12 and info["cut_weight"] == 12
