@@ -296,6 +296,112 @@ struct EmptyDominanceChecker : DominanceChecker<S> {
 };
 
 // ---------------------------------------------------------------------------
+// abstraction/dominance.rs:37-98 + implementation/dominance/simple.rs:28-117
+// ---------------------------------------------------------------------------
+/// dominance.rs:30-35
+struct DominanceCmpResult {
+    int ordering;          // <0, 0, >0
+    bool only_val_diff;
+};
+/// `Dominance` (dominance.rs:37-98).  A policy P provides:
+///   using Key = ...; struct KeyHash / KeyEq;  std::optional<Key> get_key(std::shared_ptr<const S>) const;
+///   size_t nb_dimensions(const S&) const;  isize get_coordinate(const S&, size_t) const;  bool use_value() const;
+template <class S, class P>
+struct DominanceOps {
+    /// dominance.rs:57-80
+    static std::optional<DominanceCmpResult> partial_cmp(const P& p, const S& a, isize va, const S& b, isize vb) {
+        int ordering = 0;
+        for (size_t i = 0; i < p.nb_dimensions(a); ++i) {
+            const isize ca = p.get_coordinate(a, i), cb = p.get_coordinate(b, i);
+            const int c = ca < cb ? -1 : (ca > cb ? 1 : 0);
+            if ((ordering < 0 && c > 0) || (ordering > 0 && c < 0)) return std::nullopt;
+            if (ordering == 0 && c != 0) ordering = c;
+        }
+        if (p.use_value()) {
+            const int c = va < vb ? -1 : (va > vb ? 1 : 0);
+            if ((ordering < 0 && c > 0) || (ordering > 0 && c < 0)) return std::nullopt;
+            if (ordering == 0 && c != 0) return DominanceCmpResult{c, true};
+            return DominanceCmpResult{ordering, false};
+        }
+        return DominanceCmpResult{ordering, false};
+    }
+    /// dominance.rs:82-98
+    static int cmp(const P& p, const S& a, isize va, const S& b, isize vb) {
+        if (p.use_value()) {
+            if (va < vb) return -1;
+            if (va > vb) return 1;
+        }
+        for (size_t i = 0; i < p.nb_dimensions(a); ++i) {
+            const isize ca = p.get_coordinate(a, i), cb = p.get_coordinate(b, i);
+            if (ca < cb) return -1;
+            if (ca > cb) return 1;
+        }
+        return 0;
+    }
+};
+/// dominance/simple.rs:28-117 (the DashMap becomes one mutex-protected map per depth)
+template <class S, class P>
+struct SimpleDominanceChecker : DominanceChecker<S> {
+    struct Entry {
+        std::shared_ptr<const S> state;
+        isize value;
+    };
+    using Map = std::unordered_map<typename P::Key, std::vector<Entry>, typename P::KeyHash, typename P::KeyEq>;
+    P dominance;
+    std::vector<Map> data;
+    std::vector<std::unique_ptr<std::mutex>> locks;
+    SimpleDominanceChecker(P p, size_t nb_variables) : dominance(std::move(p)), data(nb_variables + 1) {
+        for (size_t i = 0; i <= nb_variables; ++i) locks.emplace_back(new std::mutex());
+    }
+    void clear_layer(size_t depth) override {
+        std::lock_guard<std::mutex> g(*locks[depth]);
+        data[depth].clear();
+    }
+    /// simple.rs:67-111
+    DominanceCheckResult is_dominated_or_insert(std::shared_ptr<const S> state, size_t depth, isize value) override {
+        auto key = dominance.get_key(state);
+        if (!key) return {false, std::nullopt};
+        std::lock_guard<std::mutex> g(*locks[depth]);
+        auto it = data[depth].find(*key);
+        if (it == data[depth].end()) {
+            data[depth].emplace(*key, std::vector<Entry>{Entry{state, value}});
+            return {false, std::nullopt};
+        }
+        bool dominated = false;
+        std::optional<isize> threshold = ISIZE_MAX;
+        std::vector<Entry>& entries = it->second;
+        size_t w = 0;
+        for (size_t i = 0; i < entries.size(); ++i) {   // Vec::retain
+            const Entry& other = entries[i];
+            bool keep = true;
+            auto c = DominanceOps<S, P>::partial_cmp(dominance, *state, value, *other.state, other.value);
+            if (c) {
+                if (c->ordering < 0) {
+                    dominated = true;
+                    if (dominance.use_value()) {
+                        const isize t = c->only_val_diff ? sat_sub(other.value, 1) : other.value;
+                        if (t < *threshold) threshold = t;
+                    }
+                } else {
+                    keep = false;   // equal or dominated by the new state
+                }
+            }
+            if (keep) {
+                if (w != i) entries[w] = entries[i];
+                ++w;
+            }
+        }
+        entries.resize(w);
+        if (!dominated) {
+            threshold = std::nullopt;
+            entries.push_back(Entry{state, value});
+        }
+        return {dominated, threshold};
+    }
+    int cmp(const S& a, isize va, const S& b, isize vb) const override { return DominanceOps<S, P>::cmp(dominance, a, va, b, vb); }
+};
+
+// ---------------------------------------------------------------------------
 // implementation/heuristics/{width,cutoff,subproblem_ranking}.rs
 // ---------------------------------------------------------------------------
 /// width.rs:166-171

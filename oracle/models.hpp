@@ -1,7 +1,8 @@
 // =============================================================================
 // models.hpp -- CPU restatement of the ddo example models that sit on the hot
 // path: MISP (examples/misp/main.rs), 0/1 knapsack (examples/knapsack/main.rs) and
-// MAX2SAT (examples/max2sat/{data,model,relax,heuristics}.rs) and MCP (examples/mcp/{graph,model,relax}.rs).
+// MAX2SAT (examples/max2sat/{data,model,relax,heuristics}.rs), MCP (examples/mcp/{graph,model,relax}.rs) and TSPTW
+// (examples/tsptw/{instance,state,model,relax,heuristics,dominance}.rs).
 //
 // *** TEST INFRASTRUCTURE (parity oracle + CPU baseline), see ddo_oracle.hpp ***
 //
@@ -832,6 +833,338 @@ struct McpRanking : StateRanking<McpState> {
         for (isize v : b.benef) xb += v < 0 ? -v : v;
         return xa < xb ? -1 : (xa > xb ? 1 : 0);
     }
+};
+
+// ===========================================================================
+// TSPTW -- travelling salesman with time windows
+// (examples/tsptw/{instance.rs, state.rs, model.rs, relax.rs, heuristics.rs, dominance.rs})
+// ===========================================================================
+/// `smallbitset::Set256` (crate smallbitset 0.7.1, Cargo.lock; source not under /root/reference): a 256-bit set with
+/// ascending iteration; restated from its use in examples/tsptw.
+struct Set256 {
+    uint64_t w[4] = {0, 0, 0, 0};
+    void add(size_t i) { w[i >> 6] |= 1ULL << (i & 63); }
+    void remove(size_t i) { w[i >> 6] &= ~(1ULL << (i & 63)); }
+    bool contains(size_t i) const { return (w[i >> 6] >> (i & 63)) & 1ULL; }
+    void union_with(const Set256& o) { for (int k = 0; k < 4; ++k) w[k] |= o.w[k]; }
+    void inter_with(const Set256& o) { for (int k = 0; k < 4; ++k) w[k] &= o.w[k]; }
+    void diff_with(const Set256& o) { for (int k = 0; k < 4; ++k) w[k] &= ~o.w[k]; }
+    Set256 flip() const { Set256 r; for (int k = 0; k < 4; ++k) r.w[k] = ~w[k]; return r; }
+    size_t len() const { size_t c = 0; for (int k = 0; k < 4; ++k) c += (size_t)__builtin_popcountll(w[k]); return c; }
+    bool operator==(const Set256& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+    template <class F>
+    void for_each(F f) const {   // ascending; f returns false to stop
+        for (int k = 0; k < 4; ++k) {
+            uint64_t x = w[k];
+            while (x) {
+                size_t i = (size_t)k * 64 + (size_t)__builtin_ctzll(x);
+                x &= x - 1;
+                if (!f(i)) return;
+            }
+        }
+    }
+};
+
+/// instance.rs:27-109
+struct TsptwTimeWindow {
+    size_t earliest, latest;
+};
+struct TsptwInstance {
+    uint16_t nb_nodes = 0;
+    std::vector<std::vector<size_t>> distances;
+    std::vector<TsptwTimeWindow> timewindows;
+};
+/// `(x * 10000.0) as usize` on an f32 (instance.rs:87, 97-98): single-precision product, truncated, saturating at 0
+inline size_t tsptw_fixed_point(const std::string& tok) {
+    const float v = std::strtof(tok.c_str(), nullptr);
+    const float m = v * 10000.0f;
+    if (!(m > 0.0f)) return 0;
+    return (size_t)m;
+}
+inline TsptwInstance read_tsptw_instance(const std::string& fname) {
+    std::ifstream f(fname);
+    if (!f) throw std::runtime_error("io error: cannot open " + fname);
+    TsptwInstance inst;
+    size_t lc = 0;
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t b = line.find_first_not_of(" \t\r\n"), e = line.find_last_not_of(" \t\r\n");
+        if (b == std::string::npos) continue;
+        line = line.substr(b, e - b + 1);
+        if (line[0] == '#') continue;
+        std::istringstream ss(line);
+        std::string tok;
+        if (lc == 0) {
+            ss >> tok;
+            inst.nb_nodes = (uint16_t)std::stoul(tok);
+            inst.distances.assign(inst.nb_nodes, std::vector<size_t>(inst.nb_nodes, 0));
+        } else if (lc >= 1 && lc <= inst.nb_nodes) {
+            size_t j = 0;
+            while (ss >> tok) {
+                if (j < inst.nb_nodes) inst.distances[lc - 1][j] = tsptw_fixed_point(tok);
+                ++j;
+            }
+        } else {
+            std::string a, c;
+            ss >> a >> c;
+            inst.timewindows.push_back(TsptwTimeWindow{tsptw_fixed_point(a), tsptw_fixed_point(c)});
+        }
+        lc += 1;
+    }
+    return inst;
+}
+
+/// state.rs:34-101.  Position: a node, or (relaxed) one node among a set; elapsed time: fixed or an interval
+struct TsptwState {
+    bool pos_virtual = false;
+    uint16_t pos_node = 0;
+    Set256 pos_set;
+    bool fuzzy = false;
+    size_t t_earliest = 0, t_latest = 0;      // fixed: both = duration
+    Set256 must_visit;
+    bool has_maybe = false;
+    Set256 maybe_visit;
+    uint16_t depth = 0;
+    bool same_position(const TsptwState& o) const {
+        return pos_virtual == o.pos_virtual && (pos_virtual ? pos_set == o.pos_set : pos_node == o.pos_node);
+    }
+    bool operator==(const TsptwState& o) const {
+        return same_position(o) && fuzzy == o.fuzzy && t_earliest == o.t_earliest && t_latest == o.t_latest &&
+               must_visit == o.must_visit && has_maybe == o.has_maybe && (!has_maybe || maybe_visit == o.maybe_visit) &&
+               depth == o.depth;
+    }
+    size_t earliest() const { return t_earliest; }
+};
+template <>
+struct StateHash<TsptwState> {
+    size_t operator()(const TsptwState& s) const {
+        uint64_t h = 0;
+        auto mix = [&](uint64_t w) { h = (((h << 5) | (h >> 59)) ^ w) * 0x517cc1b727220a95ULL; };
+        mix(s.pos_virtual);
+        if (s.pos_virtual) for (int k = 0; k < 4; ++k) mix(s.pos_set.w[k]);
+        else mix(s.pos_node);
+        mix(s.fuzzy);
+        mix(s.t_earliest);
+        mix(s.t_latest);
+        for (int k = 0; k < 4; ++k) mix(s.must_visit.w[k]);
+        mix(s.has_maybe);
+        if (s.has_maybe) for (int k = 0; k < 4; ++k) mix(s.maybe_visit.w[k]);
+        mix(s.depth);
+        return (size_t)h;
+    }
+};
+
+/// model.rs:30-217
+struct Tsptw : Problem<TsptwState> {
+    TsptwInstance instance;
+    TsptwState initial;
+    explicit Tsptw(TsptwInstance inst) : instance(std::move(inst)) {
+        for (size_t i = 1; i < instance.nb_nodes; ++i) initial.must_visit.add(i);
+    }
+    size_t nb_variables() const override { return instance.nb_nodes; }
+    TsptwState initial_state() const override { return initial; }
+    isize initial_value() const override { return 0; }
+
+    size_t min_distance_to(const TsptwState& s, size_t j) const {   // model.rs:194-204
+        if (!s.pos_virtual) return instance.distances[s.pos_node][j];
+        size_t m = std::numeric_limits<size_t>::max();
+        s.pos_set.for_each([&](size_t i) { m = std::min(m, instance.distances[i][j]); return true; });
+        return m;
+    }
+    size_t max_distance_to(const TsptwState& s, size_t j) const {   // model.rs:205-215
+        if (!s.pos_virtual) return instance.distances[s.pos_node][j];
+        size_t m = 0;
+        s.pos_set.for_each([&](size_t i) { m = std::max(m, instance.distances[i][j]); return true; });
+        return m;
+    }
+    bool can_move_to(const TsptwState& s, size_t j) const {          // model.rs:150-157
+        return s.t_earliest + min_distance_to(s, j) <= instance.timewindows[j].latest;
+    }
+    /// model.rs:65-94
+    void for_each_in_domain(Variable var, const TsptwState& s, DecisionCallback& f) const override {
+        if ((size_t)s.depth == nb_variables() - 1) {
+            if (can_move_to(s, 0)) f.apply(Decision{var.id, 0});
+            return;
+        }
+        bool ok = true;
+        s.must_visit.for_each([&](size_t i) { ok = can_move_to(s, i); return ok; });
+        if (!ok) return;
+        s.must_visit.for_each([&](size_t i) { f.apply(Decision{var.id, (isize)i}); return true; });
+        if (s.has_maybe)
+            s.maybe_visit.for_each([&](size_t i) {
+                if (can_move_to(s, i)) f.apply(Decision{var.id, (isize)i});
+                return true;
+            });
+    }
+    /// model.rs:95-115 with arrival_time :158-193
+    TsptwState transition(const TsptwState& s, Decision d) const override {
+        const size_t j = (size_t)d.value;
+        TsptwState r;
+        r.must_visit = s.must_visit;
+        r.must_visit.remove(j);
+        r.has_maybe = s.has_maybe;
+        r.maybe_visit = s.maybe_visit;
+        if (r.has_maybe) r.maybe_visit.remove(j);
+        r.pos_virtual = false;
+        r.pos_node = (uint16_t)j;
+        r.depth = (uint16_t)(s.depth + 1);
+        // earliest / latest arrival if we never had to wait
+        size_t mn = s.t_earliest + min_distance_to(s, j);
+        size_t mx = (s.fuzzy ? s.t_latest : s.t_earliest) + max_distance_to(s, j);
+        const TsptwTimeWindow tw = instance.timewindows[j];
+        if (mn == mx) {
+            r.fuzzy = false;
+            r.t_earliest = r.t_latest = std::max(mn, tw.earliest);
+        } else {
+            size_t e = std::max(mn, tw.earliest), l = std::min(mx, tw.latest);
+            if (e == l) {
+                r.fuzzy = false;
+                r.t_earliest = r.t_latest = e;
+            } else {
+                r.fuzzy = true;
+                r.t_earliest = e;
+                r.t_latest = l;
+            }
+        }
+        return r;
+    }
+    /// model.rs:116-139: minimisation seen as maximisation of the negated travel + waiting time
+    isize transition_cost(const TsptwState& s, const TsptwState&, Decision d) const override {
+        const size_t j = (size_t)d.value;
+        const size_t travel = min_distance_to(s, j);
+        const size_t arrive = s.t_earliest + travel;
+        const size_t waiting = arrive < instance.timewindows[j].earliest ? instance.timewindows[j].earliest - arrive : 0;
+        return -(isize)(travel + waiting);
+    }
+    std::optional<Variable> next_variable(size_t depth, StateIter<TsptwState>&) const override {   // model.rs:140-147
+        if (depth == nb_variables()) return std::nullopt;
+        return Variable{depth};
+    }
+};
+
+/// relax.rs:32-265
+struct TsptwRelax : Relaxation<TsptwState> {
+    const Tsptw& pb;
+    std::vector<size_t> cheapest_edge;
+    explicit TsptwRelax(const Tsptw& p) : pb(p) {     // relax.rs:50-63: cheapest edge ENTERING each node
+        const size_t n = pb.nb_variables();
+        for (size_t i = 0; i < n; ++i) {
+            size_t m = std::numeric_limits<size_t>::max();
+            for (size_t j = 0; j < n; ++j)
+                if (i != j) m = std::min(m, pb.instance.distances[j][i]);
+            cheapest_edge.push_back(m);
+        }
+    }
+    /// relax.rs:169-191 with RelaxHelper :65-166
+    TsptwState merge(StateIter<TsptwState>& it) const override {
+        uint16_t depth = 0;
+        Set256 position, all_must, all_maybe;
+        Set256 all_agree = Set256().flip();
+        size_t earliest = std::numeric_limits<size_t>::max(), latest = 0;
+        while (const TsptwState* s = it.next()) {
+            depth = std::max(depth, s->depth);
+            if (s->pos_virtual) position.union_with(s->pos_set);
+            else position.add(s->pos_node);
+            earliest = std::min(earliest, s->t_earliest);
+            latest = std::max(latest, s->fuzzy ? s->t_latest : s->t_earliest);
+            all_agree.inter_with(s->must_visit);
+            all_must.union_with(s->must_visit);
+            if (s->has_maybe) all_maybe.union_with(s->maybe_visit);
+        }
+        TsptwState r;
+        r.depth = depth;
+        r.pos_virtual = true;
+        r.pos_set = position;
+        r.fuzzy = earliest != latest;
+        r.t_earliest = earliest;
+        r.t_latest = r.fuzzy ? latest : earliest;
+        r.must_visit = all_agree;
+        Set256 maybe = all_maybe;
+        maybe.union_with(all_must);
+        maybe.diff_with(all_agree);
+        r.has_maybe = maybe.len() > 0;
+        if (r.has_maybe) r.maybe_visit = maybe;
+        return r;
+    }
+    isize relax(const TsptwState&, const TsptwState&, const TsptwState&, Decision, isize cost) const override { return cost; }
+    /// relax.rs:196-264
+    isize fast_upper_bound(const TsptwState& s) const override {
+        size_t complete_tour = pb.nb_variables() - (size_t)s.depth;
+        std::vector<size_t> tmp;
+        size_t mandatory = 0;
+        size_t back_to_depot = std::numeric_limits<size_t>::max();
+        bool infeasible = false;
+        s.must_visit.for_each([&](size_t i) {
+            complete_tour -= 1;
+            mandatory += cheapest_edge[i];
+            back_to_depot = std::min(back_to_depot, pb.instance.distances[i][0]);
+            if (s.t_earliest + cheapest_edge[i] > pb.instance.timewindows[i].latest) {
+                infeasible = true;
+                return false;
+            }
+            return true;
+        });
+        if (infeasible) return ISIZE_MIN;
+        if (s.has_maybe) {
+            size_t violations = 0;
+            s.maybe_visit.for_each([&](size_t i) {
+                tmp.push_back(cheapest_edge[i]);
+                back_to_depot = std::min(back_to_depot, pb.instance.distances[i][0]);
+                if (s.t_earliest + cheapest_edge[i] > pb.instance.timewindows[i].latest) violations += 1;
+                return true;
+            });
+            if (tmp.size() - violations < complete_tour) return ISIZE_MIN;
+            std::sort(tmp.begin(), tmp.end());
+            for (size_t k = 0; k < complete_tour && k < tmp.size(); ++k) mandatory += tmp[k];
+        }
+        if (mandatory == 0) {
+            size_t here;
+            if (!s.pos_virtual) here = pb.instance.distances[s.pos_node][0];
+            else {
+                here = std::numeric_limits<size_t>::max();
+                s.pos_set.for_each([&](size_t x) { here = std::min(here, pb.instance.distances[x][0]); return true; });
+            }
+            back_to_depot = std::min(back_to_depot, here);
+        }
+        const size_t total = mandatory + back_to_depot;
+        if (s.t_earliest + total > pb.instance.timewindows[0].latest) return ISIZE_MIN;
+        return -(isize)total;
+    }
+};
+
+/// heuristics.rs:26-51
+struct TsptwRanking : StateRanking<TsptwState> {
+    int compare(const TsptwState& a, const TsptwState& b) const override {
+        return a.depth < b.depth ? -1 : (a.depth > b.depth ? 1 : 0);
+    }
+};
+struct TsptwWidth : WidthHeuristic<TsptwState> {
+    size_t nb_vars, factor;
+    TsptwWidth(size_t n, size_t f) : nb_vars(n), factor(f) {}
+    size_t max_width(const SubProblem<TsptwState>& sp) const override { return nb_vars * (sp.depth + 1) * factor; }
+};
+
+/// dominance.rs:26-60: states with the same (position, must_visit) are compared on their value alone
+struct TsptwDominance {
+    using Key = std::shared_ptr<const TsptwState>;
+    struct KeyHash {
+        size_t operator()(const Key& k) const {
+            uint64_t h = 0;
+            auto mix = [&](uint64_t w) { h = (((h << 5) | (h >> 59)) ^ w) * 0x517cc1b727220a95ULL; };
+            mix(k->pos_virtual);
+            if (k->pos_virtual) for (int i = 0; i < 4; ++i) mix(k->pos_set.w[i]);
+            else mix(k->pos_node);
+            for (int i = 0; i < 4; ++i) mix(k->must_visit.w[i]);
+            return (size_t)h;
+        }
+    };
+    struct KeyEq {
+        bool operator()(const Key& a, const Key& b) const { return a->same_position(*b) && a->must_visit == b->must_visit; }
+    };
+    std::optional<Key> get_key(std::shared_ptr<const TsptwState> s) const { return s; }
+    size_t nb_dimensions(const TsptwState&) const { return 0; }
+    isize get_coordinate(const TsptwState&, size_t) const { return 0; }
+    bool use_value() const { return true; }
 };
 
 }  // namespace ddo

@@ -562,4 +562,68 @@ int64_t oracle_mcp_cut_weight(const char* path, const int64_t* sides, uint64_t* 
     return total;
 }
 
+/// TSPTW (examples/tsptw): solves a .dat file the way examples/tsptw/tests.rs:32-57 does -- DefaultCachingSolver
+/// (frontier cut-set + SimpleCache), SimpleDominanceChecker(TsptwDominance), TsptwWidth(n, factor), NoDupFringe, MaxUB.
+/// tour (n entries, may be null) receives the visiting order.  Returns the best value (= -10000 x tour length), or
+/// INT64_MIN when no tour exists / INT64_MIN + 1 on io errors.
+int64_t oracle_tsptw_solve_file(const char* path, uint64_t width_factor, int nthreads, int64_t* tour, oracle_solve_out* out) {
+    try {
+        Tsptw pb(read_tsptw_instance(path));
+        TsptwRelax relax(pb);
+        TsptwRanking rank;
+        TsptwWidth width(pb.nb_variables(), width_factor ? (size_t)width_factor : 1);
+        SimpleDominanceChecker<TsptwState, TsptwDominance> dom(TsptwDominance(), pb.nb_variables());
+        NoCutoff cut;
+        MaxUB<TsptwState> mx(rank);
+        NoDupFringe<TsptwState> fringe(mx);
+        auto t0 = std::chrono::steady_clock::now();
+        ParallelSolver<TsptwState, DefaultMDDFC<TsptwState>, SimpleCache<TsptwState>> s(pb, relax, rank, width, dom, cut, fringe,
+                                                                                          (size_t)(nthreads > 0 ? nthreads : 1));
+        Completion c = s.maximize();
+        std::optional<Solution> sol = s.best_solution();
+        if (out) {
+            out->explored = s.explored();
+            out->best_lb = s.best_lower_bound();
+            out->best_ub = s.best_upper_bound();
+            out->nodes_expanded = s.counters().nodes_expanded;
+            out->arcs = s.counters().arcs;
+            out->layers = s.counters().layers;
+            out->compiles = s.counters().compiles;
+            out->has_value = c.best_value.has_value() ? 1 : 0;
+            out->is_exact = c.is_exact ? 1 : 0;
+            out->best_value = c.best_value.value_or(0);
+            out->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            out->n_solution = sol ? (int)sol->size() : 0;
+        }
+        if (sol && tour) {
+            for (size_t i = 0; i < pb.nb_variables(); ++i) tour[i] = -1;
+            for (const Decision& d : *sol) tour[d.variable] = d.value;   // variable k = k-th move of the tour
+        }
+        return c.best_value ? (int64_t)*c.best_value : INT64_MIN;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "oracle_tsptw_solve_file: %s\n", e.what());
+        return INT64_MIN + 1;
+    }
+}
+/// Independent check of a tour (the visiting order after the depot, ending with 0): total travel + waiting time in
+/// 1/10000 units, or -1 when a time window is missed / a node is visited twice.
+int64_t oracle_tsptw_tour_length(const char* path, const int64_t* tour, uint64_t* nb_nodes) {
+    TsptwInstance inst = read_tsptw_instance(path);
+    if (nb_nodes) *nb_nodes = inst.nb_nodes;
+    if (!tour) return -1;
+    std::vector<char> seen(inst.nb_nodes, 0);
+    size_t here = 0, now = 0;
+    for (size_t k = 0; k < inst.nb_nodes; ++k) {
+        if (tour[k] < 0 || tour[k] >= inst.nb_nodes) return -1;
+        const size_t j = (size_t)tour[k];
+        if (seen[j] || (j == 0 && k + 1 != inst.nb_nodes)) return -1;
+        seen[j] = 1;
+        now += inst.distances[here][j];
+        if (now < inst.timewindows[j].earliest) now = inst.timewindows[j].earliest;
+        if (now > inst.timewindows[j].latest) return -1;
+        here = j;
+    }
+    return here == 0 ? (int64_t)now : -1;
+}
+
 }  // extern "C"

@@ -149,7 +149,24 @@ class Oracle:
         L.oracle_mcp_solve_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(SolveOut)]
         L.oracle_mcp_cut_weight.restype = C.c_int64
         L.oracle_mcp_cut_weight.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.oracle_tsptw_solve_file.restype = C.c_int64
+        L.oracle_tsptw_solve_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(SolveOut)]
+        L.oracle_tsptw_tour_length.restype = C.c_int64
+        L.oracle_tsptw_tour_length.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_uint64)]
         self.L = L
+
+    def tsptw_file(self, path, width_factor=1, nthreads=1):
+        nn = C.c_uint64(0)
+        self.L.oracle_tsptw_tour_length(path.encode(), None, C.byref(nn))
+        tour = np.full(max(1, nn.value), -1, dtype=np.int64)
+        out = SolveOut()
+        v = self.L.oracle_tsptw_solve_file(path.encode(), width_factor, nthreads, tour.ctypes.data_as(C.c_void_p), C.byref(out))
+        d = out.asdict()
+        d["tour"] = [int(x) for x in tour[:nn.value]]
+        d["nb_nodes"] = int(nn.value)
+        if d["n_solution"]:
+            d["tour_length"] = int(self.L.oracle_tsptw_tour_length(path.encode(), tour.ctypes.data_as(C.c_void_p), None))
+        return int(v), d
 
     def mcp_file(self, path, width=0, nthreads=0):
         nv = C.c_uint64(0)

@@ -138,3 +138,39 @@ def test_mcp_sequential_and_fixed_width(oracle):
     for width, threads in ((0, 0), (5, 0), (50, 2)):
         v, info = oracle.mcp_file(data_path("mcp", "mcp_n30_p0.1_006.mcp"), width, threads)
         assert v == 12 and info["cut_weight"] == 12
+
+
+# ---- TSPTW: oracle (with SimpleCache, frontier cut-set and SimpleDominanceChecker) pinned on examples/tsptw/tests.rs ----
+TSPTW_KAT = [
+    ("N20ft301", 661.6), ("N20ft302", 703.0), ("N20ft303", 746.4), ("N20ft304", 817.0), ("N20ft305", 724.7), ("N20ft306", 729.5),
+    ("N20ft307", 691.8), ("N20ft308", 788.2), ("N20ft309", 751.8), ("N20ft310", 693.8), ("N20ft401", 660.9), ("N20ft402", 701.0),
+    ("N20ft403", 746.4), ("N20ft404", 817.0), ("N20ft405", 724.7), ("N20ft406", 728.5), ("N20ft407", 691.8), ("N20ft408", 786.1),
+    ("N20ft409", 749.8), ("N20ft410", 693.8), ("N40ft201", 1109.3), ("N40ft202", 1017.4), ("N40ft203", 903.1), ("N40ft204", 897.4),
+    ("N40ft205", 983.6), ("N40ft206", 1081.9), ("N40ft207", 884.9), ("N40ft208", 1051.6), ("N40ft209", 1027.5), ("N40ft210", 1035.3),
+    ("N40ft401", 1105.2), ("N40ft402", 1016.4), ("N40ft403", 903.1), ("N40ft404", 897.4), ("N40ft405", 982.6), ("N40ft406", 1081.9),
+    ("N40ft407", 872.2), ("N40ft408", 1043.5), ("N40ft409", 1025.5), ("N40ft410", 1034.3), ("N60ft201", 1375.4), ("N60ft202", 1186.4),
+    ("N60ft203", 1194.2), ("N60ft204", 1283.6), ("N60ft205", 1215.5), ("N60ft206", 1238.8), ("N60ft207", 1305.3), ("N60ft208", 1172.6),
+    ("N60ft209", 1243.8), ("N60ft210", 1273.2), ("N60ft301", 1375.4), ("N60ft302", 1184.4), ("N60ft303", 1194.2), ("N60ft304", 1283.6),
+    ("N60ft305", 1214.5), ("N60ft306", 1237.8), ("N60ft307", 1298.4), ("N60ft308", 1168.8), ("N60ft309", 1242.8), ("N60ft310", 1273.2),
+    ("N60ft401", 1375.4), ("N60ft402", 1183.4), ("N60ft403", 1194.2), ("N60ft404", 1283.6), ("N60ft405", 1212.5), ("N60ft406", 1236.8),
+    ("N60ft407", 1296.4), ("N60ft408", 1150.0), ("N60ft409", 1241.8), ("N60ft410", 1273.2),
+]
+
+
+@pytest.mark.parametrize("name,expected", TSPTW_KAT)
+def test_tsptw_langevin(oracle, name, expected):
+    """tests.rs:81-499, every non-ignored Langevin case (`solve_langevin`: width factor 1, one thread):
+    tour length = -value / 10000, compared in f32 like the reference does"""
+    path = data_path("tsptw", "Langevin", name + ".dat")
+    v, info = oracle.tsptw_file(path, 1, 1)
+    n = int(name[1:3])
+    assert info["nb_nodes"] == n and info["has_value"]
+    assert np.float32(-v) / np.float32(10000.0) == np.float32(expected)
+    assert info["tour_length"] == -v and info["tour"][-1] == 0 and sorted(info["tour"]) == list(range(n))
+
+
+def test_tsptw_config_c5_instance(oracle):
+    """tests.rs:201-203, the BASELINE config C5 instance family (n = 40): 1109.30"""
+    v, info = oracle.tsptw_file(data_path("tsptw", "Langevin", "N40ft201.dat"), 1, 4)
+    assert np.float32(-v) / np.float32(10000.0) == np.float32(1109.30)
+    assert info["tour_length"] == -v
