@@ -128,6 +128,7 @@ struct EngineParams {
     uint8_t* cls;              // [slot][capC1]          0 none / 1 kept / 2 deleted
     uint32_t* ninfo;           // [slot][max_layers][capN]   best arc + flags per node per layer
     uint32_t* arct;            // [slot][max_layers][2*capN] arc -> child position (relaxed, below LEL)
+    int32_t* arcc;             // [slot][max_layers][2*capN] arc cost (as relaxed when the arc was redirected to a merged node)
     int32_t* nlayer;           // [slot][max_layers]     nodes per layer
     int32_t* lvar;             // [slot][max_layers]     variable branched below each layer
     int32_t* ldup;             // [slot][max_layers][2]  recycled-merge duplicate (from pos, to pos)

@@ -255,7 +255,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers, wsT = model->wsT;
     size_t per_slot = engine_kind_ == 1
                           ? 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
-                                ml * capN * 4 + ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
+                                ml * capN * 4 + 2 * ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
                                 (table_lds_ ? 0 : (size_t)P.table_cap * 4)
                           : wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 * (((wsT + 8) / 8) * 8 + ((wsT + 7) / 8) * 8) +
                                 (size_t)P.capS * 12 + capN * 4 + P.ev_cap * 4 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
@@ -316,6 +316,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
         if ((rc = dev_alloc(allocs_, P.cls, S * capC1))) return rc;
         if ((rc = dev_alloc(allocs_, P.ninfo, S * ml * capN))) return rc;
         if ((rc = dev_alloc(allocs_, P.arct, S * ml * 2 * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.arcc, S * ml * 2 * capN))) return rc;
     } else {
         const size_t capS = P.capS, capW = P.capW;
         const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;

@@ -177,6 +177,7 @@ struct DDCtx {
     uint8_t* cls;
     uint32_t* ninfo;
     uint32_t* arct;
+    int32_t* arcc;       // arc costs, same indexing as arct (written when the arc is created)
     int32_t* nlayer;
     int32_t* lvar;
     int32_t* ldup;
@@ -286,8 +287,9 @@ DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth
 /// the merged node of a relaxed layer at 2*capN.
 DDO_DEV int lin2cand(int j, int nprev, int capN) { return j < nprev ? j : capN + (j - nprev); }
 
-/// 48-bit primary ranking key: (value_top, popcount) -- clean.rs:803-808 then MispRanking's len().
-DDO_DEV uint64_t k1_of(uint64_t key, uint32_t pop) { return ((key >> 32) << 16) | (uint64_t)(pop & 0xFFFFu); }
+/// 64-bit primary ranking key: (value_top, secondary rank) -- clean.rs:803-808, then the model's StateRanking where it is a
+/// number: MispRanking's len() (popcount), 0 for knapsack, later the 32-bit rank of the signed-vector models.
+DDO_DEV uint64_t k1_of(uint64_t key, uint32_t pop) { return (key & 0xFFFFFFFF00000000ULL) | (uint64_t)pop; }
 
 /// Workgroup exclusive scan of a[0..NT) (Hillis-Steele, double buffered); total in *total.
 template <class Ctx>
@@ -365,8 +367,8 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
     bool done = false;
     const uint64_t diff = sh->k1and ^ sh->k1or;
     uint64_t pivK1 = 0;
-    // ---- primary key: 6 bytes, most significant first
-    for (int b = 5; b >= 0 && !done; --b) {
+    // ---- primary key: 8 bytes, most significant first (bytes that are constant over the layer cost nothing)
+    for (int b = 7; b >= 0 && !done; --b) {
         const int shift = 8 * b;
         if (((diff >> shift) & 0xFF) == 0) {
             pivK1 |= sh->k1and & (0xFFULL << shift);
@@ -381,7 +383,7 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
             int cd = lin2cand(j, nprev, c.capN);
             if (c.ctarget[cd] == (uint32_t)cd) {
                 uint64_t k1 = k1_of(LD_U64(&key[cd]), pop[cd]);
-                bool active = (shift + 8 >= 48) || ((k1 >> (shift + 8)) == (pivK1 >> (shift + 8)));
+                bool active = (shift + 8 >= 64) || ((k1 >> (shift + 8)) == (pivK1 >> (shift + 8)));
                 if (active) LDS_ADD_U32(&c.hist[(k1 >> shift) & 0xFF], 1u);
             }
         }
@@ -848,6 +850,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         const uint64_t vbit = 1ULL << (var & 63);
         const int32_t wv = c.weight[var];
         const uint64_t kpw = kp ? (uint64_t)c.kp_weight[var] : 0;
+        int32_t* ac_next = c.arcc + (size_t)(L + 1) * 2 * capN;   // costs of the arcs entering layer L + 1
         int myarcs = 0, myuniq = 0;
         for (int pos = tid; pos < n; pos += NT) {
             const uint32_t p = c.keep[pos];
@@ -891,6 +894,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = s[k];
                 const uint64_t mykey = ((uint64_t)bias32(val) << 32) | cd;
                 c.ckey[nxt][cd] = mykey;
+                ac_next[cd] = 0;                                   // transition_cost of NO / LEAVE_IT_OUT
                 c.cpop[nxt][cd] = (uint32_t)(pop - ((hasv && !kp) ? 1 : 0));
                 c.cflags[nxt][cd] = inexact;
                 FENCE_BLOCK();
@@ -923,6 +927,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
                 const uint64_t mykey = ((uint64_t)bias32(val + wv) << 32) | cd;
                 c.ckey[nxt][cd] = mykey;
+                ac_next[cd] = wv;                                  // transition_cost of YES / TAKE_IT
                 c.cpop[nxt][cd] = (uint32_t)ypop;
                 c.cflags[nxt][cd] = inexact;
                 FENCE_BLOCK();
@@ -1108,14 +1113,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             PAR_END
             PAR_BEGIN
             const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
-            const int32_t wv = c.weight[c.lvar[Lc - 1]];
+            const int32_t* ac = c.arcc + (size_t)Lc * 2 * capN;
             const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
             for (int j = tid; j < 2 * nP; j += NT) {
                 const int d = j >= nP ? 1 : 0;
                 const int pp = j - d * nP;
                 const uint32_t t = at[d * capN + pp];
                 if (t == NONE32) continue;
-                const int32_t cost = d ? wv : 0;
+                const int32_t cost = ac[d * capN + pp];
                 int32_t v = vbA[t];
                 if (v != VB_UNMARKED) LDS_MAX_I32(&vbB[pp], v + cost);
                 if ((int)t == dfrom) {  // arcs of the re-added node were also redirected (clean.rs:851-866)
@@ -1363,6 +1368,7 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.cls = P.cls + s * capC1;
     c.ninfo = P.ninfo + s * ml * capN;
     c.arct = P.arct + s * ml * 2 * capN;
+    c.arcc = P.arcc + s * ml * 2 * capN;
     c.nlayer = P.nlayer + s * ml;
     c.lvar = P.lvar + s * ml;
     c.ldup = P.ldup + s * ml * 2;

@@ -101,7 +101,7 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
     P.nslots = 1;
     const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers;
     size_t bytes = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
-                   ml * capN * 4 + ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 + 64 * 32;
+                   ml * capN * 4 + 2 * ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 + 64 * 32;
     e->mem.assign(bytes, 0xCD);  // poison
     unsigned char* p = e->mem.data();
     P.cstate = carve<uint64_t>(p, 2 * wsT * capC1);
@@ -114,6 +114,7 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
     P.cls = carve<uint8_t>(p, capC1);
     P.ninfo = carve<uint32_t>(p, ml * capN);
     P.arct = carve<uint32_t>(p, ml * 2 * capN);
+    P.arcc = carve<int32_t>(p, ml * 2 * capN);
     P.nlayer = carve<int32_t>(p, ml);
     P.lvar = carve<int32_t>(p, ml);
     P.ldup = carve<int32_t>(p, ml * 2);
