@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # every symbol include/ddo_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ddo_last_error", "ddo_device_count", "ddo_model_create_misp", "ddo_model_read_misp", "ddo_model_create_knapsack",
-    "ddo_model_read_knapsack", "ddo_model_destroy",
+    "ddo_model_read_knapsack", "ddo_model_create_mcp", "ddo_model_read_mcp", "ddo_model_destroy",
     "ddo_model_nb_variables", "ddo_model_state_words", "ddo_model_initial_state", "ddo_model_initial_value",
     "ddo_model_compare_states", "ddo_model_export_misp", "ddo_mdd_create", "ddo_mdd_destroy", "ddo_mdd_compile",
     "ddo_mdd_compile_batch", "ddo_mdd_is_exact", "ddo_mdd_best_value", "ddo_mdd_best_exact_value",
@@ -90,6 +90,10 @@ def lib():
     L.ddo_model_create_knapsack.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
     L.ddo_model_read_knapsack.restype = C.c_void_p
     L.ddo_model_read_knapsack.argtypes = [C.c_char_p]
+    L.ddo_model_create_mcp.restype = C.c_void_p
+    L.ddo_model_create_mcp.argtypes = [C.c_int, C.c_void_p]
+    L.ddo_model_read_mcp.restype = C.c_void_p
+    L.ddo_model_read_mcp.argtypes = [C.c_char_p]
     L.ddo_model_destroy.argtypes = [C.c_void_p]
     L.ddo_model_nb_variables.argtypes = [C.c_void_p]
     L.ddo_model_state_words.argtypes = [C.c_void_p]
@@ -286,6 +290,29 @@ class Knapsack(Misp):
         weight = np.ascontiguousarray(weight, dtype=np.int64)
         return cls(lib().ddo_model_create_knapsack(len(profit), int(capacity), profit.ctypes.data_as(C.c_void_p),
                                                    weight.ctypes.data_as(C.c_void_p)))
+
+
+class Mcp(Misp):
+    """Maximum-cut model == `Mcp` + `McpRelax` + `McpRanking` (examples/mcp); the state is n signed benefits (two per
+    word) followed by a depth word; decisions are +1 (side S) / -1 (side T)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise DdoError("could not create the max-cut model: " + _err())
+        self._h = handle
+        L = lib()
+        self.n = L.ddo_model_nb_variables(handle)
+        self.ws = L.ddo_model_state_words(handle)
+
+    @classmethod
+    def read_instance(cls, path):  # graph.rs:48
+        return cls(lib().ddo_model_read_mcp(os.fspath(path).encode()))
+
+    @classmethod
+    def from_matrix(cls, adj):
+        adj = np.ascontiguousarray(adj, dtype=np.int64)
+        assert adj.ndim == 2 and adj.shape[0] == adj.shape[1]
+        return cls(lib().ddo_model_create_mcp(adj.shape[0], adj.ctypes.data_as(C.c_void_p)))
 
 class Mdd:
     """`impl DecisionDiagram for Mdd<T, LAST_EXACT_LAYER>` (mdd.rs:75-114) on the device."""

@@ -20,7 +20,7 @@ constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr int CT_EXACT = 0, CT_RELAXED = 1, CT_RESTRICTED = 2;
 
 // EngineParams.model_kind
-constexpr int MODEL_MISP = 0, MODEL_KNAPSACK = 1;
+constexpr int MODEL_MISP = 0, MODEL_KNAPSACK = 1, MODEL_MCP = 2;
 
 // DDInput.flags
 constexpr uint32_t IN_FUSED = 1u;          // restricted, then (if inexact) relaxed: parallel.rs:391-437 on device
@@ -155,6 +155,13 @@ struct EngineParams {
     int32_t pad2;
     const int32_t* kp_weight;  // knapsack: item weights [n]   (`weight` holds the profits)
     const int32_t* kp_order;   // knapsack: items by decreasing profit / weight [n]
+    // maximum cut (examples/mcp): states are n signed benefits packed two per word + a depth word
+    const int32_t* vgraph;     // [n][n] edge weights
+    const int32_t* vest;       // [n+1]  estimates (relax.rs:58-80)
+    const int32_t* vnk;        // [n+1]  nk        (relax.rs:83-106)
+    int32_t vr;                // initial value (sum of the negative edge weights)
+    int32_t pad3;
+    int32_t* lddelta;          // [slot][max_layers] relax delta of the node re-added by a recycled merge
     int32_t lex_cap;           // tie lists up to this size (<= 1024) are split by rank counting in LDS, longer ones by radix rounds
     int32_t pad1;
     uint64_t* s_state;         // [slot][ws][capS]  node states, word major (streaming scan copy)

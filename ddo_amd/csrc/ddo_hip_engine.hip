@@ -120,11 +120,24 @@ int Model::popcount(const uint64_t* a) const {
 }
 void Model::initial_state(uint64_t* out) const {
     for (int k = 0; k < ws; ++k) out[k] = 0;
+    if (kind == MODEL_MCP) return;                                              // mcp/model.rs:51-53: no benefit yet, depth 0
     if (kind == MODEL_KNAPSACK) out[0] = (uint64_t)kp_capacity;                 // knapsack/main.rs:100-102
     else for (int i = 0; i < n; ++i) out[i / 64] |= 1ULL << (i % 64);           // misp/main.rs:69-71
 }
 int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
     if (kind == MODEL_KNAPSACK) return a[0] < b[0] ? -1 : (a[0] > b[0] ? 1 : 0);   // KPRanking (knapsack/main.rs:187-194)
+    if (kind == MODEL_MCP) {                                                        // McpRanking (mcp/model.rs:154-163)
+        auto rank = [&](const uint64_t* s) {
+            int64_t r = 0;
+            for (int v = 0; v < n; ++v) {
+                const int32_t x = (int32_t)(uint32_t)(s[v >> 1] >> (32 * (v & 1)));
+                r += x < 0 ? -(int64_t)x : x;
+            }
+            return r;
+        };
+        const int64_t ra = rank(a), rb = rank(b);
+        return ra < rb ? -1 : (ra > rb ? 1 : 0);
+    }
     int pa = popcount(a), pb = popcount(b);
     if (pa != pb) return pa < pb ? -1 : 1;
     // equal popcounts: at the lowest differing member, the set owning it is the smaller one
@@ -202,7 +215,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     P.unit_weights = model->unit_weights ? 1 : 0;
     P.npad = (model->n + 63) / 64 * 64;
     // the terminal layer is never squashed (clean.rs:608-618): MISP ends in at most one node, a knapsack DD in up to 2W
-    P.capN = model->kind == MODEL_KNAPSACK ? 2 * (int)max_width + 3 : (int)max_width + 2;
+    P.capN = model->kind != MODEL_MISP ? 2 * (int)max_width + 3 : (int)max_width + 2;
     P.capC1 = 2 * P.capN + 1;
     P.max_layers = model->n + 2;
     int tc = 1024;
@@ -303,6 +316,19 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
         P.kp_weight = d_kw;
         P.kp_order = d_ko;
     }
+    if (model->kind == MODEL_MCP) {
+        int32_t *d_g = nullptr, *d_e = nullptr, *d_k = nullptr;
+        if ((rc = dev_alloc(allocs_, d_g, model->vgraph.size()))) return rc;
+        if ((rc = dev_alloc(allocs_, d_e, model->vest.size()))) return rc;
+        if ((rc = dev_alloc(allocs_, d_k, model->vnk.size()))) return rc;
+        HIP_TRY(hipMemcpy(d_g, model->vgraph.data(), model->vgraph.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_e, model->vest.data(), model->vest.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_k, model->vnk.data(), model->vnk.size() * 4, hipMemcpyHostToDevice));
+        P.vgraph = d_g;
+        P.vest = d_e;
+        P.vnk = d_k;
+        P.vr = (int32_t)model->initial_value;
+    }
 
     // ---- workspace
     if (engine_kind_ == 1) {
@@ -317,6 +343,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
         if ((rc = dev_alloc(allocs_, P.ninfo, S * ml * capN))) return rc;
         if ((rc = dev_alloc(allocs_, P.arct, S * ml * 2 * capN))) return rc;
         if ((rc = dev_alloc(allocs_, P.arcc, S * ml * 2 * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.lddelta, S * ml))) return rc;
     } else {
         const size_t capS = P.capS, capW = P.capW;
         const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
@@ -701,6 +728,65 @@ ddo_model* ddo_model_create_knapsack(int n, int64_t capacity, const int64_t* pro
     return m;
 }
 
+ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix) {
+    const int ws = (n + 1) / 2 + 1;   // two benefits per word + the depth word
+    if (n < 1 || !adj_matrix || ws > MAX_WS) {
+        set_error("ddo_model_create_mcp: 1 <= n <= 30 vertices are supported (two benefits per word, 16 words per state)");
+        return nullptr;
+    }
+    int64_t abs_sum = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            if (adj_matrix[(size_t)i * n + j] != adj_matrix[(size_t)j * n + i]) {
+                set_error("ddo_model_create_mcp: the adjacency matrix must be symmetric");
+                return nullptr;
+            }
+            abs_sum += std::llabs(adj_matrix[(size_t)i * n + j]);
+        }
+    if (abs_sum >= (1LL << 28)) {
+        set_error("ddo_model_create_mcp: sum of |weights| must stay below 2^27 (device values are int32)");
+        return nullptr;
+    }
+    ddo_model* m = new ddo_model();
+    Model& M = m->m;
+    M.kind = MODEL_MCP;
+    M.n = n;
+    M.ws = ws;
+    M.wsT = pick_ws(ws);
+    M.unit_weights = false;
+    M.weight.assign(n, 0);
+    M.weight_abs_sum = abs_sum;
+    M.vgraph.resize((size_t)n * n);
+    int64_t neg = 0;
+    for (size_t i = 0; i < M.vgraph.size(); ++i) {
+        M.vgraph[i] = (int32_t)adj_matrix[i];
+        if (adj_matrix[i] < 0) neg += adj_matrix[i];
+    }
+    M.initial_value = neg / 2;                        // graph.rs:37-42: every edge sits twice in the matrix
+    auto w = [&](int a, int b) { return (int64_t)M.vgraph[(size_t)a * n + b]; };
+    M.vest.assign(n + 1, 0);                          // relax.rs:58-80: positive edges among the vertices >= depth
+    M.vnk.assign(n + 1, 0);                           // relax.rs:83-106: negative edges among the vertices < depth
+    for (int d = 0; d <= n; ++d) {
+        int64_t e = 0, k = 0;
+        for (int a = d; a < n; ++a)
+            for (int b = a + 1; b < n; ++b)
+                if (w(a, b) > 0) e += w(a, b);
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i < j; ++i)
+                if (w(i, j) < 0) k += w(i, j);
+        M.vest[d] = (int32_t)e;
+        M.vnk[d] = (int32_t)k;
+    }
+    return m;
+}
+
+ddo_model* ddo_model_read_mcp(const char* path) {
+    int n = 0;
+    std::vector<int64_t> adj;
+    if (!path || !read_mcp(path, n, adj)) return nullptr;
+    return ddo_model_create_mcp(n, adj.data());
+}
+
 ddo_model* ddo_model_read_knapsack(const char* path) {
     int64_t capacity = 0;
     std::vector<int64_t> profit, weight;
@@ -725,7 +811,7 @@ int ddo_model_initial_state(const ddo_model* model, uint64_t* out) {
     model->m.initial_state(out);
     return DDO_OK;
 }
-int64_t ddo_model_initial_value(const ddo_model*) { return 0; }  // main.rs:73-75
+int64_t ddo_model_initial_value(const ddo_model* model) { return model ? model->m.initial_value : 0; }  // Problem::initial_value
 int ddo_model_compare_states(const ddo_model* model, const uint64_t* a, const uint64_t* b) {
     return model->m.compare_states(a, b);
 }
@@ -862,7 +948,7 @@ static int emit_path(const ddo_mdd* mdd, const std::vector<uint32_t>& p, ddo_dec
     }
     size_t k = 0;
     for (const ddo_decision& d : mdd->path_to_root) buf[k++] = d;
-    for (uint32_t x : p) buf[k++] = ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)};
+    for (uint32_t x : p) buf[k++] = ddo_decision{(int64_t)(x >> 1), mdd->model->decision_value(x & 1)};
     *len = need;
     return 1;
 }
@@ -885,7 +971,7 @@ int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
         path = mdd->path_to_root;
         for (int k = 0; k < r.cs_path_len; ++k) {
             uint32_t x = r.cs_path[(size_t)i * r.cs_path_len + k];
-            path.push_back(ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)});
+            path.push_back(ddo_decision{(int64_t)(x >> 1), mdd->model->decision_value(x & 1)});
         }
         ddo_subproblem sp;
         sp.state = r.cs_state.data() + (size_t)i * ws;

@@ -33,7 +33,14 @@ struct Model {
     int64_t kp_capacity = 0;
     std::vector<int64_t> kp_weight;  // [n]
     std::vector<int32_t> kp_order;   // [n]   items by decreasing profit / weight (main.rs:66-70)
+    // maximum cut (examples/mcp/{graph,model,relax}.rs): `Mcp` + `McpRelax` + `McpRanking`; the state is the vector of n
+    // signed benefits, two per word, followed by a depth word
+    std::vector<int32_t> vgraph;     // [n][n] symmetric edge weights
+    std::vector<int32_t> vest, vnk;  // [n+1] each (relax.rs:58-106)
+    int64_t initial_value = 0;       // Problem::initial_value (MCP: sum of the negative edge weights)
     void initial_state(uint64_t* out) const;   // Problem::initial_state
+    /// decision value of the device's decision bit: MISP / knapsack 0 | 1, MCP +1 (side S) | -1 (side T)
+    int64_t decision_value(uint32_t bit) const { return kind == MODEL_MCP ? (bit ? -1 : 1) : (int64_t)bit; }
 
     std::mutex mtx;
     std::map<std::pair<int, long>, std::weak_ptr<class Engine>> engines;  // (device, max_width)
@@ -159,6 +166,8 @@ bool read_misp_clq(const std::string& path, int& n, std::vector<uint64_t>& rows,
 /// Reads a knapsack instance the way examples/knapsack/main.rs:267-303 does ("n capacity", then n lines "profit weight";
 /// lines starting with 'c' are comments).
 bool read_knapsack(const std::string& path, int64_t& capacity, std::vector<int64_t>& profit, std::vector<int64_t>& weight);
+/// Reads a max-cut instance the way examples/mcp/graph.rs:48-79 does ("c " comments, "<vertices> <edges>", "<src> <dst> <w>").
+bool read_mcp(const std::string& path, int& n, std::vector<int64_t>& adj);
 
 }  // namespace ddo_hip
 

@@ -61,7 +61,7 @@ void block_unref(CutsetBlock* b) {
 }
 
 /// path of (block,row) from the problem root: parent path first, then this row's decisions
-void materialize_path(const CutsetBlock* b, int row, std::vector<ddo_decision>& out) {
+void materialize_path(const Model* model, const CutsetBlock* b, int row, std::vector<ddo_decision>& out) {
     std::vector<std::pair<const CutsetBlock*, int>> chain;
     while (b) {
         chain.push_back({b, row});
@@ -71,7 +71,7 @@ void materialize_path(const CutsetBlock* b, int row, std::vector<ddo_decision>& 
     for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
         const CutsetBlock* blk = it->first;
         const uint32_t* p = blk->paths.data() + (size_t)it->second * blk->path_len;
-        for (int k = 0; k < blk->path_len; ++k) out.push_back(ddo_decision{(int64_t)(p[k] >> 1), (int64_t)(p[k] & 1)});
+        for (int k = 0; k < blk->path_len; ++k) out.push_back(ddo_decision{(int64_t)(p[k] >> 1), model->decision_value(p[k] & 1)});
     }
 }
 
@@ -507,8 +507,8 @@ struct ddo_solver {
         root->ws = model->ws;
         root->states.assign(model->ws, 0);
         model->initial_state(root->states.data());   // Problem::initial_state
-        root->values.push_back(0);
-        Entry e{root, 0, 0, 0, I64_MAX, hash_words(root->states.data(), model->ws)};
+        root->values.push_back((int32_t)model->initial_value);
+        Entry e{root, 0, 0, model->initial_value, I64_MAX, hash_words(root->states.data(), model->ws)};
         block_ref(root);   // keep alive while pushing
         fringe->push(e);
         block_unref(root);
@@ -521,9 +521,9 @@ struct ddo_solver {
         if (v > best_lb) {
             best_lb = v;
             best_sol.clear();
-            materialize_path(it.block, it.row, best_sol);
+            materialize_path(model, it.block, it.row, best_sol);
             const std::vector<uint32_t>& p = r.hdr.exact_same_as_best ? r.best_path : r.exact_path;
-            for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)});
+            for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), model->decision_value(x & 1)});
             has_sol = true;
         }
     }
@@ -624,7 +624,7 @@ struct ddo_solver {
                     best_sol.clear();
                     if ((err = materialize_pool_path(its[i].block, its[i].row, best_sol)) != DDO_OK) break;
                     const std::vector<uint32_t>& p = r->hdr.exact_same_as_best ? r->best_path : r->exact_path;
-                    for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), (int64_t)(x & 1)});
+                    for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), model->decision_value(x & 1)});
                     has_sol = true;
                 }
                 const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;

@@ -150,6 +150,10 @@ struct DDShared {
     uint64_t nodes, arcs;
     uint64_t arena_off;
     int32_t xcand[64];   // per-lane partial results of the recycled-merge search
+    // signed-vector models (MCP): per-variable reductions of a merge (relax.rs:141-176) and the merged node's rank
+    uint32_t vmin[64];
+    uint64_t vposmask, vnegmask;
+    int32_t mrank, xdelta;
 };
 
 /// Everything one workgroup needs: model, slot-local workspace and LDS carve-up.
@@ -164,6 +168,12 @@ struct DDCtx {
     int depth0;                 // depth of the residual sub-problem (static variable order: main.rs:118-125)
     const int32_t* kp_weight;   // item weights
     const int32_t* kp_order;    // items by decreasing profit/weight
+    // maximum cut (examples/mcp/{model,relax}.rs): kind == MODEL_MCP
+    const int32_t* vgraph;
+    const int32_t* vest;
+    const int32_t* vnk;
+    int32_t vr;
+    int32_t* lddelta;
     // capacity
     int capN, capC1, max_layers;
     // slot workspace
@@ -245,12 +255,36 @@ DDO_DEV void add_bits(CP cnt, const uint64_t* s, int delta) {
 /// lexicographic ranking word: MISP orders states by member lists (BitSet::cmp) = brev(~word) descending;
 /// knapsack ranks by remaining capacity (examples/knapsack/main.rs:187-194)
 template <class Ctx>
-DDO_DEV uint64_t lexkey(const Ctx& c, uint64_t w) { return c.kind == MODEL_KNAPSACK ? w : dd_brev(~w); }
+DDO_DEV uint64_t lexkey(const Ctx& c, uint64_t w) { return c.kind != MODEL_MISP ? w : dd_brev(~w); }
+
+/// Signed-vector states (MCP): benefit v sits in half (v & 1) of word v / 2; the word after the last pair is the depth.
+template <int WS>
+DDO_DEV int32_t vec_get(const uint64_t* s, int v) {
+    int32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < WS; ++k)
+        if (k == (v >> 1)) r = (int32_t)(uint32_t)(s[k] >> (32 * (v & 1)));
+    return r;
+}
+DDO_DEV int32_t iabs32(int32_t x) { return x < 0 ? -x : x; }
+/// sum of |benefit| over the variables >= from (from = 0: McpRanking's key, model.rs:154-163)
+template <int WS>
+DDO_DEV int32_t vec_rank(const uint64_t* s, int n, int from) {
+    int32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        if (2 * k >= from && 2 * k < n) r += iabs32((int32_t)(uint32_t)s[k]);
+        if (2 * k + 1 >= from && 2 * k + 1 < n) r += iabs32((int32_t)(uint32_t)(s[k] >> 32));
+    }
+    return r;
+}
 
 /// Relaxation::fast_upper_bound: MISP main.rs:191-193; knapsack main.rs:158-184 (fractional bound over the remaining
 /// items in ratio order; the only floating point on the path: cap/weight * profit, floored)
 template <int WS>
 DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth) {
+    if (c.kind == MODEL_MCP)   // mcp/relax.rs:123-130
+        return vec_rank<WS>(s, c.n, depth) + c.vest[depth] - c.vr + c.vnk[depth];
     if (c.kind == MODEL_KNAPSACK) {
         int64_t cap = (int64_t)s[0];
         int64_t max_profit = 0;
@@ -564,6 +598,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         int pop = 0;
         if (c.kind == MODEL_MISP)
             for (int k = 0; k < WS; ++k) pop += dd_popc(in.state[k]);
+        if (c.kind == MODEL_MCP) pop = vec_rank<WS>(in.state, c.n, 0);
         c.ckey[0][0] = ((uint64_t)bias32(in.value) << 32) | NONE32;
         c.cpop[0][0] = (uint32_t)pop;
         c.cflags[0][0] = 0;
@@ -592,8 +627,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         PAR_END
         PAR_BEGIN
-        if (c.kind == MODEL_KNAPSACK) {   // static order (knapsack/main.rs:118-125); an empty layer ends the DD
-            if (tid == 0 && c.depth0 + L < c.n && sh->nU > 0) sh->varkey = (uint32_t)c.kp_order[c.depth0 + L];
+        if (c.kind != MODEL_MISP) {   // static order (knapsack/main.rs:118-125, mcp/model.rs:88-96); an empty layer ends the DD
+            if (tid == 0 && c.depth0 + L < c.n && sh->nU > 0)
+                sh->varkey = c.kind == MODEL_MCP ? (uint32_t)(c.depth0 + L) : (uint32_t)c.kp_order[c.depth0 + L];
         } else {
             for (int i = tid; i < c.n; i += NT) {
                 int cv = c.cnt[i];
@@ -651,6 +687,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (tid == 0) {
             sh->mergedKey = 0;
             for (int k = 0; k < WS; ++k) sh->merged[k] = 0;
+            for (int v = 0; v < 64; ++v) sh->vmin[v] = 0xFFFFFFFFu;
+            sh->vposmask = 0;
+            sh->vnegmask = 0;
+            sh->mrank = 0;
+            sh->xdelta = 0;
             sh->recycled = 0;
             sh->dup_from = -1;
             sh->dup_to = -1;
@@ -679,7 +720,32 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 #pragma unroll
                         for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + cd];
                         if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);  // it leaves the layer
-                        if (relaxed) {
+                        if (relaxed && c.kind == MODEL_MCP) {
+                            // McpRelax::merge (relax.rs:141-176): per variable the signs seen and the smallest |benefit|;
+                            // relax (relax.rs:115-121) adds rank(victim) - rank(merged) to every redirected arc, so the
+                            // merged node's value is max(value + rank) over the victims minus its own rank
+                            uint64_t pm = 0, nm = 0;
+#pragma unroll
+                            for (int k = 0; k < WS; ++k) {
+                                const int32_t a0 = (int32_t)(uint32_t)s[k], a1 = (int32_t)(uint32_t)(s[k] >> 32);
+                                if (2 * k < c.n) {
+                                    LDS_MIN_U32(&sh->vmin[2 * k], (uint32_t)iabs32(a0));
+                                    if (a0 > 0) pm |= 1ULL << (2 * k);
+                                    if (a0 < 0) nm |= 1ULL << (2 * k);
+                                }
+                                if (2 * k + 1 < c.n) {
+                                    LDS_MIN_U32(&sh->vmin[2 * k + 1], (uint32_t)iabs32(a1));
+                                    if (a1 > 0) pm |= 1ULL << (2 * k + 1);
+                                    if (a1 < 0) nm |= 1ULL << (2 * k + 1);
+                                }
+                            }
+                            if (pm) LDS_OR_U64(&sh->vposmask, pm);
+                            if (nm) LDS_OR_U64(&sh->vnegmask, nm);
+                            const int32_t adj = unbias32((uint32_t)(key >> 32)) + (int32_t)c.cpop[cur][cd];
+                            const uint64_t akey = ((uint64_t)bias32(adj) << 32) | (uint32_t)key;
+                            if (akey > mkey) mkey = akey;
+                            anydel = true;
+                        } else if (relaxed) {
                             if (c.kind == MODEL_KNAPSACK) {   // KPRelax::merge: the largest capacity (main.rs:150-152)
 #pragma unroll
                                 for (int k = 0; k < WS; ++k)
@@ -699,7 +765,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         c.tcount[tid] = kept;
         if (anydel) {
-            if (c.kind == MODEL_KNAPSACK) {
+            if (c.kind == MODEL_MCP) {
+                // reductions already done per victim
+            } else if (c.kind == MODEL_KNAPSACK) {
 #pragma unroll
                 for (int k = 0; k < WS; ++k) LDS_MAX_U64(&sh->merged[k], mor[k]);
             } else {
@@ -735,6 +803,28 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (tid == 0) {
                 uint64_t ms[WS];
                 for (int k = 0; k < WS; ++k) ms[k] = sh->merged[k];
+                if (c.kind == MODEL_MCP) {
+                    // merged benefit: all signs agree -> the value closest to zero, else 0 (relax.rs:141-176)
+                    int32_t mrank = 0;
+                    for (int k = 0; k < WS; ++k) {
+                        uint64_t w = 0;
+                        for (int hsel = 0; hsel < 2; ++hsel) {
+                            const int v = 2 * k + hsel;
+                            if (v >= c.n) continue;
+                            const bool posi = (sh->vposmask >> v) & 1ULL, nega = (sh->vnegmask >> v) & 1ULL;
+                            int32_t b = 0;
+                            if (posi && !nega) b = (int32_t)sh->vmin[v];
+                            else if (nega && !posi) b = -(int32_t)sh->vmin[v];
+                            mrank += iabs32(b);
+                            w |= (uint64_t)(uint32_t)b << (32 * hsel);
+                        }
+                        ms[k] = w;
+                    }
+                    ms[(c.n + 1) / 2] = (uint64_t)(c.depth0 + L);   // depth word (every node of the layer has it)
+                    sh->mrank = mrank;
+                    const int32_t mv = unbias32((uint32_t)(sh->mergedKey >> 32)) - mrank;
+                    sh->mergedKey = ((uint64_t)bias32(mv) << 32) | (uint32_t)sh->mergedKey;
+                }
                 uint32_t r = dedup_find<WS>(c, cur, ms, hmask);
                 if (r != NONE32 && c.cls[r] == 1) {
                     sh->recycled = 1;  // clean.rs:830
@@ -749,6 +839,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                         c.cstate[cur][(size_t)k * capC1 + MERGED] = ms[k];
                         if (c.kind == MODEL_MISP) pop += dd_popc(ms[k]);
                     }
+                    if (c.kind == MODEL_MCP) pop = sh->mrank;
                     c.ckey[cur][MERGED] = sh->mergedKey;
                     c.cpop[cur][MERGED] = (uint32_t)pop;
                     c.cflags[cur][MERGED] = NF_RELAXED | NF_INEXACT;
@@ -792,6 +883,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     c.posmap[best] = (uint32_t)nkept;
                     sh->dup_from = nkept;
                     sh->dup_to = sh->merged_pos;
+                    // its arcs were ALSO redirected to the recycled node, with relaxed costs (relax.rs:115-121)
+                    if (c.kind == MODEL_MCP) sh->xdelta = (int32_t)c.cpop[cur][best] - sh->mrank;
                 }
                 PAR_END
                 n = nkept + 1;
@@ -805,6 +898,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             c.lvar[L] = var;
             c.ldup[2 * L] = sh->dup_from;
             c.ldup[2 * L + 1] = sh->dup_to;
+            if (c.lddelta) c.lddelta[L] = sh->xdelta;
         }
         uint32_t* ni = c.ninfo + (size_t)L * capN;
         for (int pos = tid; pos < n; pos += NT) {
@@ -825,11 +919,19 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         // arcs entering this layer, translated to node positions (needed by the backward pass)
         if (relaxed && lel >= 0 && L >= 1) {
             uint32_t* at = c.arct + (size_t)L * 2 * capN;
+            int32_t* ac = c.arcc + (size_t)L * 2 * capN;
             for (int j = tid; j < ncl; j += NT) {
                 int cd = lin2cand(j, nprev, capN);
                 uint32_t t = c.ctarget[cd];
                 uint32_t out = NONE32;
-                if (t != NONE32) out = c.cls[t] == 1 ? c.posmap[t] : (uint32_t)merged_pos;
+                if (t != NONE32) {
+                    if (c.cls[t] == 1) out = c.posmap[t];
+                    else {
+                        out = (uint32_t)merged_pos;
+                        // Relaxation::relax of a redirected arc (mcp/relax.rs:115-121): + rank(old target) - rank(merged)
+                        if (c.kind == MODEL_MCP) ac[cd] += (int32_t)c.cpop[cur][t] - sh->mrank;
+                    }
+                }
                 at[cd] = out;
             }
         }
@@ -867,6 +969,69 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);
                 c.ctarget[pos] = NONE32;
                 c.ctarget[capN + pos] = NONE32;
+                continue;
+            }
+            if (c.kind == MODEL_MCP) {
+                // mcp/model.rs:60-130: vertex x = depth goes to side S (+1, slot `pos`) or T (-1, slot capN + pos; not at
+                // depth 0).  Child benefit_v = benefit_v +- w[x][v] for v >= x, 0 before; the arc costs depend on the
+                // parent's benefits.
+                const int x = var, depth = c.depth0 + L;
+                const int32_t* wrow = c.vgraph + (size_t)x * c.n;
+                const int32_t bx = vec_get<WS>(s, x);
+                int32_t sum_s = 0, sum_t = 0, rank_s = 0, rank_t = 0;
+                uint64_t cs[WS], ct[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) {
+                    uint64_t ws_ = 0, wt_ = 0;
+#pragma unroll
+                    for (int hsel = 0; hsel < 2; ++hsel) {
+                        const int v = 2 * k + hsel;
+                        if (v < x || v >= c.n) continue;
+                        const int32_t skl = (int32_t)(uint32_t)(s[k] >> (32 * hsel));
+                        const int32_t wkl = wrow[v];
+                        const int32_t mn = iabs32(skl) < iabs32(wkl) ? iabs32(skl) : iabs32(wkl);
+                        const int64_t prod = (int64_t)skl * (int64_t)wkl;
+                        if (prod <= 0) sum_s += mn;
+                        if (prod >= 0) sum_t += mn;
+                        const int32_t a = skl + wkl, b = skl - wkl;
+                        rank_s += iabs32(a);
+                        rank_t += iabs32(b);
+                        ws_ |= (uint64_t)(uint32_t)a << (32 * hsel);
+                        wt_ |= (uint64_t)(uint32_t)b << (32 * hsel);
+                    }
+                    cs[k] = ws_;
+                    ct[k] = wt_;
+                }
+#pragma unroll
+                for (int k = 0; k < WS; ++k)
+                    if (k == (c.n + 1) / 2) cs[k] = ct[k] = (uint64_t)(depth + 1);   // depth word
+                const int32_t cost_s = depth == 0 ? 0 : (bx < 0 ? -bx : 0) + sum_s;
+                const int32_t cost_t = depth == 0 ? 0 : (bx > 0 ? bx : 0) + sum_t;
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t cd = side == 0 ? (uint32_t)pos : (uint32_t)(capN + pos);
+                    if (side == 1 && depth == 0) {   // the first vertex is fixed on side S (model.rs:60-63)
+                        c.ctarget[cd] = NONE32;
+                        break;
+                    }
+                    const uint64_t* y = side == 0 ? cs : ct;
+                    const int32_t cost = side == 0 ? cost_s : cost_t;
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
+                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | cd;
+                    c.ckey[nxt][cd] = mykey;
+                    ac_next[cd] = cost;
+                    c.cpop[nxt][cd] = (uint32_t)(side == 0 ? rank_s : rank_t);
+                    c.cflags[nxt][cd] = inexact;
+                    FENCE_BLOCK();
+                    const uint32_t w = dedup_insert<WS>(c, nxt, cd, y, hmask);
+                    c.ctarget[cd] = w;
+                    ++myarcs;
+                    if (w == cd) ++myuniq;
+                    else {
+                        GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
+                        if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
+                    }
+                }
                 continue;
             }
             bool hasv = false;   // MISP: the vertex is in the state; knapsack: the item fits (main.rs:93-99)
@@ -1125,7 +1290,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 if (v != VB_UNMARKED) LDS_MAX_I32(&vbB[pp], v + cost);
                 if ((int)t == dfrom) {  // arcs of the re-added node were also redirected (clean.rs:851-866)
                     int32_t v2 = vbA[dto];
-                    if (v2 != VB_UNMARKED) LDS_MAX_I32(&vbB[pp], v2 + cost);
+                    if (v2 != VB_UNMARKED) LDS_MAX_I32(&vbB[pp], v2 + cost + (c.lddelta ? c.lddelta[Lc] : 0));
                 }
             }
             PAR_END
@@ -1352,6 +1517,11 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.depth0 = 0;   // set per work item
     c.kp_weight = P.kp_weight;
     c.kp_order = P.kp_order;
+    c.vgraph = P.vgraph;
+    c.vest = P.vest;
+    c.vnk = P.vnk;
+    c.vr = P.vr;
+    c.lddelta = P.lddelta ? P.lddelta + (size_t)slot * (size_t)P.max_layers : nullptr;
     c.capN = P.capN;
     c.capC1 = P.capC1;
     c.max_layers = P.max_layers;

@@ -173,4 +173,43 @@ bool read_knapsack(const std::string& path, int64_t& capacity, std::vector<int64
     return true;
 }
 
+bool read_mcp(const std::string& path, int& n, std::vector<int64_t>& adj) {
+    std::ifstream f(path);
+    if (!f) {
+        set_error("cannot open " + path);
+        return false;
+    }
+    n = 0;
+    adj.clear();
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t b = line.find_first_not_of(" \t\r\n"), e = line.find_last_not_of(" \t\r\n");
+        if (b == std::string::npos) continue;
+        line = line.substr(b, e - b + 1);
+        if (line.rfind("c ", 0) == 0) continue;                       // graph.rs:60-62
+        // the two line shapes of graph.rs:49-50: all-digit tokens, nothing else on the line
+        std::istringstream is(line);
+        std::vector<std::string> tok;
+        for (std::string t; is >> t;) tok.push_back(t);
+        auto is_uint = [](const std::string& t) { return !t.empty() && t.find_first_not_of("0123456789") == std::string::npos; };
+        auto is_int = [&](const std::string& t) { return !t.empty() && is_uint(t[0] == '-' ? t.substr(1) : t); };
+        if (tok.size() == 2 && is_uint(tok[0]) && is_uint(tok[1])) {   // "<vertices> <edges>": a fresh graph
+            n = (int)std::stol(tok[0]);
+            adj.assign((size_t)n * (size_t)n, 0);
+        } else if (tok.size() == 3 && is_uint(tok[0]) && is_uint(tok[1]) && is_int(tok[2])) {
+            const long x = std::stol(tok[0]) - 1, y = std::stol(tok[1]) - 1;
+            if (x < 0 || y < 0 || x >= n || y >= n) {
+                set_error("edge outside the graph in " + path);
+                return false;
+            }
+            adj[(size_t)x * n + y] = adj[(size_t)y * n + x] = std::stoll(tok[2]);   // add_bidir_edge
+        }
+    }
+    if (n < 1) {
+        set_error("malformed max-cut instance " + path);
+        return false;
+    }
+    return true;
+}
+
 }  // namespace ddo_hip

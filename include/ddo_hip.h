@@ -114,6 +114,13 @@ ddo_model* ddo_model_read_misp(const char* path);
 ddo_model* ddo_model_create_knapsack(int n, int64_t capacity, const int64_t* profit, const int64_t* weight);
 /** Reads an instance exactly as examples/knapsack/main.rs:267-303 does ("n capacity", then n x "profit weight"). */
 ddo_model* ddo_model_read_knapsack(const char* path);
+/** Maximum cut (examples/mcp/{graph,model,relax}.rs: `Mcp`, `McpRelax`, `McpRanking`).  `adj_matrix`: n x n symmetric
+ *  edge weights (graph.rs:30-46).  The state is `McpState { benef, depth }` (model.rs:27-31): n signed 32-bit benefits,
+ *  two per word (variable v in half v & 1 of word v / 2), followed by one word holding the depth; n <= 30.  Variables in
+ *  natural order (model.rs:88-96); decision +1 = side S, -1 = side T (model.rs:33-35). */
+ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix);
+/** Reads an instance exactly as examples/mcp/graph.rs:48-79 does ("c " comments, "<vertices> <edges>", "<src> <dst> <w>"). */
+ddo_model* ddo_model_read_mcp(const char* path);
 void ddo_model_destroy(ddo_model* model);
 int ddo_model_nb_variables(const ddo_model* model);
 int ddo_model_state_words(const ddo_model* model);
