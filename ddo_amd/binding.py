@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # every symbol include/ddo_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ddo_last_error", "ddo_device_count", "ddo_model_create_misp", "ddo_model_read_misp", "ddo_model_create_knapsack",
-    "ddo_model_read_knapsack", "ddo_model_create_mcp", "ddo_model_read_mcp", "ddo_model_destroy",
+    "ddo_model_read_knapsack", "ddo_model_create_mcp", "ddo_model_read_mcp", "ddo_model_create_max2sat",
+    "ddo_model_read_max2sat", "ddo_model_destroy",
     "ddo_model_nb_variables", "ddo_model_state_words", "ddo_model_initial_state", "ddo_model_initial_value",
     "ddo_model_compare_states", "ddo_model_export_misp", "ddo_mdd_create", "ddo_mdd_destroy", "ddo_mdd_compile",
     "ddo_mdd_compile_batch", "ddo_mdd_is_exact", "ddo_mdd_best_value", "ddo_mdd_best_exact_value",
@@ -94,6 +95,10 @@ def lib():
     L.ddo_model_create_mcp.argtypes = [C.c_int, C.c_void_p]
     L.ddo_model_read_mcp.restype = C.c_void_p
     L.ddo_model_read_mcp.argtypes = [C.c_char_p]
+    L.ddo_model_create_max2sat.restype = C.c_void_p
+    L.ddo_model_create_max2sat.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ddo_model_read_max2sat.restype = C.c_void_p
+    L.ddo_model_read_max2sat.argtypes = [C.c_char_p]
     L.ddo_model_destroy.argtypes = [C.c_void_p]
     L.ddo_model_nb_variables.argtypes = [C.c_void_p]
     L.ddo_model_state_words.argtypes = [C.c_void_p]
@@ -313,6 +318,33 @@ class Mcp(Misp):
         adj = np.ascontiguousarray(adj, dtype=np.int64)
         assert adj.ndim == 2 and adj.shape[0] == adj.shape[1]
         return cls(lib().ddo_model_create_mcp(adj.shape[0], adj.ctypes.data_as(C.c_void_p)))
+
+
+class Max2Sat(Misp):
+    """Weighted MAX2SAT model == `Max2Sat` + `Max2SatRelax` + `Max2SatRanking` (examples/max2sat); state and decisions as
+    for `Mcp` (+1 = true, -1 = false)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise DdoError("could not create the MAX2SAT model: " + _err())
+        self._h = handle
+        L = lib()
+        self.n = L.ddo_model_nb_variables(handle)
+        self.ws = L.ddo_model_state_words(handle)
+
+    @classmethod
+    def read_instance(cls, path):  # data.rs:67
+        return cls(lib().ddo_model_read_max2sat(os.fspath(path).encode()))
+
+    @classmethod
+    def from_clauses(cls, n, clauses):
+        """clauses: iterable of (lit_a, lit_b, weight)"""
+        cl = list(clauses)
+        a = np.ascontiguousarray([c[0] for c in cl], dtype=np.int64)
+        b = np.ascontiguousarray([c[1] for c in cl], dtype=np.int64)
+        w = np.ascontiguousarray([c[2] for c in cl], dtype=np.int64)
+        return cls(lib().ddo_model_create_max2sat(n, len(cl), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                                  w.ctypes.data_as(C.c_void_p)))
 
 class Mdd:
     """`impl DecisionDiagram for Mdd<T, LAST_EXACT_LAYER>` (mdd.rs:75-114) on the device."""

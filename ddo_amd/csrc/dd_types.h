@@ -13,14 +13,14 @@
 
 namespace ddo_hip {
 
-constexpr int MAX_WS = 16;               // 64-bit words per state supported (n <= 1024)
+constexpr int MAX_WS = 32;               // 64-bit words per state at the wire (MISP uses up to 16: n <= 1024; MAX2SAT n <= 62)
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
 // comp_type values follow include/ddo_hip.h (== mdd.rs:41-48 order)
 constexpr int CT_EXACT = 0, CT_RELAXED = 1, CT_RESTRICTED = 2;
 
 // EngineParams.model_kind
-constexpr int MODEL_MISP = 0, MODEL_KNAPSACK = 1, MODEL_MCP = 2;
+constexpr int MODEL_MISP = 0, MODEL_KNAPSACK = 1, MODEL_MCP = 2, MODEL_MAX2SAT = 3;
 
 // DDInput.flags
 constexpr uint32_t IN_FUSED = 1u;          // restricted, then (if inexact) relaxed: parallel.rs:391-437 on device
@@ -162,6 +162,13 @@ struct EngineParams {
     int32_t vr;                // initial value (sum of the negative edge weights)
     int32_t pad3;
     int32_t* lddelta;          // [slot][max_layers] relax delta of the node re-added by a recycled merge
+    // MAX2SAT (examples/max2sat): clause weights per variable pair and polarity, unit clauses, branching order
+    const int32_t* m2_wtt;     // [n][n] weight(t(k), t(l))
+    const int32_t* m2_wtf;     // [n][n] weight(t(k), f(l))
+    const int32_t* m2_wft;     // [n][n] weight(f(k), t(l))
+    const int32_t* m2_wff;     // [n][n] weight(f(k), f(l))
+    const int32_t* m2_order;   // [n]    vars_by_sum_of_clause_weights (model.rs:138-140)
+    const int32_t* m2_rankpos; // [n]    position of each variable in that order
     int32_t lex_cap;           // tie lists up to this size (<= 1024) are split by rank counting in LDS, longer ones by radix rounds
     int32_t pad1;
     uint64_t* s_state;         // [slot][ws][capS]  node states, word major (streaming scan copy)

@@ -84,11 +84,12 @@ static kernel_fn pick_kernel(int wsT) {
         case 7: return misp_compile_kernel<7, TLDS>;
         case 8: return misp_compile_kernel<8, TLDS>;
         case 16: return misp_compile_kernel<16, TLDS>;
+        case 32: return misp_compile_kernel<32, TLDS>;   // signed-vector models only (MAX2SAT n <= 62)
         default: return nullptr;
     }
 }
 static int pick_ws(int ws) {
-    const int opts[] = {1, 2, 4, 7, 8, 16};
+    const int opts[] = {1, 2, 4, 7, 8, 16, 32};
     for (int o : opts)
         if (ws <= o) return o;
     return -1;
@@ -120,13 +121,13 @@ int Model::popcount(const uint64_t* a) const {
 }
 void Model::initial_state(uint64_t* out) const {
     for (int k = 0; k < ws; ++k) out[k] = 0;
-    if (kind == MODEL_MCP) return;                                              // mcp/model.rs:51-53: no benefit yet, depth 0
+    if (kind == MODEL_MCP || kind == MODEL_MAX2SAT) return;                     // mcp/model.rs:51-53, max2sat/model.rs:259-264
     if (kind == MODEL_KNAPSACK) out[0] = (uint64_t)kp_capacity;                 // knapsack/main.rs:100-102
     else for (int i = 0; i < n; ++i) out[i / 64] |= 1ULL << (i % 64);           // misp/main.rs:69-71
 }
 int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
     if (kind == MODEL_KNAPSACK) return a[0] < b[0] ? -1 : (a[0] > b[0] ? 1 : 0);   // KPRanking (knapsack/main.rs:187-194)
-    if (kind == MODEL_MCP) {                                                        // McpRanking (mcp/model.rs:154-163)
+    if (kind == MODEL_MCP || kind == MODEL_MAX2SAT) {              // McpRanking (mcp/model.rs:154-163), Max2SatRanking
         auto rank = [&](const uint64_t* s) {
             int64_t r = 0;
             for (int v = 0; v < n; ++v) {
@@ -327,6 +328,21 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
         P.vgraph = d_g;
         P.vest = d_e;
         P.vnk = d_k;
+        P.vr = (int32_t)model->initial_value;
+    }
+    if (model->kind == MODEL_MAX2SAT) {
+        auto up = [&](const std::vector<int32_t>& v, const int32_t*& dst) -> int {
+            int32_t* d = nullptr;
+            int r = dev_alloc(allocs_, d, v.size());
+            if (r) return r;
+            if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return DDO_ERR_INTERNAL;
+            dst = d;
+            return DDO_OK;
+        };
+        if ((rc = up(model->m2_w[0], P.m2_wtt)) || (rc = up(model->m2_w[1], P.m2_wtf)) || (rc = up(model->m2_w[2], P.m2_wft)) ||
+            (rc = up(model->m2_w[3], P.m2_wff)) || (rc = up(model->m2_order, P.m2_order)) ||
+            (rc = up(model->m2_rankpos, P.m2_rankpos)) || (rc = up(model->vest, P.vest)) || (rc = up(model->vnk, P.vnk)))
+            return rc;
         P.vr = (int32_t)model->initial_value;
     }
 
@@ -662,7 +678,7 @@ ddo_model* ddo_model_create_misp(int n, const uint64_t* rows, const int64_t* wei
     }
     int ws = (n + 63) / 64;
     int wsT = pick_ws(ws);
-    if (wsT < 0 || n > 64 * MAX_WS) {
+    if (wsT < 0 || n > 1024) {
         set_error("ddo_model_create_misp: at most 1024 variables are supported");
         return nullptr;
     }
@@ -778,6 +794,105 @@ ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix) {
         M.vnk[d] = (int32_t)k;
     }
     return m;
+}
+
+ddo_model* ddo_model_create_max2sat(int n, size_t nb_clauses, const int64_t* lit_a, const int64_t* lit_b, const int64_t* weight) {
+    const int ws = (n + 1) / 2 + 1;   // two benefits per word + the depth word
+    if (n < 1 || ws > MAX_WS || (nb_clauses && (!lit_a || !lit_b || !weight))) {
+        set_error("ddo_model_create_max2sat: 1 <= n <= 62 variables are supported (two benefits per word, 32 words per state)");
+        return nullptr;
+    }
+    // data.rs:31-46 + FxHashMap::insert: clause = (min literal, max literal); a repeated clause keeps its LAST weight
+    const size_t N2 = 2 * (size_t)n;
+    auto mk_lit = [](int64_t x) { const size_t a = (size_t)((x < 0 ? -x : x) - 1); return a + a + (x > 0 ? 1 : 0); };   // model.rs:108-113
+    std::vector<int64_t> W(N2 * N2, 0);
+    std::vector<char> seen(N2 * N2, 0);
+    auto offset = [&](int64_t x, int64_t y) { const int64_t a = std::min(x, y), b = std::max(x, y); return mk_lit(a) * N2 + mk_lit(b); };
+    int64_t abs_sum = 0;
+    for (size_t k = 0; k < nb_clauses; ++k) {
+        const int64_t a = lit_a[k], b = lit_b[k];
+        if (a == 0 || b == 0 || std::llabs(a) > n || std::llabs(b) > n) {
+            set_error("ddo_model_create_max2sat: literals must be in [-n, -1] or [1, n]");
+            return nullptr;
+        }
+        W[offset(a, b)] = weight[k];
+        seen[offset(a, b)] = 1;
+    }
+    ddo_model* m = new ddo_model();
+    Model& M = m->m;
+    M.kind = MODEL_MAX2SAT;
+    M.n = n;
+    M.ws = ws;
+    M.wsT = pick_ws(ws);
+    M.unit_weights = false;
+    M.weight.assign(n, 0);
+    // model.rs:126-137: sum of clause weights per variable, tautologies into the initial value
+    std::vector<int64_t> socw(n, 0);
+    int64_t initial = 0;
+    for (size_t la = 0; la < N2; ++la)
+        for (size_t lb = 0; lb < N2; ++lb) {
+            if (!seen[la * N2 + lb]) continue;
+            const int64_t w = W[la * N2 + lb];
+            abs_sum += std::llabs(w);
+            const size_t va = la / 2, vb = lb / 2;
+            socw[va] += w;
+            if (la != lb) socw[vb] += w;                 // !is_unit
+            if (va == vb && la != lb) initial += w;      // is_tautology: a == -b
+        }
+    if (abs_sum >= (1LL << 27)) {
+        set_error("ddo_model_create_max2sat: sum of |weights| must stay below 2^27 (device values are int32)");
+        delete m;
+        return nullptr;
+    }
+    M.weight_abs_sum = abs_sum;
+    M.initial_value = initial;
+    // model.rs:138-140: worst variable first; ties keep index order (the reference's unstable sort leaves them unspecified:
+    // documented deviation shared with the oracle)
+    M.m2_order.resize(n);
+    for (int i = 0; i < n; ++i) M.m2_order[i] = i;
+    std::stable_sort(M.m2_order.begin(), M.m2_order.end(), [&](int32_t a, int32_t b) { return socw[a] < socw[b]; });
+    M.m2_rankpos.assign(n, 0);
+    for (int i = 0; i < n; ++i) M.m2_rankpos[M.m2_order[i]] = i;
+    auto lit_t = [](int v) { return (int64_t)(1 + v); };
+    auto lit_f = [](int v) { return -(int64_t)(1 + v); };
+    auto wgt = [&](int64_t x, int64_t y) { return W[offset(x, y)]; };
+    for (int q = 0; q < 4; ++q) M.m2_w[q].assign((size_t)n * n, 0);
+    for (int k = 0; k < n; ++k)
+        for (int l = 0; l < n; ++l) {
+            M.m2_w[0][(size_t)k * n + l] = (int32_t)wgt(lit_t(k), lit_t(l));
+            M.m2_w[1][(size_t)k * n + l] = (int32_t)wgt(lit_t(k), lit_f(l));
+            M.m2_w[2][(size_t)k * n + l] = (int32_t)wgt(lit_f(k), lit_t(l));
+            M.m2_w[3][(size_t)k * n + l] = (int32_t)wgt(lit_f(k), lit_f(l));
+        }
+    // model.rs:172-229: nk[k] = tautologies of the k first variables of the order; estimates[k] = best the clauses among the
+    // variables order[k..] can still yield
+    M.vest.assign(n + 1, 0);
+    M.vnk.assign(n + 1, 0);
+    for (int k = 0; k < n; ++k) {
+        int64_t sum = 0;
+        for (int i = 0; i < k; ++i) sum += wgt(lit_t(M.m2_order[i]), lit_f(M.m2_order[i]));
+        M.vnk[k] = (int32_t)sum;
+        int64_t est = 0;
+        for (int i = k; i < n; ++i) {
+            const int vi = M.m2_order[i];
+            for (int j = i + 1; j < n; ++j) {
+                const int vj = M.m2_order[j];
+                const int64_t tt = wgt(lit_t(vi), lit_t(vj)), tf = wgt(lit_t(vi), lit_f(vj));
+                const int64_t ft = wgt(lit_f(vi), lit_t(vj)), ff = wgt(lit_f(vi), lit_f(vj));
+                est += std::max(std::max(tt + tf + ft, tt + tf + ff), std::max(tt + ft + ff, tf + ft + ff));
+            }
+            est += wgt(lit_t(vi), lit_f(vi)) + std::max(wgt(lit_t(vi), lit_t(vi)), wgt(lit_f(vi), lit_f(vi)));
+        }
+        M.vest[k] = (int32_t)est;
+    }
+    return m;
+}
+
+ddo_model* ddo_model_read_max2sat(const char* path) {
+    int n = 0;
+    std::vector<int64_t> a, b, w;
+    if (!path || !read_max2sat(path, n, a, b, w)) return nullptr;
+    return ddo_model_create_max2sat(n, a.size(), a.data(), b.data(), w.data());
 }
 
 ddo_model* ddo_model_read_mcp(const char* path) {

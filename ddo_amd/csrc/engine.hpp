@@ -37,10 +37,13 @@ struct Model {
     // signed benefits, two per word, followed by a depth word
     std::vector<int32_t> vgraph;     // [n][n] symmetric edge weights
     std::vector<int32_t> vest, vnk;  // [n+1] each (relax.rs:58-106)
-    int64_t initial_value = 0;       // Problem::initial_value (MCP: sum of the negative edge weights)
+    int64_t initial_value = 0;       // Problem::initial_value (MCP: sum of the negative edge weights; MAX2SAT: tautologies)
+    // MAX2SAT (examples/max2sat/{data,model,relax,heuristics}.rs): same state layout, merge, relax and ranking as MCP
+    std::vector<int32_t> m2_w[4];    // [n][n] each: weight(t(k),t(l)), weight(t(k),f(l)), weight(f(k),t(l)), weight(f(k),f(l))
+    std::vector<int32_t> m2_order, m2_rankpos;   // vars_by_sum_of_clause_weights and its inverse
     void initial_state(uint64_t* out) const;   // Problem::initial_state
     /// decision value of the device's decision bit: MISP / knapsack 0 | 1, MCP +1 (side S) | -1 (side T)
-    int64_t decision_value(uint32_t bit) const { return kind == MODEL_MCP ? (bit ? -1 : 1) : (int64_t)bit; }
+    int64_t decision_value(uint32_t bit) const { return (kind == MODEL_MCP || kind == MODEL_MAX2SAT) ? (bit ? -1 : 1) : (int64_t)bit; }
 
     std::mutex mtx;
     std::map<std::pair<int, long>, std::weak_ptr<class Engine>> engines;  // (device, max_width)
@@ -168,6 +171,9 @@ bool read_misp_clq(const std::string& path, int& n, std::vector<uint64_t>& rows,
 bool read_knapsack(const std::string& path, int64_t& capacity, std::vector<int64_t>& profit, std::vector<int64_t>& weight);
 /// Reads a max-cut instance the way examples/mcp/graph.rs:48-79 does ("c " comments, "<vertices> <edges>", "<src> <dst> <w>").
 bool read_mcp(const std::string& path, int& n, std::vector<int64_t>& adj);
+/// Reads a weighted MAX2SAT instance the way examples/max2sat/data.rs:67-116 does: clause k = (lit_a[k], lit_b[k], weight[k]),
+/// unit clauses with lit_a == lit_b, in file order (a clause listed twice keeps its last weight: the caller applies that).
+bool read_max2sat(const std::string& path, int& n, std::vector<int64_t>& lit_a, std::vector<int64_t>& lit_b, std::vector<int64_t>& weight);
 
 }  // namespace ddo_hip
 

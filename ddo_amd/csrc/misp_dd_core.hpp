@@ -174,6 +174,8 @@ struct DDCtx {
     const int32_t* vnk;
     int32_t vr;
     int32_t* lddelta;
+    // MAX2SAT (examples/max2sat/{model,relax}.rs): kind == MODEL_MAX2SAT
+    const int32_t *m2_wtt, *m2_wtf, *m2_wft, *m2_wff, *m2_order, *m2_rankpos;
     // capacity
     int capN, capC1, max_layers;
     // slot workspace
@@ -267,6 +269,8 @@ DDO_DEV int32_t vec_get(const uint64_t* s, int v) {
     return r;
 }
 DDO_DEV int32_t iabs32(int32_t x) { return x < 0 ? -x : x; }
+/// the signed-vector models (MCP, MAX2SAT) share merge, relax, ranking and state layout; transitions and bounds differ
+DDO_DEV bool dd_is_vec(int kind) { return kind == MODEL_MCP || kind == MODEL_MAX2SAT; }
 /// sum of |benefit| over the variables >= from (from = 0: McpRanking's key, model.rs:154-163)
 template <int WS>
 DDO_DEV int32_t vec_rank(const uint64_t* s, int n, int from) {
@@ -285,6 +289,10 @@ template <int WS>
 DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth) {
     if (c.kind == MODEL_MCP)   // mcp/relax.rs:123-130
         return vec_rank<WS>(s, c.n, depth) + c.vest[depth] - c.vr + c.vnk[depth];
+    if (c.kind == MODEL_MAX2SAT) {   // max2sat/model.rs:231-240; a complete assignment (depth n) has nothing left to gain
+        if (depth >= c.n) return 0;
+        return pop + c.vest[depth] - c.vr + c.vnk[depth];
+    }
     if (c.kind == MODEL_KNAPSACK) {
         int64_t cap = (int64_t)s[0];
         int64_t max_profit = 0;
@@ -598,7 +606,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         int pop = 0;
         if (c.kind == MODEL_MISP)
             for (int k = 0; k < WS; ++k) pop += dd_popc(in.state[k]);
-        if (c.kind == MODEL_MCP) pop = vec_rank<WS>(in.state, c.n, 0);
+        if (dd_is_vec(c.kind)) pop = vec_rank<WS>(in.state, c.n, 0);
         c.ckey[0][0] = ((uint64_t)bias32(in.value) << 32) | NONE32;
         c.cpop[0][0] = (uint32_t)pop;
         c.cflags[0][0] = 0;
@@ -629,7 +637,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         PAR_BEGIN
         if (c.kind != MODEL_MISP) {   // static order (knapsack/main.rs:118-125, mcp/model.rs:88-96); an empty layer ends the DD
             if (tid == 0 && c.depth0 + L < c.n && sh->nU > 0)
-                sh->varkey = c.kind == MODEL_MCP ? (uint32_t)(c.depth0 + L) : (uint32_t)c.kp_order[c.depth0 + L];
+                sh->varkey = c.kind == MODEL_MCP       ? (uint32_t)(c.depth0 + L)
+                             : c.kind == MODEL_MAX2SAT ? (uint32_t)c.m2_order[c.n - (c.depth0 + L) - 1]   // model.rs:330-346
+                                                       : (uint32_t)c.kp_order[c.depth0 + L];
         } else {
             for (int i = tid; i < c.n; i += NT) {
                 int cv = c.cnt[i];
@@ -720,7 +730,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 #pragma unroll
                         for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + cd];
                         if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);  // it leaves the layer
-                        if (relaxed && c.kind == MODEL_MCP) {
+                        if (relaxed && dd_is_vec(c.kind)) {
                             // McpRelax::merge (relax.rs:141-176): per variable the signs seen and the smallest |benefit|;
                             // relax (relax.rs:115-121) adds rank(victim) - rank(merged) to every redirected arc, so the
                             // merged node's value is max(value + rank) over the victims minus its own rank
@@ -765,7 +775,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         c.tcount[tid] = kept;
         if (anydel) {
-            if (c.kind == MODEL_MCP) {
+            if (dd_is_vec(c.kind)) {
                 // reductions already done per victim
             } else if (c.kind == MODEL_KNAPSACK) {
 #pragma unroll
@@ -803,7 +813,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (tid == 0) {
                 uint64_t ms[WS];
                 for (int k = 0; k < WS; ++k) ms[k] = sh->merged[k];
-                if (c.kind == MODEL_MCP) {
+                if (dd_is_vec(c.kind)) {
                     // merged benefit: all signs agree -> the value closest to zero, else 0 (relax.rs:141-176)
                     int32_t mrank = 0;
                     for (int k = 0; k < WS; ++k) {
@@ -839,7 +849,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                         c.cstate[cur][(size_t)k * capC1 + MERGED] = ms[k];
                         if (c.kind == MODEL_MISP) pop += dd_popc(ms[k]);
                     }
-                    if (c.kind == MODEL_MCP) pop = sh->mrank;
+                    if (dd_is_vec(c.kind)) pop = sh->mrank;
                     c.ckey[cur][MERGED] = sh->mergedKey;
                     c.cpop[cur][MERGED] = (uint32_t)pop;
                     c.cflags[cur][MERGED] = NF_RELAXED | NF_INEXACT;
@@ -884,7 +894,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     sh->dup_from = nkept;
                     sh->dup_to = sh->merged_pos;
                     // its arcs were ALSO redirected to the recycled node, with relaxed costs (relax.rs:115-121)
-                    if (c.kind == MODEL_MCP) sh->xdelta = (int32_t)c.cpop[cur][best] - sh->mrank;
+                    if (dd_is_vec(c.kind)) sh->xdelta = (int32_t)c.cpop[cur][best] - sh->mrank;
                 }
                 PAR_END
                 n = nkept + 1;
@@ -929,7 +939,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     else {
                         out = (uint32_t)merged_pos;
                         // Relaxation::relax of a redirected arc (mcp/relax.rs:115-121): + rank(old target) - rank(merged)
-                        if (c.kind == MODEL_MCP) ac[cd] += (int32_t)c.cpop[cur][t] - sh->mrank;
+                        if (dd_is_vec(c.kind)) ac[cd] += (int32_t)c.cpop[cur][t] - sh->mrank;
                     }
                 }
                 at[cd] = out;
@@ -969,6 +979,74 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);
                 c.ctarget[pos] = NONE32;
                 c.ctarget[capN + pos] = NONE32;
+                continue;
+            }
+            if (c.kind == MODEL_MAX2SAT) {
+                // max2sat/model.rs:270-329: variable k is set to T (+1, slot `pos`) or F (-1, slot capN + pos); the benefits
+                // of the still-free variables (the first n - depth - 1 of the branching order) move by the clause weights,
+                // the arc cost is what k's assignment satisfies for sure plus the least the free variables still yield
+                const int kx = var, depth = c.depth0 + L;
+                const int nfree = c.n - depth - 1;
+                const size_t row = (size_t)kx * c.n;
+                const int32_t sk = vec_get<WS>(s, kx);
+                int32_t sum_t = c.m2_wtt[row + kx], sum_f = c.m2_wff[row + kx];   // unit clauses (k) / (-k)
+                int32_t rank_t = 0, rank_f = 0;
+                uint64_t cs[WS], ct[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) {
+                    uint64_t wt_ = 0, wf_ = 0;
+#pragma unroll
+                    for (int hsel = 0; hsel < 2; ++hsel) {
+                        const int v = 2 * k + hsel;
+                        if (v >= c.n) continue;
+                        const int32_t sl = (int32_t)(uint32_t)(s[k] >> (32 * hsel));
+                        int32_t a = sl, b = sl;                       // child benefit under T / under F
+                        if (v == kx) a = b = 0;
+                        else if (c.m2_rankpos[v] < nfree) {
+                            const int32_t wtt = c.m2_wtt[row + v], wtf = c.m2_wtf[row + v];
+                            const int32_t wft = c.m2_wft[row + v], wff = c.m2_wff[row + v];
+                            const int32_t ps = sl > 0 ? sl : 0, ns = sl < 0 ? -sl : 0;
+                            const int32_t mt = ps + wft < ns + wff ? ps + wft : ns + wff;
+                            const int32_t mf = ps + wtt < ns + wtf ? ps + wtt : ns + wtf;
+                            sum_t += (wtf + wtt) + mt;
+                            sum_f += (wff + wft) + mf;
+                            a = sl + wft - wff;
+                            b = sl + wtt - wtf;
+                        }
+                        rank_t += iabs32(a);
+                        rank_f += iabs32(b);
+                        wt_ |= (uint64_t)(uint32_t)a << (32 * hsel);
+                        wf_ |= (uint64_t)(uint32_t)b << (32 * hsel);
+                    }
+                    ct[k] = wt_;
+                    cs[k] = wf_;
+                }
+#pragma unroll
+                for (int k = 0; k < WS; ++k)
+                    if (k == (c.n + 1) / 2) cs[k] = ct[k] = (uint64_t)(depth + 1);   // depth word
+                const int32_t cost_t = (sk > 0 ? sk : 0) + sum_t;
+                const int32_t cost_f = (sk < 0 ? -sk : 0) + sum_f;
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t cd = side == 0 ? (uint32_t)pos : (uint32_t)(capN + pos);
+                    const uint64_t* y = side == 0 ? ct : cs;
+                    const int32_t cost = side == 0 ? cost_t : cost_f;
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
+                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | cd;
+                    c.ckey[nxt][cd] = mykey;
+                    ac_next[cd] = cost;
+                    c.cpop[nxt][cd] = (uint32_t)(side == 0 ? rank_t : rank_f);
+                    c.cflags[nxt][cd] = inexact;
+                    FENCE_BLOCK();
+                    const uint32_t w = dedup_insert<WS>(c, nxt, cd, y, hmask);
+                    c.ctarget[cd] = w;
+                    ++myarcs;
+                    if (w == cd) ++myuniq;
+                    else {
+                        GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
+                        if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
+                    }
+                }
                 continue;
             }
             if (c.kind == MODEL_MCP) {
@@ -1522,6 +1600,12 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.vnk = P.vnk;
     c.vr = P.vr;
     c.lddelta = P.lddelta ? P.lddelta + (size_t)slot * (size_t)P.max_layers : nullptr;
+    c.m2_wtt = P.m2_wtt;
+    c.m2_wtf = P.m2_wtf;
+    c.m2_wft = P.m2_wft;
+    c.m2_wff = P.m2_wff;
+    c.m2_order = P.m2_order;
+    c.m2_rankpos = P.m2_rankpos;
     c.capN = P.capN;
     c.capC1 = P.capC1;
     c.max_layers = P.max_layers;

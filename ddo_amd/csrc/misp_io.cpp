@@ -12,8 +12,10 @@
 #include <cctype>
 #include <cstdio>
 #include <fstream>
+#include <regex>
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "engine.hpp"
 
@@ -207,6 +209,51 @@ bool read_mcp(const std::string& path, int& n, std::vector<int64_t>& adj) {
     }
     if (n < 1) {
         set_error("malformed max-cut instance " + path);
+        return false;
+    }
+    return true;
+}
+
+bool read_max2sat(const std::string& path, int& n, std::vector<int64_t>& lit_a, std::vector<int64_t>& lit_b, std::vector<int64_t>& weight) {
+    std::ifstream f(path);
+    if (!f) {
+        set_error("cannot open " + path);
+        return false;
+    }
+    // the four line shapes of data.rs:71-74, tried in the reference's order on the trimmed line (prefix matches)
+    static const std::regex comment(R"(^c\s.*$)");
+    static const std::regex pb_decl(R"(^p\s+wcnf\s+(\d+)\s+(\d+))");
+    static const std::regex bin_decl(R"(^(-?\d+)\s+(-?\d+)\s+(-?\d+)\s+0)");
+    static const std::regex unit_decl(R"(^(-?\d+)\s+(-?\d+)-?\s+0)");
+    n = 0;
+    lit_a.clear();
+    lit_b.clear();
+    weight.clear();
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t b = line.find_first_not_of(" \t\r\n"), e = line.find_last_not_of(" \t\r\n");
+        if (b == std::string::npos) continue;
+        line = line.substr(b, e - b + 1);
+        std::smatch m;
+        if (std::regex_search(line, m, comment)) continue;
+        if (std::regex_search(line, m, pb_decl)) {
+            n = (int)std::stol(m[1].str());
+            continue;
+        }
+        if (std::regex_search(line, m, bin_decl)) {
+            weight.push_back(std::stoll(m[1].str()));
+            lit_a.push_back(std::stoll(m[2].str()));
+            lit_b.push_back(std::stoll(m[3].str()));
+            continue;
+        }
+        if (std::regex_search(line, m, unit_decl)) {
+            weight.push_back(std::stoll(m[1].str()));
+            lit_a.push_back(std::stoll(m[2].str()));
+            lit_b.push_back(std::stoll(m[2].str()));
+        }
+    }
+    if (n < 1) {
+        set_error("malformed wcnf instance " + path);
         return false;
     }
     return true;

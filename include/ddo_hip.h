@@ -121,6 +121,14 @@ ddo_model* ddo_model_read_knapsack(const char* path);
 ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix);
 /** Reads an instance exactly as examples/mcp/graph.rs:48-79 does ("c " comments, "<vertices> <edges>", "<src> <dst> <w>"). */
 ddo_model* ddo_model_read_mcp(const char* path);
+/** Weighted MAX2SAT (examples/max2sat/{data,model,relax,heuristics}.rs: `Max2Sat`, `Max2SatRelax`, `Max2SatRanking`).
+ *  Clause k is (lit_a[k] OR lit_b[k]) with weight[k]; literals are +-(1 + variable); a unit clause has lit_a == lit_b; a clause
+ *  listed twice keeps its last weight (data.rs:31-62, 96-110).  State as for max-cut: `State { depth, substates }`
+ *  (model.rs:55-60) = n signed 32-bit benefits, two per word, then one depth word; n <= 62.  Variables are branched from
+ *  the end of `vars_by_sum_of_clause_weights` (model.rs:138-140, 330-346); decision +1 = true, -1 = false. */
+ddo_model* ddo_model_create_max2sat(int n, size_t nb_clauses, const int64_t* lit_a, const int64_t* lit_b, const int64_t* weight);
+/** Reads a .wcnf file exactly as examples/max2sat/data.rs:67-116 does. */
+ddo_model* ddo_model_read_max2sat(const char* path);
 void ddo_model_destroy(ddo_model* model);
 int ddo_model_nb_variables(const ddo_model* model);
 int ddo_model_state_words(const ddo_model* model);

@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-MAX_WS = 16
+MAX_WS = 32
 CT_EXACT, CT_RELAXED, CT_RESTRICTED = 0, 1, 2
 IN_FUSED, IN_FILTER_CUTSET, IN_WANT_PATHS = 1, 2, 4
 ST_OK, ST_CUTOFF, ST_NOT_RUN = 0, 1, 77
