@@ -747,7 +747,7 @@ ddo_model* ddo_model_create_knapsack(int n, int64_t capacity, const int64_t* pro
 ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix) {
     const int ws = (n + 1) / 2 + 1;   // two benefits per word + the depth word
     if (n < 1 || !adj_matrix || ws > MAX_WS) {
-        set_error("ddo_model_create_mcp: 1 <= n <= 30 vertices are supported (two benefits per word, 16 words per state)");
+        set_error("ddo_model_create_mcp: 1 <= n <= 62 vertices are supported (two benefits per word, 32 words per state)");
         return nullptr;
     }
     int64_t abs_sum = 0;

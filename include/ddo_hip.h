@@ -116,7 +116,7 @@ ddo_model* ddo_model_create_knapsack(int n, int64_t capacity, const int64_t* pro
 ddo_model* ddo_model_read_knapsack(const char* path);
 /** Maximum cut (examples/mcp/{graph,model,relax}.rs: `Mcp`, `McpRelax`, `McpRanking`).  `adj_matrix`: n x n symmetric
  *  edge weights (graph.rs:30-46).  The state is `McpState { benef, depth }` (model.rs:27-31): n signed 32-bit benefits,
- *  two per word (variable v in half v & 1 of word v / 2), followed by one word holding the depth; n <= 30.  Variables in
+ *  two per word (variable v in half v & 1 of word v / 2), followed by one word holding the depth; n <= 62.  Variables in
  *  natural order (model.rs:88-96); decision +1 = side S, -1 = side T (model.rs:33-35). */
 ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix);
 /** Reads an instance exactly as examples/mcp/graph.rs:48-79 does ("c " comments, "<vertices> <edges>", "<src> <dst> <w>"). */

@@ -139,3 +139,41 @@ def test_knapsack_reader_agrees_with_the_oracle(oracle, name):
         v_file, _ = oracle.knapsack_file(path, 10, 0)
         v_arr, _ = oracle.knapsack([int(r[0]) for r in rows[1:1 + n]], [int(r[1]) for r in rows[1:1 + n]], cap, 10, 0)
         assert v_file == v_arr
+
+
+# ---- MAX2SAT / MCP model descriptors, host side only -----------------------------------------------------------------
+def test_max2sat_model_host_side(tmp_path):
+    """data.rs:67-126: debug2.wcnf has 3 variables; unit clause written `w x x 0`; a repeated clause keeps its last weight"""
+    m = ddo_amd.Max2Sat.read_instance(data_path("max2sat", "debug2.wcnf"))
+    assert m.n == 3 and m.ws == 3 and not m.initial_state().any() and m.initial_value() == 0
+    p = tmp_path / "t.wcnf"
+    p.write_text("c comment\np wcnf 2 3\n5 1 -1 0\n3 1 2 0\n7 1 2 0\n4 -2 0\n")   # tautology 5, (1 v 2) re-weighted to 7, unit -2
+    t = ddo_amd.Max2Sat.read_instance(p)
+    assert t.n == 2 and t.initial_value() == 5
+    same = ddo_amd.Max2Sat.from_clauses(2, [(1, -1, 5), (2, 1, 7), (-2, -2, 4)])
+    assert same.initial_value() == 5
+    # Max2SatRanking (heuristics.rs:30-37): sum of |benefit|; benefits sit two per word, the depth word is ignored
+    def pack(vals, depth):
+        w = np.zeros(m.ws, dtype=np.uint64)
+        for i, v in enumerate(vals):
+            w[i // 2] |= np.uint64(v & 0xFFFFFFFF) << np.uint64(32 * (i % 2))
+        w[(len(vals) + 1) // 2] = np.uint64(depth)
+        return w
+    assert m.compare(pack([1, -2, 0], 1), pack([0, 0, 4], 2)) < 0 and m.compare(pack([3, -3, 0], 0), pack([-6, 0, 0], 5)) == 0
+    with pytest.raises(ddo_amd.DdoError):
+        ddo_amd.Max2Sat.from_clauses(2, [(3, 1, 1)])            # literal outside [-n, n]
+    with pytest.raises(ddo_amd.DdoError):
+        ddo_amd.Max2Sat.from_clauses(63, [])                      # more than 62 variables
+
+
+def test_mcp_model_host_side(tmp_path):
+    m = ddo_amd.Mcp.read_instance(data_path("mcp", "mcp_n30_p0.1_000.mcp"))
+    assert m.n == 30 and m.ws == 16 and not m.initial_state().any()
+    p = tmp_path / "g.mcp"
+    p.write_text("c tiny\n3 2\n1 2 -4\n2 3 5\n")
+    g = ddo_amd.Mcp.read_instance(p)
+    assert g.n == 3 and g.initial_value() == -4              # graph.rs:37-42: sum of the negative edges
+    with pytest.raises(ddo_amd.DdoError):
+        ddo_amd.Mcp.from_matrix(np.array([[0, 1], [2, 0]]))    # not symmetric
+    with pytest.raises(ddo_amd.DdoError):
+        ddo_amd.Mcp.from_matrix(np.zeros((63, 63), dtype=np.int64))      # more than 62 vertices

@@ -84,3 +84,27 @@ def test_mcp_negative_weights_from_matrix(have_gpu):
         c = s.maximize()
         assert c.is_exact and c.best_value == best
         check(s, adj, best)
+
+
+def test_mcp_wider_than_16_words(have_gpu, oracle, tmp_path):
+    """n = 36 needs 19 state words (the 32-word template): same optimum as the CPU oracle, verified cut"""
+    rng = np.random.RandomState(11)
+    n = 36
+    adj = np.zeros((n, n), dtype=np.int64)
+    p = tmp_path / "g36.mcp"
+    edges = []
+    for a in range(n):
+        for b in range(a + 1, n):
+            if rng.rand() < 0.12:
+                w = int(rng.randint(-3, 8)) or 1
+                adj[a, b] = adj[b, a] = w
+                edges.append((a + 1, b + 1, w))
+    p.write_text("c random signed graph\n%d %d\n" % (n, len(edges)) + "".join("%d %d %d\n" % e for e in edges))
+    v, info = oracle.mcp_file(str(p), 0, 8)
+    assert info["is_exact"] and info["cut_weight"] == v
+    model = ddo_amd.Mcp.read_instance(str(p))
+    assert model.n == n and model.ws == 19
+    s = ParallelSolver(model, NbUnassignedWidth(n), nb_threads=128, fringe="nodup")
+    c = s.maximize()
+    assert c.is_exact and c.best_value == v
+    check(s, adj, v)
