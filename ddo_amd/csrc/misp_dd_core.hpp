@@ -790,6 +790,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         PAR_END
         block_exclusive_scan<WS>(c, c.tcount, c.tcount2);
         const int nkept = sh->scan_total;
+#if defined(DDO_HOST_EMULATION)
+        if (getenv("DD_TRACE")) std::printf("SQ L=%d squash=%d nU=%d W=%d K=%d nkept=%d pivK1=%llx nprev=%d\n", L, (int)squash, nU, W, K, nkept, (unsigned long long)sh->pivK1, nprev);
+#endif
 
         // ------------------------------------------------------------ assign positions (pass 2)
         PAR_BEGIN

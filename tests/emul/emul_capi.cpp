@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../ddo_amd/csrc/misp_dd_inplace.hpp"
+#include "../../ddo_amd/csrc/engine.hpp"   // host-side Model: emul_create_model reads the product's model descriptors
 
 using namespace ddo_hip;
 
@@ -33,6 +34,7 @@ struct Emul {
     int engine = 1;
     std::vector<unsigned char> mem2;
     std::vector<unsigned char> lds2;
+    std::vector<int32_t> aux[2], lddelta;   // knapsack tables, per-layer relax deltas
 };
 
 template <class T>
@@ -43,7 +45,7 @@ T* carve(unsigned char*& p, size_t count) {
 }
 
 int pick_ws(int ws) {
-    const int opts[] = {1, 2, 4, 7, 8, 16};
+    const int opts[] = {1, 2, 4, 7, 8, 16, 32};
     for (int o : opts)
         if (ws <= o) return o;
     return -1;
@@ -63,11 +65,15 @@ void run(Emul& e, const DDInput& in, DDResult* res2) {
 }
 }  // namespace
 
+static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int nthreads, uint64_t arena_bytes, int capN_,
+                         const int64_t* weights);
+
 extern "C" {
 
 void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int max_width, int nthreads,
                   uint64_t arena_bytes, int engine) {
     Emul* e = new Emul();
+    std::memset(&e->P, 0, sizeof(e->P));
     e->engine = engine;
     int ws = (n + 63) / 64;
     int wsT = pick_ws(ws);
@@ -83,15 +89,22 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
         e->weight[i] = (int32_t)weights[i];
         unit &= weights[i] == 1;
     }
+    return emul_finish(e, n, wsT, unit, max_width, nthreads, arena_bytes, max_width + 2, weights);
+}
+
+/// workspace and capacities for one slot (what Engine::init does on the device side)
+}  // extern "C"
+
+static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int nthreads, uint64_t arena_bytes, int capN_,
+                         const int64_t* weights) {
     EngineParams& P = e->P;
-    std::memset(&P, 0, sizeof(P));
     P.n = n;
     P.ws = wsT;
     P.unit_weights = unit;
     P.npad = (n + 63) / 64 * 64;
     P.adj = e->adj.data();
     P.weight = e->weight.data();
-    P.capN = max_width + 2;
+    P.capN = capN_;
     P.capC1 = 2 * P.capN + 1;
     P.max_layers = n + 2;
     int tc = 1024;
@@ -168,6 +181,50 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
     }
     return e;
 }
+
+extern "C" {
+/// Engine-1 emulation for ANY model descriptor of the product library (`ddo_model*` from ddo_model_create_*): the tables are
+/// read straight out of the host-side Model, like Engine::init uploads them.
+void* emul_create_model(const void* model_handle, int max_width, int nthreads, uint64_t arena_bytes) {
+    const ddo_hip::Model& M = ((const ddo_model*)model_handle)->m;
+    Emul* e = new Emul();
+    std::memset(&e->P, 0, sizeof(e->P));
+    e->engine = 1;
+    e->wsT = M.wsT;
+    e->nthreads = nthreads;
+    e->adj.assign((size_t)M.n * M.wsT, 0);
+    if (M.kind == MODEL_MISP)
+        for (int i = 0; i < M.n; ++i)
+            for (int k = 0; k < M.ws; ++k) e->adj[(size_t)i * M.wsT + k] = M.adj[(size_t)i * M.ws + k];
+    e->weight.resize(M.n);
+    for (int i = 0; i < M.n; ++i) e->weight[i] = (int32_t)M.weight[i];
+    EngineParams& P = e->P;
+    P.model_kind = M.kind;
+    if (M.kind == MODEL_KNAPSACK) {
+        e->aux[0].assign(M.kp_weight.begin(), M.kp_weight.end());
+        e->aux[1].assign(M.kp_order.begin(), M.kp_order.end());
+        P.kp_weight = e->aux[0].data();
+        P.kp_order = e->aux[1].data();
+    }
+    if (M.kind == MODEL_MCP || M.kind == MODEL_MAX2SAT) {
+        P.vest = M.vest.data();
+        P.vnk = M.vnk.data();
+        P.vr = (int32_t)M.initial_value;
+    }
+    if (M.kind == MODEL_MCP) P.vgraph = M.vgraph.data();
+    if (M.kind == MODEL_MAX2SAT) {
+        P.m2_wtt = M.m2_w[0].data();
+        P.m2_wtf = M.m2_w[1].data();
+        P.m2_wft = M.m2_w[2].data();
+        P.m2_wff = M.m2_w[3].data();
+        P.m2_order = M.m2_order.data();
+        P.m2_rankpos = M.m2_rankpos.data();
+    }
+    e->lddelta.assign((size_t)M.n + 2, 0);
+    P.lddelta = e->lddelta.data();
+    const int capN = M.kind != MODEL_MISP ? 2 * max_width + 3 : max_width + 2;   // the terminal layer is never squashed
+    return emul_finish(e, M.n, M.wsT, M.unit_weights, max_width, nthreads, arena_bytes, capN, M.weight.data());
+}
 void emul_destroy(void* h) { delete (Emul*)h; }
 int emul_state_words(void* h) { return ((Emul*)h)->wsT; }
 uint64_t emul_lds_bytes(void* h) { return ((Emul*)h)->lds.size(); }
@@ -186,6 +243,7 @@ int emul_compile(void* h, const DDInput* in, DDResult* res2, const uint8_t** are
         case 7: run<7>(*e, *in, res2); break;
         case 8: run<8>(*e, *in, res2); break;
         case 16: run<16>(*e, *in, res2); break;
+        case 32: run<32>(*e, *in, res2); break;
         default: return -2;
     }
     *arena_out = e->arena.data();

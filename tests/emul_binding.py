@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 def build_emul():
     src = os.path.join(HERE, "emul", "emul_capi.cpp")
     out = os.path.join(HERE, "emul", "libddo_emul.so")
-    deps = [src] + [os.path.join(ROOT, "ddo_amd", "csrc", f) for f in ("misp_dd_core.hpp", "misp_dd_inplace.hpp", "dd_types.h")]
+    deps = [src] + [os.path.join(ROOT, "ddo_amd", "csrc", f) for f in ("misp_dd_core.hpp", "misp_dd_inplace.hpp", "dd_types.h", "engine.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", out, src],
                        check=True)
@@ -78,3 +78,26 @@ class Emul:
             d["cutset"] = sorted((s[:self.ws_in], v, u, dp) for (s, v, u, dp) in d["cutset"])
             out.append(d)
         return out
+
+
+class ModelEmul(Emul):
+    """Engine-1 emulation bound to a model descriptor of the product library (any kind: MISP, knapsack, MCP, MAX2SAT)."""
+
+    def __init__(self, model, max_width, nthreads=256, arena_bytes=16 << 20):   # engine 1 needs >= 256 threads (256-bin scans)
+        L = C.CDLL(build_emul())
+        L.emul_create_model.restype = C.c_void_p
+        L.emul_create_model.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+        L.emul_destroy.argtypes = [C.c_void_p]
+        L.emul_state_words.argtypes = [C.c_void_p]
+        L.emul_compile.argtypes = [C.c_void_p, C.POINTER(DDInput), C.POINTER(DDResult), C.POINTER(C.c_void_p)]
+        self.L = L
+        self.model = model            # keeps the descriptor (and the tables the emulator points into) alive
+        self.n = model.n
+        self.ws_in = model.ws
+        self.h = L.emul_create_model(model._h, max_width, nthreads, arena_bytes)
+        if not self.h:
+            raise RuntimeError("emul_create_model failed")
+        self.ws = L.emul_state_words(self.h)
+
+    def compile_root(self, comp_type, width, best_lb=-(1 << 40)):
+        return self.compile(comp_type, width, best_lb, self.model.initial_state(), self.model.initial_value(), 0)

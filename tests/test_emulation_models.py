@@ -1,0 +1,97 @@
+"""CPU suite: the engine-1 device code of the NON-MISP models (knapsack, max-cut, MAX2SAT), compiled as the lock-step host
+emulation and fed with the product library's own model descriptors.  A decision diagram compiled EXACTLY (width larger than
+any layer) is a dynamic programme: its best value is the optimum; restricted / relaxed diagrams at small widths bracket it
+(clean.rs:345-381; relaxed >= optimum >= restricted), and an exact relaxed diagram proves it."""
+import itertools
+
+import numpy as np
+import pytest
+
+import ddo_amd
+from tests.conftest import data_path
+from tests.emul_binding import ModelEmul
+
+EXACT, RELAXED, RESTRICTED = 0, 1, 2
+
+
+def bracket(model, optimum, big, widths):
+    e = ModelEmul(model, big)
+    r = e.compile_root(EXACT, big)[0]
+    assert r["status"] == 0 and r["is_exact"] and r["best_value"] == optimum
+    for w in widths:
+        lo = e.compile_root(RESTRICTED, w)[0]
+        hi = e.compile_root(RELAXED, w)[0]
+        assert lo["status"] == 0 and hi["status"] == 0
+        if lo["best_value"] is not None:
+            assert lo["best_value"] <= optimum
+        assert hi["best_value"] is not None and hi["best_value"] >= optimum
+        if hi["is_exact"]:
+            assert hi["best_value"] == optimum
+        else:                      # the cut-set of an inexact relaxed DD carries upper bounds that still cover the optimum
+            assert lo["best_value"] == optimum or (hi["cutset"] and max(u for (_, _, u, _) in hi["cutset"]) >= optimum)
+
+
+def read_kp(path):
+    rows = [l.split() for l in open(path) if l.strip() and not l.startswith("c")]
+    n, cap = int(rows[0][0]), int(rows[0][1])
+    return cap, [int(r[0]) for r in rows[1:1 + n]], [int(r[1]) for r in rows[1:1 + n]]
+
+
+@pytest.mark.parametrize("name,optimum", [("f3_l-d_kp_4_20", 35), ("f4_l-d_kp_4_11", 23), ("f9_l-d_kp_5_80", 130),
+                                          ("f7_l-d_kp_7_50", 107), ("f1_l-d_kp_10_269", 295)])
+def test_knapsack_device_code_on_cpu(name, optimum):
+    model = ddo_amd.Knapsack.read_instance(data_path("knapsack", name))
+    bracket(model, optimum, 1500, [1, 2, 3, 8])
+
+
+def test_knapsack_readme_on_cpu():
+    bracket(ddo_amd.Knapsack.from_items(50, [60, 100, 120], [10, 20, 30]), 220, 64, [1, 2])
+
+
+def cut_optimum(adj):
+    n = adj.shape[0]
+    best = -10**9
+    for m in range(1 << (n - 1)):
+        sides = [1] + [1 if (m >> i) & 1 else -1 for i in range(n - 1)]
+        best = max(best, int(sum(adj[a, b] for a in range(n) for b in range(a + 1, n) if sides[a] * sides[b] < 0)))
+    return best
+
+
+@pytest.mark.parametrize("seed,n", [(1, 6), (2, 8), (3, 9), (4, 10)])
+def test_mcp_device_code_on_cpu(seed, n):
+    rng = np.random.RandomState(seed)
+    adj = np.zeros((n, n), dtype=np.int64)
+    for a in range(n):
+        for b in range(a + 1, n):
+            if rng.rand() < 0.6:
+                adj[a, b] = adj[b, a] = rng.randint(-6, 9)
+    bracket(ddo_amd.Mcp.from_matrix(adj), cut_optimum(adj), 1 << n, [1, 2, 3, 7])
+
+
+def sat_optimum(n, clauses):
+    w = {}
+    for a, b, c in clauses:
+        w[(min(a, b), max(a, b))] = c
+    best = -10**9
+    for bits in itertools.product((False, True), repeat=n):
+        val = lambda lit: bits[abs(lit) - 1] == (lit > 0)
+        best = max(best, sum(c for (a, b), c in w.items() if val(a) or val(b)))
+    return best
+
+
+@pytest.mark.parametrize("name,optimum", [("debug", 24), ("debug2", 13), ("pass", 54), ("tautology", 7), ("unit", 6),
+                                          ("negative_wt", 4258)])
+def test_max2sat_reference_instances_on_cpu(name, optimum):
+    model = ddo_amd.Max2Sat.read_instance(data_path("max2sat", name + ".wcnf"))
+    bracket(model, optimum, 1 << model.n if model.n <= 10 else 4096, [1, 2, 3])
+
+
+@pytest.mark.parametrize("seed,n", [(7, 5), (8, 7), (9, 8)])
+def test_max2sat_device_code_on_cpu(seed, n):
+    rng = np.random.RandomState(seed)
+    clauses = []
+    for _ in range(3 * n):
+        a = int(rng.randint(1, n + 1)) * (1 if rng.rand() < 0.5 else -1)
+        b = int(rng.randint(1, n + 1)) * (1 if rng.rand() < 0.5 else -1)
+        clauses.append((a, b, int(rng.randint(-4, 12))))
+    bracket(ddo_amd.Max2Sat.from_clauses(n, clauses), sat_optimum(n, clauses), 1 << n, [1, 2, 5])
