@@ -1,6 +1,8 @@
 // =============================================================================
-// ddo_hip_engine.hip -- gfx950 kernels + the device engine + the model / mdd
-// half of the C ABI (include/ddo_hip.h).
+// ddo_hip_engine.hip -- the device engine (workspace, launches) + the model /
+// mdd half of the C ABI (include/ddo_hip.h).  The gfx950 kernels are compiled in
+// kernels_inplace*.hip / kernels_core*.hip (separate translation units: the build
+// runs them in parallel).
 //
 // Execution model: one persistent workgroup per concurrently compiled decision
 // diagram ("slot").  A launch of min(batch, nslots) workgroups drains a batch of
@@ -18,76 +20,11 @@
 
 #include "../../include/ddo_hip.h"
 #include "engine.hpp"
-#include "misp_dd_inplace.hpp"
+#include "kernels.hpp"
+#include "misp_dd_inplace.hpp"   // LDS layout sizes (dd_lds_bytes / dd2_lds_bytes); the kernels themselves are not instantiated here
 
 namespace ddo_hip {
 
-// ---------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------
-template <int WS, bool TLDS>
-__global__ void __launch_bounds__(1024) misp_compile_kernel(EngineParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    DDCtx<WS> c;
-    dd_bind<WS, TLDS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
-    c.tid_ = (int)threadIdx.x;
-    for (;;) {
-        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
-        __syncthreads();
-        const int w = c.sh->work;
-        __syncthreads();
-        if (w >= P.nbatch) break;
-        run_work_item<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
-    }
-}
-
-/// in-place engine (misp_dd_inplace.hpp)
-template <int WS, int MAXT>
-__global__ void __launch_bounds__(MAXT) misp_compile_kernel2(EngineParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    DD2Ctx<WS> c;
-    dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
-    c.tid_ = (int)threadIdx.x;
-    for (;;) {
-        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
-        __syncthreads();
-        const int w = c.sh->work;
-        __syncthreads();
-        if (w >= P.nbatch) break;
-        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
-    }
-}
-
-typedef void (*kernel_fn)(EngineParams);
-// MAXT = 512 lets the register allocator use 256 VGPRs (the 1024-thread variant is capped at 128 and spills)
-template <int MAXT>
-static kernel_fn pick_kernel2t(int wsT) {
-    switch (wsT) {
-        case 1: return misp_compile_kernel2<1, MAXT>;
-        case 2: return misp_compile_kernel2<2, MAXT>;
-        case 4: return misp_compile_kernel2<4, MAXT>;
-        case 7: return misp_compile_kernel2<7, MAXT>;
-        case 8: return misp_compile_kernel2<8, MAXT>;
-        case 16: return misp_compile_kernel2<16, MAXT>;
-        default: return nullptr;
-    }
-}
-static kernel_fn pick_kernel2(int wsT, int threads) {
-    return threads <= 512 ? pick_kernel2t<512>(wsT) : pick_kernel2t<1024>(wsT);
-}
-template <bool TLDS>
-static kernel_fn pick_kernel(int wsT) {
-    switch (wsT) {
-        case 1: return misp_compile_kernel<1, TLDS>;
-        case 2: return misp_compile_kernel<2, TLDS>;
-        case 4: return misp_compile_kernel<4, TLDS>;
-        case 7: return misp_compile_kernel<7, TLDS>;
-        case 8: return misp_compile_kernel<8, TLDS>;
-        case 16: return misp_compile_kernel<16, TLDS>;
-        case 32: return misp_compile_kernel<32, TLDS>;   // signed-vector models only (MAX2SAT n <= 62)
-        default: return nullptr;
-    }
-}
 static int pick_ws(int ws) {
     const int opts[] = {1, 2, 4, 7, 8, 16, 32};
     for (int o : opts)
@@ -424,7 +361,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     ev1_ = e1;
 
     kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model->wsT, threads_)
-                                     : (table_lds_ ? pick_kernel<true>(model->wsT) : pick_kernel<false>(model->wsT));
+                                     : pick_kernel(model->wsT, table_lds_);
     if (!fn) {
         set_error("unsupported state width");
         return DDO_ERR_UNSUPPORTED;
@@ -573,7 +510,7 @@ int Engine::launch(const DDInput* inputs, int count) {
     P.arena = io.h_arena;
     const int grid = std::min(count, nslots_);
     kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT, threads_)
-                                     : (table_lds_ ? pick_kernel<true>(model_->wsT) : pick_kernel<false>(model_->wsT));
+                                     : pick_kernel(model_->wsT, table_lds_);
     HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);
     HIP_TRY(hipGetLastError());

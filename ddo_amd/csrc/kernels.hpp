@@ -1,0 +1,23 @@
+// =============================================================================
+// kernels.hpp -- entry points of the gfx950 kernels, one translation unit per
+// group so that the build compiles them in parallel.
+// =============================================================================
+#pragma once
+#include "dd_types.h"
+
+namespace ddo_hip {
+
+typedef void (*kernel_fn)(EngineParams);
+
+/// in-place engine (misp_dd_inplace.hpp): wsT in {1, 2, 4, 7, 8, 16}; threads <= 512 picks the 256-VGPR variant
+kernel_fn pick_kernel2(int wsT, int threads);
+/// layer-rebuilding engine (misp_dd_core.hpp): wsT in {1, 2, 4, 7, 8, 16, 32}; dedup table in LDS or in HBM
+kernel_fn pick_kernel(int wsT, bool table_in_lds);
+
+// the per-unit halves
+kernel_fn pick_kernel2_1024(int wsT);
+kernel_fn pick_kernel2_512(int wsT);
+kernel_fn pick_kernel_lds(int wsT);
+kernel_fn pick_kernel_glb(int wsT);
+
+}  // namespace ddo_hip

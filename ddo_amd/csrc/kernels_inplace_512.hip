@@ -1,0 +1,38 @@
+// gfx950 kernels of the in-place engine, workgroups of up to 512 threads (see kernels.hpp)
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "misp_dd_inplace.hpp"
+
+namespace ddo_hip {
+
+// MAXT = 512 lets the register allocator use 256 VGPRs (the 1024-thread variant is capped at 128 and spills)
+template <int WS, int MAXT>
+__global__ void __launch_bounds__(MAXT) misp_compile_kernel2(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    DD2Ctx<WS> c;
+    dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
+    c.tid_ = (int)threadIdx.x;
+    for (;;) {
+        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
+        __syncthreads();
+        const int w = c.sh->work;
+        __syncthreads();
+        if (w >= P.nbatch) break;
+        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+    }
+}
+
+kernel_fn pick_kernel2_512(int wsT) {
+    switch (wsT) {
+        case 1: return misp_compile_kernel2<1, 512>;
+        case 2: return misp_compile_kernel2<2, 512>;
+        case 4: return misp_compile_kernel2<4, 512>;
+        case 7: return misp_compile_kernel2<7, 512>;
+        case 8: return misp_compile_kernel2<8, 512>;
+        case 16: return misp_compile_kernel2<16, 512>;
+        default: return nullptr;
+    }
+}
+
+}  // namespace ddo_hip
