@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time",
 ]
 
-DDO_OK, DDO_CUTOFF = 0, 1
+DDO_OK, DDO_CUTOFF = 0, 2
 LAST_EXACT_LAYER, FRONTIER = 1, 2
 
 

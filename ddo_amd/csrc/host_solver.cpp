@@ -721,7 +721,7 @@ struct ddo_solver {
         if (budget_exhausted()) {
             flush_lazy();
             aborted = true;
-            best_ub = lazy->best_ub();
+            best_ub = std::max(best_lb, lazy->best_ub());   // abort_search (parallel.rs:479-489): the best open bound
             lazy->clear();
             return DDO_CUTOFF;
         }

@@ -28,8 +28,9 @@ extern "C" {
 
 /* ---- status codes ------------------------------------------------------- */
 #define DDO_OK 0
-/** compile() was interrupted by the cutoff flag == Err(Reason::CutoffOccurred), common.rs:108-111 */
-#define DDO_CUTOFF 1
+/** compile() was interrupted by the cutoff flag == Err(Reason::CutoffOccurred), common.rs:108-111; a solver whose
+ *  TimeBudget ran out (parallel.rs:479-489).  Distinct from the 1 that ddo_solver_step returns while work remains. */
+#define DDO_CUTOFF 2
 #define DDO_ERR_NO_DEVICE (-1)   /* no HIP device / HIP runtime error            */
 #define DDO_ERR_INVALID (-2)     /* bad argument                                 */
 #define DDO_ERR_CAPACITY (-3)    /* width / layer / output exceeds the capacity  */

@@ -334,3 +334,23 @@ def test_replay_at_maximum_state_sizes(have_gpu, oracle, tmp_path, n, p_edge, wi
     for i, r, got in replay_records(model, recs):
         d = diff(r, got)
         assert d is None, f"n={n} W={width} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+
+
+@pytest.mark.parametrize("fringe", ["nodup", "lazy"])
+def test_time_budget_aborts_the_search(fringe):
+    """TimeBudget (cutoff.rs:302-323) -> abort_search (parallel.rs:479-489): maximize() returns within about the
+    budget, not exact, with the incumbent as the lower bound and the best open bound above it."""
+    import time
+    model = ddo_amd.Misp.read_instance(data_path("misp", "brock400_1.clq"))
+    s = ddo_amd.ParallelSolver(model, ddo_amd.FixedWidth(1000), ddo_amd.TimeBudget(1.0), nb_threads=256, fringe=fringe)
+    t0 = time.perf_counter()
+    c = s.maximize()
+    dt = time.perf_counter() - t0
+    assert dt < 20.0
+    assert not c.is_exact and c.best_value is not None and c.best_value >= 15
+    assert s.best_lower_bound() == c.best_value
+    assert s.best_upper_bound() >= s.best_lower_bound()
+    assert s.gap() > 0.0
+    sol = sorted(d.variable for d in s.best_solution() if d.value == 1)
+    assert len(sol) == c.best_value
+    assert s.step() == ddo_amd.binding.DDO_CUTOFF   # an aborted solver stays aborted
