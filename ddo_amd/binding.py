@@ -251,7 +251,7 @@ class Misp:
         return SubProblem(state=self.initial_state(), value=self.initial_value(), path=[], depth=0)
 
 
-def _fill_input(model, comp_type, max_width, residual, best_lb, keep):
+def _fill_input(model, comp_type, max_width, residual, best_lb, keep, cutoff=None):
     ci = _CompileInput()
     ci.comp_type = comp_type
     ci.max_width = int(max_width)
@@ -268,7 +268,7 @@ def _fill_input(model, comp_type, max_width, residual, best_lb, keep):
     ci.residual.depth = int(residual.depth)
     ci.residual.path = path
     ci.residual.path_len = len(residual.path)
-    ci.cutoff = None
+    ci.cutoff = cutoff   # None, or a ctypes c_int polled like Cutoff::must_stop (clean.rs:352)
     return ci
 
 
@@ -362,9 +362,10 @@ class Mdd:
         except Exception:
             pass
 
-    def compile(self, comp_type, max_width, residual, best_lb):
+    def compile(self, comp_type, max_width, residual, best_lb, cutoff=None):
         keep = []
-        ci = _fill_input(self.model, comp_type, max_width, residual, best_lb, keep)
+        ci = _fill_input(self.model, comp_type, max_width, residual, best_lb, keep,
+                         C.pointer(cutoff) if cutoff is not None else None)   # cutoff: ctypes.c_int
         out = _Completion()
         rc = lib().ddo_mdd_compile(self._h, C.byref(ci), C.byref(out))
         if rc == DDO_CUTOFF:

@@ -1,0 +1,108 @@
+"""Entry points of include/ddo_hip.h that the parity suites do not reach: the per-compile cutoff flag, the exact
+solution of a DD, set_primal, the open-bound / device-time queries."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ddo_amd
+from ddo_amd import CompilationType, FixedWidth, ParallelSolver
+from tests.conftest import data_path
+from tests.parity_util import is_independent_set
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def brock():
+    return ddo_amd.Misp.read_instance(data_path("misp", "brock200_2.clq"))
+
+
+def test_compile_honours_the_cutoff_flag(brock):
+    """Cutoff::must_stop polled by compile (clean.rs:352-354) -> Err(Reason::CutoffOccurred)"""
+    mdd = ddo_amd.Mdd(brock, 100)
+    raised = C.c_int(1)
+    assert mdd.compile(CompilationType.Relaxed, 100, brock.root(), -(1 << 62), cutoff=raised) is None
+    lowered = C.c_int(0)
+    c = mdd.compile(CompilationType.Relaxed, 100, brock.root(), -(1 << 62), cutoff=lowered)
+    assert c is not None and c.best_value >= 12
+
+
+def test_best_exact_solution_of_a_relaxed_dd(brock):
+    """best_exact_value / best_exact_solution (mdd.rs:96-110): the best terminal reached by an exact path"""
+    mdd = ddo_amd.Mdd(brock, 50)
+    c = mdd.compile(CompilationType.Relaxed, 50, brock.root(), -(1 << 62))
+    assert c is not None and not c.is_exact
+    v = mdd.best_exact_value()
+    sol = mdd.best_exact_solution()
+    if v is None:
+        assert sol is None
+    else:
+        chosen = [d.variable for d in sol if d.value == 1]
+        rows, _w = brock.export()
+        assert len(chosen) == v and v <= 12 and is_independent_set(rows, brock.ws, chosen)
+    # a restricted DD only has exact paths: both views coincide
+    mdd.compile(CompilationType.Restricted, 50, brock.root(), -(1 << 62))
+    assert mdd.best_exact_value() == mdd.best_value()
+    assert [(d.variable, d.value) for d in mdd.best_exact_solution()] == [(d.variable, d.value) for d in mdd.best_solution()]
+
+
+def test_best_exact_solution_of_a_relaxed_knapsack_dd():
+    """a relaxed knapsack DD keeps several terminal nodes, some reached by exact paths only"""
+    rng = np.random.default_rng(7)
+    profit = rng.integers(1, 100, size=10)
+    weight = rng.integers(1, 50, size=10)
+    cap = int(weight.sum() // 2)
+    model = ddo_amd.Knapsack.from_items(cap, profit, weight)
+    mdd = ddo_amd.Mdd(model, 8)
+    seen_exact = False
+    for w in (2, 4, 6):   # width 6: inexact DD, best exact terminal 428 (same figures from the CPU emulation)
+        c = mdd.compile(CompilationType.Relaxed, w, model.root(), -(1 << 62))
+        assert c is not None and not c.is_exact
+        v, sol = mdd.best_exact_value(), mdd.best_exact_solution()
+        assert (v is None) == (sol is None)
+        if v is not None:
+            seen_exact = True
+            taken = [d.variable for d in sol if d.value == 1]
+            assert int(profit[taken].sum()) == v and int(weight[taken].sum()) <= cap and len(sol) == 10
+            assert v <= mdd.best_value()
+    assert seen_exact and v == 428 and mdd.best_value() == 473
+
+
+@pytest.mark.parametrize("fringe", ["nodup", "lazy"])
+def test_set_primal_seeds_the_incumbent(brock, fringe):
+    """Solver::set_primal (parallel.rs:630-636): a better primal replaces the incumbent, a worse one is ignored; the
+    search seeded with an optimal solution proves it with less work"""
+    ref = ParallelSolver(brock, FixedWidth(100), nb_threads=64, fringe=fringe)
+    assert ref.maximize().best_value == 12
+    opt = ref.best_solution()
+    seeded = ParallelSolver(brock, FixedWidth(100), nb_threads=64, fringe=fringe)
+    seeded.set_primal(12, opt)
+    assert seeded.best_lower_bound() == 12 and seeded.best_value() == 12
+    seeded.set_primal(5, opt[:5])            # not better: ignored
+    assert seeded.best_lower_bound() == 12
+    c = seeded.maximize()
+    assert c.is_exact and c.best_value == 12
+    assert sorted((d.variable, d.value) for d in seeded.best_solution()) == sorted((d.variable, d.value) for d in opt)
+    assert seeded.explored() <= ref.explored()
+    assert seeded.counters()["nodes_expanded"] <= ref.counters()["nodes_expanded"]
+
+
+@pytest.mark.parametrize("fringe", ["nodup", "lazy"])
+def test_open_bound_and_device_time_queries(brock, fringe):
+    s = ParallelSolver(brock, FixedWidth(100), nb_threads=16, fringe=fringe)
+    assert s.step() == 1                      # the root
+    s.flush()
+    assert s.fringe_len() > 0
+    ub0 = s.fringe_best_ub()
+    assert 12 <= ub0 <= 200
+    for _ in range(3):
+        if s.step() != 1:
+            break
+    s.flush()
+    assert s.fringe_best_ub() <= ub0          # best-first: the open bound never increases
+    ms, launches = s.device_time()
+    assert launches >= 2 and ms > 0.0
+    c = s.maximize()
+    assert c.is_exact and c.best_value == 12 and s.fringe_len() == 0
+    assert s.best_upper_bound() == s.best_lower_bound() == 12 and s.gap() == 0.0
