@@ -91,6 +91,7 @@ struct DD2Shared {
     int32_t tab_used;
     int32_t hiw;            // every live node sits in a slot below hiw (recomputed per layer: the sweeps stop there)
     int32_t hiw2;
+    int32_t fl_base;        // >= 0: the free slots of this transition are fl_base, fl_base + 1, ... (no list was built)
     int32_t merged_slot, recycled, xslot, free_slot;
     int32_t ncut, ncut2;
     uint32_t recycled_merges;
@@ -791,7 +792,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         if (tid == 0) {
             sh->varkey = 0xFFFFFFFFu;
             sh->hiw2 = 0;
-            if (c.cutoff_flag) sh->cutoff = LD_I32(c.cutoff_flag);
+            // Cutoff::must_stop (clean.rs:352) -- polled every 8th layer: the flag lives in host-visible memory and a
+            // read is a full round trip on the critical path of the layer
+            if (c.cutoff_flag && (L & 7) == 0) sh->cutoff = LD_I32(c.cutoff_flag);
         }
         PAR_END
         PAR_BEGIN
@@ -1228,6 +1231,18 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // Each thread claims room in the list for the free bits of its bitmap words with one LDS atomic; only as
         // many slots as this transition can consume are listed (at most one YES-child per work item).
         const int need_free = nwl + 1 < c.capW ? nwl + 1 : c.capW;
+        // Every slot at or above the high-water mark is dead.  While mark + need stays inside the first batch of the
+        // sweeps (NT * KS slots: sweeping them costs the same whatever the mark), the children simply take the slots
+        // above the mark and no list is built -- the common case of the many small DDs deep in a search.
+        const int hiw_now = DD_UNIFORM(sh->hiw);
+        const bool fl_implicit = hiw_now + need_free <= (capS < NT * KS ? capS : NT * KS);
+        PAR_BEGIN
+        if (tid == 0) {
+            sh->fl_base = fl_implicit ? hiw_now : -1;
+            if (fl_implicit) sh->nfl = need_free;
+        }
+        PAR_END
+        if (!fl_implicit) {
         PAR_BEGIN
         for (int ww = tid; ww < c.nbw; ww += NT) {
             if (sh->nfl >= need_free) break;
@@ -1246,6 +1261,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_BEGIN
         if (tid == 0 && sh->nfl > need_free) sh->nfl = need_free;
         PAR_END
+        }
         DD2_TICK2(PH_FREELIST, 14)
         // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
         const uint64_t aff_off = DD_UNIFORM64((sh->ev_pos + 3) & ~3ULL);   // 16-byte aligned records
@@ -1338,7 +1354,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #pragma unroll
             for (int k = 0; k < WS; ++k) y[k] = 0;
             if (fi < sh->nfl) {
-                ny = c.fl[fi];
+                ny = sh->fl_base >= 0 ? sh->fl_base + fi : (int)c.fl[fi];
                 int ypop = 0;
 #pragma unroll
                 for (int k = 0; k < WS; ++k) {
