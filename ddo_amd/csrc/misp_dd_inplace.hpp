@@ -90,7 +90,6 @@ struct DD2Shared {
     int32_t scan_total, sel_digit, sel_above, sel_bucket, sel_need;
     int32_t tab_used;
     int32_t hiw;            // every live node sits in a slot below hiw (recomputed per layer: the sweeps stop there)
-    int32_t hiw2;
     int32_t fl_base;        // >= 0: the free slots of this transition are fl_base, fl_base + 1, ... (no list was built)
     int32_t merged_slot, recycled, xslot, free_slot;
     int32_t ncut, ncut2;
@@ -742,6 +741,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         sh->cutoff = 0;
         sh->nlive = 1;
         sh->hiw = 1;
+        sh->varkey = 0xFFFFFFFFu;
         sh->ev_pos = 0;
         for (int k = 0; k < 8; ++k) sh->clk[k] = 0;
         for (int k = 0; k < 16; ++k) sh->mk[k] = 0;
@@ -788,16 +788,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 
     for (;;) {
         // ------------------------------------------------------------ next_variable (main.rs:109-143)
+        // (sh->varkey = ~0 and sh->hiw = 1 were set by the last region of the previous layer / of the initialisation)
         PAR_BEGIN
-        if (tid == 0) {
-            sh->varkey = 0xFFFFFFFFu;
-            sh->hiw2 = 0;
-            // Cutoff::must_stop (clean.rs:352) -- polled every 8th layer: the flag lives in host-visible memory and a
-            // read is a full round trip on the critical path of the layer
-            if (c.cutoff_flag && (L & 7) == 0) sh->cutoff = LD_I32(c.cutoff_flag);
-        }
-        PAR_END
-        PAR_BEGIN
+        // Cutoff::must_stop (clean.rs:352) -- polled every 8th layer: the flag lives in host-visible memory and a
+        // read is a full round trip on the critical path of the layer
+        if (tid == 0 && c.cutoff_flag && (L & 7) == 0) sh->cutoff = LD_I32(c.cutoff_flag);
         for (int i = tid; i < c.n; i += NT) {
             int cv = c.cnt[i];
             if (cv > 0) LDS_MIN_U32(&sh->varkey, ((uint32_t)cv << 12) | (uint32_t)i);
@@ -805,11 +800,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
         for (int w = tid; w < c.nbw; w += NT) {   // highest live slot: dead slots above it need not be swept
             const uint32_t lv = c.live[w];
-            if (lv) LDS_MAX_I32(&sh->hiw2, w * 32 + 32 - dd_clz32(lv));
+            if (lv) LDS_MAX_I32(&sh->hiw, w * 32 + 32 - dd_clz32(lv));
         }
-        PAR_END
-        PAR_BEGIN
-        if (tid == 0) sh->hiw = sh->hiw2 > 0 ? sh->hiw2 : 1;
         PAR_END
         var = DD_UNIFORM(sh->varkey == 0xFFFFFFFFu ? -1 : (int)(sh->varkey & 0xFFFu));
         if (var < 0) break;
@@ -1139,14 +1131,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             sh->nfl = 0;
             sh->npruned = 0;
             sh->nyes = 0;
-            c.lvar[L] = var;
-            c.lmerge[L] = merged_slot;
-            c.ldup[2 * L] = dup_from;
-            c.ldup[2 * L + 1] = dup_to;
-            uint32_t* eo = c.evoff + (size_t)L * 8;
-            eo[3] = (uint32_t)del_off;
-            eo[4] = (uint32_t)(del_off >> 32);
-            eo[5] = (uint32_t)n_del;
         }
         PAR_END
         const int vw = var >> 6;
@@ -1182,8 +1166,16 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         const int i = LDS_ADD_I32(&sh->nwl, 1);
                         if (i < c.capW) c.wl[i] = (uint16_t)s;
                     } else if (bm_test(c.fresh, s)) {
-                        const int i = LDS_ADD_I32(&sh->nwl2, 1);
-                        if (i < c.capW) c.wl[c.capW - 1 - i] = (uint16_t)s;
+                        // unit weights: the rough upper bound is the popcount held in the key (main.rs:191-193); a fresh
+                        // node that passes the check (clean.rs:362-365) is its own only child and joins the table here
+                        const uint32_t key = c.unit_weights ? K32(c, s) : 0u;
+                        if (c.unit_weights && (int64_t)(key & KEY_POP_MASK) + (int64_t)(vbase + (int32_t)(key >> KEY_POP_BITS)) > best_lb) {
+                            bm_clr(c.fresh, s);
+                            pend[b] = true;
+                        } else {
+                            const int i = LDS_ADD_I32(&sh->nwl2, 1);
+                            if (i < c.capW) c.wl[c.capW - 1 - i] = (uint16_t)s;
+                        }
                     } else {
                         pend[b] = true;   // unchanged node: into the table (all such states are distinct)
                     }
@@ -1440,10 +1432,20 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
         }
         if (tid == 0) {
+            // the bookkeeping of the layer goes out with the last region: nothing reads it before the backward pass
+            c.lvar[L] = var;
+            c.lmerge[L] = merged_slot;
+            c.ldup[2 * L] = dup_from;
+            c.ldup[2 * L + 1] = dup_to;
             uint32_t* eo = c.evoff + (size_t)L * 8;
             eo[0] = (uint32_t)aff_off;
             eo[1] = (uint32_t)(aff_off >> 32);
             eo[2] = (uint32_t)nrec;
+            eo[3] = (uint32_t)del_off;
+            eo[4] = (uint32_t)(del_off >> 32);
+            eo[5] = (uint32_t)n_del;
+            sh->varkey = 0xFFFFFFFFu;   // next layer's next_variable / high-water mark start from scratch
+            sh->hiw = 1;
             sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
             sh->nodes += (uint64_t)n;
             if (n > sh->maxn) sh->maxn = n;
