@@ -1335,8 +1335,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             const uint64_t newh = oldh ^ mixw(oldw, vw) ^ mixw(neww, vw);
             st_word<WS>(c, s, vw, neww, newh);
             const uint32_t kno = key - 1;  // popcount - 1, same value (cost 0)
-            K32_ST(c, s, kno);
-            LDS_ADD_I32(&c.cnt[var], -1);
+            K32_ST(c, s, kno);   // (cnt[var]: no state of the next layer contains the variable, it is zeroed with the layer)
             // ---- decision YES into a free slot (main.rs:95-102)
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
             int ny = -1;
@@ -1399,7 +1398,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
             // parent | NO target | YES target | slot allocated for the YES-child
             *rec4 = U32x4{(uint32_t)s, e_no, e_yes, ny >= 0 ? (uint32_t)ny : NONE32};
-            LDS_ADD_I32(&sh->nyes, 1);
         }
         PAR_END
         const int nrec = DD_UNIFORM(sh->nrec);
@@ -1449,7 +1447,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
             sh->nodes += (uint64_t)n;
             if (n > sh->maxn) sh->maxn = n;
+            sh->nyes = nrec - sh->npruned;   // every record is a pruned node or a node with a YES-child
             sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
+            c.cnt[var] = 0;
 #if defined(DDO_HOST_EMULATION)
             if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
 #endif
