@@ -90,7 +90,6 @@ struct DD2Shared {
     int32_t scan_total, sel_digit, sel_above, sel_bucket, sel_need;
     int32_t tab_used;
     int32_t hiw;            // every live node sits in a slot below hiw (recomputed per layer: the sweeps stop there)
-    int32_t fl_base;        // >= 0: the free slots of this transition are fl_base, fl_base + 1, ... (no list was built)
     int32_t merged_slot, recycled, xslot, free_slot;
     int32_t ncut, ncut2;
     uint32_t recycled_merges;
@@ -742,6 +741,13 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         sh->nlive = 1;
         sh->hiw = 1;
         sh->varkey = 0xFFFFFFFFu;
+        sh->nwl = 0;
+        sh->nwl2 = 0;
+        sh->nrec = 0;
+        sh->nnew = 0;
+        sh->nfl = 0;
+        sh->npruned = 0;
+        sh->nyes = 0;
         sh->ev_pos = 0;
         for (int k = 0; k < 8; ++k) sh->clk[k] = 0;
         for (int k = 0; k < 16; ++k) sh->mk[k] = 0;
@@ -788,8 +794,16 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 
     for (;;) {
         // ------------------------------------------------------------ next_variable (main.rs:109-143)
-        // (sh->varkey = ~0 and sh->hiw = 1 were set by the last region of the previous layer / of the initialisation)
+        // (sh->varkey = ~0, sh->hiw = 1 and the work-list counters were reset by the last region of the previous layer /
+        // of the initialisation)
+        const int nU = DD_UNIFORM(sh->nlive);
+        // _squash_if_needed (clean.rs:779-795) is decided up front: a layer that is NOT squashed never probes the dedup
+        // table of the current layer again, so the table of the next layer is cleared here and the region that would
+        // do it later disappears -- narrow layers are all barrier and round-trip latency, every region counts
+        const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
         PAR_BEGIN
+        if (!squash)
+            for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
         // Cutoff::must_stop (clean.rs:352) -- polled every 8th layer: the flag lives in host-visible memory and a
         // read is a full round trip on the critical path of the layer
         if (tid == 0 && c.cutoff_flag && (L & 7) == 0) sh->cutoff = LD_I32(c.cutoff_flag);
@@ -814,10 +828,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
         if (L >= c.max_layers - 1 || sh->status != ST_OK) { failed = true; break; }
         DD2_TICK2(PH_VAR, 15)
-        const int nU = DD_UNIFORM(sh->nlive);
-
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
-        const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
         int merged_slot = -1, dup_from = -1, dup_to = -1;
         const uint64_t del_off = DD_UNIFORM64(sh->ev_pos);
         int n_del = 0;
@@ -1121,18 +1132,20 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
 
         // ------------------------------------------------------------ work list: affected or fresh nodes
-        PAR_BEGIN
-        for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;   // dedup table of the next layer (see the sweep)
-        if (tid == 0) {
-            sh->nwl = 0;
-            sh->nwl2 = 0;
-            sh->nrec = 0;
-            sh->nnew = 0;
-            sh->nfl = 0;
-            sh->npruned = 0;
-            sh->nyes = 0;
+        if (squash) {   // the squash phases probed the table of this layer and borrowed the counters
+            PAR_BEGIN
+            for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;   // dedup table of the next layer (see the sweep)
+            if (tid == 0) {
+                sh->nwl = 0;
+                sh->nwl2 = 0;
+                sh->nrec = 0;
+                sh->nnew = 0;
+                sh->nfl = 0;
+                sh->npruned = 0;
+                sh->nyes = 0;
+            }
+            PAR_END
         }
-        PAR_END
         const int vw = var >> 6;
         const uint64_t vbit = 1ULL << (var & 63);
         // One sweep over the live slots does two jobs: (1) the work list -- nodes that contain the variable go to the
@@ -1228,12 +1241,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // above the mark and no list is built -- the common case of the many small DDs deep in a search.
         const int hiw_now = DD_UNIFORM(sh->hiw);
         const bool fl_implicit = hiw_now + need_free <= (capS < NT * KS ? capS : NT * KS);
-        PAR_BEGIN
-        if (tid == 0) {
-            sh->fl_base = fl_implicit ? hiw_now : -1;
-            if (fl_implicit) sh->nfl = need_free;
-        }
-        PAR_END
         if (!fl_implicit) {
         PAR_BEGIN
         for (int ww = tid; ww < c.nbw; ww += NT) {
@@ -1254,9 +1261,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         if (tid == 0 && sh->nfl > need_free) sh->nfl = need_free;
         PAR_END
         }
+        const int nfl_lim = fl_implicit ? need_free : DD_UNIFORM(sh->nfl);
         DD2_TICK2(PH_FREELIST, 14)
         // ------------------------------------------------------------ expand, phase 1 (clean.rs:360-370)
         const uint64_t aff_off = DD_UNIFORM64((sh->ev_pos + 3) & ~3ULL);   // 16-byte aligned records
+        if (nwl2 > 0) {
         PAR_BEGIN
         // ---- fresh nodes without the variable: bound check only (clean.rs:362-365); a survivor's only child is the
         // node itself, it joins the dedup table with its cached hash.  With unit weights the rough upper bound is the
@@ -1290,6 +1299,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
         }
         PAR_END
+        }
         // ---- nodes containing the variable: expansion AND dedup (clean.rs:738-775) in one pass.  The table holds every
         // unchanged node of the next layer now, so a thread writes its two children, makes the stores visible to the
         // workgroup and inserts them right away -- the records never have to be read back.
@@ -1344,8 +1354,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             uint32_t kyes = 0;
 #pragma unroll
             for (int k = 0; k < WS; ++k) y[k] = 0;
-            if (fi < sh->nfl) {
-                ny = sh->fl_base >= 0 ? sh->fl_base + fi : (int)c.fl[fi];
+            if (fi < nfl_lim) {
+                ny = fl_implicit ? hiw_now + fi : (int)c.fl[fi];
                 int ypop = 0;
 #pragma unroll
                 for (int k = 0; k < WS; ++k) {
@@ -1442,8 +1452,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             eo[3] = (uint32_t)del_off;
             eo[4] = (uint32_t)(del_off >> 32);
             eo[5] = (uint32_t)n_del;
-            sh->varkey = 0xFFFFFFFFu;   // next layer's next_variable / high-water mark start from scratch
-            sh->hiw = 1;
             sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
             sh->nodes += (uint64_t)n;
             if (n > sh->maxn) sh->maxn = n;
@@ -1453,6 +1461,14 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #if defined(DDO_HOST_EMULATION)
             if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
 #endif
+            sh->varkey = 0xFFFFFFFFu;   // next layer's next_variable / high-water mark / work lists start from scratch
+            sh->hiw = 1;
+            sh->nwl = 0;
+            sh->nwl2 = 0;
+            sh->nrec = 0;
+            sh->nnew = 0;
+            sh->nfl = 0;
+            sh->npruned = 0;
         }
         PAR_END
         DD2_TICK(PH_EXPAND)
