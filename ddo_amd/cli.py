@@ -81,8 +81,10 @@ def misp(args):
 
 def knapsack(args):
     model = B.Knapsack.read_instance(args.fname)
-    # the reference parses --duration but builds its solver with NoCutoff (knapsack/main.rs:326)
-    solver, completion, dt = _solve(model, args, args.threads, None)
+    # The reference parses --duration (default 30) but builds its solver with NoCutoff (knapsack/main.rs:326); its
+    # solver also has a dominance checker and a cache, which this one has not: the budget is honoured here so that a
+    # hard instance at the default width of 2 ends with a gap instead of running for hours.
+    solver, completion, dt = _solve(model, args, args.threads, args.duration)
     sol = _sorted_solution(solver)
     _report(dt, completion, solver, _list([d.value for d in sol] if sol is not None else []))
 
