@@ -97,7 +97,7 @@ struct DDResult {
     uint64_t arcs;
     uint64_t layers;
     uint64_t path_off, exact_off, cs_state_off, cs_value_off, cs_ub_off, cs_path_off;  // byte offsets from arena_off
-    uint64_t phase_clk[24];        // shader-clock ticks per phase [0..8) and per wave-0 code mark [8..24) (profiling aid; engine 2)
+    uint64_t phase_clk[32];        // shader-clock ticks per phase [0..8), per code mark [8..24), thread-0 probes inside expand [24..32) (profiling aid; engine 2)
     uint64_t pool_off;             // IN_POOL_OUT: byte offset of the cut-set block in the node pool
 };
 

@@ -440,7 +440,7 @@ struct ddo_solver {
     // optional statistics (DDO_HIP_STATS=1): per-DD layers / nodes / widest layer
     std::vector<uint32_t> st_layers, st_maxw;
     std::vector<uint64_t> st_nodes;
-    uint64_t st_clk[24] = {0};
+    uint64_t st_clk[32] = {0};
     uint64_t st_push = 0, st_push_dup = 0;
     uint64_t st_recycled = 0;
     double st_host_pop = 0, st_host_run = 0, st_host_post = 0, st_host_fetch = 0;
@@ -473,6 +473,11 @@ struct ddo_solver {
                          (double)st_clk[8] / tl, (double)st_clk[9] / tl, (double)st_clk[10] / tl, (double)st_clk[11] / tl, (double)st_clk[16] / tl,
                          (double)st_clk[12] / tl, (double)st_clk[15] / tl, (double)st_clk[13] / tl, (double)st_clk[14] / tl, (double)st_clk[17] / tl);
             for (int q = 18; q < 24; ++q) std::fprintf(stderr, " aux%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
+            if (st_clk[29]) {   // thread 0's own node in expand: the dependent chain, cycles per probed node
+                const double np = (double)st_clk[29];
+                std::fprintf(stderr, " | expand chain per node (thread 0, %.0f probes): loads %.0f, children + stores + fence %.0f, insert NO %.0f, insert YES %.0f, record %.0f",
+                             np, st_clk[24] / np, st_clk[25] / np, st_clk[26] / np, st_clk[27] / np, st_clk[28] / np);
+            }
             std::fprintf(stderr, " | recycled merges per layer %.4f", (double)st_recycled / tl);
             std::fprintf(stderr, "\n");
             std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
@@ -616,7 +621,7 @@ struct ddo_solver {
                     st_layers.push_back((uint32_t)r->hdr.layers);
                     st_maxw.push_back(r->hdr.max_width_seen);
                     st_nodes.push_back(r->hdr.nodes_expanded);
-                    for (int q = 0; q < 24; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                    for (int q = 0; q < 32; ++q) st_clk[q] += r->hdr.phase_clk[q];
                     st_recycled += r->hdr.recycled_merges;
                 }
                 if (r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
@@ -905,7 +910,7 @@ struct ddo_solver {
                     st_layers.push_back((uint32_t)r->hdr.layers);
                     st_maxw.push_back(r->hdr.max_width_seen);
                     st_nodes.push_back(r->hdr.nodes_expanded);
-                    for (int q = 0; q < 24; ++q) st_clk[q] += r->hdr.phase_clk[q];
+                    for (int q = 0; q < 32; ++q) st_clk[q] += r->hdr.phase_clk[q];
                     st_recycled += r->hdr.recycled_merges;
                 }
                 maybe_update_best(items[i], *r);

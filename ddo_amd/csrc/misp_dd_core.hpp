@@ -1534,7 +1534,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         r.cs_value_off = cs_value_off;
         r.cs_ub_off = cs_ub_off;
         r.cs_path_off = cs_path_off;
-        for (int k = 0; k < 24; ++k) r.phase_clk[k] = 0;
+        for (int k = 0; k < 32; ++k) r.phase_clk[k] = 0;
         r.pool_off = NO_POOL_SRC;
         *res = r;
     }

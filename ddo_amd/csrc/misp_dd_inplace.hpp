@@ -106,7 +106,7 @@ struct DD2Shared {
     uint64_t ev_pos;
     uint64_t clk[8];
     uint64_t clk_last;
-    uint64_t mk[16];        // statistics and auxiliary tick slots (DD2_STAT, DD2_TICK2)
+    uint64_t mk[24];        // statistics and auxiliary tick slots (DD2_STAT, DD2_TICK2), [16..24): DD2_PROBE
     int32_t xcand[64];
 };
 
@@ -129,6 +129,24 @@ struct DD2Shared {
         }                                                   \
         PAR_END                                             \
     }
+// DD2_PROBE(k): thread 0 times its own node inside expand (all its memory operations drained first): the dependent chain
+#if defined(DDO_HOST_EMULATION)
+#define DD_DRAIN() (void)0
+#else
+#define DD_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#endif
+// Compiled in only with -DDDO_HIP_PROBES (make PROBES=1): the probe registers cost 6 % at the 128-VGPR cap.
+#if defined(DDO_HIP_PROBES)
+#define DD2_PROBE(k)                                        \
+    if (probing) {                                          \
+        DD_DRAIN();                                         \
+        const uint64_t _t = dd_clock();                     \
+        probe[k] = _t - probe_t;                            \
+        probe_t = _t;                                       \
+    }
+#else
+#define DD2_PROBE(k)
+#endif
 #define DD2_TICK(ph)                                        \
     if (c.clocks) {                                         \
         PAR_BEGIN                                           \
@@ -750,7 +768,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         sh->nyes = 0;
         sh->ev_pos = 0;
         for (int k = 0; k < 8; ++k) sh->clk[k] = 0;
-        for (int k = 0; k < 16; ++k) sh->mk[k] = 0;
+        for (int k = 0; k < 24; ++k) sh->mk[k] = 0;
         sh->clk_last = dd_clock();
         int pop = 0;
         uint64_t root[WS];
@@ -1308,6 +1326,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #pragma unroll
         for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
         const int32_t wv = c.weight[var];
+#if defined(DDO_HIP_PROBES)
+        const bool probing = c.clocks && tid == 0;
+        uint64_t probe[5] = {0, 0, 0, 0, 0};
+        uint64_t probe_t = probing ? dd_clock() : 0;
+#endif
         for (int i = tid; i < nwl; i += NT) {
             const int s = c.wl[i];
             const uint32_t key = K32(c, s);
@@ -1316,6 +1339,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             uint64_t st[WS];
             uint64_t oldh = 0;
             ld_state_h<WS>(c, s, st, oldh);
+            DD2_PROBE(0)
             const int32_t rub = c.unit_weights ? pop : rub2_of<WS>(c, st);   // main.rs:191-193
             bm_clr(c.fresh, s);
             if ((int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365: no children
@@ -1375,6 +1399,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 sh->status = ST_ERR_CAPACITY - 100 * 6;
             }
             FENCE_BLOCK();   // both records are visible to the workgroup before the table publishes their slots
+            DD2_PROBE(1)
             // ---- dedup: NO-child (append_edge_to!, clean.rs:199-220)
             uint32_t e_no = (uint32_t)s, e_yes = NONE32;
             const int t0 = tab2_insert<WS>(c, s, newh, st);
@@ -1388,6 +1413,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 bm_clr(c.live, s);
                 LDS_ADD_I32(&sh->nlive, -1);
             }
+            DD2_PROBE(2)
             // ---- dedup: YES-child
             if (ny >= 0) {
                 const int t1 = tab2_insert<WS>(c, ny, yh, y);
@@ -1404,10 +1430,18 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     if (bm_test(c.inex, ny)) bm_set(c.inex, t1);
                 }
             }
+            DD2_PROBE(3)
             const int r = LDS_ADD_I32(&sh->nrec, 1);
             U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
             // parent | NO target | YES target | slot allocated for the YES-child
             *rec4 = U32x4{(uint32_t)s, e_no, e_yes, ny >= 0 ? (uint32_t)ny : NONE32};
+            DD2_PROBE(4)
+#if defined(DDO_HIP_PROBES)
+            if (probing && i == tid) {   // thread 0's first node went the whole way: charge its chain
+                for (int q = 0; q < 5; ++q) sh->mk[16 + q] += probe[q];
+                sh->mk[21] += 1;
+            }
+#endif
         }
         PAR_END
         const int nrec = DD_UNIFORM(sh->nrec);
@@ -1804,7 +1838,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         r.cs_path_off = cs_path_off;
         sh->clk[PH_FINAL] += dd_clock() - sh->clk_last;
         for (int k = 0; k < 8; ++k) r.phase_clk[k] = sh->clk[k];
-        for (int k = 0; k < 16; ++k) r.phase_clk[8 + k] = sh->mk[k];
+        for (int k = 0; k < 24; ++k) r.phase_clk[8 + k] = sh->mk[k];
         r.pool_off = pool_bytes ? pool_off : NO_POOL_SRC;
         *res = r;
     }

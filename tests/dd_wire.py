@@ -25,7 +25,7 @@ class DDResult(C.Structure):
                 ("arena_off", C.c_uint64), ("arena_bytes", C.c_uint64), ("nodes_expanded", C.c_uint64),
                 ("arcs", C.c_uint64), ("layers", C.c_uint64), ("path_off", C.c_uint64), ("exact_off", C.c_uint64),
                 ("cs_state_off", C.c_uint64), ("cs_value_off", C.c_uint64), ("cs_ub_off", C.c_uint64),
-                ("cs_path_off", C.c_uint64), ("phase_clk", C.c_uint64 * 24), ("pool_off", C.c_uint64)]
+                ("cs_path_off", C.c_uint64), ("phase_clk", C.c_uint64 * 32), ("pool_off", C.c_uint64)]
 
 
 def parse_result(res, arena_ptr, ws, depth0):
