@@ -88,17 +88,25 @@ def main():
 
     def barrier():
         solver.flush()   # the engine runs on its own HIP stream: wait for the launch in flight and absorb it
+        if dist is not None:
+            lb = incumbent.drain()   # the all-reduce in flight belongs to the steps before the barrier
+            if lb is not None:
+                solver.import_lower_bound(lb)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    from ddo_amd.distributed import exchange_incumbent, reduce_stats
+    from ddo_amd.distributed import PipelinedIncumbent, reduce_stats
+
+    incumbent = PipelinedIncumbent(dist, comm_device)
 
     def one_step():
         rc = solver.step()
         if dist is not None:   # parallel.rs:439-453: the incumbent is the only datum shared between workers
-            solver.import_lower_bound(exchange_incumbent(dist, solver.best_lower_bound(), comm_device))
+            lb = incumbent.post(solver.best_lower_bound())   # one step stale: ranks do not run in lock-step
+            if lb is not None:
+                solver.import_lower_bound(lb)
         return rc
 
     # Setup, outside warm-up and timing: the first step of a search compiles the root sub-problem alone (one

@@ -19,6 +19,36 @@ def exchange_incumbent(dist, lb, device):
     return int(buf.item())
 
 
+class PipelinedIncumbent:
+    """The same MAX all-reduce, one step stale: `post(lb)` returns the global bound of the PREVIOUS post (None the first
+    time) and starts the all-reduce of `lb` without waiting for it.  A rank therefore waits for its peers' step k only
+    when it finishes its own step k + 1: ranks whose batches take different times do not run in lock-step, and the
+    staleness is the one the reference's racing threads have (parallel.rs:439-453 reads `best_lb` under a mutex while
+    other threads are mid-compile).  Every rank must post the same number of times; `drain()` returns the last result."""
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+        self.buf, self.work = None, None
+
+    def _finish(self):
+        if self.work is None:
+            return None
+        self.work.wait()
+        self.work = None
+        return int(self.buf.item())
+
+    def post(self, lb):
+        if self.dist is None:
+            return lb
+        prev = self._finish()
+        self.buf = torch.tensor([max(int(lb), I64_LOW)], dtype=torch.int64, device=self.device)
+        self.work = self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.MAX, async_op=True)
+        return prev
+
+    def drain(self):
+        return self._finish()
+
+
 def reduce_stats(dist, elapsed, sums, device):
     """(max over ranks of elapsed, element-wise sum over ranks of `sums`)."""
     if dist is None:

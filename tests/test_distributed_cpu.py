@@ -30,10 +30,20 @@ def _worker(rank, world, port, q):
         lb = max(lb, local[step])
         lb = exchange_incumbent(dist, lb, "cpu")
         seen.append(lb)
+    from ddo_amd.distributed import PipelinedIncumbent
+    pipe, lb2, seen2 = PipelinedIncumbent(dist, "cpu"), -(1 << 63), []
+    for step in range(4):
+        lb2 = max(lb2, local[step])
+        got = pipe.post(lb2)            # the global bound of the previous post
+        seen2.append(got)
+        if got is not None:
+            lb2 = max(lb2, got)
+    seen2.append(pipe.drain())
+    assert pipe.drain() is None
     elapsed, sums = reduce_stats(dist, 1.0 + rank, [10 * (rank + 1), 3], "cpu")
     total_open = open_work(dist, [5, 0][rank], "cpu")
     done = open_work(dist, 0, "cpu")
-    q.put((rank, seen, elapsed, sums, total_open, done))
+    q.put((rank, seen, elapsed, sums, total_open, done, seen2))
     dist.destroy_process_group()
 
 
@@ -48,8 +58,9 @@ def test_incumbent_exchange_and_stats_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, seen, elapsed, sums, total_open, done in out:
+    for rank, seen, elapsed, sums, total_open, done, seen2 in out:
         assert seen == [-(1 << 62), 20, 24, 24]
+        assert seen2 == [None, -(1 << 62), 20, 24, 24]      # one step stale, same running maximum
         assert elapsed == 2.0 and sums == [30.0, 6.0]
         assert total_open == 5 and done == 0
 
@@ -58,5 +69,8 @@ def test_single_process_identity():
     from ddo_amd.distributed import exchange_incumbent, open_work, reduce_stats
 
     assert exchange_incumbent(None, 17, "cpu") == 17
+    from ddo_amd.distributed import PipelinedIncumbent
+    p = PipelinedIncumbent(None, "cpu")
+    assert p.post(5) == 5 and p.drain() is None
     assert reduce_stats(None, 0.5, [1, 2], "cpu") == (0.5, [1.0, 2.0])
     assert open_work(None, 9, "cpu") == 9
