@@ -340,7 +340,34 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
         if (const char* env = std::getenv("DDO_HIP_POOL_GB")) want = (size_t)std::max(0, std::atoi(env)) << 30;
         size_t avail = free2 > ((size_t)6 << 30) ? free2 - ((size_t)6 << 30) : 0;
         size_t pool_bytes = std::min(want, avail);
-        if (pool_bytes >= ((size_t)1 << 28)) {
+        const char* vmm = std::getenv("DDO_HIP_POOL_VMM");
+        if (!(vmm && std::atoi(vmm) == 0) && avail >= ((size_t)1 << 30)) {   // DDO_HIP_POOL_VMM=0: one fixed hipMalloc instead
+            // reserve the address range (everything that is free unless DDO_HIP_POOL_GB caps it), map the first chunks
+            hipMemAllocationProp prop{};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = device;
+            size_t gran = 0;
+            if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0) {
+                const size_t chunk = ((((size_t)2 << 30) + gran - 1) / gran) * gran;
+                const size_t cap = std::getenv("DDO_HIP_POOL_GB") ? std::min(want, avail) : avail;
+                const size_t reserve = cap / chunk * chunk;
+                void* base = nullptr;
+                if (reserve >= chunk && hipMemAddressReserve(&base, reserve, gran, nullptr, 0) == hipSuccess && base) {
+                    vm_base_ = (uint8_t*)base;
+                    vm_reserved_ = reserve;
+                    vm_chunk_ = chunk;
+                    if (pool_grow(std::min(reserve, 4 * chunk)) == DDO_OK && vm_mapped_ >= chunk) {
+                        P.pool = vm_base_;
+                        P.pool_cap = vm_mapped_;
+                    } else {
+                        pool_release();
+                    }
+                }
+            }
+            (void)hipGetLastError();   // a failed attempt falls back to the plain allocation below
+        }
+        if (!P.pool && pool_bytes >= ((size_t)1 << 28)) {
             uint8_t* pool = nullptr;
             if (dev_alloc(allocs_, pool, pool_bytes) == DDO_OK) {
                 P.pool = pool;
@@ -374,6 +401,7 @@ Engine::~Engine() {
     if (device_ >= 0) (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize((hipStream_t)stream_);
     for (void* p : allocs_) (void)hipFree(p);
+    pool_release();
     for (int k = 0; k < 2; ++k) {
         if (io_[k].d_inputs) (void)hipFree(io_[k].d_inputs);
         if (io_[k].d_results) (void)hipFree(io_[k].d_results);
@@ -395,7 +423,51 @@ int Engine::pool_reset() {
     std::lock_guard<std::mutex> g(mtx_);
     HIP_TRY(hipSetDevice(device_));
     HIP_TRY(hipMemset((uint8_t*)d_counters_ + 32, 0, 8));   // pool head
+    pool_head_bound_ = 0;
+    pool_unfetched_worst_ = 0;
     return DDO_OK;
+}
+
+/// maps physical chunks until `target` bytes of the reserved range are backed (or memory runs out: the pool then stays
+/// at its size and the kernel reports ST_ERR_CAPACITY when it is full, as with the fixed pool)
+int Engine::pool_grow(size_t target) {
+    if (!vm_base_) return DDO_OK;
+    target = std::min(target, vm_reserved_);
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device_;
+    while (vm_mapped_ < target) {
+        hipMemGenericAllocationHandle_t h{};
+        if (hipMemCreate(&h, vm_chunk_, &prop, 0) != hipSuccess) break;
+        if (hipMemMap(vm_base_ + vm_mapped_, vm_chunk_, 0, h, 0) != hipSuccess) {
+            (void)hipMemRelease(h);
+            break;
+        }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemSetAccess(vm_base_ + vm_mapped_, vm_chunk_, &acc, 1) != hipSuccess) {
+            (void)hipMemUnmap(vm_base_ + vm_mapped_, vm_chunk_);
+            (void)hipMemRelease(h);
+            break;
+        }
+        vm_handles_.push_back((void*)h);
+        vm_mapped_ += vm_chunk_;
+    }
+    (void)hipGetLastError();
+    return DDO_OK;
+}
+void Engine::pool_release() {
+    if (!vm_base_) return;
+    for (size_t i = 0; i < vm_handles_.size(); ++i) {
+        (void)hipMemUnmap(vm_base_ + i * vm_chunk_, vm_chunk_);
+        (void)hipMemRelease((hipMemGenericAllocationHandle_t)vm_handles_[i]);
+    }
+    vm_handles_.clear();
+    (void)hipMemAddressFree(vm_base_, vm_reserved_);
+    vm_base_ = nullptr;
+    vm_reserved_ = vm_mapped_ = 0;
 }
 int Engine::read_pool(uint64_t off, void* dst, size_t bytes) {
     std::lock_guard<std::mutex> g(mtx_);
@@ -512,6 +584,16 @@ int Engine::launch(const DDInput* inputs, int count) {
     kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT, threads_)
                                      : pick_kernel(model_->wsT, table_lds_);
     HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
+    if (vm_base_) {
+        // the kernel allocates blocks with one atomic on the pool head: back everything the launches that are not
+        // fetched yet (the previous one may still run) and this one can possibly take
+        const size_t worst = (size_t)count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
+        const size_t need = (size_t)pool_head_bound_ + pool_unfetched_worst_ + worst;
+        if (need > vm_mapped_) pool_grow(need + 2 * vm_chunk_);
+        pool_unfetched_worst_ += worst;
+        P_.pool_cap = vm_mapped_;
+        P.pool_cap = vm_mapped_;
+    }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)ev1_, st));
@@ -569,7 +651,14 @@ int Engine::fetch(std::vector<HostResult>& results) {
                 continue;
             }
             decode(r, io.h_arena, out);
+            if (r.n_cutset > 0 && r.pool_off != NO_POOL_SRC)
+                pool_head_bound_ = std::max<uint64_t>(pool_head_bound_, r.pool_off + pool_block_bytes((uint32_t)r.n_cutset, (uint32_t)model_->wsT,
+                                                                                                       (uint32_t)(r.lel > 0 ? r.lel : 0)));
         }
+    }
+    if (vm_base_) {   // this batch is accounted for exactly now
+        const size_t worst = (size_t)count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
+        pool_unfetched_worst_ = pool_unfetched_worst_ > worst ? pool_unfetched_worst_ - worst : 0;
     }
     return DDO_OK;
 }

@@ -156,6 +156,16 @@ class Engine {
     int fetch_set_ = -1;     // set whose kernel finished (wait() done) but whose arena is not fetched yet
     void* copy_stream_ = nullptr;
     void* d_counters_ = nullptr;   // [16] cutoff flag, [32..40) pool head
+    // Growable node pool (default; DDO_HIP_POOL_VMM=0 selects one fixed allocation): the address range is reserved once (hipMemAddressReserve), physical chunks
+    // are mapped as the search fills it -- creating a solver costs milliseconds instead of the seconds a 64 GB hipMalloc
+    // takes, co-resident solvers only hold what they use, and one search can grow into all of the 288 GB.
+    uint8_t* vm_base_ = nullptr;
+    size_t vm_reserved_ = 0, vm_mapped_ = 0, vm_chunk_ = 0;
+    std::vector<void*> vm_handles_;
+    uint64_t pool_head_bound_ = 0;     // upper bound of the pool head over every result fetched so far
+    size_t pool_unfetched_worst_ = 0;  // worst-case growth of the launches whose results were not fetched yet
+    int pool_grow(size_t target);
+    void pool_release();
     size_t arena_cap_ = 0;
     int pending_ = 0;
     double kernel_ms_ = 0, last_kernel_ms_ = 0;

@@ -459,8 +459,8 @@ struct ddo_solver {
             for (auto x : st_nodes) tn += x;
             uint64_t tc = 0;
             for (int q = 0; q < 8; ++q) tc += st_clk[q];
-            std::fprintf(stderr, "[ddo stats] host s: pop %.3f run %.3f post %.3f (of which fetch %.3f) | pushes %llu\n", st_host_pop, st_host_run,
-                         st_host_post, st_host_fetch, (unsigned long long)st_push);
+            std::fprintf(stderr, "[ddo stats] host s: pop %.3f run %.3f post %.3f (of which fetch %.3f) | pushes %llu | node pool backed %.1f GB\n", st_host_pop,
+                         st_host_run, st_host_post, st_host_fetch, (unsigned long long)st_push, engine ? engine->pool_capacity() / 1073741824.0 : 0.0);
             std::fprintf(stderr, "[ddo stats] device kcycles per layer: misc(var,sweep,freelist,final,backward) %.1f select %.1f classify+tie-break %.1f victims+merge %.1f expand+dedup %.1f (unused %.1f %.1f) hand-over %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
                          st_clk[0] / 1e3 / std::max<uint64_t>(1, tl), st_clk[1] / 1e3 / std::max<uint64_t>(1, tl), st_clk[2] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
