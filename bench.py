@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline (32 = best of the 1/32/128/256 sweep on the GPU box; 0 = all)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--prove", type=float, default=0.0, metavar="SECONDS",
+                    help="after the timed steps, also run a whole search to the proved optimum under this time budget (N = 1; about 170 s for the default workload) and report time_to_proved_optimum_s")
     ap.add_argument("--instance", default=INSTANCE)
     ap.add_argument("--width", type=int, default=WIDTH)
     args = ap.parse_args()
@@ -195,6 +197,19 @@ def main():
                           f"{r['explored']} sub-problems, {r['nodes_expanded']} nodes in {r['wall_s']:.1f} s",
             }
             out["speedup_vs_cpu"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-9)
+        if args.prove > 0 and world == 1:
+            # secondary metric of BASELINE.json: wall time of maximize() to the proved optimum
+            from ddo_amd import TimeBudget
+            del solver
+            prover = ParallelSolver(model, FixedWidth(args.width), TimeBudget(args.prove), nb_threads=conc, device=local_rank, fringe=args.fringe)
+            tp0 = time.perf_counter()
+            comp = prover.maximize()
+            tp = time.perf_counter() - tp0
+            pc = prover.counters()
+            out["time_to_proved_optimum_s"] = tp if comp.is_exact else None
+            out["proof"] = {"proved": bool(comp.is_exact), "best_value": comp.best_value, "lower_bound": prover.best_lower_bound(),
+                            "upper_bound": prover.best_upper_bound(), "wall_s": tp, "subproblems": prover.explored(),
+                            "nodes_expanded": pc["nodes_expanded"], "budget_s": args.prove}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
