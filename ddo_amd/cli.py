@@ -7,8 +7,8 @@ the GPU engine:
     python -m ddo_amd.cli mcp      -f <file> [-w WIDTH] [-t SECONDS]          (examples/mcp/main.rs:19-66)
 
 `-t/--threads` of misp / knapsack is the number of sub-problems compiled concurrently (the reference's worker threads);
-on the GPU the useful values are hundreds to thousands (tools/fringe_compare.py), so the default is 2048 for misp and 256
-for knapsack instead of 8.  The report has the reference's lines
+on the GPU the useful values are hundreds to thousands (tools/fringe_compare.py), so the default is 8192 for misp (brock400_1 / W = 10 000 is proved in 183 / 169 / 146 / 143 / 138 s with
+1024 / 2048 / 4096 / 8192 / 16384 in flight) and 256 for knapsack instead of 8.  The report has the reference's lines
 (`Duration / Objective / Upper Bnd / Lower Bnd / Gap / Aborted / [Cost] / Solution`) so that the outputs can be diffed.
 Like the reference's binaries the solvers use the duplicate-free fringe; `--fringe lazy` selects the device-resident
 block fringe (MISP only).  The knapsack binary of the reference couples a frontier cut-set, a cache and a dominance checker
@@ -151,7 +151,7 @@ def main(argv=None):
     for name, fn in (("misp", misp), ("knapsack", knapsack)):
         p = sub.add_parser(name)
         p.add_argument("fname", help="the path to the instance file")
-        p.add_argument("-t", "--threads", type=int, default=2048 if name == "misp" else 256,
+        p.add_argument("-t", "--threads", type=int, default=8192 if name == "misp" else 256,
                        help="sub-problems compiled concurrently")
         p.add_argument("-d", "--duration", type=int, default=None if name == "misp" else 30,
                        help="the maximum amount of time (s) the solver may run")
