@@ -50,9 +50,11 @@ def main():
                     help="lazy: cut-sets stay in the device node pool, SimpleFringe/MaxUB order; nodup: host NoDupFringe")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline (32 = best of the 1/32/128/256 sweep on the GPU box; 0 = all)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--prove", type=float, default=0.0, metavar="SECONDS",
-                    help="after the timed steps, also run a whole search to the proved optimum under this time budget (N = 1; about 170 s for the default workload) and report time_to_proved_optimum_s")
+    ap.add_argument("--no-cpu", action="store_true", help="timed steps only: neither the CPU baseline nor the proof search")
+    ap.add_argument("--prove", type=float, default=400.0, metavar="SECONDS",
+                    help="after the timed steps (N = 1 only), run the whole search to the PROVED optimum under this time budget and report "
+                         "time_to_proved_optimum_s, the second half of BASELINE.json's metric (about 140 s for the default workload; 0 = skip)")
+    ap.add_argument("--prove-concurrent", type=int, default=8192, help="sub-problems in flight during the proof search")
     ap.add_argument("--instance", default=INSTANCE)
     ap.add_argument("--width", type=int, default=WIDTH)
     args = ap.parse_args()
@@ -197,11 +199,12 @@ def main():
                           f"{r['explored']} sub-problems, {r['nodes_expanded']} nodes in {r['wall_s']:.1f} s",
             }
             out["speedup_vs_cpu"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-9)
-        if args.prove > 0 and world == 1:
+        if args.prove > 0 and world == 1 and not args.no_cpu:   # --no-cpu = the timed steps only (profiling, A/B tools)
             # secondary metric of BASELINE.json: wall time of maximize() to the proved optimum
             from ddo_amd import TimeBudget
             del solver
-            prover = ParallelSolver(model, FixedWidth(args.width), TimeBudget(args.prove), nb_threads=conc, device=local_rank, fringe=args.fringe)
+            prover = ParallelSolver(model, FixedWidth(args.width), TimeBudget(args.prove), nb_threads=args.prove_concurrent, device=local_rank,
+                                    fringe=args.fringe)
             tp0 = time.perf_counter()
             comp = prover.maximize()
             tp = time.perf_counter() - tp0
@@ -209,7 +212,7 @@ def main():
             out["time_to_proved_optimum_s"] = tp if comp.is_exact else None
             out["proof"] = {"proved": bool(comp.is_exact), "best_value": comp.best_value, "lower_bound": prover.best_lower_bound(),
                             "upper_bound": prover.best_upper_bound(), "wall_s": tp, "subproblems": prover.explored(),
-                            "nodes_expanded": pc["nodes_expanded"], "budget_s": args.prove}
+                            "nodes_expanded": pc["nodes_expanded"], "budget_s": args.prove, "subproblems_in_flight": args.prove_concurrent}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
