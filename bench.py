@@ -3,22 +3,31 @@
 
     MDD nodes expanded / second, MISP on DIMACS brock400_1, width 10 000   (BASELINE.json, config C4)
 
-One *step* = one round of the branch-and-bound host over the device engine (the root sub-problem is expanded during
-setup: it is a batch of one): up to `--concurrent`
-sub-problems are popped from the fringe and each gets its restricted and (when inexact) relaxed
-decision diagram compiled on the GPU in a single launch (parallel.rs:391-437), then their cut-sets
-are enqueued.  Inputs are resident in HBM when the timed region of the kernel starts (the
-sub-problem states are 56-byte records uploaded before the launch; the PCIe-inclusive wall rate is
-what `value` reports, the kernel-only rate is in `roofline`).
+The timed workload is FROZEN, so the number does not depend on --steps / --warmup:
+
+  setup   the branch-and-bound search (parallel.rs:391-437 per sub-problem: restricted DD, then -- when inexact --
+          relaxed DD, both compiled on the GPU) runs its root step plus PREFIX_STEPS steps of `--concurrent`
+          sub-problems; then the next `--batches` batches are popped in fringe order (MaxUB) and frozen together with
+          the incumbent (ddo_solver_bench_freeze).  Their residual states already sit in the device node pool (HBM).
+  step    one pass of the hot path over one frozen batch: batch (k mod --batches) is compiled exactly as a search step
+          would (same launch, same software pipeline, same host work on the (ub, value) rows coming back), but nothing
+          is folded into the fringe.  Every cycle of `--batches` steps is therefore the same work.
+
+`value` = nodes expanded in the K timed steps / wall time of those steps (whole job, all ranks).  The kernel-only rate
+(HIP events on the engine's own stream) feeds `roofline`.  After the timed steps, at N = 1 only and outside the timed
+region: a bounded CPU sample (`cpu_baseline`) and a fresh whole search to the PROVED optimum
+(`time_to_proved_optimum_s`, the second half of BASELINE.json's metric, with its own roofline figure).
 
 `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
-torch.distributed.run -- every rank owns a shard of the root cut-set and only the incumbent lower
+torch.distributed.run -- every rank owns a shard of the root cut-set (hash of the state) and only the incumbent lower
 bound crosses GPUs (one 8-byte MAX all-reduce over RCCL/xGMI per step).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,33 +36,74 @@ sys.path.insert(0, ROOT)
 INSTANCE = "brock400_1"
 WIDTH = 10000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PREFIX_STEPS = 4               # search steps between the root and the frozen batches (fixed: part of the workload)
 
 
-def cpu_baseline(seconds, threads):
-    """The CPU oracle (C++ restatement of ddo, kind = "port") on the same instance / width for a bounded
-    time budget; nodes expanded per second on `threads` host threads."""
+def physical_cores():
+    """(physical cores, logical cpus) of this host from /proc/cpuinfo."""
+    cores = set()
+    phys = core = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return (len(cores) or (os.cpu_count() or 1)), (os.cpu_count() or 1)
+
+
+def cpu_baseline(instance, width, total_seconds, threads_arg):
+    """The CPU oracle (C++ restatement of ddo, kind = "port") on the same instance / width, built -O3 -march=native for
+    the host this runs on, swept over thread counts inside a bounded time budget; the best configuration is reported."""
     from tests.oracle_binding import Oracle
 
-    o = Oracle(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
-    inst = o.misp(os.path.join(ROOT, "data", "misp", INSTANCE + ".clq"))
-    r = inst.solve(WIDTH, threads, seconds)
-    return r
+    lib = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    build = "-O3 -march=x86-64-v2 (prebuilt)"
+    try:   # the prebuilt library is portable x86-64-v2: rebuild the same source for this host, outside the tree
+        out = os.path.join(tempfile.gettempdir(), "ddo_oracle_native_%d" % os.getuid(), "liboracle_native.so")
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", "NATIVE_OUT=" + out], check=True, timeout=300,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib, build = out, "-O3 -march=native (built on this host)"
+    except Exception:
+        pass
+    o = Oracle(lib)
+    inst = o.misp(os.path.join(ROOT, "data", "misp", instance + ".clq"))
+    phys, logical = physical_cores()
+    sweep = [threads_arg] if threads_arg > 0 else sorted({t for t in (8, 16, 32, 64, phys) if t <= logical})
+    per = max(2.0, total_seconds / len(sweep))
+    runs = []
+    for t in sweep:
+        r = inst.solve(width, t, per)
+        runs.append({"threads": t, "nodes_per_s": r["nodes_expanded"] / max(r["wall_s"], 1e-9), "subproblems": r["explored"],
+                     "nodes": r["nodes_expanded"], "wall_s": r["wall_s"]})
+    best = max(runs, key=lambda x: x["nodes_per_s"])
+    return {
+        "value": best["nodes_per_s"], "unit": "nodes/s", "cores": best["threads"], "kind": "port",
+        "sample": f"oracle ParallelSolver (C++ restatement of ddo, {build}), same instance/width, TimeBudget {per:.0f} s per thread "
+                  f"count: best = {best['threads']} threads, {best['subproblems']} sub-problems, {best['nodes']} nodes in {best['wall_s']:.1f} s",
+        "physical_cores": phys, "logical_cpus": logical, "thread_sweep": runs,
+    }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--concurrent", type=int, default=2048, help="sub-problems compiled per step (== the reference's nb_threads)")
-    ap.add_argument("--fringe", default="lazy", choices=["lazy", "nodup"],
-                    help="lazy: cut-sets stay in the device node pool, SimpleFringe/MaxUB order; nodup: host NoDupFringe")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline sample")
-    ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline (32 = best of the 1/32/128/256 sweep on the GPU box; 0 = all)")
+    ap.add_argument("--batches", type=int, default=8, help="frozen batches the timed steps cycle through")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="total time budget of the CPU baseline sample (split over the thread sweep)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = sweep 8/16/32/64/physical cores, report the best)")
     ap.add_argument("--no-cpu", action="store_true", help="timed steps only: neither the CPU baseline nor the proof search")
     ap.add_argument("--prove", type=float, default=400.0, metavar="SECONDS",
                     help="after the timed steps (N = 1 only), run the whole search to the PROVED optimum under this time budget and report "
-                         "time_to_proved_optimum_s, the second half of BASELINE.json's metric (about 140 s for the default workload; 0 = skip)")
+                         "time_to_proved_optimum_s, the second half of BASELINE.json's metric (0 = skip)")
     ap.add_argument("--prove-concurrent", type=int, default=8192, help="sub-problems in flight during the proof search")
     ap.add_argument("--instance", default=INSTANCE)
     ap.add_argument("--width", type=int, default=WIDTH)
@@ -88,7 +138,11 @@ def main():
     model = ddo_amd.Misp.read_instance(os.path.join(ROOT, "data", "misp", args.instance + ".clq"))
     conc = args.concurrent
     solver = ParallelSolver(model, FixedWidth(args.width), nb_threads=conc, device=local_rank, rank=rank, world_size=world,
-                            fringe=args.fringe)
+                            fringe="lazy")
+
+    from ddo_amd.distributed import PipelinedIncumbent, reduce_stats
+
+    incumbent = PipelinedIncumbent(dist, comm_device)
 
     def barrier():
         solver.flush()   # the engine runs on its own HIP stream: wait for the launch in flight and absorb it
@@ -101,21 +155,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from ddo_amd.distributed import PipelinedIncumbent, reduce_stats
-
-    incumbent = PipelinedIncumbent(dist, comm_device)
-
-    def one_step():
-        rc = solver.step()
+    def exchange():
         if dist is not None:   # parallel.rs:439-453: the incumbent is the only datum shared between workers
             lb = incumbent.post(solver.best_lower_bound())   # one step stale: ranks do not run in lock-step
             if lb is not None:
                 solver.import_lower_bound(lb)
-        return rc
 
-    # Setup, outside warm-up and timing: the first step of a search compiles the root sub-problem alone (one
-    # workgroup); its cut-set is the initial fringe every later batch is popped from.
+    # ---- setup (untimed): root sub-problem, fixed prefix of the search, then freeze the workload
     solver.step()
+    for _ in range(PREFIX_STEPS):
+        solver.step()
+        exchange()
+    barrier()
+    nfrozen = solver.bench_freeze(args.batches)
+    if nfrozen < 1:
+        raise SystemExit("bench.py: the fringe ran dry before the workload could be frozen")
+
+    def one_step():
+        solver.bench_step()
+        exchange()
+
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -123,15 +182,14 @@ def main():
     k0, l0 = solver.device_time()
     e0 = solver.explored()
     t0 = time.perf_counter()
-    done_steps = 0
     for _ in range(args.steps):
         one_step()
-        done_steps += 1
     barrier()
     t1 = time.perf_counter()
     c1 = solver.counters()
     k1, l1 = solver.device_time()
     e1 = solver.explored()
+    done_steps = args.steps
 
     elapsed, (nodes, arcs, subs, compiles) = reduce_stats(
         dist, t1 - t0, [c1["nodes_expanded"] - c0["nodes_expanded"], c1["arcs"] - c0["arcs"], e1 - e0,
@@ -147,18 +205,19 @@ def main():
         kernel_s = (k1 - k0) / 1e3
         ws_t = next(w for w in (1, 2, 4, 7, 8, 16) if w >= (model.n + 63) // 64)
         achieved = my_nodes * bytes_per_node / max(kernel_s, 1e-12) / 1e9   # GB/s over the kernel's own time
-        # HBM traffic: PMC counters cannot be read from inside this process; the committed rocprofv3 passes of this
-        # very command (tools/profile_round.sh -> profiles/<round>/pmc_summary.json) give bytes per expanded node,
-        # scaled here by the nodes one launch of THIS run processed.
+        # HBM traffic: PMC counters cannot be read from inside this process; the committed rocprofv3 passes of this very
+        # command and workload (tools/profile_round.sh -> profiles/<round>/pmc_summary.json; the workload is frozen, so
+        # the profiled launches ARE these launches) give bytes per expanded node, scaled by the nodes of one launch.
         traffic, traffic_src = None, None
-        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-            pj = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
+        pdir = os.path.join(ROOT, "profiles")
+        for rnd in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+            pj = os.path.join(pdir, rnd, "pmc_summary.json")
             if os.path.exists(pj):
                 try:
                     tj = json.load(open(pj)).get("traffic")
                     if tj and tj.get("hbm_bytes_per_node"):
                         traffic = tj["hbm_bytes_per_node"] * my_nodes / launches
-                        traffic_src = f"profiles/{rnd}/pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per node) x nodes of this run's launches"
+                        traffic_src = f"profiles/{rnd}/pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per node, same frozen workload) x nodes per launch"
                         break
                 except (ValueError, OSError):
                     pass
@@ -174,14 +233,17 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64",
-            "data": "real instance (DIMACS brock400_1 complement graph shipped with the reference); search state synthetic-free",
-            "config": {"workload": f"MISP {args.instance}.clq FixedWidth({args.width}) LEL cut-set, EmptyCache, "
-                                   + ("SimpleFringe(MaxUB) kept in the device node pool" if args.fringe == "lazy" else "NoDupFringe(MaxUB) on the host"),
-                       "subproblems_per_step": conc, "parallelism": f"fringe-shard x{world}"},
+            "dtype_note": "states are u64 bit-set words; values, bounds and ranking keys are 32-bit integers on the device "
+                          "(key32 = (value - vbase) << 11 | popcount), bit-exact against the i64 oracle for sum|w| < 2^20",
+            "data": "real instance (DIMACS brock400_1 complement graph shipped with the reference); frozen batches of the live search",
+            "config": {"workload": f"MISP {args.instance}.clq FixedWidth({args.width}) LEL cut-set, EmptyCache, SimpleFringe(MaxUB) kept in "
+                                   f"the device node pool; frozen workload: batches {PREFIX_STEPS + 1}..{PREFIX_STEPS + nfrozen} "
+                                   f"of {conc} sub-problems of the best-first search, cycled",
+                       "subproblems_per_step": conc, "frozen_batches": nfrozen, "prefix_steps": PREFIX_STEPS,
+                       "parallelism": f"fringe-shard x{world}"},
             "subproblems_per_s": subs / elapsed,
             "compiles": compiles,
             "best_lb": solver.best_lower_bound(),
-            "fringe_len_rank0": solver.fringe_len(),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
@@ -191,28 +253,30 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu:
-            threads = min(args.cpu_threads, os.cpu_count() or 1) if args.cpu_threads > 0 else (os.cpu_count() or 1)
-            r = cpu_baseline(args.cpu_seconds, threads)
-            out["cpu_baseline"] = {
-                "value": r["nodes_expanded"] / max(r["wall_s"], 1e-9), "unit": "nodes/s", "cores": threads, "kind": "port",
-                "sample": f"oracle ParallelSolver (C++ restatement of ddo), same instance/width, TimeBudget {args.cpu_seconds:.0f} s: "
-                          f"{r['explored']} sub-problems, {r['nodes_expanded']} nodes in {r['wall_s']:.1f} s",
-            }
+            out["cpu_baseline"] = cpu_baseline(args.instance, args.width, args.cpu_seconds, args.cpu_threads)
             out["speedup_vs_cpu"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-9)
         if args.prove > 0 and world == 1 and not args.no_cpu:   # --no-cpu = the timed steps only (profiling, A/B tools)
             # secondary metric of BASELINE.json: wall time of maximize() to the proved optimum
             from ddo_amd import TimeBudget
             del solver
             prover = ParallelSolver(model, FixedWidth(args.width), TimeBudget(args.prove), nb_threads=args.prove_concurrent, device=local_rank,
-                                    fringe=args.fringe)
+                                    fringe="lazy")
             tp0 = time.perf_counter()
             comp = prover.maximize()
             tp = time.perf_counter() - tp0
             pc = prover.counters()
+            pk_ms, pl = prover.device_time()
+            p_c = pc["arcs"] / max(1, pc["nodes_expanded"])
+            p_bpn = (ws_bytes + 8) + p_c * (ws_bytes + 16)
+            p_ach = pc["nodes_expanded"] * p_bpn / max(pk_ms / 1e3, 1e-12) / 1e9
             out["time_to_proved_optimum_s"] = tp if comp.is_exact else None
             out["proof"] = {"proved": bool(comp.is_exact), "best_value": comp.best_value, "lower_bound": prover.best_lower_bound(),
                             "upper_bound": prover.best_upper_bound(), "wall_s": tp, "subproblems": prover.explored(),
-                            "nodes_expanded": pc["nodes_expanded"], "budget_s": args.prove, "subproblems_in_flight": args.prove_concurrent}
+                            "nodes_expanded": pc["nodes_expanded"], "budget_s": args.prove, "subproblems_in_flight": args.prove_concurrent,
+                            "nodes_per_s": pc["nodes_expanded"] / max(tp, 1e-9),
+                            "roofline": {"bound": "hbm", "achieved": p_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": p_ach / HBM_PEAK_GBS,
+                                         "kernel_s": pk_ms / 1e3, "launches": pl, "bytes_per_node": p_bpn,
+                                         "note": "all compile launches of the whole search (their kernel time, HIP events)"}}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

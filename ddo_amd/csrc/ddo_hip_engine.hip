@@ -469,6 +469,14 @@ void Engine::pool_release() {
     vm_base_ = nullptr;
     vm_reserved_ = vm_mapped_ = 0;
 }
+int Engine::read_pool_head(uint64_t* out) {
+    std::lock_guard<std::mutex> g(mtx_);
+    HIP_TRY(hipSetDevice(device_));
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpy(&h, (uint8_t*)d_counters_ + 32, 8, hipMemcpyDeviceToHost));
+    *out = h;
+    return DDO_OK;
+}
 int Engine::read_pool(uint64_t off, void* dst, size_t bytes) {
     std::lock_guard<std::mutex> g(mtx_);
     if (!P_.pool || off + bytes > P_.pool_cap) {
@@ -520,6 +528,11 @@ void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) co
 int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results) {
     results.resize((size_t)std::max(count, 0) * 2);
     if (count <= 0) return DDO_OK;
+    // One engine is shared by every ddo_mdd of a (model, device, width) and has a single launch in flight: the three
+    // halves below must not interleave between host threads (mdd.rs: one DecisionDiagram per worker thread,
+    // parallel.rs:576-602).  The asynchronous launch()/wait()/fetch() path belongs to the lazy solver, which owns a
+    // private engine.
+    std::lock_guard<std::mutex> batch_guard(batch_mtx_);
     int rc = launch(inputs, count);
     if (rc != DDO_OK) return rc;
     return collect(results);
@@ -583,6 +596,12 @@ int Engine::launch(const DDInput* inputs, int count) {
     const int grid = std::min(count, nslots_);
     kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT, threads_)
                                      : pick_kernel(model_->wsT, table_lds_);
+    if (rewind_ >= 0) {   // bench: the frozen batch overwrites the blocks of its previous run
+        rewind_val_ = (unsigned long long)rewind_;
+        rewind_ = -1;
+        HIP_TRY(hipMemcpyAsync((uint8_t*)d_counters_ + 32, &rewind_val_, 8, hipMemcpyHostToDevice, st));
+        pool_head_bound_ = rewind_val_;
+    }
     HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
     if (vm_base_) {
         // the kernel allocates blocks with one atomic on the pool head: back everything the launches that are not

@@ -115,6 +115,11 @@ class Engine {
     bool has_pool() const { return P_.pool != nullptr; }
     uint64_t pool_capacity() const { return P_.pool_cap; }
     int pool_reset();
+    /// bench support: the next launch() first rewinds the pool's bump allocator to `head` (on the engine stream, ahead
+    /// of the kernel), so that a frozen batch can be compiled again and again without growing the pool
+    void set_pool_rewind(uint64_t head) { rewind_ = (long long)head; }
+    /// current head of the pool's bump allocator (synchronous: call with no launch in flight)
+    int read_pool_head(uint64_t* out);
     int read_pool(uint64_t off, void* dst, size_t bytes);
     int words_per_state_device() const { return P_.ws; }
 
@@ -171,6 +176,9 @@ class Engine {
     double kernel_ms_ = 0, last_kernel_ms_ = 0;
     uint64_t launches_ = 0;
     std::mutex mtx_;
+    long long rewind_ = -1;
+    unsigned long long rewind_val_ = 0;
+    std::mutex batch_mtx_;   // held across launch + wait + fetch of run_batch: concurrent compile() calls on distinct mdds serialise
 };
 
 /// Reads a DIMACS-like .clq file the way examples/misp/main.rs:258-317 does.

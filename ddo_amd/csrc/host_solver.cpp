@@ -268,6 +268,7 @@ struct DevBlock {
     int64_t cap_ub = I64_MAX;        // ub of the sub-problem the DD was compiled from (parallel.rs:460)
     std::vector<int32_t> value, ub;
     std::vector<uint32_t> order;     // rows sorted by (ub, value) descending
+    std::vector<uint8_t> mine;       // sharded search, root cut-set only: 1 = this rank owns the row (hash of the state)
     size_t cursor = 0;
     uint64_t id = 0;
     int64_t head_ub() const { return std::min<int64_t>(cap_ub, ub[order[cursor]]); }
@@ -295,17 +296,20 @@ class LazyFringe {
     size_t len() const { return open_; }
     bool empty() const { return heap_.empty(); }
     /// rows with min(cap_ub, ub) > best_lb are ordered by (ub, value) descending with two counting sorts
-    void push_block(DevBlock* b, int64_t best_lb, int rank, int world) {
-        if (prepare_block(b, best_lb, rank, world)) commit_block(b);
+    void push_block(DevBlock* b, int64_t best_lb) {
+        if (prepare_block(b, best_lb)) commit_block(b);
     }
     /// Thread-safe half of push_block: filters and orders the rows of `b` (b->order).  False: nothing to enqueue.
-    static bool prepare_block(DevBlock* b, int64_t best_lb, int rank, int world) {
+    /// Rows of the root cut-set that belong to another rank (b->mine) are left out: the owner of a row is a function
+    /// of its STATE, never of its position -- row positions come from device atomics and differ between ranks.
+    static bool prepare_block(DevBlock* b, int64_t best_lb) {
         const int n = b->rows;
         std::vector<uint32_t> tmp;
         tmp.reserve(n);
         int32_t vmin = INT32_MAX, vmax = INT32_MIN, umin = INT32_MAX, umax = INT32_MIN;
         for (int j = 0; j < n; ++j) {
             if (std::min<int64_t>(b->cap_ub, b->ub[j]) <= best_lb) continue;
+            if (!b->mine.empty() && !b->mine[j]) continue;
             tmp.push_back((uint32_t)j);
             vmin = std::min(vmin, b->value[j]);
             vmax = std::max(vmax, b->value[j]);
@@ -327,13 +331,6 @@ class LazyFringe {
         };
         counting(b->value, vmin, vmax);   // LSD: secondary key first
         counting(b->ub, umin, umax);
-        if (world > 1 && b->depth >= 0 && b->parent && b->parent->parent == nullptr && b->parent->off == NO_POOL_SRC) {
-            std::vector<uint32_t> mine;    // root cut-set: dealt round-robin over the ranks
-            for (size_t k = 0; k < tmp.size(); ++k)
-                if ((int)(k % (size_t)world) == rank) mine.push_back(tmp[k]);
-            tmp.swap(mine);
-            if (tmp.empty()) return false;
-        }
         b->order.swap(tmp);
         b->cursor = 0;
         return true;
@@ -441,10 +438,17 @@ struct ddo_solver {
     std::vector<uint32_t> st_layers, st_maxw;
     std::vector<uint64_t> st_nodes;
     uint64_t st_clk[32] = {0};
+    uint64_t st_bk_cnt[20] = {0}, st_bk_nodes[20] = {0}, st_bk_clk[20] = {0};   // by log2 of the DD's widest layer
     uint64_t st_push = 0, st_push_dup = 0;
     uint64_t st_recycled = 0;
     double st_host_pop = 0, st_host_run = 0, st_host_post = 0, st_host_fetch = 0;
     bool want_stats = false;
+    // bench support (ddo_solver_bench_freeze / _bench_step): frozen batches of sub-problems compiled again and again
+    std::vector<std::vector<LazyItem>> frozen;
+    int64_t frozen_lb = I64_MIN;
+    uint64_t frozen_mark = 0;
+    size_t frozen_next = 0;
+    bool bench_mode = false;
     // scratch
     std::vector<DDInput> inputs;
     std::vector<Entry> items;
@@ -480,11 +484,19 @@ struct ddo_solver {
             }
             std::fprintf(stderr, " | recycled merges per layer %.4f", (double)st_recycled / tl);
             std::fprintf(stderr, "\n");
+            for (int bk = 0; bk < 20; ++bk)
+                if (st_bk_cnt[bk])
+                    std::fprintf(stderr, "[ddo stats] widest layer <= %6u: %10llu DDs %14llu nodes (%5.1f %%) %8.3f Gcycles (%5.1f %%)  %.0f cycles/node\n", 1u << bk,
+                                 (unsigned long long)st_bk_cnt[bk], (unsigned long long)st_bk_nodes[bk], 100.0 * st_bk_nodes[bk] / std::max<uint64_t>(1, tn),
+                                 st_bk_clk[bk] / 1e9, 100.0 * st_bk_clk[bk] / std::max<uint64_t>(1, tc), (double)st_bk_clk[bk] / std::max<uint64_t>(1, st_bk_nodes[bk]));
             std::fprintf(stderr, "[ddo stats] DDs %zu  layers: mean %.1f p50 %llu p90 %llu max %llu | widest layer: p10 %llu p50 %llu p75 %llu p90 %llu p99 %llu max %llu | nodes/DD: mean %.0f p50 %llu p90 %llu max %llu | nodes/layer mean %.1f\n",
                          a.size(), (double)tl / a.size(), (unsigned long long)pct(a, .5), (unsigned long long)pct(a, .9), (unsigned long long)pct(a, 1.0),
                          (unsigned long long)pct(b, .1), (unsigned long long)pct(b, .5), (unsigned long long)pct(b, .75), (unsigned long long)pct(b, .9), (unsigned long long)pct(b, .99), (unsigned long long)pct(b, 1.0),
                          (double)tn / a.size(), (unsigned long long)pct(st_nodes, .5), (unsigned long long)pct(st_nodes, .9), (unsigned long long)pct(st_nodes, 1.0), (double)tn / std::max<uint64_t>(1, tl));
         }
+        for (auto& b : frozen)
+            for (LazyItem& e : b) dev_unref(e.block);
+        for (LazyItem& e : flight) dev_unref(e.block);
         delete fringe;
         delete lazy;
     }
@@ -597,6 +609,24 @@ struct ddo_solver {
         return DDO_OK;
     }
 
+    /// Sharded search: the root cut-set is dealt over the ranks.  Every rank compiles the root
+    /// itself and obtains the same SET of rows, but in an order that depends on the scheduling of device atomics, so
+    /// the owner of a row is hash(state) % world_size -- the states are read back from the node pool once.
+    int deal_root_rows(DevBlock* b) {
+        PoolBlockHeader h;
+        int rc = engine->read_pool(b->off, &h, sizeof(h));
+        if (rc != DDO_OK) return rc;
+        std::vector<uint64_t> st((size_t)h.ws * h.rows);
+        if ((rc = engine->read_pool(b->off + h.off_states, st.data(), st.size() * 8)) != DDO_OK) return rc;
+        b->mine.assign(h.rows, 0);
+        std::vector<uint64_t> row(std::max<uint32_t>(h.ws, (uint32_t)model->ws));
+        for (uint32_t j = 0; j < h.rows; ++j) {
+            for (uint32_t k = 0; k < h.ws; ++k) row[k] = st[(size_t)k * h.rows + j];   // word-major in the pool
+            b->mine[j] = (int)(hash_words(row.data(), model->ws) % (uint64_t)cfg.world_size) == cfg.rank ? 1 : 0;
+        }
+        return DDO_OK;
+    }
+
     /// results of a finished lazy launch -> incumbent, counters, new cut-set blocks (parallel.rs:420-434)
     int absorb_lazy(std::vector<LazyItem>& its, std::vector<HostResult>& res) {
         int err = DDO_OK;
@@ -623,8 +653,13 @@ struct ddo_solver {
                     st_nodes.push_back(r->hdr.nodes_expanded);
                     for (int q = 0; q < 32; ++q) st_clk[q] += r->hdr.phase_clk[q];
                     st_recycled += r->hdr.recycled_merges;
+                    int bk = 0;
+                    while (bk < 19 && (1u << bk) < r->hdr.max_width_seen) ++bk;
+                    st_bk_cnt[bk] += 1;
+                    st_bk_nodes[bk] += r->hdr.nodes_expanded;
+                    for (int q = 0; q < 8; ++q) st_bk_clk[bk] += r->hdr.phase_clk[q];
                 }
-                if (r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
+                if (!bench_mode && r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
                     best_lb = r->hdr.best_exact_value;
                     best_sol.clear();
                     if ((err = materialize_pool_path(its[i].block, its[i].row, best_sol)) != DDO_OK) break;
@@ -647,6 +682,11 @@ struct ddo_solver {
                     b->ub = std::move(r->cs_ub);
                     dev_ref(b);
                     st_push += (uint64_t)b->rows;
+                    if (cfg.world_size > 1 && its[i].block->parent == nullptr && its[i].block->off == NO_POOL_SRC &&
+                        (err = deal_root_rows(b)) != DDO_OK) {
+                        dev_unref(b);
+                        break;
+                    }
                     fresh_blocks.push_back(b);
                 }
             }
@@ -659,7 +699,7 @@ struct ddo_solver {
             const int nthreads = (int)std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 4)), fresh_blocks.size());
             auto work = [&](int t) {
                 for (size_t q = (size_t)t; q < fresh_blocks.size(); q += (size_t)nthreads)
-                    keep[q] = LazyFringe::prepare_block(fresh_blocks[q], best_lb, cfg.rank, cfg.world_size) ? 1 : 0;
+                    keep[q] = LazyFringe::prepare_block(fresh_blocks[q], best_lb) ? 1 : 0;
             };
             if (nthreads > 1) {
                 std::vector<std::thread> pool;
@@ -670,7 +710,7 @@ struct ddo_solver {
                 work(0);
             }
             for (size_t q = 0; q < fresh_blocks.size(); ++q) {
-                if (keep[q]) lazy->commit_block(fresh_blocks[q]);
+                if (keep[q] && !bench_mode) lazy->commit_block(fresh_blocks[q]);   // bench: the ordered block is dropped
                 dev_unref(fresh_blocks[q]);
             }
         }
@@ -696,6 +736,78 @@ struct ddo_solver {
         return rc;
     }
 
+    void fill_lazy_inputs(const std::vector<LazyItem>& its, int64_t lb) {
+        inputs.resize(its.size());
+        const int64_t lim = (int64_t)1 << 40;
+        for (size_t i = 0; i < its.size(); ++i) {
+            DDInput& in = inputs[i];
+            std::memset(&in, 0, sizeof(in));
+            in.comp_type = CT_RESTRICTED;
+            in.flags = IN_FUSED | IN_FILTER_CUTSET | IN_POOL_OUT;
+            in.width = cfg.width_policy == DDO_WIDTH_FIXED ? (int)cfg.width : std::max(1, model->n - its[i].depth);
+            in.value = (int32_t)its[i].value;
+            in.depth = its[i].depth;
+            in.best_lb = std::max(-lim, std::min(lim, lb));
+            in.src_off = its[i].block->off;
+            in.src_row = (uint32_t)its[i].row;
+            if (in.src_off == NO_POOL_SRC) model->initial_state(in.state);
+        }
+    }
+
+    /// Bench support: takes the next `nbatches` x nb_concurrent sub-problems off the fringe (MaxUB order, as step()
+    /// would) and FREEZES them together with the incumbent and the pool head.  bench_step() then compiles batch
+    /// (k mod nbatches) exactly as step() does -- same launch, same pipelining, same host work on the results -- but
+    /// folds nothing into the fringe, so every step of a timed region is the same piece of work whatever --steps and
+    /// --warmup are.  Returns the number of frozen batches.
+    int bench_freeze(int nbatches) {
+        if (!lazy) {
+            set_error("ddo_solver_bench_freeze needs DDO_FRINGE_LAZY");
+            return DDO_ERR_UNSUPPORTED;
+        }
+        int rc = flush_lazy();
+        if (rc != DDO_OK) return rc;
+        const int B = std::max(1, cfg.nb_concurrent);
+        LazyItem it;
+        for (int b = 0; b < nbatches; ++b) {
+            std::vector<LazyItem> batch;
+            while ((int)batch.size() < B && lazy->pop(it, best_lb)) batch.push_back(it);   // pop() hands over one reference
+            if (batch.empty()) break;
+            if (batch.size() > 2)
+                std::stable_sort(batch.begin(), batch.end(), [](const LazyItem& a, const LazyItem& b2) {
+                    if (a.depth != b2.depth) return a.depth < b2.depth;
+                    return (a.ub - a.value) > (b2.ub - b2.value);
+                });
+            frozen.push_back(std::move(batch));
+        }
+        frozen_lb = best_lb;
+        if ((rc = engine->read_pool_head(&frozen_mark)) != DDO_OK) return rc;
+        bench_mode = true;
+        frozen_next = 0;
+        return (int)frozen.size();
+    }
+    int bench_step() {
+        if (!bench_mode || frozen.empty()) {
+            set_error("ddo_solver_bench_step: call ddo_solver_bench_freeze first");
+            return DDO_ERR_INVALID;
+        }
+        const std::vector<LazyItem>& batch = frozen[frozen_next++ % frozen.size()];
+        fill_lazy_inputs(batch, frozen_lb);
+        explored += batch.size();
+        std::vector<HostResult> prev_results;
+        std::vector<LazyItem> prev_items;
+        int rc;
+        if (!flight.empty()) {
+            if ((rc = engine->wait()) != DDO_OK) return rc;
+            prev_items.swap(flight);
+        }
+        engine->set_pool_rewind(frozen_mark);
+        if ((rc = engine->launch(inputs.data(), (int)inputs.size())) != DDO_OK) return rc;
+        if (!prev_items.empty() && (rc = engine->fetch(prev_results)) != DDO_OK) return rc;
+        flight = batch;
+        for (LazyItem& e : flight) dev_ref(e.block);   // absorb_lazy releases one reference per item
+        return prev_items.empty() ? 1 : (absorb_lazy(prev_items, prev_results) == DDO_OK ? 1 : DDO_ERR_INTERNAL);
+    }
+
     /// step() with the lazy block fringe: payload in the device node pool, (value, ub) keys on the host.
     /// Software pipeline: the batch popped in this call is launched BEFORE the results of the previous one are
     /// turned into fringe blocks, so the host work overlaps the device (the sub-problems of a batch therefore do not
@@ -709,7 +821,7 @@ struct ddo_solver {
             root->rows = 1;
             root->value.push_back(0);
             root->ub.push_back(INT32_MAX);
-            lazy->push_block(root, I64_MIN, 0, 1);
+            lazy->push_block(root, I64_MIN);
         }
         if (finished) return 0;
         if (aborted) return DDO_CUTOFF;
@@ -748,29 +860,20 @@ struct ddo_solver {
             }
             return 1;
         }
-        if (cfg.world_size <= 1) best_ub = litems[0].ub == INT32_MAX ? I64_MAX : litems[0].ub;
+        if (cfg.world_size <= 1) {
+            // the batch still in flight was popped earlier, with bounds at least as large, and is not absorbed yet: the
+            // open bound is the largest of both (only then does gap() never dip below the true bound mid-search)
+            int64_t top = litems[0].ub;
+            for (const LazyItem& e : flight) top = std::max(top, e.ub);
+            best_ub = top == INT32_MAX ? I64_MAX : top;
+        }
         // longest-processing-time-first: shallow sub-problems with a lot of slack are the big DDs
         if (litems.size() > 2)
             std::stable_sort(litems.begin(), litems.end(), [](const LazyItem& a, const LazyItem& b) {
                 if (a.depth != b.depth) return a.depth < b.depth;
                 return (a.ub - a.value) > (b.ub - b.value);
             });
-        inputs.resize(litems.size());
-        const int64_t lim = (int64_t)1 << 40;
-        for (size_t i = 0; i < litems.size(); ++i) {
-            DDInput& in = inputs[i];
-            std::memset(&in, 0, sizeof(in));
-            in.comp_type = CT_RESTRICTED;
-            in.flags = IN_FUSED | IN_FILTER_CUTSET | IN_POOL_OUT;
-            in.width = cfg.width_policy == DDO_WIDTH_FIXED ? (int)cfg.width : std::max(1, model->n - litems[i].depth);
-            in.value = (int32_t)litems[i].value;
-            in.depth = litems[i].depth;
-            in.best_lb = std::max(-lim, std::min(lim, best_lb));
-            in.src_off = litems[i].block->off;
-            in.src_row = (uint32_t)litems[i].row;
-            if (in.src_off == NO_POOL_SRC)
-                for (int v = 0; v < model->n; ++v) in.state[v / 64] |= 1ULL << (v % 64);
-        }
+        fill_lazy_inputs(litems, best_lb);
         // the previous launch must have left the device before its buffers are reused
         std::vector<HostResult> prev_results;
         std::vector<LazyItem> prev_items;
@@ -965,6 +1068,14 @@ void ddo_solver_destroy(ddo_solver* s) { delete s; }
 int ddo_solver_step(ddo_solver* s) {
     if (!s) return DDO_ERR_INVALID;
     return s->step();
+}
+int ddo_solver_bench_freeze(ddo_solver* s, int nbatches) {
+    if (!s || nbatches < 1) return DDO_ERR_INVALID;
+    return s->bench_freeze(nbatches);
+}
+int ddo_solver_bench_step(ddo_solver* s) {
+    if (!s) return DDO_ERR_INVALID;
+    return s->bench_step();
 }
 int ddo_solver_flush(ddo_solver* s) {
     if (!s) return DDO_ERR_INVALID;

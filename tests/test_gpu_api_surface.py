@@ -106,3 +106,39 @@ def test_open_bound_and_device_time_queries(brock, fringe):
     c = s.maximize()
     assert c.is_exact and c.best_value == 12 and s.fringe_len() == 0
     assert s.best_upper_bound() == s.best_lower_bound() == 12 and s.gap() == 0.0
+
+
+def test_concurrent_compiles_on_distinct_mdds(brock, oracle):
+    """include/ddo_hip.h: distinct ddo_mdd objects may be used concurrently (one DecisionDiagram per worker thread,
+    parallel.rs:576-602).  All mdds of a (model, device, width) share one device engine: 8 host threads hammer it with
+    different sub-problems and every result must equal the oracle's for THAT thread's input."""
+    import threading
+
+    from tests.parity_util import canon_from_mdd, diff
+
+    inst = oracle.misp(data_path("misp", "brock200_2.clq"))
+    _, recs = inst.trace_solve(60, 48)
+    assert len(recs) >= 16
+    nthreads = 8
+    errors = []
+
+    def worker(t):
+        try:
+            mdd = ddo_amd.Mdd(brock, 60)
+            for rep in range(3):
+                for r in recs[t::nthreads]:
+                    sub = ddo_amd.SubProblem(state=np.array(r["state"], dtype=np.uint64), value=r["value"], path=[], depth=r["depth"])
+                    comp = mdd.compile(r["comp_type"], r["width"], sub, r["best_lb"])
+                    d = diff(r, canon_from_mdd(mdd, comp, brock.ws))
+                    if d is not None:
+                        errors.append(f"thread {t} rep {rep}: {d}")
+                        return
+        except Exception as e:   # e.g. 'a batch is already in flight'
+            errors.append(f"thread {t}: {e!r}")
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors[:3]

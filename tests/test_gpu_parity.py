@@ -119,18 +119,31 @@ def test_solver_lazy_device_fringe(have_gpu, name, expected, width, threads):
     assert sum(int(w[v]) for v in chosen) == expected and is_independent_set(rows, model.ws, chosen)
 
 
-def test_sharded_lazy_fringe(have_gpu):
-    model = ddo_amd.Misp.read_instance(data_path("misp", "brock200_2.clq"))
-    ranks = [ParallelSolver(model, FixedWidth(100), nb_threads=32, rank=r, world_size=2, fringe="lazy") for r in range(2)]
-    live = [True, True]
-    while any(live):
-        for r, s in enumerate(ranks):
-            if live[r]:
-                live[r] = s.step() == 1
-        lb = max(s.best_lower_bound() for s in ranks)
+@pytest.mark.parametrize("name,expected,width,world", [
+    ("brock200_2", 12, 100, 2), ("brock200_2", 12, 30, 3), ("keller4", 11, 20, 2), ("p_hat300-1", 8, 25, 4),
+    ("johnson8-4-4", 14, 8, 3), ("hamming6-4", 4, 6, 2),
+])
+def test_sharded_lazy_fringe(have_gpu, name, expected, width, world):
+    """The root cut-set is dealt by hash(state) % world (row positions are scheduling dependent and must not decide):
+    unit-weight instances are full of (ub, value) ties, where a position-based deal lost or duplicated sub-problems.
+    Every shard is searched to exhaustion; together they prove the optimum, and with the incumbent exchange switched
+    OFF the shards still cover the problem (each open node belongs to exactly one rank)."""
+    model = ddo_amd.Misp.read_instance(data_path("misp", name + ".clq"))
+    for exchange in (True, False):
+        ranks = [ParallelSolver(model, FixedWidth(width), nb_threads=16, rank=r, world_size=world, fringe="lazy") for r in range(world)]
+        live = [True] * world
+        while any(live):
+            for r, s in enumerate(ranks):
+                if live[r]:
+                    live[r] = s.step() == 1
+            if exchange:
+                lb = max(s.best_lower_bound() for s in ranks)
+                for s in ranks:
+                    s.import_lower_bound(lb)
         for s in ranks:
-            s.import_lower_bound(lb)
-    assert max(s.best_lower_bound() for s in ranks) == 12
+            s.flush()
+        assert max(s.best_lower_bound() for s in ranks) == expected, (name, width, world, exchange)
+        assert all(s.fringe_len() == 0 for s in ranks)
 
 
 # ---- (3) golden fixtures (generated by tests/golden/make_golden.py from the oracle) ----------------
