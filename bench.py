@@ -6,9 +6,13 @@
 The timed workload is FROZEN, so the number does not depend on --steps / --warmup:
 
   setup   the branch-and-bound search (parallel.rs:391-437 per sub-problem: restricted DD, then -- when inexact --
-          relaxed DD, both compiled on the GPU) runs its root step plus PREFIX_STEPS steps of `--concurrent`
-          sub-problems; then the next `--batches` batches are popped in fringe order (MaxUB) and frozen together with
-          the incumbent (ddo_solver_bench_freeze).  Their residual states already sit in the device node pool (HBM).
+          relaxed DD, both compiled on the GPU) runs its root step: the cut-set of the root's relaxed DD (<= 10 000
+          nodes of ONE layer, all of them width-saturating sub-problems) is the initial fringe.  Its first `--batches`
+          batches of `--concurrent` sub-problems, in fringe order (MaxUB), are frozen together with the incumbent
+          (ddo_solver_bench_freeze).  Their residual states already sit in the device node pool (HBM).
+          Later batches of a live search are NOT like these: a best-first search soon runs on small sub-problems
+          (61 % of all nodes of the whole search sit in DDs that fill the width, but 97 % of the DDs do not), which
+          is why the whole search is reported separately (`proof`, with its own roofline figure).
   step    one pass of the hot path over one frozen batch: batch (k mod --batches) is compiled exactly as a search step
           would (same launch, same software pipeline, same host work on the (ub, value) rows coming back), but nothing
           is folded into the fringe.  Every cycle of `--batches` steps is therefore the same work.
@@ -36,7 +40,7 @@ sys.path.insert(0, ROOT)
 INSTANCE = "brock400_1"
 WIDTH = 10000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PREFIX_STEPS = 4               # search steps between the root and the frozen batches (fixed: part of the workload)
+PREFIX_STEPS = 0               # search steps between the root step and the frozen batches (fixed: part of the workload)
 
 
 def physical_cores():
@@ -94,10 +98,10 @@ def cpu_baseline(instance, width, total_seconds, threads_arg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--concurrent", type=int, default=2048, help="sub-problems compiled per step (== the reference's nb_threads)")
-    ap.add_argument("--batches", type=int, default=8, help="frozen batches the timed steps cycle through")
+    ap.add_argument("--batches", type=int, default=4, help="frozen batches the timed steps cycle through")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="total time budget of the CPU baseline sample (split over the thread sweep)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = sweep 8/16/32/64/physical cores, report the best)")
     ap.add_argument("--no-cpu", action="store_true", help="timed steps only: neither the CPU baseline nor the proof search")
@@ -237,8 +241,8 @@ def main():
                           "(key32 = (value - vbase) << 11 | popcount), bit-exact against the i64 oracle for sum|w| < 2^20",
             "data": "real instance (DIMACS brock400_1 complement graph shipped with the reference); frozen batches of the live search",
             "config": {"workload": f"MISP {args.instance}.clq FixedWidth({args.width}) LEL cut-set, EmptyCache, SimpleFringe(MaxUB) kept in "
-                                   f"the device node pool; frozen workload: batches {PREFIX_STEPS + 1}..{PREFIX_STEPS + nfrozen} "
-                                   f"of {conc} sub-problems of the best-first search, cycled",
+                                   f"the device node pool; frozen workload: the first {nfrozen} batches of {conc} sub-problems of the root cut-set "
+                                   f"in fringe order, cycled",
                        "subproblems_per_step": conc, "frozen_batches": nfrozen, "prefix_steps": PREFIX_STEPS,
                        "parallelism": f"fringe-shard x{world}"},
             "subproblems_per_s": subs / elapsed,

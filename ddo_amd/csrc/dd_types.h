@@ -191,9 +191,11 @@ struct EngineParams {
 // node flag bits (node_flags.rs:48-185 restricted to what the device needs)
 constexpr uint32_t NF_INEXACT = 1u;   // !F_EXACT
 constexpr uint32_t NF_RELAXED = 2u;   // F_RELAXED
+constexpr uint32_t NF_OKPATH = 4u;    // signed-vector models: the best arc comes from a node with an exact best path
 // ninfo word: bits 0..27 best arc (parent position << 1 | decision), 28 = no arc (root), 30/31 flags
 constexpr uint32_t NI_ARC_MASK = 0x0FFFFFFFu;
 constexpr uint32_t NI_NOARC = 0x10000000u;
+constexpr uint32_t NI_OKPATH = 0x20000000u;
 constexpr uint32_t NI_INEXACT = 0x40000000u;
 constexpr uint32_t NI_RELAXED = 0x80000000u;
 

@@ -74,7 +74,13 @@ int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
             return r;
         };
         const int64_t ra = rank(a), rb = rank(b);
-        return ra < rb ? -1 : (ra > rb ? 1 : 0);
+        if (ra != rb) return ra < rb ? -1 : 1;
+        // Deterministic tie-break shared with the device kernels (lexkey = raw word, misp_dd_core.hpp) and with the
+        // oracle (oracle/models.hpp compare_signed_vectors): the reference leaves ties of this ranking to the
+        // iteration order of its hash map; here the packed state words decide, compared from word 0, larger first.
+        for (int k = 0; k < ws; ++k)
+            if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
+        return 0;
     }
     int pa = popcount(a), pb = popcount(b);
     if (pa != pb) return pa < pb ? -1 : 1;

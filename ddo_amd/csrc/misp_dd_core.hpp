@@ -125,6 +125,15 @@ __device__ __forceinline__ uint64_t dd_brev(uint64_t x) { return __brevll(x); }
 namespace ddo_hip {
 
 constexpr uint32_t TAB_EMPTY = 0xFFFFFFFFu;
+// Signed-vector models (MAX2SAT, MCP): bit 31 of the arc half of a candidate key says "the parent of this arc has an exact
+// best path".  The 64-bit atomicMax of (value, arc) then resolves ties between equal-valued arcs in favour of such a
+// parent, whatever order the threads run in: EBPO (clean.rs:643-655) and the best paths become order independent.  The
+// reference leaves these ties to its hash map's iteration order; the oracle applies the same rule (Problem::canonical_ties).
+constexpr uint32_t KEY_OK = 0x80000000u;
+DDO_DEV uint32_t key_arc(uint64_t key) {   // candidate index of the best arc, NONE32 for the root
+    const uint32_t a = (uint32_t)key;
+    return a == NONE32 ? NONE32 : (a & ~KEY_OK);
+}
 constexpr int32_t VB_UNMARKED = INT32_MIN;  // value_bot = isize::MIN  <=> !MARKED (clean.rs:392, 464)
 
 /// Workgroup-shared scalars (one per workgroup, lives in LDS).
@@ -916,8 +925,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         uint32_t* ni = c.ninfo + (size_t)L * capN;
         for (int pos = tid; pos < n; pos += NT) {
             uint32_t cd = c.keep[pos];
-            uint32_t arc = (uint32_t)LD_U64(&c.ckey[cur][cd]);
+            const uint64_t nkey = LD_U64(&c.ckey[cur][cd]);
+            uint32_t arc = key_arc(nkey);
             uint32_t fl = LD_U32(&c.cflags[cur][cd]);
+            if (dd_is_vec(c.kind) && arc != NONE32 && ((uint32_t)nkey & KEY_OK)) fl |= NF_OKPATH;
             uint32_t w;
             if (arc == NONE32) w = NI_NOARC;
             else {
@@ -927,6 +938,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             }
             if (fl & NF_INEXACT) w |= NI_INEXACT;
             if (fl & NF_RELAXED) w |= NI_RELAXED;
+            if (fl & NF_OKPATH) w |= NI_OKPATH;
             ni[pos] = w;
         }
         // arcs entering this layer, translated to node positions (needed by the backward pass)
@@ -977,6 +989,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             const int pop = (int)c.cpop[cur][p];
             const uint32_t pfl = LD_U32(&c.cflags[cur][p]);
             const uint32_t inexact = (pfl & (NF_INEXACT | NF_RELAXED)) ? NF_INEXACT : 0u;
+            // signed-vector models: does this parent have an exact best path (see KEY_OK) ?
+            const uint32_t pok = (!inexact || (!(pfl & NF_RELAXED) && (uint32_t)pkey != NONE32 && ((uint32_t)pkey & KEY_OK))) ? KEY_OK : 0u;
             const int32_t rub = rub_of<WS>(c, s, pop, c.depth0 + L);
             if ((int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded
                 if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);
@@ -1035,7 +1049,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     const int32_t cost = side == 0 ? cost_t : cost_f;
 #pragma unroll
                     for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
-                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | cd;
+                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
                     c.ckey[nxt][cd] = mykey;
                     ac_next[cd] = cost;
                     c.cpop[nxt][cd] = (uint32_t)(side == 0 ? rank_t : rank_f);
@@ -1098,7 +1112,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     const int32_t cost = side == 0 ? cost_s : cost_t;
 #pragma unroll
                     for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
-                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | cd;
+                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
                     c.ckey[nxt][cd] = mykey;
                     ac_next[cd] = cost;
                     c.cpop[nxt][cd] = (uint32_t)(side == 0 ? rank_s : rank_t);
@@ -1261,8 +1275,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         for (int pos = tid; pos < nT; pos += NT) {
             uint32_t cd = c.keep[pos];
             uint64_t key = LD_U64(&c.ckey[cur][cd]);
-            uint32_t arc = (uint32_t)key;
+            uint32_t arc = key_arc(key);
             uint32_t fl = LD_U32(&c.cflags[cur][cd]);
+            const bool okp = dd_is_vec(c.kind) && arc != NONE32 && ((uint32_t)key & KEY_OK) && !(fl & NF_RELAXED);
             uint32_t w;
             if (arc == NONE32) w = NI_NOARC;
             else {
@@ -1271,9 +1286,12 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             }
             if (fl & NF_INEXACT) w |= NI_INEXACT;
             if (fl & NF_RELAXED) w |= NI_RELAXED;
+            if (okp) w |= NI_OKPATH;
             ni[pos] = w;
-            // _find_best_node (clean.rs:620-632): max value_top; position breaks ties deterministically
-            uint64_t bk = (key & 0xFFFFFFFF00000000ULL) | (uint32_t)pos;
+            // _find_best_node (clean.rs:620-632): max value_top; position breaks ties deterministically -- signed-vector
+            // models: a node with an exact best path first (order-independent EBPO, see KEY_OK)
+            const bool nok = !(fl & (NF_INEXACT | NF_RELAXED)) || okp;
+            uint64_t bk = (key & 0xFFFFFFFF00000000ULL) | (dd_is_vec(c.kind) && nok ? KEY_OK : 0u) | (uint32_t)pos;
             LDS_MAX_U64(&sh->bestKey, bk + 1);  // +1 so that 0 means "none"
             if (!(fl & (NF_INEXACT | NF_RELAXED))) LDS_MAX_U64(&sh->bestExactKey, bk + 1);
         }
@@ -1302,14 +1320,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     int best_pos = -1, best_value = 0;
     if (has_best) {
         uint64_t bk = sh->bestKey - 1;
-        best_pos = (int)(uint32_t)bk;
+        best_pos = (int)((uint32_t)bk & ~KEY_OK);
         best_value = unbias32((uint32_t)(bk >> 32));
     }
     bool has_best_exact = !failed && sh->bestExactKey != 0;
     int exact_pos = -1, exact_value = 0;
     if (has_best_exact) {
         uint64_t bk = sh->bestExactKey - 1;
-        exact_pos = (int)(uint32_t)bk;
+        exact_pos = (int)((uint32_t)bk & ~KEY_OK);
         exact_value = unbias32((uint32_t)(bk >> 32));
     }
     // _has_exact_best_path (clean.rs:643-655), EBPO
@@ -1325,6 +1343,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     bool ex = !(w & (NI_INEXACT | NI_RELAXED));
                     if (ex) { res_e = 1; break; }
                     if (w & NI_RELAXED) { res_e = 0; break; }
+                    if (dd_is_vec(c.kind)) { res_e = (w & NI_OKPATH) ? 1 : 0; break; }   // the key carried the answer (KEY_OK)
                     if (w & NI_NOARC) { res_e = 1; break; }
                     p = (int)((w & NI_ARC_MASK) >> 1);
                     Lc -= 1;

@@ -132,6 +132,11 @@ struct Problem {
     virtual std::optional<Variable> next_variable(size_t depth, StateIter<S>& next_layer) const = 0;
     virtual void for_each_in_domain(Variable var, const S& state, DecisionCallback& f) const = 0;
     virtual bool is_impacted_by(Variable, const S&) const { return true; }
+    /// NOT in the reference.  Models whose ranking is not a total order (MAX2SAT, MCP) opt into ORDER-INDEPENDENT
+    /// handling of equal-valued best arcs / best terminal nodes (see Mdd::append_edge_to): the reference resolves those
+    /// ties by the iteration order of its FxHashMap, which nothing pins; oracle and device
+    /// resolve them the same, documented way so that every compile() is comparable bit by bit.
+    virtual bool canonical_ties() const { return false; }
 };
 
 /// dp.rs:77-107
@@ -689,6 +694,7 @@ class Mdd {
         std::optional<isize> theta;
         NodeFlags flags;
         size_t depth;
+        bool best_ok = false;   // canonical_ties: the best arc comes from a node that has an exact best path
     };
     /// clean.rs:74-85
     struct Edge {
@@ -721,6 +727,11 @@ class Mdd {
     std::optional<size_t> best_node, best_exact_node;
     bool is_exact_ = true;
     bool has_exact_best_path_ = false;
+    bool canonical_ = false;   // Problem::canonical_ties() of the compile in progress
+
+    /// canonical_ties: the node is reached by an exact best path (== what _has_exact_best_path would answer for it when
+    /// every tie between equal-valued inbound arcs is resolved in favour of such a path)
+    bool node_ok(const Node& n) const { return n.flags.is_exact() || (n.best_ok && !n.flags.is_relaxed()); }
 
     static constexpr size_t NIL = 0;  // clean.rs:168
 
@@ -850,9 +861,22 @@ class Mdd {
         bool exact = parent_exact & node.flags.is_exact();
         node.flags.set_exact(exact);
         node.inbound = lst_id;
-        if (value >= node.value_top) {
-            node.best = new_eid;
-            node.value_top = value;
+        if (!canonical_) {
+            if (value >= node.value_top) {   // the reference: the LAST arc of maximal value wins
+                node.best = new_eid;
+                node.value_top = value;
+            }
+        } else {
+            // Order-independent variant (Problem::canonical_ties): among arcs of equal value the one whose parent has an
+            // exact best path wins.  Values are unchanged; only _has_exact_best_path (EBPO, clean.rs:643-655) and the
+            // decisions of the best path can differ from what SOME hash order of the reference would give, and the
+            // outcome is sound: the path it reports exact IS exact.
+            const bool pok = node_ok(parent);
+            if (value > node.value_top || (value == node.value_top && (pok || !node.best_ok))) {
+                node.best = new_eid;
+                node.value_top = value;
+                node.best_ok = pok;
+            }
         }
     }
 
@@ -873,6 +897,7 @@ class Mdd {
         _clear();
         last_counters = MddCounters();
         last_counters.compiles = 1;
+        canonical_ = input.problem->canonical_ties();
         _initialize(input);
 
         std::vector<size_t> curr_l;
@@ -1083,7 +1108,9 @@ class Mdd {
         best_node.reset();
         best_exact_node.reset();
         for (size_t id : next_order) {
-            if (!best_node || nodes[id].value_top >= nodes[*best_node].value_top) best_node = id;
+            if (canonical_ && best_node && nodes[id].value_top == nodes[*best_node].value_top) {
+                if (node_ok(nodes[id]) || !node_ok(nodes[*best_node])) best_node = id;   // ties: prefer an exact best path
+            } else if (!best_node || nodes[id].value_top >= nodes[*best_node].value_top) best_node = id;
             if (nodes[id].flags.is_exact()) {
                 if (!best_exact_node || nodes[id].value_top >= nodes[*best_exact_node].value_top) best_exact_node = id;
             }

@@ -470,6 +470,7 @@ inline Weighed2Sat read_max2sat_instance(const std::string& fname) {
 
 /// model.rs:91-346.  DP model of Bergman, Cire, van Hoeve (INFORMS J. Comp. 2016).
 struct Max2Sat : Problem<Max2SatState> {
+    bool canonical_ties() const override { return true; }   // ranking is not a total order: see Problem::canonical_ties
     static constexpr isize T = 1, F = -1;                       // model.rs:29-31
     size_t nb_vars = 0;
     isize initial = 0;
@@ -637,11 +638,43 @@ struct Max2SatRelax : Relaxation<Max2SatState> {
     isize fast_upper_bound(const Max2SatState& s) const override { return pb.fast_upper_bound(s); }
 };
 
-/// heuristics.rs:30-37
+/// Signed-vector states on the wire (include/ddo_hip.h, ddo_model_create_max2sat / _mcp): benefit v is the 32-bit half
+/// (v & 1) of word v / 2, the word after the last pair holds the depth.
+inline void pack_signed_vector(const std::vector<isize>& b, size_t depth, uint64_t* out) {
+    const size_t np = (b.size() + 1) / 2;
+    for (size_t k = 0; k < np; ++k) {
+        const uint64_t lo = (uint32_t)(int32_t)b[2 * k];
+        const uint64_t hi = 2 * k + 1 < b.size() ? (uint32_t)(int32_t)b[2 * k + 1] : 0u;
+        out[k] = lo | (hi << 32);
+    }
+    out[np] = (uint64_t)depth;
+}
+/// DETERMINISTIC TIE-BREAK shared with the device engine ("Exactness of selection"): the
+/// reference ranks these states by sum |benefit| alone and leaves ties to the iteration order of its FxHashMap
+/// (unpinned); oracle and device both break them by the packed state words, compared as
+/// unsigned 64-bit numbers from word 0 (the larger word ranks higher).  Parity with the reference itself stays on
+/// optimum + proof for these models; oracle <-> device parity becomes bit-exact per compile.
+inline int compare_signed_vectors(const std::vector<isize>& a, size_t da, const std::vector<isize>& b, size_t db) {
+    const size_t np = (std::max(a.size(), b.size()) + 1) / 2;
+    auto word = [](const std::vector<isize>& v, size_t d, size_t k, size_t npairs) -> uint64_t {
+        if (k == npairs) return (uint64_t)d;
+        const uint64_t lo = 2 * k < v.size() ? (uint32_t)(int32_t)v[2 * k] : 0u;
+        const uint64_t hi = 2 * k + 1 < v.size() ? (uint32_t)(int32_t)v[2 * k + 1] : 0u;
+        return lo | (hi << 32);
+    };
+    for (size_t k = 0; k <= np; ++k) {
+        const uint64_t x = word(a, da, k, np), y = word(b, db, k, np);
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return 0;
+}
+
+/// heuristics.rs:30-37, then the shared tie-break
 struct Max2SatRanking : StateRanking<Max2SatState> {
     int compare(const Max2SatState& a, const Max2SatState& b) const override {
         const isize x = a.rank(), y = b.rank();
-        return x < y ? -1 : (x > y ? 1 : 0);
+        if (x != y) return x < y ? -1 : 1;
+        return compare_signed_vectors(a.substates, a.depth, b.substates, b.depth);
     }
 };
 
@@ -710,6 +743,7 @@ struct StateHash<McpState> {
 
 /// model.rs:37-130: vertices are assigned to side S (+1) or T (-1) in natural order; the first one is fixed to S
 struct Mcp : Problem<McpState> {
+    bool canonical_ties() const override { return true; }   // ranking is not a total order: see Problem::canonical_ties
     static constexpr isize SIDE_S = 1, SIDE_T = -1;
     McpGraph graph;
     explicit Mcp(McpGraph g) : graph(std::move(g)) {}
@@ -825,13 +859,14 @@ struct McpRelax : Relaxation<McpState> {
     }
 };
 
-/// model.rs:154-163
+/// model.rs:154-163, then the tie-break shared with the device (see compare_signed_vectors)
 struct McpRanking : StateRanking<McpState> {
     int compare(const McpState& a, const McpState& b) const override {
         isize xa = 0, xb = 0;
         for (isize v : a.benef) xa += v < 0 ? -v : v;
         for (isize v : b.benef) xb += v < 0 ? -v : v;
-        return xa < xb ? -1 : (xa > xb ? 1 : 0);
+        if (xa != xb) return xa < xb ? -1 : 1;
+        return compare_signed_vectors(a.benef, a.depth, b.benef, b.depth);
     }
 };
 

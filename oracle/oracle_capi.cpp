@@ -52,8 +52,11 @@ void state_to_words(const BitSet& s, size_t ws, uint64_t* out) {
     for (size_t k = 0; k < ws; ++k) out[k] = k < s.w.size() ? s.w[k] : 0;
 }
 
-template <class D>
-void record(Trace& tr, size_t ws, const SubProblem<BitSet>& node, CompilationType t, size_t width, isize lb, D& mdd,
+void state_to_words(const Max2SatState& s, size_t, uint64_t* out) { pack_signed_vector(s.substates, s.depth, out); }
+void state_to_words(const McpState& s, size_t, uint64_t* out) { pack_signed_vector(s.benef, s.depth, out); }
+
+template <class T, class D>
+void record(Trace& tr, size_t ws, const SubProblem<T>& node, CompilationType t, size_t width, isize lb, D& mdd,
             bool with_cutset) {
     TraceRec r;
     r.comp_type = (int)t;
@@ -77,7 +80,7 @@ void record(Trace& tr, size_t ws, const SubProblem<BitSet>& node, CompilationTyp
     if (with_cutset) {
         // drain_cutset consumes the cut-set; take a copy of the DD so the solver still sees it
         D copy = mdd;
-        copy.drain_cutset([&](SubProblem<BitSet> sp) {
+        copy.drain_cutset([&](SubProblem<T> sp) {
             size_t off = r.cs_states.size();
             r.cs_states.resize(off + ws);
             state_to_words(*sp.state, ws, r.cs_states.data() + off);
@@ -235,6 +238,79 @@ void* oracle_misp_trace_solve(void* hh, uint64_t width, uint64_t max_compiles, o
     }
     return tr;
 }
+}  // extern "C"
+
+namespace {
+/// traced sequential solve of a signed-vector model (MAX2SAT, MCP): same records as the MISP trace, states packed as on
+/// the device wire (two benefits per word + a depth word)
+template <class T, class PB, class RELAX, class RANK>
+Trace* traced_vector_solve(PB& pb, RELAX& relax, RANK& rank, size_t nvars, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {
+    FixedWidth<T> fixed(width);
+    NbUnassignedWidth<T> unassigned(nvars);
+    const WidthHeuristic<T>& w = width ? (const WidthHeuristic<T>&)fixed : unassigned;
+    EmptyDominanceChecker<T> dom;
+    struct CountCutoff : Cutoff {
+        const Trace* tr;
+        uint64_t max;
+        bool must_stop() const override { return max && tr->recs.size() >= max; }
+    } cut;
+    MaxUB<T> mx(rank);
+    NoDupFringe<T> fringe(mx);
+    auto* tr = new Trace();
+    tr->ws = (nvars + 1) / 2 + 1;
+    cut.tr = tr;
+    cut.max = max_compiles;
+    SequentialSolver<T> s(pb, relax, rank, w, dom, cut, fringe);
+    s.on_compile = [&](const SubProblem<T>& node, CompilationType t, size_t width_, isize lb, DefaultMDDLEL<T>& mdd) {
+        record<T>(*tr, tr->ws, node, t, width_, lb, mdd, t == CompilationType::Relaxed);
+    };
+    auto t0 = std::chrono::steady_clock::now();
+    Completion c = s.maximize();
+    if (out) {
+        out->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        out->has_value = c.best_value.has_value();
+        out->best_value = c.best_value.value_or(-1);
+        out->is_exact = c.is_exact;
+        out->best_lb = s.best_lower_bound();
+        out->best_ub = s.best_upper_bound();
+        out->explored = s.explored();
+        out->nodes_expanded = s.counters().nodes_expanded;
+        out->arcs = s.counters().arcs;
+        out->layers = s.counters().layers;
+        out->compiles = s.counters().compiles;
+        out->n_solution = 0;
+    }
+    return tr;
+}
+}  // namespace
+
+extern "C" {
+/// traced solves of the signed-vector models: the trace is read with oracle_trace_len / _get / _get_cutset / _free;
+/// every state has oracle_trace_state_words() words
+void* oracle_max2sat_trace_solve(const char* path, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {
+    try {
+        Weighed2Sat inst = read_max2sat_instance(path);
+        Max2Sat pb(inst);
+        Max2SatRelax relax(pb);
+        Max2SatRanking rank;
+        return traced_vector_solve<Max2SatState>(pb, relax, rank, pb.nb_variables(), width, max_compiles, out);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "oracle_max2sat_trace_solve: %s\n", e.what());
+        return nullptr;
+    }
+}
+void* oracle_mcp_trace_solve(const char* path, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {
+    try {
+        Mcp pb(read_mcp_instance(path));
+        McpRelax relax(pb);
+        McpRanking rank;
+        return traced_vector_solve<McpState>(pb, relax, rank, pb.nb_variables(), width, max_compiles, out);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "oracle_mcp_trace_solve: %s\n", e.what());
+        return nullptr;
+    }
+}
+uint64_t oracle_trace_state_words(void* t) { return ((Trace*)t)->ws; }
 void oracle_trace_free(void* t) { delete (Trace*)t; }
 uint64_t oracle_trace_len(void* t) { return ((Trace*)t)->recs.size(); }
 

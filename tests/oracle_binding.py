@@ -35,6 +35,29 @@ def _canon(hdr, state, cs_states, cs_value, cs_ub, cs_depth, ws):
     }
 
 
+def read_trace(L, t, ws):
+    """Canonical records of a trace handle (freed here)."""
+    recs = []
+    try:
+        n = L.oracle_trace_len(t)
+        for i in range(n):
+            hdr = TraceHdr()
+            st = np.zeros(ws, dtype=np.uint64)
+            L.oracle_trace_get(t, i, C.byref(hdr), st.ctypes.data_as(C.c_void_p))
+            k = int(hdr.n_cutset)
+            cs = np.zeros(max(k, 1) * ws, dtype=np.uint64)
+            cv = np.zeros(max(k, 1), dtype=np.int64)
+            cu = np.zeros(max(k, 1), dtype=np.int64)
+            cd = np.zeros(max(k, 1), dtype=np.uint64)
+            if k:
+                L.oracle_trace_get_cutset(t, i, cs.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
+                                          cu.ctypes.data_as(C.c_void_p), cd.ctypes.data_as(C.c_void_p))
+            recs.append(_canon(hdr, st, cs, cv[:k], cu[:k], cd[:k], ws))
+    finally:
+        L.oracle_trace_free(t)
+    return recs
+
+
 class MispInstance:
     def __init__(self, oracle, path):
         self.o = oracle
@@ -72,25 +95,7 @@ class MispInstance:
         """Sequential B&B recording every compile(); returns (summary, [canonical records])."""
         out = SolveOut()
         t = self.L.oracle_misp_trace_solve(self.h, width, max_compiles, C.byref(out))
-        recs = []
-        try:
-            n = self.L.oracle_trace_len(t)
-            for i in range(n):
-                hdr = TraceHdr()
-                st = np.zeros(self.ws, dtype=np.uint64)
-                self.L.oracle_trace_get(t, i, C.byref(hdr), st.ctypes.data_as(C.c_void_p))
-                k = int(hdr.n_cutset)
-                cs = np.zeros(max(k, 1) * self.ws, dtype=np.uint64)
-                cv = np.zeros(max(k, 1), dtype=np.int64)
-                cu = np.zeros(max(k, 1), dtype=np.int64)
-                cd = np.zeros(max(k, 1), dtype=np.uint64)
-                if k:
-                    self.L.oracle_trace_get_cutset(t, i, cs.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
-                                                   cu.ctypes.data_as(C.c_void_p), cd.ctypes.data_as(C.c_void_p))
-                recs.append(_canon(hdr, st, cs, cv[:k], cu[:k], cd[:k], self.ws))
-        finally:
-            self.L.oracle_trace_free(t)
-        return out.asdict(), recs
+        return out.asdict(), read_trace(self.L, t, self.ws)
 
     def compile(self, comp_type, width, best_lb, state, value, depth):
         """One compile() of an arbitrary residual sub-problem -> canonical record (+ best path)."""
@@ -153,7 +158,22 @@ class Oracle:
         L.oracle_tsptw_solve_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(SolveOut)]
         L.oracle_tsptw_tour_length.restype = C.c_int64
         L.oracle_tsptw_tour_length.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        for fn in ("oracle_max2sat_trace_solve", "oracle_mcp_trace_solve"):
+            getattr(L, fn).restype = C.c_void_p
+            getattr(L, fn).argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(SolveOut)]
+        L.oracle_trace_state_words.restype = C.c_uint64
+        L.oracle_trace_state_words.argtypes = [C.c_void_p]
         self.L = L
+
+    def vector_trace(self, kind, path, width=0, max_compiles=0):
+        """Traced sequential solve of a signed-vector model ("max2sat" | "mcp"): (summary, canonical records); states
+        are packed as on the device wire (two i32 benefits per word + a depth word)."""
+        out = SolveOut()
+        t = getattr(self.L, f"oracle_{kind}_trace_solve")(path.encode(), width, max_compiles, C.byref(out))
+        if not t:
+            raise RuntimeError(f"oracle_{kind}_trace_solve failed on {path}")
+        ws = int(self.L.oracle_trace_state_words(t))
+        return out.asdict(), read_trace(self.L, t, ws)
 
     def tsptw_file(self, path, width_factor=1, nthreads=1):
         nn = C.c_uint64(0)

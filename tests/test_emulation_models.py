@@ -95,3 +95,54 @@ def test_max2sat_device_code_on_cpu(seed, n):
         b = int(rng.randint(1, n + 1)) * (1 if rng.rand() < 0.5 else -1)
         clauses.append((a, b, int(rng.randint(-4, 12))))
     bracket(ddo_amd.Max2Sat.from_clauses(n, clauses), sat_optimum(n, clauses), 1 << n, [1, 2, 5])
+
+
+# ---- per-compile parity of the signed-vector models (MAX2SAT, MCP) ---------------------------------------------------
+# The reference ranks these states by sum |benefit| only and leaves ties to hash order; oracle and device share ONE
+# deterministic tie-break (packed state words, oracle/models.hpp compare_signed_vectors == lexkey in misp_dd_core.hpp), so
+# every compile() of an oracle search can be replayed: values, counters and cut-set multisets must be equal.
+from tests.parity_util import diff  # noqa: E402
+
+VEC_CASES = [
+    ("max2sat", "pass.wcnf", 2, 0), ("max2sat", "pass.wcnf", 3, 0), ("max2sat", "debug2.wcnf", 1, 0), ("max2sat", "unit.wcnf", 2, 0),
+    ("max2sat", "negative_wt.wcnf", 2, 0), ("max2sat", "tautology.wcnf", 1, 0),
+    ("max2sat", "frb10-6-1.wcnf", 8, 40), ("max2sat", "frb10-6-2.wcnf", 25, 30), ("max2sat", "frb10-6-3.wcnf", 0, 30),
+    ("mcp", "mcp_n30_p0.1_000.mcp", 3, 60), ("mcp", "mcp_n30_p0.1_001.mcp", 10, 60), ("mcp", "mcp_n30_p0.1_004.mcp", 0, 60),
+    ("mcp", "mcp_n30_p0.1_007.mcp", 2, 80),
+]
+
+
+@pytest.mark.parametrize("kind,fname,width,max_compiles", VEC_CASES)
+def test_vector_models_replay_oracle_trace(oracle, kind, fname, width, max_compiles):
+    path = data_path(kind, fname)
+    model = (ddo_amd.Max2Sat if kind == "max2sat" else ddo_amd.Mcp).read_instance(path)
+    _, recs = oracle.vector_trace(kind, path, width, max_compiles)
+    assert recs and len(recs[0]["state"]) == model.ws
+    e = ModelEmul(model, max(int(r["width"]) for r in recs))
+    relaxed_inexact = 0
+    for i, r in enumerate(recs):
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"])[0]
+        assert g["status"] == 0
+        d = diff(r, g)
+        assert d is None, f"{kind} {fname} W={width} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+        relaxed_inexact += (r["comp_type"] == RELAXED and not r["is_exact"])
+    if width and model.n >= 30:
+        assert relaxed_inexact > 0    # merges (and their relaxed arc costs) are exercised
+
+
+def test_vector_ranking_tie_break_is_the_packed_words():
+    """Model::compare_states (host fringe order) == rank, then packed words from word 0 -- the order the device selects by"""
+    m = ddo_amd.Mcp.from_matrix(np.array([[0, 1, -2], [1, 0, 3], [-2, 3, 0]], dtype=np.int64))
+
+    def pack(b, depth):
+        w = np.zeros(m.ws, dtype=np.uint64)
+        for v, x in enumerate(b):
+            w[v // 2] |= np.uint64((x & 0xFFFFFFFF) << (32 * (v & 1)))
+        w[(len(b) + 1) // 2] = np.uint64(depth)
+        return w
+
+    assert m.compare(pack([1, 2, 3], 1), pack([1, 2, -4], 1)) < 0          # rank 6 < 7
+    assert m.compare(pack([3, -2, 1], 1), pack([1, -2, 3], 1)) > 0          # equal rank: word 0 low half 3 > 1
+    assert m.compare(pack([1, -2, 3], 1), pack([1, 2, 3], 1)) > 0           # -2 as u32 is the larger half
+    assert m.compare(pack([1, 2, 3], 2), pack([1, 2, 3], 1)) > 0            # depth word last
+    assert m.compare(pack([1, 2, 3], 1), pack([1, 2, 3], 1)) == 0
