@@ -7,9 +7,11 @@ The timed workload is FROZEN, so the number does not depend on --steps / --warmu
 
   setup   the branch-and-bound search (parallel.rs:391-437 per sub-problem: restricted DD, then -- when inexact --
           relaxed DD, both compiled on the GPU) runs its root step: the cut-set of the root's relaxed DD (<= 10 000
-          nodes of ONE layer, all of them width-saturating sub-problems) is the initial fringe.  Its first `--batches`
-          batches of `--concurrent` sub-problems, in fringe order (MaxUB), are frozen together with the incumbent
-          (ddo_solver_bench_freeze).  Their residual states already sit in the device node pool (HBM).
+          nodes of ONE layer, all of them width-saturating sub-problems) is the initial fringe.  Every GPU freezes
+          `--concurrent` (1024) of them together with the incumbent (ddo_solver_bench_freeze): with N ranks the root
+          cut-set is sharded by state hash, and a rank keeps every (8/N)-th node of its shard in fringe order (MaxUB),
+          so that for N = 1, 2, 4, 8 each GPU works on a statistically identical 1-in-8 sample of the same 8192+
+          sub-problems (weak scaling: per-GPU work fixed).  The residual states already sit in the node pool (HBM).
           Later batches of a live search are NOT like these: a best-first search soon runs on small sub-problems
           (61 % of all nodes of the whole search sit in DDs that fill the width, but 97 % of the DDs do not), which
           is why the whole search is reported separately (`proof`, with its own roofline figure).
@@ -100,8 +102,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--concurrent", type=int, default=2048, help="sub-problems compiled per step (== the reference's nb_threads)")
-    ap.add_argument("--batches", type=int, default=4, help="frozen batches the timed steps cycle through")
+    ap.add_argument("--concurrent", type=int, default=1024, help="sub-problems compiled per step and GPU (== the reference's nb_threads)")
+    ap.add_argument("--batches", type=int, default=1, help="frozen batches the timed steps cycle through")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="total time budget of the CPU baseline sample (split over the thread sweep)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = sweep 8/16/32/64/physical cores, report the best)")
     ap.add_argument("--no-cpu", action="store_true", help="timed steps only: neither the CPU baseline nor the proof search")
@@ -171,7 +173,8 @@ def main():
         solver.step()
         exchange()
     barrier()
-    nfrozen = solver.bench_freeze(args.batches)
+    stride = max(1, 8 // world)
+    nfrozen = solver.bench_freeze(args.batches, stride)
     if nfrozen < 1:
         raise SystemExit("bench.py: the fringe ran dry before the workload could be frozen")
 
@@ -241,8 +244,8 @@ def main():
                           "(key32 = (value - vbase) << 11 | popcount), bit-exact against the i64 oracle for sum|w| < 2^20",
             "data": "real instance (DIMACS brock400_1 complement graph shipped with the reference); frozen batches of the live search",
             "config": {"workload": f"MISP {args.instance}.clq FixedWidth({args.width}) LEL cut-set, EmptyCache, SimpleFringe(MaxUB) kept in "
-                                   f"the device node pool; frozen workload: the first {nfrozen} batches of {conc} sub-problems of the root cut-set "
-                                   f"in fringe order, cycled",
+                                   f"the device node pool; frozen workload per GPU: {solver.bench_frozen()} sub-problems of the root cut-set "
+                                   f"(every {stride}-th node of the rank's shard in fringe order), {nfrozen} batch(es), cycled",
                        "subproblems_per_step": conc, "frozen_batches": nfrozen, "prefix_steps": PREFIX_STEPS,
                        "parallelism": f"fringe-shard x{world}"},
             "subproblems_per_s": subs / elapsed,

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "ddo_solver_best_solution", "ddo_solver_best_lower_bound", "ddo_solver_best_upper_bound", "ddo_solver_set_primal",
     "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_flush",
     "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time",
-    "ddo_solver_bench_freeze", "ddo_solver_bench_step",
+    "ddo_solver_bench_freeze", "ddo_solver_bench_step", "ddo_solver_bench_frozen",
 ]
 
 DDO_OK, DDO_CUTOFF = 0, 2
@@ -139,7 +139,9 @@ def lib():
     L.ddo_solver_counters.argtypes = [C.c_void_p, C.POINTER(_Counters)]
     L.ddo_solver_step.argtypes = [C.c_void_p]
     L.ddo_solver_flush.argtypes = [C.c_void_p]
-    L.ddo_solver_bench_freeze.argtypes = [C.c_void_p, C.c_int]
+    L.ddo_solver_bench_freeze.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ddo_solver_bench_frozen.restype = C.c_uint64
+    L.ddo_solver_bench_frozen.argtypes = [C.c_void_p]
     L.ddo_solver_bench_step.argtypes = [C.c_void_p]
     L.ddo_solver_import_lower_bound.argtypes = [C.c_void_p, C.c_int64]
     L.ddo_solver_fringe_len.restype = C.c_uint64
@@ -500,9 +502,12 @@ class ParallelSolver:
             raise DdoError(f"ddo_solver_flush rc={rc}: {_err()}")
         return rc
 
-    def bench_freeze(self, nbatches):
-        """Measurement support: freeze the next `nbatches` batches of the fringe (see include/ddo_hip.h)."""
-        rc = lib().ddo_solver_bench_freeze(self._h, int(nbatches))
+    def bench_frozen(self):
+        return lib().ddo_solver_bench_frozen(self._h)
+
+    def bench_freeze(self, nbatches, stride=1):
+        """Measurement support: freeze `nbatches` batches made of every stride-th node of the fringe (see include/ddo_hip.h)."""
+        rc = lib().ddo_solver_bench_freeze(self._h, int(nbatches), int(stride))
         if rc < 0:
             raise DdoError(f"ddo_solver_bench_freeze rc={rc}: {_err()}")
         return rc

@@ -759,7 +759,7 @@ struct ddo_solver {
     /// (k mod nbatches) exactly as step() does -- same launch, same pipelining, same host work on the results -- but
     /// folds nothing into the fringe, so every step of a timed region is the same piece of work whatever --steps and
     /// --warmup are.  Returns the number of frozen batches.
-    int bench_freeze(int nbatches) {
+    int bench_freeze(int nbatches, int stride) {
         if (!lazy) {
             set_error("ddo_solver_bench_freeze needs DDO_FRINGE_LAZY");
             return DDO_ERR_UNSUPPORTED;
@@ -768,9 +768,14 @@ struct ddo_solver {
         if (rc != DDO_OK) return rc;
         const int B = std::max(1, cfg.nb_concurrent);
         LazyItem it;
+        uint64_t popped = 0;
+        stride = std::max(1, stride);
         for (int b = 0; b < nbatches; ++b) {
             std::vector<LazyItem> batch;
-            while ((int)batch.size() < B && lazy->pop(it, best_lb)) batch.push_back(it);   // pop() hands over one reference
+            while ((int)batch.size() < B && lazy->pop(it, best_lb)) {   // pop() hands over one reference
+                if (popped++ % (uint64_t)stride == 0) batch.push_back(it);   // every stride-th node in fringe order
+                else dev_unref(it.block);
+            }
             if (batch.empty()) break;
             if (batch.size() > 2)
                 std::stable_sort(batch.begin(), batch.end(), [](const LazyItem& a, const LazyItem& b2) {
@@ -1069,9 +1074,15 @@ int ddo_solver_step(ddo_solver* s) {
     if (!s) return DDO_ERR_INVALID;
     return s->step();
 }
-int ddo_solver_bench_freeze(ddo_solver* s, int nbatches) {
-    if (!s || nbatches < 1) return DDO_ERR_INVALID;
-    return s->bench_freeze(nbatches);
+int ddo_solver_bench_freeze(ddo_solver* s, int nbatches, int stride) {
+    if (!s || nbatches < 1 || stride < 1) return DDO_ERR_INVALID;
+    return s->bench_freeze(nbatches, stride);
+}
+uint64_t ddo_solver_bench_frozen(const ddo_solver* s) {
+    uint64_t n = 0;
+    if (s)
+        for (const auto& b : s->frozen) n += b.size();
+    return n;
 }
 int ddo_solver_bench_step(ddo_solver* s) {
     if (!s) return DDO_ERR_INVALID;

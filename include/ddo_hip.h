@@ -216,13 +216,14 @@ int ddo_solver_step(ddo_solver* s);
 /** With DDO_FRINGE_LAZY a step leaves its launch in flight and folds the results in during the next step;
  *  flush waits for it and absorbs the results (counters, incumbent and fringe are then up to date). */
 int ddo_solver_flush(ddo_solver* s);
-/** Measurement support (extension, DDO_FRINGE_LAZY only; no counterpart in the reference).  freeze: pops the next
- *  `nbatches` x nb_concurrent sub-problems in fringe order and freezes them with the incumbent; returns how many batches
- *  were taken (< nbatches when the fringe ran dry) or DDO_ERR_*.  bench_step: compiles frozen batch (k mod nbatches)
+/** Measurement support (extension, DDO_FRINGE_LAZY only; no counterpart in the reference).  freeze: pops sub-problems
+ *  in fringe order, keeps every `stride`-th one until `nbatches` x nb_concurrent are kept (or the fringe runs dry) and
+ *  freezes them with the incumbent; returns how many batches were taken or DDO_ERR_*; bench_frozen = sub-problems kept.  bench_step: compiles frozen batch (k mod nbatches)
  *  exactly as ddo_solver_step would (same launch, same pipelining, same host work on the results) without folding the
  *  cut-sets into the fringe, so a timed region is the same work whatever its length.  Counters / explored /
  *  device_time accumulate as usual; ddo_solver_flush waits for the step in flight. */
-int ddo_solver_bench_freeze(ddo_solver* s, int nbatches);
+int ddo_solver_bench_freeze(ddo_solver* s, int nbatches, int stride);
+uint64_t ddo_solver_bench_frozen(const ddo_solver* s);
 int ddo_solver_bench_step(ddo_solver* s);
 /** Lower bound seen by the next step (max-reduced across ranks by the caller, parallel.rs:439-453). */
 int ddo_solver_import_lower_bound(ddo_solver* s, int64_t best_lb);
