@@ -65,6 +65,7 @@ struct DDInput {
 
 // DDResult.status
 constexpr int ST_OK = 0, ST_CUTOFF = 1, ST_ERR_CAPACITY = -3, ST_ERR_INTERNAL = -5, ST_NOT_RUN = 77;
+constexpr int ST_RETRY = 78;   // capacity tier: the DD outgrew this tier's node slots (host: compile it on the next tier)
 
 /// Everything observable about one compiled DD (clean.rs:237-266).  Variable
 /// sized data lives in the output arena at `arena_off` (8-byte units):
@@ -186,6 +187,11 @@ struct EngineParams {
     uint8_t* pool;
     uint64_t pool_cap;
     unsigned long long* pool_head;
+    // ---- capacity tiers (engine.hpp): a tier engine has node slots for narrow decision diagrams only and never
+    // squashes (its layer capacity is below every width it is asked for): a DD that outgrows it reports ST_RETRY and is
+    // compiled again by the next tier.  hist_bins < 2048 shrinks the LDS area only the squash phases use.
+    int32_t hist_bins;         // 0 = 2048
+    int32_t tier;              // 0 = full-width engine, 1 = capacity tier
 };
 
 // node flag bits (node_flags.rs:48-185 restricted to what the device needs)

@@ -117,6 +117,17 @@ std::shared_ptr<Engine> Engine::create_private(Model* model, int device, long ma
     return e;
 }
 
+std::shared_ptr<Engine> Engine::create_tier(Model* model, int device, Engine* owner, int cap_width, int threads) {
+    if (!owner || owner->engine_kind() != 2 || !owner->has_pool() || cap_width < 8 || 2 * (long)cap_width > owner->max_width() ||
+        threads < 64 || threads > 256 || threads % 64) {
+        set_error("Engine::create_tier: needs an in-place owner engine with a node pool, 8 <= cap_width <= max_width / 2, 64..256 threads");
+        return nullptr;
+    }
+    std::shared_ptr<Engine> e(new Engine());
+    if (e->init(model, device, owner->max_width(), false, owner, cap_width, threads) != DDO_OK) return nullptr;
+    return e;
+}
+
 template <class T>
 static int dev_alloc(std::vector<void*>& allocs, T*& ptr, size_t count) {
     void* p = nullptr;
@@ -131,8 +142,10 @@ static int dev_alloc(std::vector<void*>& allocs, T*& ptr, size_t count) {
     return DDO_OK;
 }
 
-int Engine::init(Model* model, int device, long max_width, bool want_pool) {
+int Engine::init(Model* model, int device, long max_width, bool want_pool, Engine* owner, int cap_width, int tier_threads) {
     model_ = model;
+    owner_ = owner;
+    cap_width_ = owner ? cap_width : 0;
     device_ = device;
     max_width_ = max_width;
     int ndev = 0;
@@ -159,14 +172,16 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     P.unit_weights = model->unit_weights ? 1 : 0;
     P.npad = (model->n + 63) / 64 * 64;
     // the terminal layer is never squashed (clean.rs:608-618): MISP ends in at most one node, a knapsack DD in up to 2W
-    P.capN = model->kind != MODEL_MISP ? 2 * (int)max_width + 3 : (int)max_width + 2;
+    const long slot_width = owner ? (long)cap_width : max_width;   // what the node slots are sized for
+    P.capN = model->kind != MODEL_MISP ? 2 * (int)slot_width + 3 : (int)slot_width + 2;
     P.capC1 = 2 * P.capN + 1;
     P.max_layers = model->n + 2;
     int tc = 1024;
     while (tc * 2 < P.capC1 * 3 || tc < 2 * P.capN) tc <<= 1;
     P.table_cap = tc;
     threads_ = max_width >= 2048 ? 1024 : 256;
-    if (const char* env = std::getenv("DDO_HIP_THREADS")) {
+    if (owner) threads_ = tier_threads;
+    else if (const char* env = std::getenv("DDO_HIP_THREADS")) {
         int t = std::atoi(env);
         if (t >= 256 && t <= 1024 && t % 64 == 0) threads_ = t;
     }
@@ -176,7 +191,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     lds_bytes_ = table_lds_ ? lds_with_table : dd_lds_bytes(0, P.npad, threads_);
     P.table_in_lds = table_lds_ ? 1 : 0;
     // ---- engine 2 (in-place layers) when its LDS footprint fits and values fit the packed 21-bit key
-    P.capS = 2 * (int)max_width + 8;
+    P.capS = 2 * (int)slot_width + 8;
+    P.tier = owner ? 1 : 0;
+    P.hist_bins = owner ? 64 : 2048;   // a tier never squashes: the histogram / tie-break area of LDS is not needed
     P.capW = P.capN;
     int t2 = 1024;
     while (t2 < 3 * P.capW) t2 <<= 1;
@@ -191,21 +208,27 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 3) & ~3ull;   // 16-byte event records stay aligned per slot
     engine_kind_ = 2;
     if (const char* env = std::getenv("DDO_HIP_ENGINE")) engine_kind_ = std::atoi(env) == 1 ? 1 : 2;
-    size_t lds2 = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, true);
-    const size_t lds2g = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, false);
+    size_t lds2 = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, true, P.hist_bins);
+    const size_t lds2g = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, false, P.hist_bins);
     // the dedup table always lives in LDS; the ranking keys join it when both fit, else they stay in HBM (L2-hot)
     keys_global_ = lds2 > lds_max;
     if (const char* env = std::getenv("DDO_HIP_KEYS_GLOBAL")) keys_global_ = std::atoi(env) != 0;
     if (keys_global_) lds2 = lds2g;
     if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
     if (model->kind != MODEL_MISP) engine_kind_ = 1;   // scalar-state models run on the layer-rebuilding engine
+    if (owner && engine_kind_ != 2) {
+        set_error("Engine::create_tier: the tier does not fit the in-place engine");
+        return DDO_ERR_UNSUPPORTED;
+    }
     if (engine_kind_ == 2) lds_bytes_ = lds2;
 
     // ---- how many DDs in flight: residency of the kernel, then HBM
     int blocks_per_cu = (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(2048 / threads_));
     blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+    if (owner)   // tier kernel: 3 waves per SIMD = 12 waves per CU (kernels_inplace_tier.hip)
+        blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(12 / (threads_ / 64))));
     int nslots = prop.multiProcessorCount * blocks_per_cu;
-    if (const char* env = std::getenv("DDO_HIP_SLOTS")) {
+    if (const char* env = std::getenv(owner ? "DDO_HIP_TIER_SLOTS" : "DDO_HIP_SLOTS")) {
         int s = std::atoi(env);
         if (s > 0) nslots = s;
     }
@@ -220,6 +243,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     // output arena: restricted/relaxed results of one batch (cut-set rows + paths), sized by the slots that can run
     size_t arena_mb = std::min<size_t>(1024, std::max<size_t>(64, ((size_t)nslots * (size_t)P.capN * 256) >> 20));
+    if (owner) arena_mb = std::min<size_t>(arena_mb, 256);
     if (const char* env = std::getenv("DDO_HIP_ARENA_MB")) arena_mb = (size_t)std::max(16, std::atoi(env));
     arena_cap_ = arena_mb << 20;
     size_t budget = free_b > (arena_cap_ + (2ull << 30)) ? (size_t)((free_b - arena_cap_ - (1ull << 30)) * 0.8) : 0;
@@ -339,6 +363,12 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     HIP_TRY(hipMemset(cnt, 0, 64));
     P.cutoff_flag = (const int32_t*)(cnt + 16);
     P.pool_head = (unsigned long long*)(cnt + 32);
+    if (owner) {   // the tier allocates its cut-set blocks in the owner's node pool and obeys the owner's cutoff flag
+        P.cutoff_flag = owner->P_.cutoff_flag;
+        P.pool_head = owner->P_.pool_head;
+        P.pool = owner->P_.pool;
+        P.pool_cap = owner->P_.pool_cap;
+    }
     if (engine_kind_ == 2 && want_pool) {   // node pool: whatever HBM is left (capped), for cut-sets that stay on the device
         size_t free2 = 0, total2 = 0;
         HIP_TRY(hipMemGetInfo(&free2, &total2));
@@ -393,13 +423,23 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool) {
     ev0_ = e0;
     ev1_ = e1;
 
-    kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model->wsT, threads_)
-                                     : pick_kernel(model->wsT, table_lds_);
+    kernel_fn fn = owner ? pick_kernel2_tier(model->wsT)
+                   : engine_kind_ == 2 ? pick_kernel2(model->wsT, threads_)
+                                       : pick_kernel(model->wsT, table_lds_);
     if (!fn) {
         set_error("unsupported state width");
         return DDO_ERR_UNSUPPORTED;
     }
-    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_));
+    {   // several engines (tiers, widths) share a kernel: the attribute must cover the largest of them
+        static std::mutex attr_mtx;
+        static std::map<std::pair<int, const void*>, size_t> attr_max;
+        std::lock_guard<std::mutex> g(attr_mtx);
+        size_t& m = attr_max[{device, (const void*)fn}];
+        if (lds_bytes_ > m) {
+            HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_));
+            m = lds_bytes_;
+        }
+    }
     return DDO_OK;
 }
 
@@ -575,7 +615,8 @@ int Engine::launch(const DDInput* inputs, int count) {
         io.in_cap = cap;
     }
     for (int i = 0; i < count; ++i) {
-        if (inputs[i].width + 2 > P_.capN || inputs[i].width < 1) {
+        if ((!owner_ && inputs[i].width + 2 > P_.capN) || inputs[i].width < 1 || inputs[i].width > max_width_ ||
+            (owner_ && inputs[i].width <= P_.capW)) {   // a tier never squashes: its layer capacity must be below the width
             set_error("compile width exceeds the max_width the mdd was created with (or is < 1)");
             return DDO_ERR_CAPACITY;
         }
@@ -605,8 +646,8 @@ int Engine::launch(const DDInput* inputs, int count) {
     if (rewind_ >= 0) {   // bench: the frozen batch overwrites the blocks of its previous run
         rewind_val_ = (unsigned long long)rewind_;
         rewind_ = -1;
-        HIP_TRY(hipMemcpyAsync((uint8_t*)d_counters_ + 32, &rewind_val_, 8, hipMemcpyHostToDevice, st));
-        pool_head_bound_ = rewind_val_;
+        HIP_TRY(hipMemcpyAsync((void*)P_.pool_head, &rewind_val_, 8, hipMemcpyHostToDevice, st));
+        pool_owner()->pool_head_bound_ = rewind_val_;
     }
     HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
     if (vm_base_) {
@@ -677,13 +718,14 @@ int Engine::fetch(std::vector<HostResult>& results) {
             }
             decode(r, io.h_arena, out);
             if (r.n_cutset > 0 && r.pool_off != NO_POOL_SRC)
-                pool_head_bound_ = std::max<uint64_t>(pool_head_bound_, r.pool_off + pool_block_bytes((uint32_t)r.n_cutset, (uint32_t)model_->wsT,
-                                                                                                       (uint32_t)(r.lel > 0 ? r.lel : 0)));
+                pool_owner()->pool_head_bound_ = std::max<uint64_t>(pool_owner()->pool_head_bound_,
+                                                                    r.pool_off + pool_block_bytes((uint32_t)r.n_cutset, (uint32_t)model_->wsT, (uint32_t)(r.lel > 0 ? r.lel : 0)));
         }
     }
-    if (vm_base_) {   // this batch is accounted for exactly now
+    if (pool_owner()->vm_base_) {   // this batch is accounted for exactly now
+        Engine* po = pool_owner();
         const size_t worst = (size_t)count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
-        pool_unfetched_worst_ = pool_unfetched_worst_ > worst ? pool_unfetched_worst_ - worst : 0;
+        po->pool_unfetched_worst_ = po->pool_unfetched_worst_ > worst ? po->pool_unfetched_worst_ - worst : 0;
     }
     return DDO_OK;
 }

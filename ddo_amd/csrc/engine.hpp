@@ -84,6 +84,11 @@ class Engine {
     static std::shared_ptr<Engine> get(Model* model, int device, long max_width);
     /// an engine of its own (not shared through the model): needed by owners of the device node pool
     static std::shared_ptr<Engine> create_private(Model* model, int device, long max_width);
+    /// A capacity tier of `owner` (in-place engine only): node slots for decision diagrams whose layers stay within
+    /// `cap_width` nodes, `threads` per workgroup, many workgroups per CU.  It compiles the same sub-problems with the
+    /// same width semantics (widths up to owner->max_width()) out of the owner's node pool, never squashes, and reports
+    /// ST_RETRY for a DD that outgrows it.  The owner must outlive the tier.
+    static std::shared_ptr<Engine> create_tier(Model* model, int device, Engine* owner, int cap_width, int threads);
     ~Engine();
 
     /// Runs `count` work items in one launch.  results: 2 per item ([1] used by IN_FUSED).
@@ -103,6 +108,8 @@ class Engine {
     int device() const { return device_; }
     long max_width() const { return max_width_; }
     int nslots() const { return nslots_; }
+    int cap_width() const { return cap_width_; }
+    bool is_tier() const { return owner_ != nullptr; }
     int threads() const { return threads_; }
     int engine_kind() const { return engine_kind_; }
     size_t lds_bytes() const { return lds_bytes_; }
@@ -125,7 +132,10 @@ class Engine {
 
   private:
     Engine() = default;
-    int init(Model* model, int device, long max_width, bool want_pool);
+    int init(Model* model, int device, long max_width, bool want_pool, Engine* owner = nullptr, int cap_width = 0, int tier_threads = 0);
+    Engine* pool_owner() { return owner_ ? owner_ : this; }
+    Engine* owner_ = nullptr;        // capacity tier: the engine whose node pool / cutoff flag this one shares
+    int cap_width_ = 0;              // capacity tier: layer capacity (0 = full-width engine)
     void decode(const DDResult& r, const uint8_t* arena, HostResult& out) const;
 
     Model* model_ = nullptr;

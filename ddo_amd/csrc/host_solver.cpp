@@ -470,6 +470,11 @@ struct ddo_solver {
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[6] / 1e3 / std::max<uint64_t>(1, tl), st_clk[7] / 1e3 / std::max<uint64_t>(1, tl),
                          tc / 1e3 / std::max<uint64_t>(1, tl), tc / 1e6 / a.size());
+            for (size_t t = 0; t < tiers.size(); ++t)
+                std::fprintf(stderr, "[ddo stats] tier %zu: layer capacity %d, %d slots x %d threads, LDS %zu B | %llu launches, %llu sub-problems, %llu retried (%.1f %%), kernels %.1f ms\n",
+                             t, tiers[t]->is_tier() ? tiers[t]->cap_width() : (int)tiers[t]->max_width(), tiers[t]->nslots(), tiers[t]->threads(), tiers[t]->lds_bytes(),
+                             (unsigned long long)st_tier_launch[t], (unsigned long long)st_tier_items[t], (unsigned long long)st_tier_retry[t],
+                             100.0 * st_tier_retry[t] / std::max<uint64_t>(1, st_tier_items[t]), tiers[t]->kernel_ms());
             if (engine && engine->kernel_ms() > 0)   // busy share of the slots: sum of per-DD shader clocks vs slots x kernel time
                 std::fprintf(stderr, "[ddo stats] slot utilisation: %.1f %% (sum of DD cycles %.3g over %d slots x %.1f ms of kernels at 2.4 GHz)\n",
                              100.0 * (double)tc / (2.4e6 * engine->kernel_ms() * engine->nslots()), (double)tc, engine->nslots(), engine->kernel_ms());
@@ -497,6 +502,8 @@ struct ddo_solver {
         for (auto& b : frozen)
             for (LazyItem& e : b) dev_unref(e.block);
         for (LazyItem& e : flight) dev_unref(e.block);
+        for (auto& pr : todo)
+            for (LazyItem& e : pr.first) dev_unref(e.block);
         delete fringe;
         delete lazy;
     }
@@ -719,19 +726,165 @@ struct ddo_solver {
         return err;
     }
 
-    /// waits for the launch in flight (if any) and absorbs its results
-    int flush_lazy() {
-        if (!lazy || flight.empty()) return DDO_OK;
-        auto t0 = std::chrono::steady_clock::now();
-        int rc = engine->collect(results);
-        auto t1 = std::chrono::steady_clock::now();
-        st_host_run += std::chrono::duration<double>(t1 - t0).count();
-        if (rc != DDO_OK) {
-            for (LazyItem& e : flight) dev_unref(e.block);
-            flight.clear();
-            return rc;
+    // ---- capacity tiers -----------------------------------------------------------------------------------------
+    // A best-first search is made of SMALL decision diagrams (brock400_1, W = 10 000: half of the 72 M DDs never hold more
+    // than 57 nodes in a layer; DDs that stay within 256 nodes take 37 % of the device time for 4 % of the nodes), and
+    // a narrow DD is pure latency: a layer costs a fixed chain of dependent memory round trips.  The full-width engine
+    // runs one DD per CU (its LDS); a tier engine has slots for narrow DDs only and runs 12 of them per CU.  Every
+    // sub-problem starts in the lowest tier its depth has not been seen to outgrow; a DD that outgrows a tier comes
+    // back ST_RETRY (cheap: it failed while it was still small) and moves up.  Results are identical by construction:
+    // a tier never squashes, so whatever it completes is what the full-width engine would have produced.
+    std::vector<std::shared_ptr<Engine>> tiers;   // ascending capacity; tiers.back() == engine
+    int flight_tier = -1;                          // engine of the launch in flight (flight = its items)
+    std::vector<std::pair<std::vector<LazyItem>, std::vector<HostResult>>> todo;   // finished, not folded in yet
+    static constexpr int HINT_DEPTHS = 1024;
+    struct TierHint { uint32_t tried[3] = {0, 0, 0}, retried[3] = {0, 0, 0}; };
+    std::vector<TierHint> hints;
+    uint64_t probe_ctr = 0;
+    uint64_t st_tier_items[4] = {0, 0, 0, 0}, st_tier_retry[4] = {0, 0, 0, 0}, st_tier_launch[4] = {0, 0, 0, 0};
+
+    bool pending() const { return !flight.empty() || !todo.empty(); }
+
+    int start_tier(const LazyItem& e) {
+        const int T = (int)tiers.size();
+        if (T <= 1) return 0;
+        if (hints.empty()) hints.resize(HINT_DEPTHS);
+        const TierHint& h = hints[std::min(std::max(e.depth, 0), HINT_DEPTHS - 1)];
+        const bool probe = (++probe_ctr & 63) == 0;   // keep sampling the lower tiers: the search moves on
+        for (int t = 0; t + 1 < T; ++t)
+            if (probe || h.tried[t] < 32 || (uint64_t)h.retried[t] * 10 < (uint64_t)h.tried[t] * 9) return t;
+        return T - 1;
+    }
+    void note_tier(const LazyItem& e, int t, bool retried) {
+        if (t + 1 >= (int)tiers.size()) return;
+        TierHint& h = hints[std::min(std::max(e.depth, 0), HINT_DEPTHS - 1)];
+        h.tried[t] += 1;
+        h.retried[t] += retried ? 1 : 0;
+        if (h.tried[t] >= 8192) {
+            h.tried[t] >>= 1;
+            h.retried[t] >>= 1;
         }
-        rc = absorb_lazy(flight, results);
+    }
+    static void drop_items(std::vector<LazyItem>& v) {
+        for (LazyItem& e : v) dev_unref(e.block);
+        v.clear();
+    }
+    int absorb_todo() {
+        int err = DDO_OK;
+        for (auto& pr : todo) {
+            if (err == DDO_OK) err = absorb_lazy(pr.first, pr.second);
+            else drop_items(pr.first);
+        }
+        todo.clear();
+        return err;
+    }
+
+    /// Compiles `batch` (restricted + relaxed DD per sub-problem, parallel.rs:391-437) through the tiers.  Software
+    /// pipeline: the first launch of this call goes out BEFORE the results of the previous call are folded into the
+    /// fringe, and every hand-over between tiers overlaps the host work on what the lower tier finished.  The launch
+    /// of the last tier stays in flight when the call returns.  Takes over the references held by `batch`.
+    int dispatch(std::vector<LazyItem>& batch, int64_t lb, bool rewind) {
+        const int T = (int)tiers.size();
+        std::vector<std::vector<LazyItem>> lists((size_t)T);
+        for (LazyItem& e : batch) lists[(size_t)start_tier(e)].push_back(e);
+        batch.clear();
+        auto fail = [&](int rc) {
+            for (auto& l : lists) drop_items(l);
+            return rc;
+        };
+        int rc;
+        auto t_run0 = std::chrono::steady_clock::now();
+        // tiers run one after the other (a full-width workgroup owns a whole CU): the launch in flight must have left
+        if (flight_tier >= 0 && (rc = tiers[(size_t)flight_tier]->wait()) != DDO_OK) {
+            drop_items(flight);
+            flight_tier = -1;
+            return fail(rc);
+        }
+        for (int t = 0; t < T; ++t) {
+            if (lists[(size_t)t].empty()) continue;
+            std::vector<LazyItem>& cur = lists[(size_t)t];
+            fill_lazy_inputs(cur, lb);
+            if (rewind) {
+                tiers[(size_t)t]->set_pool_rewind(frozen_mark);
+                rewind = false;
+            }
+            if ((rc = tiers[(size_t)t]->launch(inputs.data(), (int)inputs.size())) != DDO_OK) return fail(rc);
+            st_tier_launch[t] += 1;
+            st_tier_items[t] += cur.size();
+            if (want_stats) std::fprintf(stderr, "[ddo stats] tier %d: launch of %zu sub-problems (fringe %zu open, best_lb %lld)\n", t, cur.size(),
+                                         lazy->len(), (long long)lb);
+            auto t_run1 = std::chrono::steady_clock::now();
+            st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
+            // ... while the device works: results of the launch that was in flight, then everything deferred
+            if (flight_tier >= 0) {
+                std::vector<HostResult> res;
+                rc = tiers[(size_t)flight_tier]->fetch(res);
+                flight_tier = -1;
+                if (rc != DDO_OK) {
+                    drop_items(flight);
+                    return fail(rc);
+                }
+                todo.emplace_back(std::move(flight), std::move(res));
+                flight.clear();
+            }
+            st_host_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
+            rc = absorb_todo();
+            st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
+            if (rc != DDO_OK) {
+                tiers[(size_t)t]->wait();
+                std::vector<HostResult> junk;
+                tiers[(size_t)t]->fetch(junk);
+                return fail(rc);
+            }
+            t_run0 = std::chrono::steady_clock::now();
+            if (t + 1 == T) {   // the full-width engine: nothing above it, its launch stays in flight
+                flight.swap(cur);
+                flight_tier = t;
+                break;
+            }
+            std::vector<HostResult> res;
+            if ((rc = tiers[(size_t)t]->collect(res)) != DDO_OK) return fail(rc);
+            std::vector<LazyItem> done;
+            std::vector<HostResult> done_res;
+            done.reserve(cur.size());
+            done_res.reserve(2 * cur.size());
+            for (size_t i = 0; i < cur.size(); ++i) {
+                const bool retry = res[2 * i].hdr.status == ST_RETRY || res[2 * i + 1].hdr.status == ST_RETRY;
+                note_tier(cur[i], t, retry);
+                if (retry) {
+                    st_tier_retry[t] += 1;
+                    lists[(size_t)t + 1].push_back(cur[i]);
+                } else {
+                    done.push_back(cur[i]);
+                    done_res.push_back(std::move(res[2 * i]));
+                    done_res.push_back(std::move(res[2 * i + 1]));
+                }
+            }
+            cur.clear();
+            if (!done.empty()) todo.emplace_back(std::move(done), std::move(done_res));
+        }
+        st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
+        return DDO_OK;
+    }
+
+    /// waits for the launch in flight (if any) and folds every finished result into the fringe
+    int flush_lazy() {
+        if (!lazy) return DDO_OK;
+        auto t0 = std::chrono::steady_clock::now();
+        if (flight_tier >= 0) {
+            std::vector<HostResult> res;
+            int rc = tiers[(size_t)flight_tier]->collect(res);
+            flight_tier = -1;
+            st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rc != DDO_OK) {
+                drop_items(flight);
+                return rc;
+            }
+            todo.emplace_back(std::move(flight), std::move(res));
+            flight.clear();
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        int rc = absorb_todo();
         st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         return rc;
     }
@@ -795,22 +948,11 @@ struct ddo_solver {
             set_error("ddo_solver_bench_step: call ddo_solver_bench_freeze first");
             return DDO_ERR_INVALID;
         }
-        const std::vector<LazyItem>& batch = frozen[frozen_next++ % frozen.size()];
-        fill_lazy_inputs(batch, frozen_lb);
+        std::vector<LazyItem> batch = frozen[frozen_next++ % frozen.size()];
+        for (LazyItem& e : batch) dev_ref(e.block);   // dispatch / absorb_lazy release one reference per item
         explored += batch.size();
-        std::vector<HostResult> prev_results;
-        std::vector<LazyItem> prev_items;
-        int rc;
-        if (!flight.empty()) {
-            if ((rc = engine->wait()) != DDO_OK) return rc;
-            prev_items.swap(flight);
-        }
-        engine->set_pool_rewind(frozen_mark);
-        if ((rc = engine->launch(inputs.data(), (int)inputs.size())) != DDO_OK) return rc;
-        if (!prev_items.empty() && (rc = engine->fetch(prev_results)) != DDO_OK) return rc;
-        flight = batch;
-        for (LazyItem& e : flight) dev_ref(e.block);   // absorb_lazy releases one reference per item
-        return prev_items.empty() ? 1 : (absorb_lazy(prev_items, prev_results) == DDO_OK ? 1 : DDO_ERR_INTERNAL);
+        int rc = dispatch(batch, frozen_lb, true);
+        return rc == DDO_OK ? 1 : rc;
     }
 
     /// step() with the lazy block fringe: payload in the device node pool, (value, ub) keys on the host.
@@ -835,7 +977,7 @@ struct ddo_solver {
             int rc = flush_lazy();
             if (rc != DDO_OK) return rc;
         }
-        if (lazy->empty() && flight.empty()) {
+        if (lazy->empty() && !pending()) {
             if (cfg.world_size <= 1) best_ub = best_lb;
             finished = true;
             return 0;
@@ -870,6 +1012,8 @@ struct ddo_solver {
             // open bound is the largest of both (only then does gap() never dip below the true bound mid-search)
             int64_t top = litems[0].ub;
             for (const LazyItem& e : flight) top = std::max(top, e.ub);
+            for (const auto& pr : todo)
+                for (const LazyItem& e : pr.first) top = std::max(top, e.ub);
             best_ub = top == INT32_MAX ? I64_MAX : top;
         }
         // longest-processing-time-first: shallow sub-problems with a lot of slack are the big DDs
@@ -878,43 +1022,9 @@ struct ddo_solver {
                 if (a.depth != b.depth) return a.depth < b.depth;
                 return (a.ub - a.value) > (b.ub - b.value);
             });
-        fill_lazy_inputs(litems, best_lb);
-        // the previous launch must have left the device before its buffers are reused
-        std::vector<HostResult> prev_results;
-        std::vector<LazyItem> prev_items;
-        auto t_run0 = std::chrono::steady_clock::now();
-        st_host_pop += std::chrono::duration<double>(t_run0 - t_pop0).count();
-        if (!flight.empty()) {
-            int rc = engine->wait();   // the previous kernel has finished; its arena stays on the device for now
-            if (rc != DDO_OK) {
-                for (LazyItem& e : flight) dev_unref(e.block);
-                for (LazyItem& e : litems) dev_unref(e.block);
-                flight.clear();
-                return rc;
-            }
-            prev_items.swap(flight);
-        }
-        int rc = engine->launch(inputs.data(), (int)inputs.size());
-        if (want_stats) std::fprintf(stderr, "[ddo stats] launch of %zu sub-problems (fringe %zu open, best_lb %lld, top ub %lld)\n", inputs.size(),
-                                     lazy->len(), (long long)best_lb, (long long)litems[0].ub);
-        auto t_run1 = std::chrono::steady_clock::now();
-        st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
-        if (rc != DDO_OK) {
-            for (LazyItem& e : litems) dev_unref(e.block);
-            for (LazyItem& e : prev_items) dev_unref(e.block);
-            return rc;
-        }
-        if (!prev_items.empty() && (rc = engine->fetch(prev_results)) != DDO_OK) {   // overlaps the new kernel
-            for (LazyItem& e : litems) dev_unref(e.block);
-            for (LazyItem& e : prev_items) dev_unref(e.block);
-            return rc;
-        }
-        flight.swap(litems);
-        st_host_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
-        // ... and while the device works on it, fold the previous batch into the fringe
-        int err = prev_items.empty() ? DDO_OK : absorb_lazy(prev_items, prev_results);
-        st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
-        if (err != DDO_OK) return err;
+        st_host_pop += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pop0).count();
+        int rc = dispatch(litems, best_lb, false);
+        if (rc != DDO_OK) return rc;
         return 1;
     }
 
@@ -1064,7 +1174,37 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
             return nullptr;
         }
         s->lazy = new LazyFringe();
+        // capacity tiers below the full-width engine (see ddo_solver::dispatch): only where the width leaves room for them
+        std::vector<std::pair<int, int>> spec;   // (layer capacity, threads per workgroup)
+        if (s->cfg.width_policy == DDO_WIDTH_FIXED && s->cfg.width >= 4096) {
+            spec.push_back({256, 64});
+            if (s->cfg.width >= 8192) spec.push_back({2048, 256});
+        }
+        if (const char* env = std::getenv("DDO_HIP_TIERS")) {   // "0" = none, "256:64,2048:256" = explicit list
+            spec.clear();
+            std::string v(env);
+            size_t pos = 0;
+            while (pos < v.size() && v != "0") {
+                size_t end = v.find(',', pos);
+                if (end == std::string::npos) end = v.size();
+                const std::string tok = v.substr(pos, end - pos);
+                const size_t colon = tok.find(':');
+                const int w = std::atoi(tok.c_str());
+                const int th = colon == std::string::npos ? (w <= 512 ? 64 : 256) : std::atoi(tok.c_str() + colon + 1);
+                if (w >= 8 && s->cfg.width_policy == DDO_WIDTH_FIXED && 2 * (size_t)w <= s->cfg.width && spec.size() < 2) spec.push_back({w, th});
+                pos = end + 1;
+            }
+        }
+        for (auto& sp : spec) {
+            auto t = Engine::create_tier(s->model, cfg->device, s->engine.get(), sp.first, sp.second);
+            if (!t) {
+                delete s;
+                return nullptr;
+            }
+            s->tiers.push_back(t);
+        }
     }
+    s->tiers.push_back(s->engine);
     s->want_stats = std::getenv("DDO_HIP_STATS") != nullptr;
     return s;
 }
@@ -1173,8 +1313,14 @@ int64_t ddo_solver_fringe_best_ub(const ddo_solver* s) {
 }
 int ddo_solver_device_time(const ddo_solver* s, double* kernel_ms, uint64_t* launches) {
     if (!s) return DDO_ERR_INVALID;
-    if (kernel_ms) *kernel_ms = s->engine->kernel_ms();
-    if (launches) *launches = s->engine->launches();
+    double ms = 0;
+    uint64_t n = 0;
+    for (const auto& t : s->tiers) {
+        ms += t->kernel_ms();
+        n += t->launches();
+    }
+    if (kernel_ms) *kernel_ms = ms;
+    if (launches) *launches = n;
     return DDO_OK;
 }
 

@@ -17,6 +17,8 @@ kernel_fn pick_kernel(int wsT, bool table_in_lds);
 // the per-unit halves
 kernel_fn pick_kernel2_1024(int wsT);
 kernel_fn pick_kernel2_512(int wsT);
+/// capacity tiers: workgroups of 64..256 threads, 3 waves per SIMD (168 VGPRs: no spills, 12 waves per CU)
+kernel_fn pick_kernel2_tier(int wsT);
 kernel_fn pick_kernel_lds(int wsT);
 kernel_fn pick_kernel_glb(int wsT);
 

@@ -1,0 +1,40 @@
+// gfx950 kernels of the in-place engine for the capacity tiers (engine.hpp: Engine::create_tier): workgroups of 64 to 256
+// threads, many of them per CU.  Narrow decision diagrams are all latency (a layer is a chain of dependent memory round
+// trips whatever its size), so the lever is how many DDs a CU overlaps: 3 waves per SIMD leave 168 VGPRs per lane -- no
+// spills -- and let 12 one-wave workgroups (or 3 of 256 threads) share a CU.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "misp_dd_inplace.hpp"
+
+namespace ddo_hip {
+
+template <int WS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) misp_compile_kernel2_tier(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    DD2Ctx<WS> c;
+    dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
+    c.tid_ = (int)threadIdx.x;
+    for (;;) {
+        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
+        __syncthreads();
+        const int w = c.sh->work;
+        __syncthreads();
+        if (w >= P.nbatch) break;
+        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+    }
+}
+
+kernel_fn pick_kernel2_tier(int wsT) {
+    switch (wsT) {
+        case 1: return misp_compile_kernel2_tier<1>;
+        case 2: return misp_compile_kernel2_tier<2>;
+        case 4: return misp_compile_kernel2_tier<4>;
+        case 7: return misp_compile_kernel2_tier<7>;
+        case 8: return misp_compile_kernel2_tier<8>;
+        case 16: return misp_compile_kernel2_tier<16>;
+        default: return nullptr;
+    }
+}
+
+}  // namespace ddo_hip

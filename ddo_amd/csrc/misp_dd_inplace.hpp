@@ -207,6 +207,7 @@ struct DD2Ctx {
     int NT;
     int lex_cap;
     int clocks;        // per-phase shader-clock accounting (DDO_HIP_STATS): costs one barrier per phase
+    int tier;          // capacity tier: no squash phases (their LDS is not there), capacity errors mean ST_RETRY
 #if !defined(DDO_HOST_EMULATION)
     int tid_;
 #endif
@@ -850,6 +851,13 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         int merged_slot = -1, dup_from = -1, dup_to = -1;
         const uint64_t del_off = DD_UNIFORM64(sh->ev_pos);
         int n_del = 0;
+        if (squash && c.tier) {   // cannot happen: a tier's layer capacity is below the width (the host guarantees it)
+            PAR_BEGIN
+            if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 11;
+            PAR_END
+            failed = true;
+            break;
+        }
         if (squash) {
             if (lel < 0) {
                 lel = L - 1;   // _maybe_save_lel
@@ -1810,6 +1818,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     if (tid == 0) {
         DDResult r;
         r.status = sh->status;
+        // a capacity tier that ran out of node slots / work-list / event space hands the DD to the next tier (the
+        // shared output arena and node pool are not the tier's: those stay errors)
+        if (c.tier && (sh->status == ST_ERR_CAPACITY || (sh->status <= ST_ERR_CAPACITY - 100 && sh->status != ST_ERR_CAPACITY - 700 &&
+                                                         sh->status != ST_ERR_CAPACITY - 800 && sh->status != ST_ERR_CAPACITY - 1100)))
+            r.status = ST_RETRY;
         r.comp_type = comp_type;
         r.is_exact = is_exact ? 1 : 0;
         r.has_exact_best_path = ebpo ? 1 : 0;
@@ -1877,7 +1890,7 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
 }
 
 /// LDS bytes of one in-place workgroup
-inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool keys_in_lds = true) {
+inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool keys_in_lds = true, int hist_bins = 2048) {
     const size_t nbw = ((size_t)capS + 31) / 32;
     size_t b = keys_in_lds ? (size_t)capS * 4 : 0;   // key32 / value_bot
     b = (b + 15) & ~(size_t)15;
@@ -1885,7 +1898,7 @@ inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool 
     b += 4 * nbw * 4;                      // live, inex, okb, fresh
     b = (b + 15) & ~(size_t)15;
     b += (size_t)npad * 4;                 // cnt
-    b += 2048 * 4;                         // hist
+    b += (size_t)(hist_bins > 0 ? hist_bins : 2048) * 4;   // hist (squash phases only)
     b += (size_t)nthreads * 4 * 2;         // scan scratch
     b += (sizeof(DD2Shared) + 15) & ~(size_t)15;
     return (b + 15) & ~(size_t)15;
@@ -1942,7 +1955,7 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.cnt = (LDS_PTR(int32_t))p;
     p += (size_t)P.npad * 4;
     c.hist = (LDS_PTR(uint32_t))p;
-    p += 2048 * 4;
+    p += (size_t)(P.hist_bins > 0 ? P.hist_bins : 2048) * 4;
     c.wl = P.s_wl + s * 2 * capW;          // work lists live in HBM (written and read once per layer, coalesced)
     c.fl = c.wl + capW;
     c.tcount = (LDS_PTR(int32_t))p;
@@ -1960,6 +1973,7 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.vbase_off = P.vbase_off;
     c.clocks = P.phase_clocks;
     c.lex_cap = P.lex_cap > 0 && P.lex_cap <= 1024 ? P.lex_cap : 1024;
+    c.tier = P.tier;
     c.NT = nthreads;
 }
 

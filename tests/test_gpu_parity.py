@@ -146,6 +146,36 @@ def test_sharded_lazy_fringe(have_gpu, name, expected, width, world):
         assert all(s.fringe_len() == 0 for s in ranks)
 
 
+@pytest.mark.parametrize("name,expected,width,tiers,threads", [
+    ("brock200_2", 12, 100, "8:64,32:64", 1), ("brock200_2", 12, 100, "16:64", 48), ("keller4", 11, 64, "8:64,24:128", 1),
+    ("p_hat300-1", 8, 128, "32:64,64:256", 1), ("brock200_4", 17, 300, "16:64,100:256", 256), ("MANN_a9", 16, 40, "8:64", 1),
+])
+def test_capacity_tiers_do_not_change_the_search(have_gpu, monkeypatch, name, expected, width, tiers, threads):
+    """Capacity tiers (host_solver.cpp: dispatch): narrow DDs are compiled by engines with few node slots per DD and many
+    DDs per CU; a DD that outgrows a tier is compiled again by the next one.  A tier never squashes, so whatever it
+    completes is what the full-width engine produces: with one sub-problem in flight the whole search -- explored
+    sub-problems, nodes, arcs, layers, compiles -- is identical with and without tiers; with many in flight the proved
+    optimum is."""
+    model = ddo_amd.Misp.read_instance(data_path("misp", name + ".clq"))
+
+    def run(spec):
+        monkeypatch.setenv("DDO_HIP_TIERS", spec)
+        s = ParallelSolver(model, FixedWidth(width), nb_threads=threads, fringe="lazy")
+        c = s.maximize()
+        assert c.is_exact and c.best_value == expected
+        sol = [d.variable for d in s.best_solution() if d.value == 1]
+        rows, w = model.export()
+        assert len(sol) == expected and is_independent_set(rows, model.ws, sol)
+        return s.explored(), s.counters()
+
+    base = run("0")
+    tiered = run(tiers)
+    if threads == 1:
+        assert tiered == base
+    else:
+        assert tiered[1]["compiles"] > 0
+
+
 # ---- (3) golden fixtures (generated by tests/golden/make_golden.py from the oracle) ----------------
 def _golden_cases():
     with open(GOLDEN) as f:
