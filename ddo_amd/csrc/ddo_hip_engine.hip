@@ -76,7 +76,7 @@ int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
         const int64_t ra = rank(a), rb = rank(b);
         if (ra != rb) return ra < rb ? -1 : 1;
         // Deterministic tie-break shared with the device kernels (lexkey = raw word, misp_dd_core.hpp) and with the
-        // oracle (oracle/models.hpp compare_signed_vectors): the reference leaves ties of this ranking to the
+        // CPU restatement used by the tests (compare_signed_vectors): the reference leaves ties of this ranking to the
         // iteration order of its hash map; here the packed state words decide, compared from word 0, larger first.
         for (int k = 0; k < ws; ++k)
             if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;

@@ -152,14 +152,16 @@ def test_max2sat_model_host_side(tmp_path):
     assert t.n == 2 and t.initial_value() == 5
     same = ddo_amd.Max2Sat.from_clauses(2, [(1, -1, 5), (2, 1, 7), (-2, -2, 4)])
     assert same.initial_value() == 5
-    # Max2SatRanking (heuristics.rs:30-37): sum of |benefit|; benefits sit two per word, the depth word is ignored
+    # Max2SatRanking (heuristics.rs:30-37): sum of |benefit|; ties fall to the packed words (the deterministic tie-break
+    # shared by oracle, host and device: SURVEY.md section 7), word 0 first, the depth word last
     def pack(vals, depth):
         w = np.zeros(m.ws, dtype=np.uint64)
         for i, v in enumerate(vals):
             w[i // 2] |= np.uint64(v & 0xFFFFFFFF) << np.uint64(32 * (i % 2))
         w[(len(vals) + 1) // 2] = np.uint64(depth)
         return w
-    assert m.compare(pack([1, -2, 0], 1), pack([0, 0, 4], 2)) < 0 and m.compare(pack([3, -3, 0], 0), pack([-6, 0, 0], 5)) == 0
+    assert m.compare(pack([1, -2, 0], 1), pack([0, 0, 4], 2)) < 0 and m.compare(pack([3, -3, 0], 0), pack([-6, 0, 0], 5)) > 0
+    assert m.compare(pack([3, -3, 0], 0), pack([3, -3, 0], 5)) < 0 and m.compare(pack([3, -3, 0], 5), pack([3, -3, 0], 5)) == 0
     with pytest.raises(ddo_amd.DdoError):
         ddo_amd.Max2Sat.from_clauses(2, [(3, 1, 1)])            # literal outside [-n, n]
     with pytest.raises(ddo_amd.DdoError):

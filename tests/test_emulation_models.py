@@ -146,3 +146,24 @@ def test_vector_ranking_tie_break_is_the_packed_words():
     assert m.compare(pack([1, -2, 3], 1), pack([1, 2, 3], 1)) > 0           # -2 as u32 is the larger half
     assert m.compare(pack([1, 2, 3], 2), pack([1, 2, 3], 1)) > 0            # depth word last
     assert m.compare(pack([1, 2, 3], 1), pack([1, 2, 3], 1)) == 0
+
+
+def _vector_golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "vector_compile_golden.json")) as f:
+        return [c for c in json.load(f)["cases"] if c["width"] <= 100]
+
+
+@pytest.mark.parametrize("case", _vector_golden(), ids=lambda c: c["id"])
+def test_vector_models_match_golden_on_cpu(case):
+    """the committed vectors (tests/golden/make_vector_golden.py) through the emulated device code; the width-5000 cases
+    run on the GPU only (tests/test_gpu_vector_parity.py)"""
+    from tests.parity_util import cutset_digest
+    model = (ddo_amd.Max2Sat if case["kind"] == "max2sat" else ddo_amd.Mcp).read_instance(data_path(case["kind"], case["file"]))
+    e = ModelEmul(model, case["width"])
+    g = e.compile(case["comp_type"], case["width"], case["best_lb"], [int(x) for x in case["state"]], case["value"], case["depth"])[0]
+    assert g["status"] == 0
+    for k in ("is_exact", "best_value", "best_exact_value", "nodes_expanded", "arcs", "layers"):
+        assert g[k] == case[k], (case["id"], k, g[k], case[k])
+    assert len(g["cutset"]) == case["n_cutset"] and cutset_digest(g["cutset"]) == case["cutset_digest"]
