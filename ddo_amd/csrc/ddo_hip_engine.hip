@@ -523,6 +523,29 @@ int Engine::read_pool_head(uint64_t* out) {
     *out = h;
     return DDO_OK;
 }
+int Engine::pool_append(const void* data, size_t bytes, uint64_t* off) {
+    uint64_t head = 0;
+    int rc = read_pool_head(&head);
+    if (rc != DDO_OK) return rc;
+    std::lock_guard<std::mutex> g(mtx_);
+    head = (head + 63) & ~63ull;
+    const size_t padded = (bytes + 63) & ~(size_t)63;
+    if (vm_base_ && head + padded > vm_mapped_) {
+        pool_grow(head + padded + vm_chunk_);
+        P_.pool_cap = vm_mapped_;
+    }
+    if (!P_.pool || head + padded > P_.pool_cap) {
+        set_error("pool_append: the device node pool is full");
+        return DDO_ERR_CAPACITY;
+    }
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipMemcpy(P_.pool + head, data, bytes, hipMemcpyHostToDevice));
+    const unsigned long long nh = head + padded;
+    HIP_TRY(hipMemcpy((void*)P_.pool_head, &nh, 8, hipMemcpyHostToDevice));
+    pool_head_bound_ = std::max<uint64_t>(pool_head_bound_, nh);
+    *off = head;
+    return DDO_OK;
+}
 int Engine::read_pool(uint64_t off, void* dst, size_t bytes) {
     std::lock_guard<std::mutex> g(mtx_);
     if (!P_.pool || off + bytes > P_.pool_cap) {

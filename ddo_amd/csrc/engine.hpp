@@ -127,6 +127,8 @@ class Engine {
     void set_pool_rewind(uint64_t head) { rewind_ = (long long)head; }
     /// current head of the pool's bump allocator (synchronous: call with no launch in flight)
     int read_pool_head(uint64_t* out);
+    /// appends a host-built block to the node pool (imported sub-problems); call with no launch in flight
+    int pool_append(const void* data, size_t bytes, uint64_t* off);
     int read_pool(uint64_t off, void* dst, size_t bytes);
     int words_per_state_device() const { return P_.ws; }
 

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <thread>
 
 #include "../../include/ddo_hip.h"
@@ -269,6 +270,7 @@ struct DevBlock {
     std::vector<int32_t> value, ub;
     std::vector<uint32_t> order;     // rows sorted by (ub, value) descending
     std::vector<uint8_t> mine;       // sharded search, root cut-set only: 1 = this rank owns the row (hash of the state)
+    std::vector<std::vector<ddo_decision>> host_paths;   // imported sub-problems: decisions from the problem root, per row
     size_t cursor = 0;
     uint64_t id = 0;
     int64_t head_ub() const { return std::min<int64_t>(cap_ub, ub[order[cursor]]); }
@@ -601,6 +603,11 @@ struct ddo_solver {
         }
         for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
             const DevBlock* blk = it->first;
+            if (!blk->host_paths.empty()) {   // handed over by another rank: the path travelled with the node
+                const auto& hp = blk->host_paths[(size_t)it->second];
+                out.insert(out.end(), hp.begin(), hp.end());
+                continue;
+            }
             if (blk->off == NO_POOL_SRC || blk->lel == 0) continue;
             PoolBlockHeader h;
             int rc = engine->read_pool(blk->off, &h, sizeof(h));
@@ -616,6 +623,146 @@ struct ddo_solver {
         return DDO_OK;
     }
 
+    // ---- work hand-over between ranks ("optional send/recv of sub-problem batches") ----------
+    /// Pops up to `max_count` open sub-problems in fringe order and writes them out as self-contained records: state
+    /// words, value, ub, depth and the decisions from the problem root (path_off[i] .. path_off[i+1] in `paths`).
+    /// Stops early when `path_cap` decisions do not suffice.  The nodes leave this solver for good.
+    int export_nodes(size_t max_count, uint64_t* states, int64_t* value, int64_t* ub, int64_t* depth, uint64_t* path_off,
+                     ddo_decision* paths, size_t path_cap, size_t* n_out) {
+        *n_out = 0;
+        int rc = lazy ? flush_lazy() : DDO_OK;
+        if (rc != DDO_OK) return rc;
+        const int ws = model->ws;
+        size_t np = 0;
+        path_off[0] = 0;
+        std::vector<ddo_decision> path;
+        while (*n_out < max_count) {
+            path.clear();
+            const size_t i = *n_out;
+            if (lazy) {
+                LazyItem it;
+                // a node whose path may not fit is not popped: worst case is one decision per variable
+                if (np + (size_t)model->n > path_cap || !lazy->pop(it, best_lb)) break;
+                std::vector<uint64_t> row((size_t)std::max(ws, engine->words_per_state_device()), 0);
+                if (it.block->off == NO_POOL_SRC) model->initial_state(row.data());
+                else {
+                    PoolBlockHeader h;
+                    if ((rc = engine->read_pool(it.block->off, &h, sizeof(h))) != DDO_OK) return rc;
+                    for (uint32_t k = 0; k < h.ws && k < row.size(); ++k)
+                        if ((rc = engine->read_pool(it.block->off + h.off_states + ((uint64_t)k * h.rows + (uint64_t)it.row) * 8, &row[k], 8)) != DDO_OK) return rc;
+                }
+                std::memcpy(states + i * (size_t)ws, row.data(), (size_t)ws * 8);
+                value[i] = it.value;
+                ub[i] = it.ub;
+                depth[i] = it.depth;
+                rc = materialize_pool_path(it.block, it.row, path);
+                dev_unref(it.block);
+                if (rc != DDO_OK) return rc;
+            } else {
+                Entry e;
+                if (np + (size_t)model->n > path_cap || !fringe->pop(e)) break;
+                if (e.ub <= best_lb) {   // nothing relevant is left (parallel.rs:531-535)
+                    block_unref(e.block);
+                    fringe->clear();
+                    break;
+                }
+                std::memcpy(states + i * (size_t)ws, e.block->state(e.row), (size_t)ws * 8);
+                value[i] = e.value;
+                ub[i] = e.ub;
+                depth[i] = e.depth;
+                materialize_path(model, e.block, e.row, path);
+                block_unref(e.block);
+            }
+            std::memcpy(paths + np, path.data(), path.size() * sizeof(ddo_decision));
+            np += path.size();
+            path_off[i + 1] = np;
+            *n_out += 1;
+        }
+        return DDO_OK;
+    }
+
+    /// Takes over sub-problems exported by another rank's solver (same model).  With the lazy fringe the states are
+    /// written into this device's node pool (one block per depth), the paths stay on the host.
+    int import_nodes(size_t count, const uint64_t* states, const int64_t* value, const int64_t* ub, const int64_t* depth,
+                     const uint64_t* path_off, const ddo_decision* paths) {
+        if (count == 0) return DDO_OK;
+        if (!initialized) {   // every rank compiles the root itself (its share of the root cut-set is its initial fringe)
+            set_error("ddo_solver_import_subproblems: call ddo_solver_step at least once before importing");
+            return DDO_ERR_INVALID;
+        }
+        const int ws = model->ws;
+        if (lazy) {
+            int rc = flush_lazy();
+            if (rc != DDO_OK) return rc;
+            std::map<int64_t, std::vector<size_t>> by_depth;
+            for (size_t i = 0; i < count; ++i)
+                if (ub[i] > best_lb) by_depth[depth[i]].push_back(i);
+            const uint32_t wsT = (uint32_t)engine->words_per_state_device();
+            for (auto& kv : by_depth) {
+                const std::vector<size_t>& idx = kv.second;
+                const uint32_t rows = (uint32_t)idx.size();
+                std::vector<uint8_t> blk((size_t)pool_block_bytes(rows, wsT, 0), 0);
+                PoolBlockHeader* h = (PoolBlockHeader*)blk.data();
+                h->rows = rows;
+                h->ws = wsT;
+                h->lel = 0;
+                h->depth = (uint32_t)kv.first;
+                h->parent_off = NO_POOL_SRC;
+                h->parent_row = 0;
+                h->pw = 0;
+                h->off_lvar = 64;
+                h->off_states = 64;
+                h->off_paths = h->off_states + (uint64_t)wsT * rows * 8;
+                h->off_values = h->off_paths;
+                h->off_ubs = h->off_values + (((uint64_t)rows * 4 + 7) & ~7ULL);
+                uint64_t* st = (uint64_t*)(blk.data() + h->off_states);
+                int32_t* pv = (int32_t*)(blk.data() + h->off_values);
+                int32_t* pu = (int32_t*)(blk.data() + h->off_ubs);
+                DevBlock* b = new DevBlock();
+                b->rows = (int)rows;
+                b->depth = (int)kv.first;
+                b->lel = 0;
+                b->value.resize(rows);
+                b->ub.resize(rows);
+                b->host_paths.resize(rows);
+                for (uint32_t j = 0; j < rows; ++j) {
+                    const size_t i = idx[j];
+                    for (int k = 0; k < ws; ++k) st[(size_t)k * rows + j] = states[i * (size_t)ws + (size_t)k];
+                    pv[j] = b->value[j] = (int32_t)value[i];
+                    pu[j] = b->ub[j] = (int32_t)std::min<int64_t>(ub[i], INT32_MAX);
+                    b->host_paths[j].assign(paths + path_off[i], paths + path_off[i + 1]);
+                }
+                if ((rc = engine->pool_append(blk.data(), blk.size(), &b->off)) != DDO_OK) {
+                    delete b;
+                    return rc;
+                }
+                dev_ref(b);
+                lazy->push_block(b, best_lb);
+                dev_unref(b);
+            }
+        } else {
+            for (size_t i = 0; i < count; ++i) {
+                if (ub[i] <= best_lb) continue;
+                CutsetBlock* b = new CutsetBlock();   // one block per node: paths differ in length and variables
+                b->depth = (int)depth[i];
+                b->path_len = (int)(path_off[i + 1] - path_off[i]);
+                b->ws = ws;
+                b->states.assign(states + i * (size_t)ws, states + (i + 1) * (size_t)ws);
+                b->values.push_back((int32_t)value[i]);
+                b->paths.resize((size_t)b->path_len);
+                for (int k = 0; k < b->path_len; ++k) {
+                    const ddo_decision& d = paths[path_off[i] + (size_t)k];
+                    const uint32_t bit = model->decision_value(1) == d.value ? 1u : 0u;
+                    b->paths[(size_t)k] = ((uint32_t)d.variable << 1) | bit;
+                }
+                block_ref(b);
+                fringe->push(Entry{b, 0, b->depth, value[i], ub[i], hash_words(b->states.data(), ws)});
+                block_unref(b);
+            }
+        }
+        finished = false;
+        return DDO_OK;
+    }
     /// Sharded search: the root cut-set is dealt over the ranks.  Every rank compiles the root
     /// itself and obtains the same SET of rows, but in an order that depends on the scheduling of device atomics, so
     /// the owner of a row is hash(state) % world_size -- the states are read back from the node pool once.
@@ -1227,6 +1374,16 @@ uint64_t ddo_solver_bench_frozen(const ddo_solver* s) {
 int ddo_solver_bench_step(ddo_solver* s) {
     if (!s) return DDO_ERR_INVALID;
     return s->bench_step();
+}
+int ddo_solver_export_subproblems(ddo_solver* s, size_t max_count, uint64_t* states, int64_t* value, int64_t* ub, int64_t* depth,
+                                   uint64_t* path_off, ddo_decision* paths, size_t path_cap, size_t* count) {
+    if (!s || !states || !value || !ub || !depth || !path_off || !paths || !count) return DDO_ERR_INVALID;
+    return s->export_nodes(max_count, states, value, ub, depth, path_off, paths, path_cap, count);
+}
+int ddo_solver_import_subproblems(ddo_solver* s, size_t count, const uint64_t* states, const int64_t* value, const int64_t* ub,
+                                   const int64_t* depth, const uint64_t* path_off, const ddo_decision* paths) {
+    if (!s || (count && (!states || !value || !ub || !depth || !path_off || !paths))) return DDO_ERR_INVALID;
+    return s->import_nodes(count, states, value, ub, depth, path_off, paths);
 }
 int ddo_solver_flush(ddo_solver* s) {
     if (!s) return DDO_ERR_INVALID;

@@ -227,6 +227,16 @@ uint64_t ddo_solver_bench_frozen(const ddo_solver* s);
 int ddo_solver_bench_step(ddo_solver* s);
 /** Lower bound seen by the next step (max-reduced across ranks by the caller, parallel.rs:439-453). */
 int ddo_solver_import_lower_bound(ddo_solver* s, int64_t best_lb);
+/** Work hand-over between the solvers of a sharded search (one rank per GPU): export pops up to
+ *  `max_count` open sub-problems in fringe order as self-contained records -- `state_words` words each, value, ub, depth
+ *  and the decisions from the problem root (paths[path_off[i] .. path_off[i+1]), path_off has max_count + 1 entries; the
+ *  export stops early when fewer than nb_variables of the `path_cap` decisions are left).  The nodes leave this solver;
+ *  import hands them to another solver of the same model (any fringe kind, any device), which explores them as its
+ *  own.  The caller moves the bytes (torch.distributed broadcast in ddo_amd/distributed.py). */
+int ddo_solver_export_subproblems(ddo_solver* s, size_t max_count, uint64_t* states, int64_t* value, int64_t* ub, int64_t* depth,
+                                  uint64_t* path_off, ddo_decision* paths, size_t path_cap, size_t* count);
+int ddo_solver_import_subproblems(ddo_solver* s, size_t count, const uint64_t* states, const int64_t* value, const int64_t* ub,
+                                  const int64_t* depth, const uint64_t* path_off, const ddo_decision* paths);
 /** Open sub-problems on this shard (fringe length), for termination detection (parallel.rs:512). */
 uint64_t ddo_solver_fringe_len(const ddo_solver* s);
 /** Largest upper bound left on this shard's fringe (INT64_MIN when empty). */
