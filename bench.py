@@ -262,28 +262,43 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.instance, args.width, args.cpu_seconds, args.cpu_threads)
             out["speedup_vs_cpu"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-9)
-        if args.prove > 0 and world == 1 and not args.no_cpu:   # --no-cpu = the timed steps only (profiling, A/B tools)
-            # secondary metric of BASELINE.json: wall time of maximize() to the proved optimum
-            from ddo_amd import TimeBudget
-            del solver
-            prover = ParallelSolver(model, FixedWidth(args.width), TimeBudget(args.prove), nb_threads=args.prove_concurrent, device=local_rank,
-                                    fringe="lazy")
-            tp0 = time.perf_counter()
-            comp = prover.maximize()
-            tp = time.perf_counter() - tp0
-            pc = prover.counters()
-            pk_ms, pl = prover.device_time()
-            p_c = pc["arcs"] / max(1, pc["nodes_expanded"])
+    else:
+        out = None
+    # ---- secondary metric of BASELINE.json: wall time of maximize() to the PROVED optimum, on
+    # all N GPUs: every rank searches its shard of the root cut-set; incumbent, termination test and work hand-over go
+    # through ddo_amd.distributed.DistributedSearch (one 40-byte MAX all-reduce per step)
+    proof = None
+    if args.prove > 0 and not args.no_cpu:   # --no-cpu = the timed steps only (profiling, A/B tools)
+        from ddo_amd import TimeBudget
+        from ddo_amd.distributed import DistributedSearch
+        del solver
+        prover = ParallelSolver(model, FixedWidth(args.width), TimeBudget(args.prove), nb_threads=args.prove_concurrent, device=local_rank,
+                                rank=rank, world_size=world, fringe="lazy")
+        search = DistributedSearch(prover, dist, comm_device)
+        if dist is not None:
+            dist.barrier()
+        tp0 = time.perf_counter()
+        proved, best = search.maximize()
+        tp = time.perf_counter() - tp0
+        pc = prover.counters()
+        pk_ms, pl = prover.device_time()
+        tp, (p_nodes, p_arcs, p_subs, p_kms, p_sent) = reduce_stats(
+            dist, tp, [pc["nodes_expanded"], pc["arcs"], prover.explored(), pk_ms, search.nodes_sent], comm_device)
+        proof = (proved, best, tp, p_nodes, p_arcs, p_subs, p_kms, p_sent, pl, prover.best_upper_bound())
+    if rank == 0:
+        if proof is not None:
+            proved, best, tp, p_nodes, p_arcs, p_subs, p_kms, p_sent, pl, p_ub = proof
+            ws_bytes = 8 * ((model.n + 63) // 64)
+            p_c = p_arcs / max(1.0, p_nodes)
             p_bpn = (ws_bytes + 8) + p_c * (ws_bytes + 16)
-            p_ach = pc["nodes_expanded"] * p_bpn / max(pk_ms / 1e3, 1e-12) / 1e9
-            out["time_to_proved_optimum_s"] = tp if comp.is_exact else None
-            out["proof"] = {"proved": bool(comp.is_exact), "best_value": comp.best_value, "lower_bound": prover.best_lower_bound(),
-                            "upper_bound": prover.best_upper_bound(), "wall_s": tp, "subproblems": prover.explored(),
-                            "nodes_expanded": pc["nodes_expanded"], "budget_s": args.prove, "subproblems_in_flight": args.prove_concurrent,
-                            "nodes_per_s": pc["nodes_expanded"] / max(tp, 1e-9),
-                            "roofline": {"bound": "hbm", "achieved": p_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": p_ach / HBM_PEAK_GBS,
-                                         "kernel_s": pk_ms / 1e3, "launches": pl, "bytes_per_node": p_bpn,
-                                         "note": "all compile launches of the whole search (their kernel time, HIP events)"}}
+            p_ach = p_nodes * p_bpn / max(p_kms / 1e3 / world, 1e-12) / 1e9 / world    # per GPU: kernel seconds are summed over ranks
+            out["time_to_proved_optimum_s"] = tp if proved else None
+            out["proof"] = {"proved": bool(proved), "best_value": best, "wall_s": tp, "subproblems": int(p_subs), "nodes_expanded": int(p_nodes),
+                            "budget_s": args.prove, "subproblems_in_flight_per_gpu": args.prove_concurrent, "n_gpus": world,
+                            "nodes_per_s": p_nodes / max(tp, 1e-9), "subproblems_handed_over": int(p_sent),
+                            "roofline": {"bound": "hbm", "achieved": p_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "frac": p_ach / HBM_PEAK_GBS,
+                                         "kernel_s_sum_over_gpus": p_kms / 1e3, "launches_rank0": pl, "bytes_per_node": p_bpn,
+                                         "note": "every compile launch of the whole search, all capacity tiers (their kernel time, HIP events)"}}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_flush",
     "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time",
     "ddo_solver_bench_freeze", "ddo_solver_bench_step", "ddo_solver_bench_frozen",
+    "ddo_solver_export_subproblems", "ddo_solver_import_subproblems",
 ]
 
 DDO_OK, DDO_CUTOFF = 0, 2
@@ -143,6 +144,10 @@ def lib():
     L.ddo_solver_bench_frozen.restype = C.c_uint64
     L.ddo_solver_bench_frozen.argtypes = [C.c_void_p]
     L.ddo_solver_bench_step.argtypes = [C.c_void_p]
+    L.ddo_solver_export_subproblems.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ddo_solver_import_subproblems.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]
     L.ddo_solver_import_lower_bound.argtypes = [C.c_void_p, C.c_int64]
     L.ddo_solver_fringe_len.restype = C.c_uint64
     L.ddo_solver_fringe_len.argtypes = [C.c_void_p]
@@ -517,6 +522,42 @@ class ParallelSolver:
         if rc < 0:
             raise DdoError(f"ddo_solver_bench_step rc={rc}: {_err()}")
         return rc
+
+    def export_subproblems(self, max_count):
+        """Work hand-over (include/ddo_hip.h): pops up to max_count open sub-problems; returns a dict of numpy arrays
+        {states [k, ws] u64, value, ub, depth [k] i64, path_off [k+1] u64, paths [total, 2] i64 (variable, value)}."""
+        max_count = int(max_count)
+        ws, n = self.problem.ws, self.problem.n
+        states = np.zeros((max(1, max_count), ws), dtype=np.uint64)
+        value = np.zeros(max(1, max_count), dtype=np.int64)
+        ub = np.zeros(max(1, max_count), dtype=np.int64)
+        depth = np.zeros(max(1, max_count), dtype=np.int64)
+        path_off = np.zeros(max_count + 1, dtype=np.uint64)
+        cap = max(1, max_count) * n + n
+        paths = np.zeros((cap, 2), dtype=np.int64)
+        cnt = C.c_size_t(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = lib().ddo_solver_export_subproblems(self._h, max_count, p(states), p(value), p(ub), p(depth), p(path_off), p(paths), cap,
+                                                 C.byref(cnt))
+        if rc < 0:
+            raise DdoError(f"ddo_solver_export_subproblems rc={rc}: {_err()}")
+        k = cnt.value
+        tot = int(path_off[k]) if k else 0
+        return {"states": states[:k].copy(), "value": value[:k].copy(), "ub": ub[:k].copy(), "depth": depth[:k].copy(),
+                "path_off": path_off[:k + 1].copy(), "paths": paths[:tot].copy()}
+
+    def import_subproblems(self, nodes):
+        """Takes over sub-problems another solver of the same model exported (dict as returned by export_subproblems)."""
+        k = len(nodes["value"])
+        if k == 0:
+            return
+        arr = {key: np.ascontiguousarray(nodes[key], dtype=dt) for key, dt in
+               (("states", np.uint64), ("value", np.int64), ("ub", np.int64), ("depth", np.int64), ("path_off", np.uint64), ("paths", np.int64))}
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = lib().ddo_solver_import_subproblems(self._h, k, p(arr["states"]), p(arr["value"]), p(arr["ub"]), p(arr["depth"]),
+                                                 p(arr["path_off"]), p(arr["paths"]))
+        if rc < 0:
+            raise DdoError(f"ddo_solver_import_subproblems rc={rc}: {_err()}")
 
     def best_value(self):
         v = C.c_int64()

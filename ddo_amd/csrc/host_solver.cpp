@@ -897,7 +897,7 @@ struct ddo_solver {
         if (T <= 1) return 0;
         if (hints.empty()) hints.resize(HINT_DEPTHS);
         const TierHint& h = hints[std::min(std::max(e.depth, 0), HINT_DEPTHS - 1)];
-        const bool probe = (++probe_ctr & 63) == 0;   // keep sampling the lower tiers: the search moves on
+        const bool probe = !bench_mode && (++probe_ctr & 63) == 0;   // keep sampling the lower tiers: the search moves on (a frozen bench batch does not)
         for (int t = 0; t + 1 < T; ++t)
             if (probe || h.tried[t] < 32 || (uint64_t)h.retried[t] * 10 < (uint64_t)h.tried[t] * 9) return t;
         return T - 1;

@@ -74,3 +74,92 @@ def test_single_process_identity():
     assert p.post(5) == 5 and p.drain() is None
     assert reduce_stats(None, 0.5, [1, 2], "cpu") == (0.5, [1.0, 2.0])
     assert open_work(None, 9, "cpu") == 9
+
+
+# ---- DistributedSearch (termination + hand-over) with a deterministic stand-in for the device-backed solver ----------
+class _FakeProblem:
+    ws, n = 2, 8
+
+
+class _FakeSolver:
+    """Work units are integers; processing unit u at step time spawns children 2u+1, 2u+2 while u < limit -- a binary tree
+    with a known node count.  The incumbent is the largest unit seen.  Only rank 0 starts with the root: every other rank
+    depends on the hand-over to get any work at all."""
+
+    def __init__(self, rank, limit, batch):
+        self.problem = _FakeProblem()
+        self.open = [0] if rank == 0 else []
+        self.limit, self.batch = limit, batch
+        self.lb = -(1 << 62)
+        self.done = 0
+
+    def step(self):
+        if not self.open:
+            return 0
+        take, self.open = self.open[:self.batch], self.open[self.batch:]
+        for u in take:
+            self.done += 1
+            self.lb = max(self.lb, u)
+            if u < self.limit:
+                self.open += [2 * u + 1, 2 * u + 2]
+        return 1
+
+    def flush(self):
+        return 0
+
+    def fringe_len(self):
+        return len(self.open)
+
+    def best_lower_bound(self):
+        return self.lb
+
+    def import_lower_bound(self, lb):
+        self.lb = max(self.lb, lb)
+
+    def export_subproblems(self, k):
+        import numpy as np
+        take, self.open = self.open[:k], self.open[k:]
+        n = len(take)
+        return {"states": np.array([[u, u + 1] for u in take], dtype=np.uint64).reshape(n, 2), "value": np.array(take, dtype=np.int64),
+                "ub": np.array(take, dtype=np.int64), "depth": np.zeros(n, dtype=np.int64),
+                "path_off": np.arange(n + 1, dtype=np.uint64), "paths": np.array([[u, 1] for u in take], dtype=np.int64).reshape(n, 2)}
+
+    def import_subproblems(self, nodes):
+        for i, u in enumerate(nodes["value"]):
+            assert int(nodes["states"][i][0]) == int(u) and int(nodes["states"][i][1]) == int(u) + 1
+            lo, hi = int(nodes["path_off"][i]), int(nodes["path_off"][i + 1])
+            assert hi - lo == 1 and int(nodes["paths"][lo][0]) == int(u)
+            self.open.append(int(u))
+
+
+def _search_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ddo_amd.distributed import DistributedSearch
+
+    s = _FakeSolver(rank, limit=2000, batch=16)
+    search = DistributedSearch(s, dist, "cpu", rebalance_every=2, donate_min=4, donate_max=64)
+    proved, best = search.maximize()
+    q.put((rank, proved, best, s.done, search.nodes_sent, search.nodes_received, len(s.open)))
+    dist.destroy_process_group()
+
+
+def test_distributed_search_terminates_and_hands_work_over_world3_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_search_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the tree: units 0..limit-1 have two children each -> 2 * limit + 1 units in total, largest unit 2 * (limit - 1) + 2
+    assert sum(o[3] for o in out) == 2 * 2000 + 1
+    assert all(o[1] is True and o[2] == 2 * 1999 + 2 for o in out)        # every rank knows the global incumbent
+    assert all(o[6] == 0 for o in out)                                     # nothing left open anywhere
+    assert out[1][3] > 0 and out[2][3] > 0                                 # the ranks that started empty did get work
+    assert sum(o[4] for o in out) == sum(o[5] for o in out) > 0           # every node sent was received exactly once

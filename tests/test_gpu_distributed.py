@@ -1,0 +1,88 @@
+"""Multi-rank search on the device (`-m gpu`): sub-problem hand-over between solvers through the C ABI, and the real
+multi-process path -- two ranks sharing cuda:0 (DDO_BENCH_ONE_GPU=1: gloo rendezvous, both processes on one GPU), each with
+its own solver, incumbent exchange, termination test and work hand-over as on an 8-GPU node."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ddo_amd
+from ddo_amd import FixedWidth, ParallelSolver
+from tests.conftest import ROOT, data_path
+from tests.parity_util import is_independent_set
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_solution(model, solver, expected):
+    sol = solver.best_solution()
+    assert sorted(d.variable for d in sol) == sorted(set(d.variable for d in sol))
+    chosen = [d.variable for d in sol if d.value == 1]
+    rows, w = model.export()
+    assert sum(int(w[v]) for v in chosen) == expected and is_independent_set(rows, model.ws, chosen)
+
+
+@pytest.mark.parametrize("fringe", ["lazy", "nodup"])
+@pytest.mark.parametrize("name,expected,width", [("brock200_2", 12, 60), ("keller4", 11, 30), ("johnson8-4-4", 14, 6)])
+def test_handover_of_a_whole_shard(fringe, name, expected, width):
+    """Rank 0 and rank 1 of a 2-rank search each compile the root; rank 0 then hands ALL its open sub-problems to rank 1
+    (states, values, bounds, depths and root paths travel as plain arrays) and has nothing left; rank 1 proves the optimum
+    alone, and its incumbent's path -- partly built from imported decisions -- is a feasible solution of that value."""
+    model = ddo_amd.Misp.read_instance(data_path("misp", name + ".clq"))
+    a, b = (ParallelSolver(model, FixedWidth(width), nb_threads=16, rank=r, world_size=2, fringe=fringe) for r in range(2))
+    for s in (a, b):
+        assert s.step() == 1
+        s.flush()
+    for _ in range(2):      # let rank 0 go a little deeper: the exported nodes then sit at several depths
+        a.step()
+    a.flush()
+    open_a = a.fringe_len()
+    assert open_a > 0
+    nodes = a.export_subproblems(open_a + 10)
+    k = len(nodes["value"])
+    assert 0 < k <= open_a and a.fringe_len() == 0
+    assert nodes["states"].shape == (k, model.ws) and len(nodes["path_off"]) == k + 1
+    assert all(int(nodes["path_off"][i + 1] - nodes["path_off"][i]) == int(nodes["depth"][i]) for i in range(k))   # MISP: one decision per level
+    assert np.all(nodes["ub"] >= nodes["value"])
+    b.import_lower_bound(a.best_lower_bound())
+    b.import_subproblems(nodes)
+    assert b.fringe_len() >= 1
+    while b.step() == 1:
+        pass
+    b.flush()
+    while a.step() == 1:    # rank 0: nothing left
+        pass
+    assert max(a.best_lower_bound(), b.best_lower_bound()) == expected
+    if b.best_value() == expected:
+        _check_solution(model, b, expected)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("name,expected,width,world,extra", [
+    ("brock200_2", 12, 100, 2, []), ("brock200_2", 12, 100, 3, ["--fringe", "nodup"]), ("brock200_4", 17, 200, 2, ["--no-handover"]),
+    ("p_hat300-1", 8, 50, 2, []),
+])
+def test_two_processes_on_one_gpu_prove_the_optimum(name, expected, width, world, extra):
+    env = dict(os.environ, DDO_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "ddo_amd.dist_main", data_path("misp", name + ".clq"), "-w", str(width), "-t", "64"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["proved"] and out["best_value"] == expected and out["n_gpus"] == world
+    assert len(out["subproblems_per_rank"]) == world and sum(out["subproblems_per_rank"]) == out["subproblems"]
+    assert out["handed_over"] == out["received"]
+    if "--no-handover" in extra:
+        assert out["handed_over"] == 0
