@@ -1325,7 +1325,7 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
         std::vector<std::pair<int, int>> spec;   // (layer capacity, threads per workgroup)
         if (s->cfg.width_policy == DDO_WIDTH_FIXED && s->cfg.width >= 4096) {
             spec.push_back({256, 64});
-            if (s->cfg.width >= 8192) spec.push_back({2048, 256});
+            if (s->cfg.width >= 4096) spec.push_back({1024, 128});
         }
         if (const char* env = std::getenv("DDO_HIP_TIERS")) {   // "0" = none, "256:64,2048:256" = explicit list
             spec.clear();
@@ -1337,7 +1337,7 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
                 const std::string tok = v.substr(pos, end - pos);
                 const size_t colon = tok.find(':');
                 const int w = std::atoi(tok.c_str());
-                const int th = colon == std::string::npos ? (w <= 512 ? 64 : 256) : std::atoi(tok.c_str() + colon + 1);
+                const int th = colon == std::string::npos ? (w <= 512 ? 64 : (w <= 1024 ? 128 : 256)) : std::atoi(tok.c_str() + colon + 1);
                 if (w >= 8 && s->cfg.width_policy == DDO_WIDTH_FIXED && 2 * (size_t)w <= s->cfg.width && spec.size() < 2) spec.push_back({w, th});
                 pos = end + 1;
             }

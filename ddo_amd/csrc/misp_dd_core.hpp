@@ -125,7 +125,7 @@ __device__ __forceinline__ uint64_t dd_brev(uint64_t x) { return __brevll(x); }
 namespace ddo_hip {
 
 constexpr uint32_t TAB_EMPTY = 0xFFFFFFFFu;
-// Signed-vector models (MAX2SAT, MCP): bit 31 of the arc half of a candidate key says "the parent of this arc has an exact
+// Bit 31 of the arc half of a candidate key says "the parent of this arc has an exact
 // best path".  The 64-bit atomicMax of (value, arc) then resolves ties between equal-valued arcs in favour of such a
 // parent, whatever order the threads run in: EBPO (clean.rs:643-655) and the best paths become order independent.  The
 // reference leaves these ties to its hash map's iteration order; the oracle applies the same rule (Problem::canonical_ties).
@@ -928,7 +928,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             const uint64_t nkey = LD_U64(&c.ckey[cur][cd]);
             uint32_t arc = key_arc(nkey);
             uint32_t fl = LD_U32(&c.cflags[cur][cd]);
-            if (dd_is_vec(c.kind) && arc != NONE32 && ((uint32_t)nkey & KEY_OK)) fl |= NF_OKPATH;
+            if (arc != NONE32 && ((uint32_t)nkey & KEY_OK)) fl |= NF_OKPATH;
             uint32_t w;
             if (arc == NONE32) w = NI_NOARC;
             else {
@@ -989,7 +989,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             const int pop = (int)c.cpop[cur][p];
             const uint32_t pfl = LD_U32(&c.cflags[cur][p]);
             const uint32_t inexact = (pfl & (NF_INEXACT | NF_RELAXED)) ? NF_INEXACT : 0u;
-            // signed-vector models: does this parent have an exact best path (see KEY_OK) ?
+            // does this parent have an exact best path (see KEY_OK) ?
             const uint32_t pok = (!inexact || (!(pfl & NF_RELAXED) && (uint32_t)pkey != NONE32 && ((uint32_t)pkey & KEY_OK))) ? KEY_OK : 0u;
             const int32_t rub = rub_of<WS>(c, s, pop, c.depth0 + L);
             if ((int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded
@@ -1152,7 +1152,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 const uint32_t cd = (uint32_t)pos;
 #pragma unroll
                 for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = s[k];
-                const uint64_t mykey = ((uint64_t)bias32(val) << 32) | cd;
+                const uint64_t mykey = ((uint64_t)bias32(val) << 32) | pok | cd;
                 c.ckey[nxt][cd] = mykey;
                 ac_next[cd] = 0;                                   // transition_cost of NO / LEAVE_IT_OUT
                 c.cpop[nxt][cd] = (uint32_t)(pop - ((hasv && !kp) ? 1 : 0));
@@ -1185,7 +1185,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 const uint32_t cd = (uint32_t)(capN + pos);
 #pragma unroll
                 for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
-                const uint64_t mykey = ((uint64_t)bias32(val + wv) << 32) | cd;
+                const uint64_t mykey = ((uint64_t)bias32(val + wv) << 32) | pok | cd;
                 c.ckey[nxt][cd] = mykey;
                 ac_next[cd] = wv;                                  // transition_cost of YES / TAKE_IT
                 c.cpop[nxt][cd] = (uint32_t)ypop;
@@ -1277,7 +1277,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             uint64_t key = LD_U64(&c.ckey[cur][cd]);
             uint32_t arc = key_arc(key);
             uint32_t fl = LD_U32(&c.cflags[cur][cd]);
-            const bool okp = dd_is_vec(c.kind) && arc != NONE32 && ((uint32_t)key & KEY_OK) && !(fl & NF_RELAXED);
+            const bool okp = arc != NONE32 && ((uint32_t)key & KEY_OK) && !(fl & NF_RELAXED);
             uint32_t w;
             if (arc == NONE32) w = NI_NOARC;
             else {
@@ -1288,10 +1288,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (fl & NF_RELAXED) w |= NI_RELAXED;
             if (okp) w |= NI_OKPATH;
             ni[pos] = w;
-            // _find_best_node (clean.rs:620-632): max value_top; position breaks ties deterministically -- signed-vector
-            // models: a node with an exact best path first (order-independent EBPO, see KEY_OK)
+            // _find_best_node (clean.rs:620-632): max value_top; among equal values a node with an exact best path first
+            // (order-independent EBPO, see KEY_OK), then the position
             const bool nok = !(fl & (NF_INEXACT | NF_RELAXED)) || okp;
-            uint64_t bk = (key & 0xFFFFFFFF00000000ULL) | (dd_is_vec(c.kind) && nok ? KEY_OK : 0u) | (uint32_t)pos;
+            uint64_t bk = (key & 0xFFFFFFFF00000000ULL) | (nok ? KEY_OK : 0u) | (uint32_t)pos;
             LDS_MAX_U64(&sh->bestKey, bk + 1);  // +1 so that 0 means "none"
             if (!(fl & (NF_INEXACT | NF_RELAXED))) LDS_MAX_U64(&sh->bestExactKey, bk + 1);
         }
@@ -1337,17 +1337,13 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (tid == 0) {
             int res_e = 1;
             if (has_best) {
-                int Lc = n_layers - 1, p = best_pos;
-                for (;;) {
-                    uint32_t w = c.ninfo[(size_t)Lc * capN + p];
-                    bool ex = !(w & (NI_INEXACT | NI_RELAXED));
-                    if (ex) { res_e = 1; break; }
-                    if (w & NI_RELAXED) { res_e = 0; break; }
-                    if (dd_is_vec(c.kind)) { res_e = (w & NI_OKPATH) ? 1 : 0; break; }   // the key carried the answer (KEY_OK)
-                    if (w & NI_NOARC) { res_e = 1; break; }
-                    p = (int)((w & NI_ARC_MASK) >> 1);
-                    Lc -= 1;
-                }
+                // _has_exact_best_path (clean.rs:643-655) walks the best arcs up to the first exact (-> true) or relaxed
+                // (-> false) node; the best arc of every node already prefers a parent for which that walk succeeds
+                // (KEY_OK), so the answer for the best terminal node is in its own word
+                const uint32_t w = c.ninfo[(size_t)(n_layers - 1) * capN + best_pos];
+                if (!(w & (NI_INEXACT | NI_RELAXED))) res_e = 1;
+                else if (w & NI_RELAXED) res_e = 0;
+                else res_e = (w & NI_OKPATH) ? 1 : 0;
             }
             sh->sel_digit = res_e;
         }

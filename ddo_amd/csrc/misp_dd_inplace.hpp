@@ -1465,6 +1465,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // The arc that RAISED its target's key and still equals the target's final key is the one that set
         // the maximum (`value >= value_top`, clean.rs:215-218): the target inherits the loser's path.  Losers
         // are dead, targets alive, so no path is read and written in the same phase.
+        const bool tie_pass = relaxed && lel >= 0;   // see the region after this one
         PAR_BEGIN
         for (int r = tid; r < nrec; r += NT) {
             uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
@@ -1481,38 +1482,96 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 rec[1 + which] = w & ~EV_RAISED;
             }
         }
-        if (tid == 0) {
-            // the bookkeeping of the layer goes out with the last region: nothing reads it before the backward pass
-            c.lvar[L] = var;
-            c.lmerge[L] = merged_slot;
-            c.ldup[2 * L] = dup_from;
-            c.ldup[2 * L + 1] = dup_to;
-            uint32_t* eo = c.evoff + (size_t)L * 8;
-            eo[0] = (uint32_t)aff_off;
-            eo[1] = (uint32_t)(aff_off >> 32);
-            eo[2] = (uint32_t)nrec;
-            eo[3] = (uint32_t)del_off;
-            eo[4] = (uint32_t)(del_off >> 32);
-            eo[5] = (uint32_t)n_del;
-            sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
-            sh->nodes += (uint64_t)n;
-            if (n > sh->maxn) sh->maxn = n;
-            sh->nyes = nrec - sh->npruned;   // every record is a pruned node or a node with a YES-child
-            sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
-            c.cnt[var] = 0;
-#if defined(DDO_HOST_EMULATION)
-            if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
-#endif
-            sh->varkey = 0xFFFFFFFFu;   // next layer's next_variable / high-water mark / work lists start from scratch
-            sh->hiw = 1;
-            sh->nwl = 0;
-            sh->nwl2 = 0;
-            sh->nrec = 0;
-            sh->nnew = 0;
-            sh->nfl = 0;
-            sh->npruned = 0;
+        // Equal-valued arcs (order-independent EBPO, same rule as KEY_OK in misp_dd_core.hpp and Problem::canonical_ties in
+        // the CPU restatement): when an arc TIES with its target's final value and comes from a node with an exact best
+        // path, the target has one too -- whichever thread got there first.  Only inexact layers can disagree (before the
+        // first squash every path is exact), so the extra region exists only below the last exact layer of a relaxed DD;
+        // the lane that flips the bit copies its path (one winner: no two paths are mixed).
+        if (!tie_pass) {
+            if (tid == 0) {
+                // the bookkeeping of the layer goes out with the last region: nothing reads it before the backward pass
+                c.lvar[L] = var;
+                c.lmerge[L] = merged_slot;
+                c.ldup[2 * L] = dup_from;
+                c.ldup[2 * L + 1] = dup_to;
+                uint32_t* eo = c.evoff + (size_t)L * 8;
+                eo[0] = (uint32_t)aff_off;
+                eo[1] = (uint32_t)(aff_off >> 32);
+                eo[2] = (uint32_t)nrec;
+                eo[3] = (uint32_t)del_off;
+                eo[4] = (uint32_t)(del_off >> 32);
+                eo[5] = (uint32_t)n_del;
+                sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
+                sh->nodes += (uint64_t)n;
+                if (n > sh->maxn) sh->maxn = n;
+                sh->nyes = nrec - sh->npruned;   // every record is a pruned node or a node with a YES-child
+                sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
+                c.cnt[var] = 0;
+    #if defined(DDO_HOST_EMULATION)
+                if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
+    #endif
+                sh->varkey = 0xFFFFFFFFu;   // next layer's next_variable / high-water mark / work lists start from scratch
+                sh->hiw = 1;
+                sh->nwl = 0;
+                sh->nwl2 = 0;
+                sh->nrec = 0;
+                sh->nnew = 0;
+                sh->nfl = 0;
+                sh->npruned = 0;
+            }
         }
         PAR_END
+        if (tie_pass) {
+            PAR_BEGIN
+            for (int r = tid; r < nrec; r += NT) {
+                const uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
+                if (rec[1] == NONE32) continue;
+                for (int which = 0; which < 2; ++which) {
+                    const uint32_t w = rec[1 + which];
+                    if (w == NONE32) continue;
+                    const int t = (int)(w & EV_SLOT_MASK);
+                    const int x = which == 0 ? (int)rec[0] : (int)rec[3];
+                    if (t == x) continue;   // the child is the holder itself
+                    if (K32(c, t) == K32(c, x) && bm_test(c.okb, x) && !bm_test(c.okb, t)) {
+                        const uint32_t bit = 1u << (t & 31);
+                        const uint32_t old = LDS_OR_U32(&c.okb[t >> 5], bit);
+                        if (!(old & bit)) copy_path<WS>(c, t, x, npw);
+                    }
+                }
+            }
+            if (tid == 0) {
+                // the bookkeeping of the layer goes out with the last region: nothing reads it before the backward pass
+                c.lvar[L] = var;
+                c.lmerge[L] = merged_slot;
+                c.ldup[2 * L] = dup_from;
+                c.ldup[2 * L + 1] = dup_to;
+                uint32_t* eo = c.evoff + (size_t)L * 8;
+                eo[0] = (uint32_t)aff_off;
+                eo[1] = (uint32_t)(aff_off >> 32);
+                eo[2] = (uint32_t)nrec;
+                eo[3] = (uint32_t)del_off;
+                eo[4] = (uint32_t)(del_off >> 32);
+                eo[5] = (uint32_t)n_del;
+                sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
+                sh->nodes += (uint64_t)n;
+                if (n > sh->maxn) sh->maxn = n;
+                sh->nyes = nrec - sh->npruned;   // every record is a pruned node or a node with a YES-child
+                sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
+                c.cnt[var] = 0;
+    #if defined(DDO_HOST_EMULATION)
+                if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
+    #endif
+                sh->varkey = 0xFFFFFFFFu;   // next layer's next_variable / high-water mark / work lists start from scratch
+                sh->hiw = 1;
+                sh->nwl = 0;
+                sh->nwl2 = 0;
+                sh->nrec = 0;
+                sh->nnew = 0;
+                sh->nfl = 0;
+                sh->npruned = 0;
+            }
+            PAR_END
+        }
         DD2_TICK(PH_EXPAND)
         L += 1;
     }

@@ -132,6 +132,7 @@ constexpr isize MISP_YES = 1, MISP_NO = 0;
 
 /// main.rs:37-51
 struct Misp : Problem<BitSet> {
+    bool canonical_ties() const override { return true; }   // equal-valued best arcs: an exact best path wins (Problem::canonical_ties)
     size_t nb_vars = 0;
     std::vector<BitSet> neighbors;  // COMPLEMENT adjacency rows (bit i itself stays set)
     std::vector<isize> weight;
@@ -271,6 +272,7 @@ constexpr isize TAKE_IT = 1, LEAVE_IT_OUT = 0;
 
 /// main.rs:53-72
 struct Knapsack : Problem<KnapsackState> {
+    bool canonical_ties() const override { return true; }   // equal-valued best arcs: an exact best path wins (Problem::canonical_ties)
     size_t capacity;
     std::vector<isize> profit;
     std::vector<size_t> weight;
@@ -991,6 +993,7 @@ struct StateHash<TsptwState> {
 
 /// model.rs:30-217
 struct Tsptw : Problem<TsptwState> {
+    bool canonical_ties() const override { return true; }   // equal-valued best arcs: an exact best path wins (Problem::canonical_ties)
     TsptwInstance instance;
     TsptwState initial;
     explicit Tsptw(TsptwInstance inst) : instance(std::move(inst)) {
