@@ -23,10 +23,12 @@ ABI_SYMBOLS = [
     "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time",
     "ddo_solver_bench_freeze", "ddo_solver_bench_step", "ddo_solver_bench_frozen",
     "ddo_solver_export_subproblems", "ddo_solver_import_subproblems",
+    "ddo_cache_create", "ddo_cache_destroy", "ddo_cache_clear", "ddo_cache_stats", "ddo_cache_get_threshold", "ddo_cache_update_threshold",
 ]
 
 DDO_OK, DDO_CUTOFF = 0, 2
 LAST_EXACT_LAYER, FRONTIER = 1, 2
+MDD_CACHING = 0x10
 
 
 class DdoError(RuntimeError):
@@ -48,7 +50,7 @@ class _SubProblem(C.Structure):
 
 class _CompileInput(C.Structure):
     _fields_ = [("comp_type", C.c_int), ("max_width", C.c_size_t), ("best_lb", C.c_int64), ("residual", _SubProblem),
-                ("cutoff", C.POINTER(C.c_int))]
+                ("cutoff", C.POINTER(C.c_int)), ("cache", C.c_void_p)]
 
 
 class _Completion(C.Structure):
@@ -62,7 +64,7 @@ class _Counters(C.Structure):
 class _SolverConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("width_policy", C.c_int), ("width", C.c_size_t), ("nb_concurrent", C.c_int),
                 ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int), ("fringe", C.c_int),
-                ("sequential", C.c_int)]
+                ("sequential", C.c_int), ("cutset_type", C.c_int), ("cache_entries", C.c_size_t)]
 
 
 _CUTSET_CB = C.CFUNCTYPE(None, C.POINTER(_SubProblem), C.c_void_p)
@@ -109,6 +111,13 @@ def lib():
     L.ddo_model_initial_value.argtypes = [C.c_void_p]
     L.ddo_model_compare_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ddo_model_export_misp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ddo_cache_create.restype = C.c_void_p
+    L.ddo_cache_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.ddo_cache_destroy.argtypes = [C.c_void_p]
+    L.ddo_cache_clear.argtypes = [C.c_void_p]
+    L.ddo_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.ddo_cache_get_threshold.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    L.ddo_cache_update_threshold.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int]
     L.ddo_mdd_create.restype = C.c_void_p
     L.ddo_mdd_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t]
     L.ddo_mdd_destroy.argtypes = [C.c_void_p]
@@ -261,7 +270,7 @@ class Misp:
         return SubProblem(state=self.initial_state(), value=self.initial_value(), path=[], depth=0)
 
 
-def _fill_input(model, comp_type, max_width, residual, best_lb, keep, cutoff=None):
+def _fill_input(model, comp_type, max_width, residual, best_lb, keep, cutoff=None, cache=None):
     ci = _CompileInput()
     ci.comp_type = comp_type
     ci.max_width = int(max_width)
@@ -279,6 +288,7 @@ def _fill_input(model, comp_type, max_width, residual, best_lb, keep, cutoff=Non
     ci.residual.path = path
     ci.residual.path_len = len(residual.path)
     ci.cutoff = cutoff   # None, or a ctypes c_int polled like Cutoff::must_stop (clean.rs:352)
+    ci.cache = cache._h if cache is not None else None
     return ci
 
 
@@ -356,12 +366,53 @@ class Max2Sat(Misp):
         return cls(lib().ddo_model_create_max2sat(n, len(cl), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
                                                   w.ctypes.data_as(C.c_void_p)))
 
-class Mdd:
-    """`impl DecisionDiagram for Mdd<T, LAST_EXACT_LAYER>` (mdd.rs:75-114) on the device."""
+class SimpleCache:
+    """`SimpleCache` (cache/simple.rs:36-73) in device memory: one table of (depth, state) -> Threshold shared by every
+    compile that names it."""
 
-    def __init__(self, model, max_width, device=0, cutset_type=LAST_EXACT_LAYER):
+    def __init__(self, model, capacity=1 << 20, device=0):
         self.model = model
-        self._h = lib().ddo_mdd_create(model._h, device, cutset_type, int(max_width))
+        self._h = lib().ddo_cache_create(model._h, device, int(capacity))
+        if not self._h:
+            raise DdoError("ddo_cache_create failed: " + _err())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ddo_cache_destroy(self._h)
+        except Exception:
+            pass
+
+    def clear(self):  # cache.rs:56
+        lib().ddo_cache_clear(self._h)
+
+    def stats(self):
+        u, d = C.c_uint64(), C.c_uint64()
+        lib().ddo_cache_stats(self._h, C.byref(u), C.byref(d))
+        return {"used": u.value, "dropped": d.value}
+
+    def get_threshold(self, state, depth):  # cache.rs:44 -> (value, explored) or None
+        st = np.ascontiguousarray(state, dtype=np.uint64)
+        v, e = C.c_int64(), C.c_int()
+        rc = lib().ddo_cache_get_threshold(self._h, st.ctypes.data_as(C.c_void_p), int(depth), C.byref(v), C.byref(e))
+        if rc < 0:
+            raise DdoError(f"ddo_cache_get_threshold rc={rc}: {_err()}")
+        return (v.value, bool(e.value)) if rc == 1 else None
+
+    def update_threshold(self, state, depth, value, explored):  # cache.rs:47
+        st = np.ascontiguousarray(state, dtype=np.uint64)
+        rc = lib().ddo_cache_update_threshold(self._h, st.ctypes.data_as(C.c_void_p), int(depth), int(value), 1 if explored else 0)
+        if rc < 0:
+            raise DdoError(f"ddo_cache_update_threshold rc={rc}: {_err()}")
+
+
+class Mdd:
+    """`impl DecisionDiagram for Mdd<T, CUTSET_TYPE>` (mdd.rs:75-114) on the device: LAST_EXACT_LAYER or FRONTIER cut-set;
+    caching=True lets compile() take a SimpleCache."""
+
+    def __init__(self, model, max_width, device=0, cutset_type=LAST_EXACT_LAYER, caching=False):
+        self.model = model
+        self._h = lib().ddo_mdd_create(model._h, device, cutset_type | (MDD_CACHING if caching else 0), int(max_width))
         if not self._h:
             raise DdoError("ddo_mdd_create failed: " + _err())
 
@@ -372,10 +423,10 @@ class Mdd:
         except Exception:
             pass
 
-    def compile(self, comp_type, max_width, residual, best_lb, cutoff=None):
+    def compile(self, comp_type, max_width, residual, best_lb, cutoff=None, cache=None):
         keep = []
         ci = _fill_input(self.model, comp_type, max_width, residual, best_lb, keep,
-                         C.pointer(cutoff) if cutoff is not None else None)   # cutoff: ctypes.c_int
+                         C.pointer(cutoff) if cutoff is not None else None, cache)   # cutoff: ctypes.c_int
         out = _Completion()
         rc = lib().ddo_mdd_compile(self._h, C.byref(ci), C.byref(out))
         if rc == DDO_CUTOFF:
@@ -385,12 +436,12 @@ class Mdd:
         return Completion(bool(out.is_exact), out.best_value if out.has_best_value else None)
 
     @staticmethod
-    def compile_batch(mdds, comp_types, max_widths, residuals, best_lbs):
+    def compile_batch(mdds, comp_types, max_widths, residuals, best_lbs, cache=None):
         n = len(mdds)
         keep = []
         cis = (_CompileInput * n)()
         for i in range(n):
-            cis[i] = _fill_input(mdds[i].model, comp_types[i], max_widths[i], residuals[i], best_lbs[i], keep)
+            cis[i] = _fill_input(mdds[i].model, comp_types[i], max_widths[i], residuals[i], best_lbs[i], keep, None, cache)
         hs = (C.c_void_p * n)(*[m._h for m in mdds])
         outs = (_Completion * n)()
         sts = (C.c_int * n)()
@@ -454,13 +505,17 @@ class Mdd:
 DefaultMDD = DefaultMDDLEL = Mdd  # mdd/mod.rs:42-49
 
 
+def DefaultMDDFC(model, max_width, device=0, caching=False):  # mdd/mod.rs:46-49
+    return Mdd(model, max_width, device=device, cutset_type=FRONTIER, caching=caching)
+
+
 class ParallelSolver:
     """`ParallelSolver::custom(problem, relaxation, ranking, width, dominance, cutoff, fringe, nb_threads)`
     (parallel.rs:320-358); relaxation / ranking are carried by the model, dominance is the empty checker,
     the fringe is the NoDupFringe<MaxUB>.  `nb_threads` = sub-problems compiled concurrently on the GPU."""
 
     def __init__(self, problem, width, cutoff=None, nb_threads=256, device=0, rank=0, world_size=1, fringe="nodup",
-                 sequential=False):
+                 sequential=False, cutset_type=LAST_EXACT_LAYER, cache_entries=0):
         self.problem = problem
         cfg = _SolverConfig()
         cfg.device = device
@@ -475,6 +530,8 @@ class ParallelSolver:
         cfg.rank, cfg.world_size = int(rank), int(world_size)
         cfg.fringe = {"nodup": 0, "lazy": 1}[fringe]  # NoDupFringe (exact ddo order) | lazy block SimpleFringe on device
         cfg.sequential = 1 if sequential else 0
+        cfg.cutset_type = int(cutset_type)          # the `D` of ParallelSolver<State, D, C>: DefaultMDDLEL | DefaultMDDFC
+        cfg.cache_entries = int(cache_entries)      # the `C`: 0 = EmptyCache, else SimpleCache with that many entries on the device
         self._h = lib().ddo_solver_create(problem._h, C.byref(cfg))
         if not self._h:
             raise DdoError("ddo_solver_create failed: " + _err())
@@ -614,9 +671,15 @@ class ParallelSolver:
 DefaultSolver = ParallelSolver
 
 
+def DefaultCachingSolver(problem, width, cutoff=None, nb_threads=256, device=0, cache_entries=1 << 22, cutset_type=FRONTIER, **kw):
+    """`DefaultCachingSolver` (solver/mod.rs): ParallelSolver<State, DefaultMDDFC<State>, SimpleCache<State>>"""
+    return ParallelSolver(problem, width, cutoff, nb_threads=nb_threads, device=device, cutset_type=cutset_type, cache_entries=cache_entries, **kw)
+
+
 class SequentialSolver(ParallelSolver):
     """SequentialSolver (sequential.rs:202-527): one sub-problem at a time, NoDupFringe, and its `explored` bookkeeping."""
 
-    def __init__(self, problem, width, cutoff=None, device=0):
-        super().__init__(problem, width, cutoff=cutoff, nb_threads=1, device=device, fringe="nodup", sequential=True)
+    def __init__(self, problem, width, cutoff=None, device=0, cutset_type=LAST_EXACT_LAYER, cache_entries=0):
+        super().__init__(problem, width, cutoff=cutoff, nb_threads=1, device=device, fringe="nodup", sequential=True,
+                         cutset_type=cutset_type, cache_entries=cache_entries)
   # solver/mod.rs:28

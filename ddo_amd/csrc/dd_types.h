@@ -27,6 +27,10 @@ constexpr uint32_t IN_FUSED = 1u;          // restricted, then (if inexact) rela
 constexpr uint32_t IN_FILTER_CUTSET = 2u;  // emit only cut-set nodes with ub > best_lb (parallel.rs:461)
 constexpr uint32_t IN_WANT_PATHS = 4u;     // always emit best paths (else only when value > best_lb)
 constexpr uint32_t IN_POOL_OUT = 8u;       // keep the cut-set in the device node pool; ship only (ub, value) per node
+constexpr uint32_t IN_FRONTIER = 16u;      // CUTSET_TYPE == FRONTIER (clean.rs:586-606) instead of the last exact layer
+constexpr uint32_t IN_CACHE = 32u;         // SimpleCache behind the compile: _filter_with_cache, thresholds, cache updates
+constexpr uint32_t IN_MUST_EXPLORE = 64u;  // solver pop: Cache::must_explore first (sequential.rs:341, parallel.rs:537); ST_SKIPPED when it says no
+constexpr uint32_t IN_MARK_EXPLORED = 128u; // ... and update_threshold(state, depth, value, true) when it says yes (parallel.rs:538 only)
 constexpr uint64_t NO_POOL_SRC = ~0ULL;    // DDInput.src_off: the residual state is inline (not a pool row)
 
 /// A cut-set block in the device node pool (all offsets in bytes from the block start, 8-byte aligned):
@@ -65,6 +69,7 @@ struct DDInput {
 
 // DDResult.status
 constexpr int ST_OK = 0, ST_CUTOFF = 1, ST_ERR_CAPACITY = -3, ST_ERR_INTERNAL = -5, ST_NOT_RUN = 77;
+constexpr int ST_SKIPPED = 79; // IN_MUST_EXPLORE: the cache says this sub-problem need not be explored (cache.rs:32-39)
 constexpr int ST_RETRY = 78;   // capacity tier: the DD outgrew this tier's node slots (host: compile it on the next tier)
 
 /// Everything observable about one compiled DD (clean.rs:237-266).  Variable
@@ -100,6 +105,9 @@ struct DDResult {
     uint64_t path_off, exact_off, cs_state_off, cs_value_off, cs_ub_off, cs_path_off;  // byte offsets from arena_off
     uint64_t phase_clk[32];        // shader-clock ticks per phase [0..8), per code mark [8..24), thread-0 probes inside expand [24..32) (profiling aid; engine 2)
     uint64_t pool_off;             // IN_POOL_OUT: byte offset of the cut-set block in the node pool
+    uint64_t cs_depth_off;         // frontier cut-set: n_cutset x i32, layer of every node below the DD's root (0: all at `lel`)
+    int32_t cs_path_stride;        // u32 words per row of the cut-set paths (lel, or n_layers - 1 for a frontier cut-set)
+    uint32_t cache_hits;           // nodes removed by _filter_with_cache
 };
 
 /// Kernel arguments: model tables, capacities, per-slot workspace and batch I/O.
@@ -192,14 +200,34 @@ struct EngineParams {
     // compiled again by the next tier.  hist_bins < 2048 shrinks the LDS area only the squash phases use.
     int32_t hist_bins;         // 0 = 2048
     int32_t tier;              // 0 = full-width engine, 1 = capacity tier
+    // ---- frontier cut-set / thresholds / cache (engine 1, dd_thresholds.hpp): every layer of the DD is kept
+    int32_t tmode;             // 1: the per-layer arrays below exist
+    int32_t lstride;           // nodes per layer in ninfo / lstate / lval / ... (capN, or 2 * capN + 2 with tmode)
+    uint64_t* lstate;          // [slot][max_layers][ws][lstride]
+    int32_t* lval;             // [slot][max_layers][lstride]  value_top
+    int32_t* lrub;             // [slot][max_layers][lstride]  rough upper bound (INT32_MAX: never computed)
+    int32_t* lvb;              // [slot][max_layers][lstride]  value_bot (VB_UNMARKED: not marked)
+    int32_t* lth;              // [slot][max_layers][lstride]  theta (TH_NONE / TH_INF / value); then [slot][capC1] scratch
+    int32_t* lntot;            // [slot][max_layers] nodes per layer including the ones the cache pruned
+    // SimpleCache (cache/simple.rs:36-73) as one open-addressing table in HBM shared by every compile of a solver / mdd:
+    // entry = [tag | lock, packed threshold, depth, state words...]
+    uint64_t* cache_tab;
+    uint64_t cache_cap;        // entries (power of two); 0: no cache (EmptyCache)
+    int32_t cache_stride;      // u64 words per entry
+    int32_t pad4;
+    unsigned long long* cache_stats;   // [0] entries in use, [1] insertions refused (table full)
 };
 
 // node flag bits (node_flags.rs:48-185 restricted to what the device needs)
 constexpr uint32_t NF_INEXACT = 1u;   // !F_EXACT
 constexpr uint32_t NF_RELAXED = 2u;   // F_RELAXED
+constexpr uint32_t NF_CACHE = 8u;     // F_CACHE
 constexpr uint32_t NF_OKPATH = 4u;    // signed-vector models: the best arc comes from a node with an exact best path
-// ninfo word: bits 0..27 best arc (parent position << 1 | decision), 28 = no arc (root), 30/31 flags
-constexpr uint32_t NI_ARC_MASK = 0x0FFFFFFFu;
+// ninfo word: bits 0..25 best arc (parent position << 1 | decision), 26 pruned by the cache, 27 frontier cut-set,
+// 28 = no arc (root), 29 ok best path, 30/31 flags
+constexpr uint32_t NI_ARC_MASK = 0x03FFFFFFu;
+constexpr uint32_t NI_CACHE = 0x04000000u;    // F_CACHE: pruned by _filter_with_cache (kept in the layer, never expanded)
+constexpr uint32_t NI_CUTSET = 0x08000000u;   // F_CUTSET of a frontier cut-set
 constexpr uint32_t NI_NOARC = 0x10000000u;
 constexpr uint32_t NI_OKPATH = 0x20000000u;
 constexpr uint32_t NI_INEXACT = 0x40000000u;

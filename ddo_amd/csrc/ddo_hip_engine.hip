@@ -98,15 +98,15 @@ int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
 // ---------------------------------------------------------------------------
 // Engine
 // ---------------------------------------------------------------------------
-std::shared_ptr<Engine> Engine::get(Model* model, int device, long max_width) {
+std::shared_ptr<Engine> Engine::get(Model* model, int device, long max_width, int features) {
     std::lock_guard<std::mutex> g(model->mtx);
-    auto key = std::make_pair(device, max_width);
+    auto key = std::make_pair(device, max_width * 8 + features);
     auto it = model->engines.find(key);
     if (it != model->engines.end()) {
         if (auto sp = it->second.lock()) return sp;
     }
     std::shared_ptr<Engine> e(new Engine());
-    if (e->init(model, device, max_width, false) != DDO_OK) return nullptr;
+    if (e->init(model, device, max_width, false, nullptr, 0, 0, features) != DDO_OK) return nullptr;
     model->engines[key] = e;
     return e;
 }
@@ -142,7 +142,7 @@ static int dev_alloc(std::vector<void*>& allocs, T*& ptr, size_t count) {
     return DDO_OK;
 }
 
-int Engine::init(Model* model, int device, long max_width, bool want_pool, Engine* owner, int cap_width, int tier_threads) {
+int Engine::init(Model* model, int device, long max_width, bool want_pool, Engine* owner, int cap_width, int tier_threads, int features) {
     model_ = model;
     owner_ = owner;
     cap_width_ = owner ? cap_width : 0;
@@ -216,6 +216,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     if (keys_global_) lds2 = lds2g;
     if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
     if (model->kind != MODEL_MISP) engine_kind_ = 1;   // scalar-state models run on the layer-rebuilding engine
+    if (features & ENGINE_KEEP_LAYERS) engine_kind_ = 1;   // frontier cut-set / thresholds / cache need every layer of the DD
+    P.tmode = (features & ENGINE_KEEP_LAYERS) ? 1 : 0;
+    P.lstride = P.tmode ? P.capC1 + 1 : P.capN;
     if (owner && engine_kind_ != 2) {
         set_error("Engine::create_tier: the tier does not fit the in-place engine");
         return DDO_ERR_UNSUPPORTED;
@@ -239,6 +242,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
                                 (table_lds_ ? 0 : (size_t)P.table_cap * 4)
                           : wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 * (((wsT + 8) / 8) * 8 + ((wsT + 7) / 8) * 8) +
                                 (size_t)P.capS * 12 + capN * 4 + P.ev_cap * 4 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
+    if (P.tmode) per_slot += ml * (size_t)P.lstride * (wsT * 8 + 5 * 4) + capC1 * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     // output arena: restricted/relaxed results of one batch (cut-set rows + paths), sized by the slots that can run
@@ -320,10 +324,18 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         if ((rc = dev_alloc(allocs_, P.cpop, S * 2 * capC1))) return rc;
         if ((rc = dev_alloc(allocs_, P.cflags, S * 2 * capC1))) return rc;
         if ((rc = dev_alloc(allocs_, P.ctarget, S * 2 * capN))) return rc;
-        if ((rc = dev_alloc(allocs_, P.keep, S * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.keep, S * (P.tmode ? capC1 : capN)))) return rc;
         if ((rc = dev_alloc(allocs_, P.posmap, S * capC1))) return rc;
         if ((rc = dev_alloc(allocs_, P.cls, S * capC1))) return rc;
-        if ((rc = dev_alloc(allocs_, P.ninfo, S * ml * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.ninfo, S * ml * (size_t)P.lstride))) return rc;
+        if (P.tmode) {
+            const size_t lsz = S * ml * (size_t)P.lstride;
+            if ((rc = dev_alloc(allocs_, P.lstate, lsz * wsT))) return rc;
+            if ((rc = dev_alloc(allocs_, P.lval, lsz))) return rc;
+            if ((rc = dev_alloc(allocs_, P.lrub, lsz))) return rc;
+            if ((rc = dev_alloc(allocs_, P.lvb, lsz))) return rc;
+            if ((rc = dev_alloc(allocs_, P.lth, lsz + S * capC1))) return rc;
+        }
         if ((rc = dev_alloc(allocs_, P.arct, S * ml * 2 * capN))) return rc;
         if ((rc = dev_alloc(allocs_, P.arcc, S * ml * 2 * capN))) return rc;
         if ((rc = dev_alloc(allocs_, P.lddelta, S * ml))) return rc;
@@ -344,6 +356,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         if ((rc = dev_alloc(allocs_, P.s_cs_path, S * wsT * capW))) return rc;
     }
     if ((rc = dev_alloc(allocs_, P.nlayer, S * ml))) return rc;
+    if ((rc = dev_alloc(allocs_, P.lntot, S * ml))) return rc;
     if ((rc = dev_alloc(allocs_, P.lvar, S * ml))) return rc;
     if ((rc = dev_alloc(allocs_, P.ldup, S * ml * 2))) return rc;
     if ((rc = dev_alloc(allocs_, P.cs_state, S * wsT * capN))) return rc;
@@ -557,6 +570,47 @@ int Engine::read_pool(uint64_t off, void* dst, size_t bytes) {
     return DDO_OK;
 }
 
+CacheTable* CacheTable::create(const Model* model, int device, size_t capacity_entries) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error("ddo_cache_create: no such HIP device (the cache lives in device memory: there is no CPU fallback)");
+        return nullptr;
+    }
+    size_t cap = 1024;
+    while (cap < capacity_entries) cap <<= 1;
+    CacheTable* t = new CacheTable();
+    t->device = device;
+    t->cap = cap;
+    t->stride = 3 + model->wsT;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&t->tab, cap * (size_t)t->stride * 8) != hipSuccess ||
+        hipMalloc((void**)&t->stats, 64) != hipSuccess || t->clear() != DDO_OK) {
+        set_error("ddo_cache_create: could not allocate the table in device memory");
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+CacheTable::~CacheTable() {
+    (void)hipSetDevice(device);
+    if (tab) (void)hipFree(tab);
+    if (stats) (void)hipFree(stats);
+}
+int CacheTable::clear() {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemset(tab, 0, cap * (size_t)stride * 8));
+    HIP_TRY(hipMemset(stats, 0, 64));
+    return DDO_OK;
+}
+int CacheTable::read_stats(uint64_t* used, uint64_t* dropped) const {
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(v, stats, 16, hipMemcpyDeviceToHost));
+    if (used) *used = v[0];
+    if (dropped) *dropped = v[1];
+    return DDO_OK;
+}
+
 void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) const {
     out.clear();
     out.hdr = r;
@@ -574,7 +628,7 @@ void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) co
         out.exact_path.assign(p, p + r.exact_len);
     }
     out.n_cutset = r.n_cutset;
-    out.cs_path_len = r.lel > 0 ? r.lel : 0;
+    out.cs_path_len = r.cs_path_stride;
     if (r.n_cutset && r.pool_off != NO_POOL_SRC) {
         const int32_t* v = (const int32_t*)(base + r.cs_value_off);
         out.cs_value.assign(v, v + r.n_cutset);
@@ -591,10 +645,14 @@ void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) co
         out.cs_ub.assign(u, u + r.n_cutset);
         const uint32_t* pth = (const uint32_t*)(base + r.cs_path_off);
         out.cs_path.assign(pth, pth + (size_t)r.n_cutset * out.cs_path_len);
+        if (r.cs_depth_off) {
+            const int32_t* dp = (const int32_t*)(base + r.cs_depth_off);
+            out.cs_depth.assign(dp, dp + r.n_cutset);
+        }
     }
 }
 
-int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results) {
+int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache) {
     results.resize((size_t)std::max(count, 0) * 2);
     if (count <= 0) return DDO_OK;
     // One engine is shared by every ddo_mdd of a (model, device, width) and has a single launch in flight: the three
@@ -602,12 +660,12 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
     // parallel.rs:576-602).  The asynchronous launch()/wait()/fetch() path belongs to the lazy solver, which owns a
     // private engine.
     std::lock_guard<std::mutex> batch_guard(batch_mtx_);
-    int rc = launch(inputs, count);
+    int rc = launch(inputs, count, cache);
     if (rc != DDO_OK) return rc;
     return collect(results);
 }
 
-int Engine::launch(const DDInput* inputs, int count) {
+int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache) {
     std::lock_guard<std::mutex> g(mtx_);
     if (pending_ > 0) {
         set_error("Engine::launch: a batch is already in flight");
@@ -663,6 +721,15 @@ int Engine::launch(const DDInput* inputs, int count) {
     P.work_counter = (int32_t*)io.d_cnt;
     P.arena_head = (unsigned long long*)(io.d_cnt + 8);
     P.arena = io.h_arena;
+    if (cache && P_.tmode && cache->device == device_) {
+        P.cache_tab = cache->tab;
+        P.cache_cap = cache->cap;
+        P.cache_stride = cache->stride;
+        P.cache_stats = cache->stats;
+    } else {
+        P.cache_tab = nullptr;
+        P.cache_cap = 0;
+    }
     const int grid = std::min(count, nslots_);
     kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT, threads_)
                                      : pick_kernel(model_->wsT, table_lds_);
@@ -761,15 +828,75 @@ int Engine::collect(std::vector<HostResult>& results) {
 
 }  // namespace ddo_hip
 
+// ---------------------------------------------------------------------------
+// host views of the device cache table (Cache::get_threshold / update_threshold for tests and tools)
+// ---------------------------------------------------------------------------
+namespace ddo_hip {
+struct CacheView {
+    uint64_t* cache_tab;
+    uint64_t cache_cap;
+    int cache_stride;
+    unsigned long long* cache_stats;
+};
+template <int WS>
+__global__ void cache_probe_kernel(CacheView v, const uint64_t* state, int depth, int op, long long packed_in, long long* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t s[WS];
+    for (int k = 0; k < WS; ++k) s[k] = state[k];
+    if (op == 0) {
+        int64_t packed = 0;
+        out[0] = cache_get<WS>(v, s, depth, &packed) ? 1 : 0;
+        out[1] = packed;
+    } else {
+        cache_update<WS>(v, s, depth, (int64_t)packed_in);
+    }
+}
+static int cache_probe(const CacheTable* t, int wsT, const uint64_t* state, int ws, int depth, int op, long long packed_in, long long* out2) {
+    HIP_TRY(hipSetDevice(t->device));
+    uint64_t* d_state = nullptr;
+    long long* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_state, (size_t)wsT * 8));
+    HIP_TRY(hipMalloc((void**)&d_out, 16));
+    std::vector<uint64_t> padded((size_t)wsT, 0);
+    for (int k = 0; k < ws; ++k) padded[(size_t)k] = state[k];
+    HIP_TRY(hipMemcpy(d_state, padded.data(), (size_t)wsT * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_out, 0, 16));
+    CacheView v{t->tab, t->cap, t->stride, t->stats};
+    switch (wsT) {
+        case 1: hipLaunchKernelGGL(cache_probe_kernel<1>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
+        case 2: hipLaunchKernelGGL(cache_probe_kernel<2>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
+        case 4: hipLaunchKernelGGL(cache_probe_kernel<4>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
+        case 7: hipLaunchKernelGGL(cache_probe_kernel<7>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
+        case 8: hipLaunchKernelGGL(cache_probe_kernel<8>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
+        case 16: hipLaunchKernelGGL(cache_probe_kernel<16>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
+        case 32: hipLaunchKernelGGL(cache_probe_kernel<32>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
+        default: set_error("cache_probe: unsupported state width"); return DDO_ERR_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (out2) HIP_TRY(hipMemcpy(out2, d_out, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d_state);
+    (void)hipFree(d_out);
+    return DDO_OK;
+}
+}  // namespace ddo_hip
+
 // =============================================================================
 // C ABI: models and decision diagrams
 // =============================================================================
 using namespace ddo_hip;
 
+struct ddo_cache {
+    CacheTable* t = nullptr;
+    Model* model = nullptr;
+    ~ddo_cache() { delete t; }
+};
+
 struct ddo_mdd {
     Model* model = nullptr;
     std::shared_ptr<Engine> engine;
     int cutset_type = DDO_LAST_EXACT_LAYER;
+    bool caching = false;
     HostResult res;
     // residual of the latest compile (clean.rs:149 path_to_root, :398 depth)
     std::vector<ddo_decision> path_to_root;
@@ -1058,17 +1185,21 @@ ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, siz
         set_error("ddo_mdd_create: null model");
         return nullptr;
     }
-    if (cutset_type != DDO_LAST_EXACT_LAYER) {
-        set_error("ddo_mdd_create: only the LAST_EXACT_LAYER cut-set is implemented on device");
+    const bool caching = (cutset_type & DDO_MDD_CACHING) != 0;
+    cutset_type &= ~DDO_MDD_CACHING;
+    if (cutset_type != DDO_LAST_EXACT_LAYER && cutset_type != DDO_FRONTIER) {
+        set_error("ddo_mdd_create: cutset_type must be DDO_LAST_EXACT_LAYER or DDO_FRONTIER (optionally | DDO_MDD_CACHING)");
         return nullptr;
     }
     Model* m = const_cast<Model*>(&model->m);
-    auto eng = Engine::get(m, device, (long)max_width);
+    const bool keep = caching || cutset_type == DDO_FRONTIER;   // both need every layer of the DD on the device
+    auto eng = Engine::get(m, device, (long)max_width, keep ? Engine::ENGINE_KEEP_LAYERS : 0);
     if (!eng) return nullptr;
     ddo_mdd* d = new ddo_mdd();
     d->model = m;
     d->engine = eng;
     d->cutset_type = cutset_type;
+    d->caching = caching;
     return d;
 }
 void ddo_mdd_destroy(ddo_mdd* mdd) { delete mdd; }
@@ -1099,9 +1230,14 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
     std::vector<DDInput> din;
     std::vector<size_t> active;
     din.reserve(count);
+    const ddo_cache* cache = inputs[0].cache;
     for (size_t i = 0; i < count; ++i) {
         if (!mdds[i] || mdds[i]->engine.get() != eng) {
             set_error("ddo_mdd_compile_batch: all mdds must come from the same model, device and max_width");
+            return DDO_ERR_INVALID;
+        }
+        if (inputs[i].cache != cache || (cache && (!mdds[i]->caching || cache->model != mdds[i]->model))) {
+            set_error("ddo_mdd_compile_batch: one ddo_cache (of the same model) per batch, and only for mdds created with DDO_MDD_CACHING");
             return DDO_ERR_INVALID;
         }
         mdds[i]->res.clear();
@@ -1112,7 +1248,8 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
             continue;
         }
         DDInput di;
-        int rc = fill_input(*mdds[i]->model, &inputs[i], di, IN_WANT_PATHS);
+        int rc = fill_input(*mdds[i]->model, &inputs[i], di,
+                            IN_WANT_PATHS | (mdds[i]->cutset_type == DDO_FRONTIER ? IN_FRONTIER : 0u) | (cache ? IN_CACHE : 0u));
         if (rc != DDO_OK) {
             set_error("ddo_mdd_compile: invalid compile input");
             return rc;
@@ -1126,7 +1263,7 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
         active.push_back(i);
     }
     std::vector<HostResult> res;
-    int rc = eng->run_batch(din.data(), (int)din.size(), res);
+    int rc = eng->run_batch(din.data(), (int)din.size(), res, cache ? cache->t : nullptr);
     if (rc != DDO_OK) return rc;
     int worst = DDO_OK;
     for (size_t a = 0; a < active.size(); ++a) {
@@ -1200,7 +1337,8 @@ int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
     std::vector<ddo_decision> path;
     for (int i = 0; i < r.n_cutset; ++i) {
         path = mdd->path_to_root;
-        for (int k = 0; k < r.cs_path_len; ++k) {
+        const int plen = r.cs_depth.empty() ? r.cs_path_len : r.cs_depth[i];   // frontier cut-set: nodes of several layers
+        for (int k = 0; k < plen; ++k) {
             uint32_t x = r.cs_path[(size_t)i * r.cs_path_len + k];
             path.push_back(ddo_decision{(int64_t)(x >> 1), mdd->model->decision_value(x & 1)});
         }
@@ -1209,13 +1347,48 @@ int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
         sp.state_words = (size_t)ws;
         sp.value = r.cs_value[i];
         sp.ub = r.cs_ub[i];
-        sp.depth = mdd->depth + (size_t)r.cs_path_len;
+        sp.depth = mdd->depth + (size_t)plen;
         sp.path = path.data();
         sp.path_len = path.size();
         cb(&sp, user);
     }
     return DDO_OK;
 }
+ddo_cache* ddo_cache_create(const ddo_model* model, int device, size_t capacity_entries) {
+    if (!model || capacity_entries < 1) {
+        set_error("ddo_cache_create: invalid arguments");
+        return nullptr;
+    }
+    CacheTable* t = CacheTable::create(&model->m, device, capacity_entries);
+    if (!t) return nullptr;
+    ddo_cache* c = new ddo_cache();
+    c->t = t;
+    c->model = const_cast<Model*>(&model->m);
+    return c;
+}
+void ddo_cache_destroy(ddo_cache* cache) { delete cache; }
+int ddo_cache_clear(ddo_cache* cache) { return cache ? cache->t->clear() : DDO_ERR_INVALID; }
+int ddo_cache_stats(const ddo_cache* cache, uint64_t* used, uint64_t* dropped) {
+    return cache ? cache->t->read_stats(used, dropped) : DDO_ERR_INVALID;
+}
+
+int ddo_cache_get_threshold(const ddo_cache* cache, const uint64_t* state, size_t depth, int64_t* value, int* explored) {
+    if (!cache || !state) return DDO_ERR_INVALID;
+    long long out[2] = {0, 0};
+    int rc = cache_probe(cache->t, cache->model->wsT, state, cache->model->ws, (int)depth, 0, 0, out);
+    if (rc != DDO_OK) return rc;
+    if (!out[0]) return 0;
+    const int32_t tv = th_value((int64_t)out[1]);
+    if (value) *value = tv == TH_INF ? INT64_MAX : (int64_t)tv;   // isize::MAX and everything saturating arithmetic derives from it
+    if (explored) *explored = th_explored((int64_t)out[1]) ? 1 : 0;
+    return 1;
+}
+int ddo_cache_update_threshold(ddo_cache* cache, const uint64_t* state, size_t depth, int64_t value, int explored) {
+    if (!cache || !state) return DDO_ERR_INVALID;
+    const int32_t tv = value >= (int64_t)TH_INF ? TH_INF : (value < INT32_MIN + 2 ? INT32_MIN + 2 : (int32_t)value);
+    return cache_probe(cache->t, cache->model->wsT, state, cache->model->ws, (int)depth, 1, (long long)th_pack(tv, explored != 0), nullptr);
+}
+
 int ddo_mdd_last_counters(const ddo_mdd* mdd, ddo_counters* out) {
     if (!mdd || !out) return DDO_ERR_INVALID;
     out->nodes_expanded = mdd->res.hdr.nodes_expanded;

@@ -53,6 +53,20 @@ struct Model {
     int popcount(const uint64_t* a) const;
 };
 
+/// SimpleCache (cache/simple.rs:36-73) on the device: one open-addressing table in HBM (dd_thresholds.hpp) that every
+/// compile launched with it reads (_filter_with_cache, must_explore) and updates (_maybe_update_cache).
+struct CacheTable {
+    int device = 0;
+    uint64_t* tab = nullptr;
+    uint64_t cap = 0;                  // entries, power of two
+    int stride = 0;                    // u64 words per entry: tag, threshold, depth, state words
+    unsigned long long* stats = nullptr;   // device: [0] entries in use, [1] updates dropped because the table was full
+    ~CacheTable();
+    static CacheTable* create(const Model* model, int device, size_t capacity_entries);
+    int clear();
+    int read_stats(uint64_t* used, uint64_t* dropped) const;
+};
+
 /// One decoded compile() result living on the host.
 struct HostResult {
     DDResult hdr{};
@@ -63,6 +77,7 @@ struct HostResult {
     std::vector<uint64_t> cs_state;     // n_cutset x ws (ABI words)
     std::vector<int32_t> cs_value, cs_ub;
     std::vector<uint32_t> cs_path;      // n_cutset x cs_path_len, node first
+    std::vector<int32_t> cs_depth;      // frontier cut-set: layer of every node below the DD's root (empty: all at cs_path_len)
     uint64_t pool_off = ~0ULL;          // IN_POOL_OUT: the cut-set block stayed in the device node pool
     bool valid = false;
     void clear() {
@@ -75,13 +90,17 @@ struct HostResult {
         cs_value.clear();
         cs_ub.clear();
         cs_path.clear();
+        cs_depth.clear();
     }
 };
 
 /// Device engine: HBM workspace for `nslots` concurrent decision diagrams + batch launcher.
 class Engine {
   public:
-    static std::shared_ptr<Engine> get(Model* model, int device, long max_width);
+    /// features: ENGINE_KEEP_LAYERS = every layer of a DD is kept (frontier cut-set, thresholds, cache): layer-rebuilding engine
+    static constexpr int ENGINE_KEEP_LAYERS = 1;
+    static std::shared_ptr<Engine> get(Model* model, int device, long max_width, int features = 0);
+    bool keeps_layers() const { return P_.tmode != 0; }
     /// an engine of its own (not shared through the model): needed by owners of the device node pool
     static std::shared_ptr<Engine> create_private(Model* model, int device, long max_width);
     /// A capacity tier of `owner` (in-place engine only): node slots for decision diagrams whose layers stay within
@@ -93,10 +112,10 @@ class Engine {
 
     /// Runs `count` work items in one launch.  results: 2 per item ([1] used by IN_FUSED).
     /// Returns DDO_OK or a negative error.  Thread-safe (serialised internally).
-    int run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results);
+    int run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache = nullptr);
     /// The two halves of run_batch: launch() enqueues upload + kernel + download of the result headers and
     /// returns at once; collect() waits, fetches the arena and decodes.  One launch may be in flight.
-    int launch(const DDInput* inputs, int count);
+    int launch(const DDInput* inputs, int count, const CacheTable* cache = nullptr);
     int collect(std::vector<HostResult>& results);   // == wait() + fetch()
     /// wait(): the launch in flight has left the device (its result headers are on the host).  After it a new
     /// launch() may be issued at once -- it uses the other buffer set -- and fetch() then downloads and decodes
@@ -134,7 +153,8 @@ class Engine {
 
   private:
     Engine() = default;
-    int init(Model* model, int device, long max_width, bool want_pool, Engine* owner = nullptr, int cap_width = 0, int tier_threads = 0);
+    int init(Model* model, int device, long max_width, bool want_pool, Engine* owner = nullptr, int cap_width = 0, int tier_threads = 0,
+             int features = 0);
     Engine* pool_owner() { return owner_ ? owner_ : this; }
     Engine* owner_ = nullptr;        // capacity tier: the engine whose node pool / cutoff flag this one shares
     int cap_width_ = 0;              // capacity tier: layer capacity (0 = full-width engine)

@@ -47,6 +47,7 @@ struct CutsetBlock {
     std::vector<uint64_t> states;    // rows x ws
     std::vector<int32_t> values;
     std::vector<uint32_t> paths;     // rows x path_len, node first (clean.rs:329-343 order)
+    std::vector<int32_t> row_len;    // frontier cut-set: decisions (== layers below the parent) per row; empty: path_len for all
     const uint64_t* state(int row) const { return states.data() + (size_t)row * ws; }
 };
 
@@ -72,7 +73,9 @@ void materialize_path(const Model* model, const CutsetBlock* b, int row, std::ve
     for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
         const CutsetBlock* blk = it->first;
         const uint32_t* p = blk->paths.data() + (size_t)it->second * blk->path_len;
-        for (int k = 0; k < blk->path_len; ++k) out.push_back(ddo_decision{(int64_t)(p[k] >> 1), model->decision_value(p[k] & 1)});
+        const int plen = blk->row_len.empty() ? blk->path_len : blk->row_len[(size_t)it->second];
+        // rows are stored node first (towards the parent): a frontier row uses the first plen entries of its stride
+        for (int k = 0; k < plen; ++k) out.push_back(ddo_decision{(int64_t)(p[k] >> 1), model->decision_value(p[k] & 1)});
     }
 }
 
@@ -422,6 +425,7 @@ struct ddo_solver {
     Model* model = nullptr;
     ddo_solver_config cfg{};
     std::shared_ptr<Engine> engine;
+    CacheTable* cache = nullptr;         // SimpleCache in device memory (cfg.cache_entries > 0)
     NoDupFringe* fringe = nullptr;
     LazyFringe* lazy = nullptr;          // DDO_FRINGE_LAZY
     std::vector<LazyItem> litems, flight;   // flight: the batch currently on the device
@@ -508,6 +512,7 @@ struct ddo_solver {
             for (LazyItem& e : pr.first) dev_unref(e.block);
         delete fringe;
         delete lazy;
+        delete cache;
     }
 
     long engine_width() const {
@@ -568,6 +573,7 @@ struct ddo_solver {
         b->states = std::move(r.cs_state);
         b->values = std::move(r.cs_value);
         b->paths = std::move(r.cs_path);
+        b->row_len = std::move(r.cs_depth);
         block_ref(b);
         std::vector<int> order(r.n_cutset);
         for (int j = 0; j < r.n_cutset; ++j) order[j] = j;
@@ -585,7 +591,8 @@ struct ddo_solver {
             if (deal && (k % cfg.world_size) != cfg.rank) continue;
             int64_t ub = std::min<int64_t>(it.ub, r.cs_ub[j]);   // :460
             if (ub > best_lb) {                                   // :461
-                Entry e{b, j, b->depth, b->values[j], ub, hash_words(b->state(j), model->ws)};
+                const int dj = b->row_len.empty() ? b->depth : it.depth + b->row_len[(size_t)j];
+                Entry e{b, j, dj, b->values[j], ub, hash_words(b->state(j), model->ws)};
                 fringe->push(e);
                 st_push += 1;
             }
@@ -1228,7 +1235,10 @@ struct ddo_solver {
             DDInput& in = inputs[i];
             std::memset(&in, 0, sizeof(in));
             in.comp_type = CT_RESTRICTED;
-            in.flags = IN_FUSED | IN_FILTER_CUTSET;
+            in.flags = IN_FUSED | IN_FILTER_CUTSET | (cfg.cutset_type == DDO_FRONTIER ? IN_FRONTIER : 0u);
+            // DefaultCachingSolver: must_explore at the pop (sequential.rs:341 / parallel.rs:537-549; the parallel solver
+            // also marks the node explored), thresholds and cache filter inside the compiles
+            if (cache) in.flags |= IN_CACHE | IN_MUST_EXPLORE | (cfg.sequential ? 0u : IN_MARK_EXPLORED);
             in.width = width_of(items[i]);
             in.value = (int32_t)items[i].value;
             in.depth = items[i].depth;
@@ -1237,7 +1247,7 @@ struct ddo_solver {
             std::memcpy(in.state, items[i].block->state(items[i].row), (size_t)model->ws * 8);
         }
         auto t_run0 = std::chrono::steady_clock::now();
-        int rc = engine->run_batch(inputs.data(), (int)inputs.size(), results);
+        int rc = engine->run_batch(inputs.data(), (int)inputs.size(), results, cache);
         auto t_run1 = std::chrono::steady_clock::now();
         st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
         if (rc != DDO_OK) {
@@ -1250,7 +1260,7 @@ struct ddo_solver {
                 results[2 * i].hdr.status <= -100 || results[2 * i + 1].hdr.status <= -100) {
                 // the shared output arena overflowed: redo this sub-problem on its own
                 std::vector<HostResult> solo;
-                int rc2 = engine->run_batch(&inputs[i], 1, solo);
+                int rc2 = engine->run_batch(&inputs[i], 1, solo, cache);
                 if (rc2 != DDO_OK || solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY) {
                     set_error("device compile failed: output arena too small for one sub-problem");
                     err = DDO_ERR_CAPACITY;
@@ -1258,6 +1268,10 @@ struct ddo_solver {
                 }
                 results[2 * i] = std::move(solo[0]);
                 results[2 * i + 1] = std::move(solo[1]);
+            }
+            if (results[2 * i].hdr.status == ST_SKIPPED) {   // Cache::must_explore said no: the node is dropped
+                if (!cfg.sequential) explored -= 1;           // parallel.rs:553 counts what passes; sequential.rs:456 every pop
+                continue;
             }
             for (int k = 0; k < 2; ++k) {
                 HostResult* r = &results[2 * i + k];
@@ -1306,10 +1320,21 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
     s->cfg = *cfg;
     if (s->cfg.world_size < 1) s->cfg.world_size = 1;
     if (s->cfg.rank < 0 || s->cfg.rank >= s->cfg.world_size) s->cfg.rank = 0;
+    if (s->cfg.cutset_type == 0) s->cfg.cutset_type = DDO_LAST_EXACT_LAYER;
+    const bool keep_layers = s->cfg.cutset_type == DDO_FRONTIER || s->cfg.cache_entries > 0;
+    if ((s->cfg.cutset_type != DDO_LAST_EXACT_LAYER && s->cfg.cutset_type != DDO_FRONTIER) || (keep_layers && cfg->fringe == DDO_FRINGE_LAZY)) {
+        set_error("ddo_solver_create: cutset_type must be LAST_EXACT_LAYER or FRONTIER; a frontier cut-set or a cache need DDO_FRINGE_NODUP");
+        delete s;
+        return nullptr;
+    }
     // the lazy fringe keeps its nodes in the engine's device pool and leaves launches in flight: it owns its engine
     s->engine = cfg->fringe == DDO_FRINGE_LAZY ? Engine::create_private(s->model, cfg->device, s->engine_width())
-                                               : Engine::get(s->model, cfg->device, s->engine_width());
+                                               : Engine::get(s->model, cfg->device, s->engine_width(), keep_layers ? Engine::ENGINE_KEEP_LAYERS : 0);
     if (!s->engine) {
+        delete s;
+        return nullptr;
+    }
+    if (s->cfg.cache_entries > 0 && !(s->cache = CacheTable::create(s->model, cfg->device, s->cfg.cache_entries))) {
         delete s;
         return nullptr;
     }

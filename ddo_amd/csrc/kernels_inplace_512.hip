@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(MAXT) misp_compile_kernel2(EngineParams P) {
         const int w = c.sh->work;
         __syncthreads();
         if (w >= P.nbatch) break;
-        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+        run_work_item2<WS, 1>(c, P.inputs[w], P.results + 2 * (size_t)w);   // DEEP: 256 VGPRs pay for deeper sweeps
     }
 }
 

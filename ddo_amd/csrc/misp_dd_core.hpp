@@ -122,6 +122,8 @@ __device__ __forceinline__ uint64_t dd_brev(uint64_t x) { return __brevll(x); }
 }  // namespace ddo_hip
 #endif
 
+#include "dd_thresholds.hpp"
+
 namespace ddo_hip {
 
 constexpr uint32_t TAB_EMPTY = 0xFFFFFFFFu;
@@ -158,6 +160,8 @@ struct DDShared {
     uint64_t bestKey, bestExactKey;
     uint64_t nodes, arcs;
     uint64_t arena_off;
+    int32_t ncache;      // candidates removed by _filter_with_cache in the layer being built
+    uint32_t cache_hits;
     int32_t xcand[64];   // per-lane partial results of the recycled-merge search
     // signed-vector models (MCP): per-variable reductions of a merge (relax.rs:141-176) and the merged node's rank
     uint32_t vmin[64];
@@ -213,6 +217,16 @@ struct DDCtx {
     int32_t* tcount;     // NT
     int32_t* tcount2;    // NT
     DDShared* sh;
+    // frontier cut-set / thresholds / cache (dd_thresholds.hpp): every layer is kept
+    int tmode, lstride;
+    uint64_t* lstate;
+    int32_t *lval, *lrub, *lvb, *lth;
+    int32_t* cth;        // [capC1] theta of the candidates the cache pruned in the layer being built
+    int32_t* lntot;      // [max_layers] nodes per layer including the ones the cache pruned
+    uint64_t* cache_tab;
+    uint64_t cache_cap;
+    int cache_stride;
+    unsigned long long* cache_stats;
     // output
     uint8_t* arena;
     uint64_t arena_cap;
@@ -334,6 +348,12 @@ DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth
     return sum;
 }
 
+/// a candidate that is in `curr_l`: unique (it won the dedup) and not removed by _filter_with_cache (clean.rs:710-726)
+template <class Ctx>
+DDO_DEV bool cand_live(const Ctx& c, int cur, int cd) {
+    return c.ctarget[cd] == (uint32_t)cd && !(c.tmode && (c.cflags[cur][cd] & NF_CACHE));
+}
+
 /// candidate numbering: NO-children of parent position p live at p, YES-children at capN + p,
 /// the merged node of a relaxed layer at 2*capN.
 DDO_DEV int lin2cand(int j, int nprev, int capN) { return j < nprev ? j : capN + (j - nprev); }
@@ -402,7 +422,7 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
     int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
     for (int j = lo; j < hi; ++j) {
         int cd = lin2cand(j, nprev, c.capN);
-        if (c.ctarget[cd] == (uint32_t)cd) {
+        if (cand_live(c, cur, cd)) {
             uint64_t k1 = k1_of(LD_U64(&key[cd]), pop[cd]);
             a &= k1;
             o |= k1;
@@ -432,7 +452,7 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
         for (int j = lo; j < hi; ++j) {
             int cd = lin2cand(j, nprev, c.capN);
-            if (c.ctarget[cd] == (uint32_t)cd) {
+            if (cand_live(c, cur, cd)) {
                 uint64_t k1 = k1_of(LD_U64(&key[cd]), pop[cd]);
                 bool active = (shift + 8 >= 64) || ((k1 >> (shift + 8)) == (pivK1 >> (shift + 8)));
                 if (active) LDS_ADD_U32(&c.hist[(k1 >> shift) & 0xFF], 1u);
@@ -469,7 +489,7 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
         for (int j = lo; j < hi; ++j) {
             int cd = lin2cand(j, nprev, c.capN);
-            if (c.ctarget[cd] != (uint32_t)cd) continue;
+            if (!cand_live(c, cur, cd)) continue;
             if (k1_of(LD_U64(&key[cd]), pop[cd]) != pivK1) continue;
             bool active = true;
             for (int k = 0; k < wj && active; ++k)
@@ -596,6 +616,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     const int MERGED = 2 * capN;
     const bool relaxed = comp_type == CT_RELAXED;
     const bool restricted = comp_type == CT_RESTRICTED;
+    const int LS = c.tmode ? c.lstride : capN;                        // nodes per layer in the per-layer arrays
+    const bool frontier = c.tmode && (in.flags & IN_FRONTIER) != 0;   // CUTSET_TYPE == FRONTIER
+    const bool use_cache = c.tmode && (in.flags & IN_CACHE) != 0 && c.cache_cap != 0;
 
     // ---------------------------------------------------------------- _clear + _initialize
     int cur = 0;
@@ -611,6 +634,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         sh->recycled_merges = 0;
         sh->maxn = 0;
         sh->cutoff = 0;
+        sh->ncache = 0;
+        sh->cache_hits = 0;
         for (int k = 0; k < WS; ++k) c.cstate[0][(size_t)k * capC1] = in.state[k];
         int pop = 0;
         if (c.kind == MODEL_MISP)
@@ -666,12 +691,40 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             failed = true;
             break;
         }
-        const int nU = sh->nU;
         if (L >= c.max_layers - 1 || sh->status != ST_OK) { failed = true; break; }
+        // ------------------------------------------------------------ _filter_with_cache (clean.rs:710-726)
+        // not for the root layer (clean.rs:671): a unique candidate whose value does not exceed the threshold the cache
+        // holds for (depth, state) leaves curr_l; it stays in the layer (its theta is propagated upwards, clean.rs:502)
+        if (use_cache && L >= 1) {
+            PAR_BEGIN
+            if (tid == 0) sh->ncache = 0;
+            PAR_END
+            PAR_BEGIN
+            const int nclx = 2 * nprev;
+            for (int j = tid; j < nclx; j += NT) {
+                const int cd = lin2cand(j, nprev, capN);
+                if (c.ctarget[cd] != (uint32_t)cd) continue;
+                uint64_t s[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + cd];
+                int64_t packed = 0;
+                if (!cache_get<WS>(c, s, c.depth0 + L, &packed)) continue;
+                const int32_t val = unbias32((uint32_t)(LD_U64(&c.ckey[cur][cd]) >> 32));
+                const int32_t tv = th_value(packed);
+                if (tv != TH_INF && val > tv) continue;            // node.value_top > threshold.value: keep
+                c.cflags[cur][cd] = LD_U32(&c.cflags[cur][cd]) | NF_CACHE;
+                c.cth[cd] = tv;
+                if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);   // it leaves the layer next_variable will look at
+                LDS_ADD_I32(&sh->ncache, 1);
+            }
+            PAR_END
+        }
+        const int ncache = (use_cache && L >= 1) ? sh->ncache : 0;
+        const int nU = sh->nU - ncache;                               // |curr_l| after the filter
 
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
         const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
-        if (!squash && nU > capN) {  // Exact DD wider than the workspace
+        if ((!squash && nU > capN) || (c.tmode && nU + ncache + 1 > LS)) {  // Exact DD wider than the workspace
             PAR_BEGIN
             if (tid == 0) sh->status = ST_ERR_CAPACITY;
             PAR_END
@@ -728,7 +781,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         for (int j = lo; j < hi; ++j) {
             int cd = lin2cand(j, nprev, capN);
             uint8_t cl = 0;
-            if (c.ctarget[cd] == (uint32_t)cd) {
+            if (c.ctarget[cd] == (uint32_t)cd && c.tmode && (c.cflags[cur][cd] & NF_CACHE)) {
+                cl = 3;   // pruned by the cache: a node of the layer, not of curr_l
+            } else if (c.ctarget[cd] == (uint32_t)cd) {
                 cl = 1;
                 if (squash) {
                     uint64_t key = LD_U64(&c.ckey[cur][cd]);
@@ -913,19 +968,56 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             }
         }
 
+        // nodes the cache pruned: positions behind the nodes of curr_l (they are part of the layer: arcs point at them and
+        // their theta travels upwards in _compute_thresholds)
+        int ntot = n;
+        if (ncache > 0) {
+            PAR_BEGIN
+            int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+            int cnt3 = 0;
+            for (int j = lo; j < hi; ++j) cnt3 += c.cls[lin2cand(j, nprev, capN)] == 3 ? 1 : 0;
+            c.tcount[tid] = cnt3;
+            PAR_END
+            block_exclusive_scan<WS>(c, c.tcount, c.tcount2);
+            PAR_BEGIN
+            int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+            int pos = n + c.tcount[tid];
+            for (int j = lo; j < hi; ++j) {
+                int cd = lin2cand(j, nprev, capN);
+                if (c.cls[cd] == 3) {
+                    c.keep[pos] = (uint32_t)cd;
+                    c.posmap[cd] = (uint32_t)pos;
+                    ++pos;
+                }
+            }
+            if (tid == 0) sh->cache_hits += (uint32_t)ncache;
+            PAR_END
+            ntot = n + ncache;
+        }
+
         // ------------------------------------------------------------ layers.push (clean.rs:678-684)
         PAR_BEGIN
         if (tid == 0) {
+            if (c.tmode) c.lntot[L] = ntot;
             c.nlayer[L] = n;
             c.lvar[L] = var;
             c.ldup[2 * L] = sh->dup_from;
             c.ldup[2 * L + 1] = sh->dup_to;
             if (c.lddelta) c.lddelta[L] = sh->xdelta;
         }
-        uint32_t* ni = c.ninfo + (size_t)L * capN;
-        for (int pos = tid; pos < n; pos += NT) {
+        uint32_t* ni = c.ninfo + (size_t)L * LS;
+        for (int pos = tid; pos < ntot; pos += NT) {
             uint32_t cd = c.keep[pos];
             const uint64_t nkey = LD_U64(&c.ckey[cur][cd]);
+            if (c.tmode) {   // the layer is kept: state, value, and the slots the backward passes fill
+                const size_t li = (size_t)L * LS + pos;
+#pragma unroll
+                for (int k = 0; k < WS; ++k) c.lstate[((size_t)L * WS + k) * LS + pos] = c.cstate[cur][(size_t)k * capC1 + cd];
+                c.lval[li] = unbias32((uint32_t)(nkey >> 32));
+                c.lrub[li] = INT32_MAX;
+                c.lvb[li] = VB_UNMARKED;
+                c.lth[li] = pos >= n ? c.cth[cd] : TH_NONE;
+            }
             uint32_t arc = key_arc(nkey);
             uint32_t fl = LD_U32(&c.cflags[cur][cd]);
             if (arc != NONE32 && ((uint32_t)nkey & KEY_OK)) fl |= NF_OKPATH;
@@ -939,10 +1031,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (fl & NF_INEXACT) w |= NI_INEXACT;
             if (fl & NF_RELAXED) w |= NI_RELAXED;
             if (fl & NF_OKPATH) w |= NI_OKPATH;
+            if (pos >= n) w |= NI_CACHE;
             ni[pos] = w;
         }
         // arcs entering this layer, translated to node positions (needed by the backward pass)
-        if (relaxed && lel >= 0 && L >= 1) {
+        if (((relaxed && lel >= 0) || c.tmode) && L >= 1) {
             uint32_t* at = c.arct + (size_t)L * 2 * capN;
             int32_t* ac = c.arcc + (size_t)L * 2 * capN;
             for (int j = tid; j < ncl; j += NT) {
@@ -950,7 +1043,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 uint32_t t = c.ctarget[cd];
                 uint32_t out = NONE32;
                 if (t != NONE32) {
-                    if (c.cls[t] == 1) out = c.posmap[t];
+                    if (c.cls[t] == 1 || c.cls[t] == 3) out = c.posmap[t];
                     else {
                         out = (uint32_t)merged_pos;
                         // Relaxation::relax of a redirected arc (mcp/relax.rs:115-121): + rank(old target) - rank(merged)
@@ -992,6 +1085,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             // does this parent have an exact best path (see KEY_OK) ?
             const uint32_t pok = (!inexact || (!(pfl & NF_RELAXED) && (uint32_t)pkey != NONE32 && ((uint32_t)pkey & KEY_OK))) ? KEY_OK : 0u;
             const int32_t rub = rub_of<WS>(c, s, pop, c.depth0 + L);
+            if (c.tmode) c.lrub[(size_t)L * LS + pos] = rub;   // node.rub (clean.rs:363), read again by _compute_thresholds
             if ((int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded
                 if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);
                 c.ctarget[pos] = NONE32;
@@ -1227,7 +1321,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     const int nU = sh->nU;
     const int ncl = 2 * nprev;
     const int q = (ncl + NT - 1) / NT;
-    if (!failed && nU > capN) {
+    if (!failed && nU > (c.tmode ? LS : capN)) {
         PAR_BEGIN
         if (tid == 0) sh->status = ST_ERR_CAPACITY;
         PAR_END
@@ -1267,14 +1361,24 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         PAR_BEGIN
         if (tid == 0) {
             c.nlayer[L] = nT;
+            if (c.tmode) c.lntot[L] = nT;
             c.lvar[L] = -1;
             c.ldup[2 * L] = -1;
             c.ldup[2 * L + 1] = -1;
         }
-        uint32_t* ni = c.ninfo + (size_t)L * capN;
+        uint32_t* ni = c.ninfo + (size_t)L * LS;
         for (int pos = tid; pos < nT; pos += NT) {
             uint32_t cd = c.keep[pos];
             uint64_t key = LD_U64(&c.ckey[cur][cd]);
+            if (c.tmode) {
+                const size_t li = (size_t)L * LS + pos;
+#pragma unroll
+                for (int k = 0; k < WS; ++k) c.lstate[((size_t)L * WS + k) * LS + pos] = c.cstate[cur][(size_t)k * capC1 + cd];
+                c.lval[li] = unbias32((uint32_t)(key >> 32));
+                c.lrub[li] = INT32_MAX;      // the terminal layer is never bounded (clean.rs:360 does not reach it)
+                c.lvb[li] = VB_UNMARKED;
+                c.lth[li] = TH_NONE;
+            }
             uint32_t arc = key_arc(key);
             uint32_t fl = LD_U32(&c.cflags[cur][cd]);
             const bool okp = arc != NONE32 && ((uint32_t)key & KEY_OK) && !(fl & NF_RELAXED);
@@ -1295,7 +1399,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             LDS_MAX_U64(&sh->bestKey, bk + 1);  // +1 so that 0 means "none"
             if (!(fl & (NF_INEXACT | NF_RELAXED))) LDS_MAX_U64(&sh->bestExactKey, bk + 1);
         }
-        if (relaxed && lel >= 0 && L >= 1) {
+        if (((relaxed && lel >= 0) || c.tmode) && L >= 1) {
             uint32_t* at = c.arct + (size_t)L * 2 * capN;
             for (int j = tid; j < ncl; j += NT) {
                 int cd = lin2cand(j, nprev, capN);
@@ -1340,7 +1444,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 // _has_exact_best_path (clean.rs:643-655) walks the best arcs up to the first exact (-> true) or relaxed
                 // (-> false) node; the best arc of every node already prefers a parent for which that walk succeeds
                 // (KEY_OK), so the answer for the best terminal node is in its own word
-                const uint32_t w = c.ninfo[(size_t)(n_layers - 1) * capN + best_pos];
+                const uint32_t w = c.ninfo[(size_t)(n_layers - 1) * LS + best_pos];
                 if (!(w & (NI_INEXACT | NI_RELAXED))) res_e = 1;
                 else if (w & NI_RELAXED) res_e = 0;
                 else res_e = (w & NI_OKPATH) ? 1 : 0;
@@ -1362,7 +1466,131 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     const bool want_cutset = relaxed && !failed && lel >= 0 && lel < n_layers && has_best;
     int32_t* vbA = (int32_t*)c.table;
     int32_t* vbB = vbA + capN;
-    if (want_cutset) {
+    // ================================================================ kept layers: local bounds of EVERY layer, cut-set flags,
+    // thresholds and cache updates (clean.rs:448-606); the cut-set is emitted from the kept layers further down
+    if (c.tmode && !failed) {
+        const int T = n_layers - 1;
+        const int lel_eff = lel < 0 ? n_layers : lel;                       // clean.rs:548-550
+        const bool th_on = relaxed || is_exact;                              // clean.rs:479, 551
+        if (relaxed && lel >= 0 && lel < n_layers) {                          // _compute_local_bounds (clean.rs:448-475)
+            PAR_BEGIN
+            for (int pos = tid; pos < c.lntot[T]; pos += NT) c.lvb[(size_t)T * LS + pos] = 0;
+            PAR_END
+            for (int Lc = T; Lc >= 1; --Lc) {
+                const int nP = c.nlayer[Lc - 1];
+                PAR_BEGIN
+                const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
+                const int32_t* ac = c.arcc + (size_t)Lc * 2 * capN;
+                const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
+                for (int j = tid; j < 2 * nP; j += NT) {
+                    const int d = j >= nP ? 1 : 0;
+                    const int pp = j - d * nP;
+                    const uint32_t t = at[d * capN + pp];
+                    if (t == NONE32) continue;
+                    const int32_t cost = ac[d * capN + pp];
+                    const int32_t v = LD_I32(&c.lvb[(size_t)Lc * LS + t]);
+                    if (v != VB_UNMARKED) GLB_MAX_I32(&c.lvb[(size_t)(Lc - 1) * LS + pp], v + cost);
+                    if ((int)t == dfrom) {   // the arcs of the node a recycled merge re-added also go to the merged node
+                        const int32_t v2 = LD_I32(&c.lvb[(size_t)Lc * LS + dto]);
+                        if (v2 != VB_UNMARKED) GLB_MAX_I32(&c.lvb[(size_t)(Lc - 1) * LS + pp], v2 + cost + (c.lddelta ? c.lddelta[Lc] : 0));
+                    }
+                }
+                PAR_END
+            }
+        }
+        if (th_on) {
+            // ---- _finalize_cutset (clean.rs:547-606)
+            PAR_BEGIN
+            if (!frontier) {
+                if (lel_eff < n_layers)
+                    for (int pos = tid; pos < c.lntot[lel_eff]; pos += NT) c.ninfo[(size_t)lel_eff * LS + pos] |= NI_CUTSET;
+            } else {
+                for (int Lc = 1; Lc <= T; ++Lc) {
+                    const int nP = c.nlayer[Lc - 1];
+                    const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
+                    const int dfrom = c.ldup[2 * Lc];
+                    for (int j = tid; j < 2 * nP; j += NT) {
+                        const int d = j >= nP ? 1 : 0;
+                        const int pp = j - d * nP;
+                        const uint32_t t = at[d * capN + pp];
+                        if (t == NONE32) continue;
+                        const bool child_inexact = (c.ninfo[(size_t)Lc * LS + t] & (NI_INEXACT | NI_RELAXED)) != 0 || (int)t == dfrom;
+                        if (!child_inexact) continue;
+                        const uint32_t pw = LD_U32(&c.ninfo[(size_t)(Lc - 1) * LS + pp]);
+                        if (!(pw & (NI_INEXACT | NI_RELAXED | NI_CUTSET))) GLB_OR_U32(&c.ninfo[(size_t)(Lc - 1) * LS + pp], NI_CUTSET);
+                    }
+                }
+            }
+            PAR_END
+            // ---- _compute_thresholds (clean.rs:478-532) + _maybe_update_cache (:534-545)
+            int64_t bk64 = best_lb;
+            if (has_best_exact && (int64_t)exact_value > bk64) bk64 = exact_value;
+            const int32_t bk = bk64 < -(1 << 30) ? -(1 << 30) : (int32_t)bk64;   // values are far above: same comparisons
+            if (has_best_exact && T >= 0 && nT > 0) {
+                PAR_BEGIN
+                for (int pos = tid; pos < nT; pos += NT) {
+                    const bool nex = !(c.ninfo[(size_t)T * LS + pos] & (NI_INEXACT | NI_RELAXED));
+                    if ((!frontier && is_exact) || (frontier && nex)) c.lth[(size_t)T * LS + pos] = bk;
+                }
+                PAR_END
+            }
+            for (int Lc = T; Lc >= 0; --Lc) {
+                PAR_BEGIN
+                for (int pos = tid; pos < c.lntot[Lc]; pos += NT) {
+                    const size_t li = (size_t)Lc * LS + pos;
+                    const uint32_t w = LD_U32(&c.ninfo[li]);
+                    if (w & NI_CACHE) continue;                       // its theta is the cached threshold: only propagated
+                    const bool nex = !(w & (NI_INEXACT | NI_RELAXED));
+                    const int32_t val = c.lval[li], rub = c.lrub[li];
+                    int32_t th = LD_I32(&c.lth[li]);
+                    if (rub != INT32_MAX && (int64_t)val + rub <= (int64_t)bk) {
+                        th = bk - rub;
+                    } else if (w & NI_CUTSET) {
+                        const int32_t vb = LD_I32(&c.lvb[li]);
+                        if (vb == VB_UNMARKED || (int64_t)val + vb <= (int64_t)bk) {
+                            const int32_t cand = vb == VB_UNMARKED ? TH_INF : bk - vb;   // best_known - isize::MIN saturates
+                            const int32_t old = th == TH_NONE ? TH_INF : th;
+                            th = cand < old ? cand : old;
+                        } else {
+                            th = val;
+                        }
+                    } else if (nex && th == TH_NONE) {
+                        th = TH_INF;                                   // large theta for dangling nodes
+                    }
+                    c.lth[li] = th;
+                    const bool above = frontier ? nex : Lc <= lel_eff;
+                    if (use_cache && th != TH_NONE && above) {
+                        uint64_t st[WS];
+#pragma unroll
+                        for (int k = 0; k < WS; ++k) st[k] = c.lstate[((size_t)Lc * WS + k) * LS + pos];
+                        cache_update<WS>(c, st, c.depth0 + Lc, th_pack(th, !(w & NI_CUTSET)));
+                    }
+                }
+                PAR_END
+                if (Lc == 0) break;
+                const int nP = c.nlayer[Lc - 1];
+                PAR_BEGIN
+                const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
+                const int32_t* ac = c.arcc + (size_t)Lc * 2 * capN;
+                const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
+                for (int j = tid; j < 2 * nP; j += NT) {
+                    const int d = j >= nP ? 1 : 0;
+                    const int pp = j - d * nP;
+                    const uint32_t t = at[d * capN + pp];
+                    if (t == NONE32) continue;
+                    const int32_t cost = ac[d * capN + pp];
+                    const int32_t th = LD_I32(&c.lth[(size_t)Lc * LS + t]);
+                    if (th != TH_NONE) GLB_MIN_I32(&c.lth[(size_t)(Lc - 1) * LS + pp], th_sub(th, cost));
+                    if ((int)t == dfrom) {
+                        const int32_t th2 = LD_I32(&c.lth[(size_t)Lc * LS + dto]);
+                        if (th2 != TH_NONE) GLB_MIN_I32(&c.lth[(size_t)(Lc - 1) * LS + pp], th_sub(th2, cost + (c.lddelta ? c.lddelta[Lc] : 0)));
+                    }
+                }
+                PAR_END
+            }
+        }
+    }
+    if (want_cutset && !c.tmode) {
         const int T = n_layers - 1;
         PAR_BEGIN
         for (int pos = tid; pos < c.nlayer[T]; pos += NT) vbA[pos] = 0;
@@ -1405,7 +1633,31 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         sh->ncut2 = 0;
     }
     PAR_END
-    if (want_cutset) {
+    // kept layers: the cut-set nodes carry NI_CUTSET -- the last exact layer, or (frontier) exact nodes with an inexact child
+    // anywhere in the DD (clean.rs:417-445 emits the MARKED ones)
+    const int cs_first = frontier ? 0 : lel, cs_last = frontier ? n_layers - 2 : lel;
+    if (want_cutset && c.tmode) {
+        PAR_BEGIN
+        int mine = 0;
+        for (int Lc = cs_first; Lc <= cs_last; ++Lc)
+            for (int pos = tid; pos < c.lntot[Lc]; pos += NT) {
+                const size_t li = (size_t)Lc * LS + pos;
+                if (!(LD_U32(&c.ninfo[li]) & NI_CUTSET)) continue;
+                const int32_t vb = LD_I32(&c.lvb[li]);
+                if (vb == VB_UNMARKED) continue;
+                if (filter) {
+                    const int64_t v = c.lval[li];
+                    int64_t ub = c.lrub[li] == INT32_MAX ? INT64_MAX : v + c.lrub[li];
+                    if (v + vb < ub) ub = v + vb;
+                    if (best_value < ub) ub = best_value;
+                    if (ub <= best_lb) continue;
+                }
+                ++mine;
+            }
+        if (mine) LDS_ADD_I32(&sh->ncut, mine);
+        PAR_END
+    }
+    if (want_cutset && !c.tmode) {
         PAR_BEGIN
         int mine = 0;
         for (int pos = tid; pos < ncs_layer; pos += NT) {
@@ -1434,7 +1686,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     const int path_len = n_layers > 0 ? n_layers - 1 : 0;
     const int best_len = emit_best ? path_len : 0;
     const int exact_len = (emit_exact && !same) ? path_len : 0;
-    const int cs_path_len = lel > 0 ? lel : 0;
+    const int cs_path_len = frontier ? (n_layers > 1 ? n_layers - 1 : 0) : (lel > 0 ? lel : 0);
 
     // arena layout (all 8-byte aligned)
     uint64_t off = 0;
@@ -1450,6 +1702,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
     const uint64_t cs_path_off = off;
     off += ((uint64_t)ncut * cs_path_len * 4 + 7) & ~7ULL;
+    const uint64_t cs_depth_off = off;
+    if (c.tmode) off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
     const uint64_t total = off;
 
     PAR_BEGIN
@@ -1469,7 +1723,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             uint32_t* out = (uint32_t*)(base + path_off);
             int p = best_pos;
             for (int Lc = n_layers - 1, i = 0; Lc >= 1; --Lc, ++i) {
-                uint32_t w = c.ninfo[(size_t)Lc * capN + p];
+                uint32_t w = c.ninfo[(size_t)Lc * LS + p];
                 uint32_t arc = w & NI_ARC_MASK;
                 out[i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
                 p = (int)(arc >> 1);
@@ -1479,14 +1733,44 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             uint32_t* out = (uint32_t*)(base + exact_off);
             int p = exact_pos;
             for (int Lc = n_layers - 1, i = 0; Lc >= 1; --Lc, ++i) {
-                uint32_t w = c.ninfo[(size_t)Lc * capN + p];
+                uint32_t w = c.ninfo[(size_t)Lc * LS + p];
                 uint32_t arc = w & NI_ARC_MASK;
                 out[i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
                 p = (int)(arc >> 1);
             }
         }
         // cut-set nodes (clean.rs:421-443)
-        if (want_cutset && ncut) {
+        if (want_cutset && ncut && c.tmode) {
+            uint64_t* o_state = (uint64_t*)(base + cs_state_off);
+            int32_t* o_value = (int32_t*)(base + cs_value_off);
+            int32_t* o_ub = (int32_t*)(base + cs_ub_off);
+            uint32_t* o_path = (uint32_t*)(base + cs_path_off);
+            int32_t* o_depth = (int32_t*)(base + cs_depth_off);
+            for (int Lc = cs_first; Lc <= cs_last; ++Lc)
+                for (int pos = tid; pos < c.lntot[Lc]; pos += NT) {
+                    const size_t li = (size_t)Lc * LS + pos;
+                    if (!(LD_U32(&c.ninfo[li]) & NI_CUTSET)) continue;
+                    const int32_t vb = LD_I32(&c.lvb[li]);
+                    if (vb == VB_UNMARKED) continue;
+                    const int64_t v = c.lval[li];
+                    int64_t ub = c.lrub[li] == INT32_MAX ? INT64_MAX : v + c.lrub[li];
+                    if (v + vb < ub) ub = v + vb;
+                    if (best_value < ub) ub = best_value;
+                    if (filter && ub <= best_lb) continue;
+                    const int idx = LDS_ADD_I32(&sh->ncut2, 1);
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) o_state[(size_t)idx * WS + k] = c.lstate[((size_t)Lc * WS + k) * LS + pos];
+                    o_value[idx] = (int32_t)v;
+                    o_ub[idx] = (int32_t)ub;
+                    o_depth[idx] = Lc;
+                    int p = pos;
+                    for (int Lw = Lc, i = 0; Lw >= 1; --Lw, ++i) {
+                        const uint32_t arc = c.ninfo[(size_t)Lw * LS + p] & NI_ARC_MASK;
+                        o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lw - 1] << 1) | (arc & 1u);
+                        p = (int)(arc >> 1);
+                    }
+                }
+        } else if (want_cutset && ncut) {
             uint64_t* o_state = (uint64_t*)(base + cs_state_off);
             int32_t* o_value = (int32_t*)(base + cs_value_off);
             int32_t* o_ub = (int32_t*)(base + cs_ub_off);
@@ -1509,7 +1793,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 o_ub[idx] = (int32_t)ub;
                 int p = pos;
                 for (int Lc = lel, i = 0; Lc >= 1; --Lc, ++i) {
-                    uint32_t w = c.ninfo[(size_t)Lc * capN + p];
+                    uint32_t w = c.ninfo[(size_t)Lc * LS + p];
                     uint32_t arc = w & NI_ARC_MASK;
                     o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
                     p = (int)(arc >> 1);
@@ -1551,6 +1835,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         r.cs_path_off = cs_path_off;
         for (int k = 0; k < 32; ++k) r.phase_clk[k] = 0;
         r.pool_off = NO_POOL_SRC;
+        r.cs_depth_off = c.tmode ? cs_depth_off : 0;
+        r.cs_path_stride = cs_path_len;
+        r.cache_hits = sh->cache_hits;
         *res = r;
     }
     PAR_END
@@ -1563,6 +1850,32 @@ DDO_DEV void run_work_item(DDCtx<WS>& c, const DDInput& in, DDResult* res2) {
     DD_TID_SETUP(c)
     (void)NT;
     c.depth0 = in.depth;
+    if ((in.flags & IN_MUST_EXPLORE) && c.tmode && c.cache_cap) {
+        // the solver's pop (parallel.rs:537-549): Cache::must_explore (cache.rs:32-39), then update_threshold(.., explored)
+        PAR_BEGIN
+        if (tid == 0) {
+            int64_t packed = 0;
+            bool explore = true;
+            if (cache_get<WS>(c, in.state, in.depth, &packed)) {
+                const int32_t tv = th_value(packed);
+                explore = tv != TH_INF && (in.value > tv || (in.value == tv && !th_explored(packed)));
+            }
+            if (explore && (in.flags & IN_MARK_EXPLORED)) cache_update<WS>(c, in.state, in.depth, th_pack(in.value, true));
+            c.sh->sel_above = explore ? 1 : 0;
+        }
+        PAR_END
+        const bool explore = c.sh->sel_above != 0;
+        DD_SYNC();
+        if (!explore) {
+            PAR_BEGIN
+            if (tid == 0) {
+                res2[0].status = ST_SKIPPED;
+                res2[1].status = ST_NOT_RUN;
+            }
+            PAR_END
+            return;
+        }
+    }
     if (in.flags & IN_FUSED) {
         run_dd<WS>(c, in, CT_RESTRICTED, in.best_lb, &res2[0]);
         // all threads read the restricted result through shared memory state written by thread 0
@@ -1648,6 +1961,26 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.cs_value = P.cs_value + s * capN;
     c.cs_pop = P.cs_pop + s * capN;
     c.table_cap = P.table_cap;
+    c.tmode = P.tmode;
+    c.lstride = P.tmode ? P.lstride : P.capN;
+    c.lstate = nullptr;
+    c.lval = c.lrub = c.lvb = c.lth = c.cth = nullptr;
+    if (P.tmode) {
+        const size_t lsz = ml * (size_t)P.lstride;
+        c.ninfo = P.ninfo + s * lsz;
+        c.lstate = P.lstate + s * lsz * (size_t)WS;
+        c.lval = P.lval + s * lsz;
+        c.lrub = P.lrub + s * lsz;
+        c.lvb = P.lvb + s * lsz;
+        c.lth = P.lth + s * lsz;
+        c.cth = (int32_t*)(P.lth + (size_t)P.nslots * lsz) + s * capC1;   // behind the theta arrays: [slot][capC1]
+        c.keep = P.keep + s * capC1;
+    }
+    c.lntot = P.lntot + s * ml;
+    c.cache_tab = P.cache_tab;
+    c.cache_cap = P.tmode ? P.cache_cap : 0;
+    c.cache_stride = P.cache_stride;
+    c.cache_stats = P.cache_stats;
     unsigned char* p = lds;
     if (TLDS) {
         c.table = (uint32_t*)p;

@@ -421,9 +421,10 @@ DDO_DEV int32_t rub2_of(const DD2Ctx<WS>& c, const uint64_t* s) {
 /// them stay (then the unresolved low digits of pivKey are zero and "kept <=> key >= pivKey").
 /// Keys may live in HBM (L2) at large widths: every sweep fetches KB keys per thread before it touches them, so the
 /// sweep costs hi / (NT * KB) dependent round trips instead of hi / NT.
-constexpr int KB = 8;
-template <int WS>
+/// DEEP (workgroups of up to 512 threads: 256 VGPRs per lane) doubles the loads in flight per thread in every sweep.
+template <int WS, int DEEP = 0>
 DDO_DEV void select_key2(DD2Ctx<WS>& c, int K) {
+    constexpr int KB = DEEP ? 16 : 8;
     DD_TID_SETUP(c)
     LDS_PTR(DD2Shared) sh = c.sh;
     const int hi = DD_UNIFORM(sh->hiw);
@@ -730,8 +731,9 @@ constexpr uint32_t EV_RAISED = 0x40000000u;
 constexpr uint32_t EV_SLOT_MASK = 0x000FFFFFu;
 
 
-template <int WS>
+template <int WS, int DEEP = 0>
 DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
+    constexpr int KB = DEEP ? 16 : 8;
     DD_TID_SETUP(c)
     LDS_PTR(DD2Shared) sh = c.sh;
     const int capS = c.capS;
@@ -870,7 +872,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
             const int K = restricted ? W : W - 1;
-            if (K > 0) select_key2<WS>(c, K);
+            if (K > 0) select_key2<WS, DEEP>(c, K);
             DD2_TICK(PH_SELECT)
             PAR_BEGIN
             if (tid == 0) {
@@ -1179,7 +1181,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // other node stays unchanged in the next layer and enters the dedup table right away with its cached hash
         // (fresh survivors follow in expand 1, changed / new nodes in expand 2).  Word `var/64` of every slot and
         // the hashes are contiguous streams; the loads of a batch are in flight before the first is used.
-        constexpr int KS = 4;
+        constexpr int KS = DEEP ? 8 : 4;
         PAR_BEGIN
         {
             const uint64_t* row = c.st + (size_t)vw * capS;
@@ -1912,18 +1914,21 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         for (int k = 0; k < 8; ++k) r.phase_clk[k] = sh->clk[k];
         for (int k = 0; k < 24; ++k) r.phase_clk[8 + k] = sh->mk[k];
         r.pool_off = pool_bytes ? pool_off : NO_POOL_SRC;
+        r.cs_depth_off = 0;
+        r.cs_path_stride = cs_path_len;
+        r.cache_hits = 0;
         *res = r;
     }
     PAR_END
 }
 
 /// restricted, then (when inexact) relaxed: the device half of process_one_node (parallel.rs:391-437)
-template <int WS>
+template <int WS, int DEEP = 0>
 DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
     DD_TID_SETUP(c)
     (void)NT;
     if (in.flags & IN_FUSED) {
-        run_dd2<WS>(c, in, CT_RESTRICTED, in.best_lb, &res2[0]);
+        run_dd2<WS, DEEP>(c, in, CT_RESTRICTED, in.best_lb, &res2[0]);
         PAR_BEGIN
         if (tid == 0) {
             c.sh->sel_above = (res2[0].status == ST_OK && !res2[0].is_exact) ? 1 : 0;
@@ -1934,14 +1939,14 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
         const bool go = c.sh->sel_above != 0;
         int64_t lb = in.best_lb;
         if (c.sh->sel_bucket && (int64_t)c.sh->sel_digit > lb) lb = c.sh->sel_digit;  // maybe_update_best
-        if (go) run_dd2<WS>(c, in, CT_RELAXED, lb, &res2[1]);
+        if (go) run_dd2<WS, DEEP>(c, in, CT_RELAXED, lb, &res2[1]);
         else {
             PAR_BEGIN
             if (tid == 0) res2[1].status = ST_NOT_RUN;
             PAR_END
         }
     } else {
-        run_dd2<WS>(c, in, in.comp_type, in.best_lb, &res2[0]);
+        run_dd2<WS, DEEP>(c, in, in.comp_type, in.best_lb, &res2[0]);
         PAR_BEGIN
         if (tid == 0) res2[1].status = ST_NOT_RUN;
         PAR_END

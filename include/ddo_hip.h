@@ -44,7 +44,10 @@ extern "C" {
 
 /* ---- mdd.rs:24-28  cut-set types ---------------------------------------- */
 #define DDO_LAST_EXACT_LAYER 1
-#define DDO_FRONTIER 2 /* not implemented on device yet: DDO_ERR_UNSUPPORTED */
+#define DDO_FRONTIER 2
+/** OR into the cutset_type of ddo_mdd_create: compile() may be handed a ddo_cache (every layer of the DD is then kept on the
+ *  device for _compute_thresholds, clean.rs:478-545; costs memory, not needed with the EmptyCache) */
+#define DDO_MDD_CACHING 0x10
 
 /** common.rs:58-61  struct Decision { variable: Variable, value: isize } */
 typedef struct ddo_decision {
@@ -65,17 +68,22 @@ typedef struct ddo_subproblem {
     size_t path_len;
 } ddo_subproblem;
 
+typedef struct ddo_cache ddo_cache;
+
 /** mdd.rs:51-71  struct CompilationInput.  problem / relaxation / ranking are
  *  fixed by the ddo_model the mdd was created from (the device cannot call
- *  `&dyn Problem`); cache and dominance are the Empty* implementations.
+ *  `&dyn Problem`); dominance is the EmptyDominanceChecker.
  *  `cutoff` points to a host flag polled between launches (heuristics.rs:100-105
- *  Cutoff::must_stop); NULL == NoCutoff. */
+ *  Cutoff::must_stop); NULL == NoCutoff.
+ *  `cache`: NULL == EmptyCache (cache/empty.rs), else a SimpleCache living in device memory (ddo_cache_create); the
+ *  mdd must have been created with DDO_MDD_CACHING. */
 typedef struct ddo_compile_input {
     int comp_type; /* DDO_EXACT | DDO_RELAXED | DDO_RESTRICTED */
     size_t max_width;
     int64_t best_lb;
     ddo_subproblem residual;
     const volatile int* cutoff;
+    ddo_cache* cache;
 } ddo_compile_input;
 
 /** common.rs:115-121  struct Completion { is_exact, best_value: Option<isize> } */
@@ -141,6 +149,22 @@ int ddo_model_compare_states(const ddo_model* model, const uint64_t* a, const ui
 /** Copies the descriptor back (n rows * words, n weights); buffers may be NULL. */
 int ddo_model_export_misp(const ddo_model* model, uint64_t* compl_adj_rows, int64_t* weights);
 
+/* ---- Cache (abstraction/cache.rs:27-57; implementation/cache/simple.rs:36-73) ------------------------------------ */
+/** SimpleCache for the states of `model`, as one hash table of at least `capacity_entries` (depth, state) -> Threshold
+ *  entries in the memory of `device`.  It is shared by every compile() that names it and by the solver that owns it;
+ *  a full table drops new thresholds (sound: less pruning), see ddo_cache_stats. */
+ddo_cache* ddo_cache_create(const ddo_model* model, int device, size_t capacity_entries);
+void ddo_cache_destroy(ddo_cache* cache);
+/** Cache::clear (cache.rs:56) */
+int ddo_cache_clear(ddo_cache* cache);
+/** entries in use / thresholds dropped because the table was full */
+int ddo_cache_stats(const ddo_cache* cache, uint64_t* used, uint64_t* dropped);
+/** Cache::get_threshold (cache.rs:44): 1 and (*value, *explored) when (state, depth) has a threshold, else 0.
+ *  Cache::update_threshold (cache.rs:47): keeps the larger of the stored and the given threshold.
+ *  Host-side views of the device table (tests, debugging): one small kernel launch each. */
+int ddo_cache_get_threshold(const ddo_cache* cache, const uint64_t* state, size_t depth, int64_t* value, int* explored);
+int ddo_cache_update_threshold(ddo_cache* cache, const uint64_t* state, size_t depth, int64_t value, int explored);
+
 /* ---- DecisionDiagram (mdd.rs:75-114) -------------------------------------------------------- */
 /** == `D::default()` bound to a model and a device.  `max_width` is the largest width any
  *  compile() on this object will ask for (sizes the HBM workspace). */
@@ -192,6 +216,10 @@ typedef struct ddo_solver_config {
     int sequential;        /* 1 (with nb_concurrent 1, DDO_FRINGE_NODUP): SequentialSolver's bookkeeping
                               (sequential.rs:433-461: `explored` counts every popped node, also the ones
                               skipped because ub <= best_lb) instead of ParallelSolver's (parallel.rs:531-553) */
+    int cutset_type;       /* 0 / DDO_LAST_EXACT_LAYER | DDO_FRONTIER: the `D` of ParallelSolver<State, D, C>
+                              (DefaultMDDLEL / DefaultMDDFC, mdd/mod.rs:42-49); DDO_FRONTIER needs DDO_FRINGE_NODUP */
+    size_t cache_entries;  /* 0: EmptyCache; else a SimpleCache of at least that many entries in device memory
+                              (the `C` of the solver: DefaultCachingSolver, solver/mod.rs); needs DDO_FRINGE_NODUP */
 } ddo_solver_config;
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg);

@@ -52,6 +52,10 @@ void state_to_words(const BitSet& s, size_t ws, uint64_t* out) {
     for (size_t k = 0; k < ws; ++k) out[k] = k < s.w.size() ? s.w[k] : 0;
 }
 
+void state_to_words(const KnapsackState& s, size_t, uint64_t* out) {   // device wire: word 0 capacity, word 1 depth
+    out[0] = (uint64_t)s.capacity;
+    out[1] = (uint64_t)s.depth;
+}
 void state_to_words(const Max2SatState& s, size_t, uint64_t* out) { pack_signed_vector(s.substates, s.depth, out); }
 void state_to_words(const McpState& s, size_t, uint64_t* out) { pack_signed_vector(s.benef, s.depth, out); }
 
@@ -285,6 +289,103 @@ Trace* traced_vector_solve(PB& pb, RELAX& relax, RANK& rank, size_t nvars, uint6
 }  // namespace
 
 extern "C" {
+}  // extern "C"
+
+namespace {
+/// traced sequential solve with any decision-diagram type D (last exact layer / frontier cut-set) and cache type C
+template <class T, class D, class C, class PB, class RELAX, class RANK>
+Trace* traced_solve_dc(PB& pb, RELAX& relax, RANK& rank, size_t nvars, size_t ws, uint64_t width, uint64_t max_compiles,
+                       oracle_solve_out* out) {
+    FixedWidth<T> fixed(width);
+    NbUnassignedWidth<T> unassigned(nvars);
+    const WidthHeuristic<T>& w = width ? (const WidthHeuristic<T>&)fixed : unassigned;
+    EmptyDominanceChecker<T> dom;
+    struct CountCutoff : Cutoff {
+        const Trace* tr;
+        uint64_t max;
+        bool must_stop() const override { return max && tr->recs.size() >= max; }
+    } cut;
+    MaxUB<T> mx(rank);
+    NoDupFringe<T> fringe(mx);
+    auto* tr = new Trace();
+    tr->ws = ws;
+    cut.tr = tr;
+    cut.max = max_compiles;
+    SequentialSolver<T, D, C> s(pb, relax, rank, w, dom, cut, fringe);
+    s.on_compile = [&](const SubProblem<T>& node, CompilationType t, size_t width_, isize lb, D& mdd) {
+        record<T>(*tr, ws, node, t, width_, lb, mdd, t == CompilationType::Relaxed);
+    };
+    auto t0 = std::chrono::steady_clock::now();
+    Completion c = s.maximize();
+    if (out) {
+        out->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        out->has_value = c.best_value.has_value();
+        out->best_value = c.best_value.value_or(-1);
+        out->is_exact = c.is_exact;
+        out->best_lb = s.best_lower_bound();
+        out->best_ub = s.best_upper_bound();
+        out->explored = s.explored();
+        out->nodes_expanded = s.counters().nodes_expanded;
+        out->arcs = s.counters().arcs;
+        out->layers = s.counters().layers;
+        out->compiles = s.counters().compiles;
+        out->n_solution = 0;
+    }
+    return tr;
+}
+template <class T, class PB, class RELAX, class RANK>
+Trace* traced_solve_any(PB& pb, RELAX& relax, RANK& rank, size_t nvars, size_t ws, uint64_t width, uint64_t max_compiles, int frontier,
+                        int cache, oracle_solve_out* out) {
+    if (frontier && cache) return traced_solve_dc<T, DefaultMDDFC<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out);
+    if (frontier) return traced_solve_dc<T, DefaultMDDFC<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out);
+    if (cache) return traced_solve_dc<T, DefaultMDDLEL<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out);
+    return traced_solve_dc<T, DefaultMDDLEL<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out);
+}
+}  // namespace
+
+extern "C" {
+/// Traced SEQUENTIAL solve (sequential.rs) of an instance file with the decision-diagram / cache combination of the
+/// reference's solver aliases (solver/mod.rs): frontier = 0 last-exact-layer cut-set, 1 frontier cut-set; cache = 0
+/// EmptyCache, 1 SimpleCache.  kind: "misp" | "knapsack" | "max2sat" | "mcp".  Records are read like every other trace.
+void* oracle_trace_solve_ex(const char* kind, const char* path, uint64_t width, uint64_t max_compiles, int frontier, int cache,
+                            oracle_solve_out* out) {
+    try {
+        const std::string k(kind);
+        if (k == "misp") {
+            Misp pb = read_misp_instance(path);
+            MispRelax relax(pb);
+            MispRanking rank;
+            return traced_solve_any<BitSet>(pb, relax, rank, pb.nb_vars, (pb.nb_vars + 63) / 64, width, max_compiles, frontier, cache, out);
+        }
+        if (k == "knapsack") {
+            Knapsack pb = read_knapsack_instance(path);
+            KPRelax relax(pb);
+            KPRanking rank;
+            return traced_solve_any<KnapsackState>(pb, relax, rank, pb.nb_variables(), 2, width, max_compiles, frontier, cache, out);
+        }
+        if (k == "max2sat") {
+            Weighed2Sat inst = read_max2sat_instance(path);
+            Max2Sat pb(inst);
+            Max2SatRelax relax(pb);
+            Max2SatRanking rank;
+            return traced_solve_any<Max2SatState>(pb, relax, rank, pb.nb_variables(), (pb.nb_variables() + 1) / 2 + 1, width, max_compiles,
+                                                  frontier, cache, out);
+        }
+        if (k == "mcp") {
+            Mcp pb(read_mcp_instance(path));
+            McpRelax relax(pb);
+            McpRanking rank;
+            return traced_solve_any<McpState>(pb, relax, rank, pb.nb_variables(), (pb.nb_variables() + 1) / 2 + 1, width, max_compiles, frontier,
+                                              cache, out);
+        }
+        std::fprintf(stderr, "oracle_trace_solve_ex: unknown kind %s\n", kind);
+        return nullptr;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "oracle_trace_solve_ex: %s\n", e.what());
+        return nullptr;
+    }
+}
+
 /// traced solves of the signed-vector models: the trace is read with oracle_trace_len / _get / _get_cutset / _free;
 /// every state has oracle_trace_state_words() words
 void* oracle_max2sat_trace_solve(const char* path, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {

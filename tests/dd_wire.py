@@ -7,6 +7,7 @@ import numpy as np
 MAX_WS = 32
 CT_EXACT, CT_RELAXED, CT_RESTRICTED = 0, 1, 2
 IN_FUSED, IN_FILTER_CUTSET, IN_WANT_PATHS = 1, 2, 4
+IN_FRONTIER, IN_CACHE, IN_MUST_EXPLORE = 16, 32, 64
 ST_OK, ST_CUTOFF, ST_NOT_RUN = 0, 1, 77
 
 
@@ -25,7 +26,8 @@ class DDResult(C.Structure):
                 ("arena_off", C.c_uint64), ("arena_bytes", C.c_uint64), ("nodes_expanded", C.c_uint64),
                 ("arcs", C.c_uint64), ("layers", C.c_uint64), ("path_off", C.c_uint64), ("exact_off", C.c_uint64),
                 ("cs_state_off", C.c_uint64), ("cs_value_off", C.c_uint64), ("cs_ub_off", C.c_uint64),
-                ("cs_path_off", C.c_uint64), ("phase_clk", C.c_uint64 * 32), ("pool_off", C.c_uint64)]
+                ("cs_path_off", C.c_uint64), ("phase_clk", C.c_uint64 * 32), ("pool_off", C.c_uint64),
+                ("cs_depth_off", C.c_uint64), ("cs_path_stride", C.c_int32), ("cache_hits", C.c_uint32)]
 
 
 def parse_result(res, arena_ptr, ws, depth0):
@@ -39,15 +41,16 @@ def parse_result(res, arena_ptr, ws, depth0):
         return np.frombuffer(buf, dtype=dtype).copy()
 
     k = res.n_cutset
-    lel = max(res.lel, 0)
+    lel = res.cs_path_stride
+    cs_depth = arr(res.cs_depth_off, k, C.c_int32, np.int32) if res.cs_depth_off else None
     cs_states = arr(res.cs_state_off, k * ws, C.c_uint64, np.uint64)
     cs_value = arr(res.cs_value_off, k, C.c_int32, np.int32)
     cs_ub = arr(res.cs_ub_off, k, C.c_int32, np.int32)
     cs_paths = arr(res.cs_path_off, k * lel, C.c_uint32, np.uint32).reshape(k, lel) if k else np.zeros((0, lel), np.uint32)
     best_path = arr(res.path_off, res.best_len, C.c_uint32, np.uint32)
     exact_path = arr(res.exact_off, res.exact_len, C.c_uint32, np.uint32)
-    cut = sorted((tuple(int(x) for x in cs_states[i * ws:(i + 1) * ws]), int(cs_value[i]), int(cs_ub[i]), depth0 + lel)
-                 for i in range(k))
+    cut = sorted((tuple(int(x) for x in cs_states[i * ws:(i + 1) * ws]), int(cs_value[i]), int(cs_ub[i]),
+                  depth0 + (int(cs_depth[i]) if cs_depth is not None else lel)) for i in range(k))
     return {
         "status": res.status, "comp_type": res.comp_type,
         "is_exact": bool(res.is_exact) or bool(res.has_exact_best_path),
@@ -58,5 +61,6 @@ def parse_result(res, arena_ptr, ws, depth0):
         "cutset_raw": (cs_states.reshape(k, ws) if k else np.zeros((0, ws), np.uint64), cs_value, cs_ub, cs_paths),
         "best_path": [(int(x) >> 1, int(x) & 1) for x in best_path],
         "exact_path": [(int(x) >> 1, int(x) & 1) for x in exact_path],
-        "lel": res.lel, "n_layers": res.n_layers, "recycled_merges": res.recycled_merges,
+        "lel": res.lel, "n_layers": res.n_layers, "recycled_merges": res.recycled_merges, "cache_hits": res.cache_hits,
+        "cs_depth": cs_depth,
     }

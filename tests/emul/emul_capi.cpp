@@ -35,6 +35,9 @@ struct Emul {
     std::vector<unsigned char> mem2;
     std::vector<unsigned char> lds2;
     std::vector<int32_t> aux[2], lddelta;   // knapsack tables, per-layer relax deltas
+    std::vector<unsigned char> mem3;         // kept layers (frontier cut-set / thresholds / cache)
+    std::vector<uint64_t> cache_tab;
+    unsigned long long cache_stats[8] = {0};
 };
 
 template <class T>
@@ -89,7 +92,9 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
         e->weight[i] = (int32_t)weights[i];
         unit &= weights[i] == 1;
     }
-    return emul_finish(e, n, wsT, unit, max_width, nthreads, arena_bytes, max_width + 2, weights);
+    void* h = emul_finish(e, n, wsT, unit, max_width, nthreads, arena_bytes, max_width + 2, weights);
+    if (h && engine == 2 && std::getenv("DDO_EMUL_TIER")) e->P.tier = 1;   // capacity tier: max_width is the layer capacity, widths above it are accepted
+    return h;
 }
 
 /// workspace and capacities for one slot (what Engine::init does on the device side)
@@ -113,8 +118,9 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
     P.table_in_lds = 1;
     P.nslots = 1;
     const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers;
-    size_t bytes = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
-                   ml * capN * 4 + 2 * ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 + 64 * 32;
+    const size_t LSm = capC1 + 1;   // nodes per kept layer (emul_set_keep_layers switches P.tmode / P.lstride on)
+    size_t bytes = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capC1 * 4 + capC1 * 4 + capC1 +
+                   ml * LSm * 4 + 2 * ml * 2 * capN * 4 + ml * 5 * 4 + wsT * capN * 8 + capN * 8 + 64 * 32;
     e->mem.assign(bytes, 0xCD);  // poison
     unsigned char* p = e->mem.data();
     P.cstate = carve<uint64_t>(p, 2 * wsT * capC1);
@@ -122,13 +128,14 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
     P.cpop = carve<uint32_t>(p, 2 * capC1);
     P.cflags = carve<uint32_t>(p, 2 * capC1);
     P.ctarget = carve<uint32_t>(p, 2 * capN);
-    P.keep = carve<uint32_t>(p, capN);
+    P.keep = carve<uint32_t>(p, capC1);
     P.posmap = carve<uint32_t>(p, capC1);
     P.cls = carve<uint8_t>(p, capC1);
-    P.ninfo = carve<uint32_t>(p, ml * capN);
+    P.ninfo = carve<uint32_t>(p, ml * LSm);
     P.arct = carve<uint32_t>(p, ml * 2 * capN);
     P.arcc = carve<int32_t>(p, ml * 2 * capN);
     P.nlayer = carve<int32_t>(p, ml);
+    P.lntot = carve<int32_t>(p, ml);
     P.lvar = carve<int32_t>(p, ml);
     P.ldup = carve<int32_t>(p, ml * 2);
     P.cs_state = carve<uint64_t>(p, wsT * capN);
@@ -137,6 +144,22 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
     if ((size_t)(p - e->mem.data()) > bytes) {
         std::fprintf(stderr, "emul: workspace overflow\n");
         std::abort();
+    }
+    {
+        size_t b3 = ml * LSm * ((size_t)wsT * 8 + 4 * 4) + capC1 * 4 + 64 * 8;
+        e->mem3.assign(b3, 0xCD);
+        unsigned char* r = e->mem3.data();
+        P.lstate = carve<uint64_t>(r, ml * LSm * wsT);
+        P.lval = carve<int32_t>(r, ml * LSm);
+        P.lrub = carve<int32_t>(r, ml * LSm);
+        P.lvb = carve<int32_t>(r, ml * LSm);
+        P.lth = carve<int32_t>(r, ml * LSm + capC1);
+        if ((size_t)(r - e->mem3.data()) > b3) {
+            std::fprintf(stderr, "emul: workspace3 overflow\n");
+            std::abort();
+        }
+        P.tmode = 0;
+        P.lstride = (int32_t)LSm;
     }
     e->lds.assign(dd_lds_bytes(P.table_cap, P.npad, nthreads), 0xEE);
     e->arena.assign(arena_bytes, 0);
@@ -225,6 +248,24 @@ void* emul_create_model(const void* model_handle, int max_width, int nthreads, u
     const int capN = M.kind != MODEL_MISP ? 2 * max_width + 3 : max_width + 2;   // the terminal layer is never squashed
     return emul_finish(e, M.n, M.wsT, M.unit_weights, max_width, nthreads, arena_bytes, capN, M.weight.data());
 }
+/// keep every layer (frontier cut-set, thresholds, cache) on / off; cache_entries > 0 (re)creates an EMPTY cache table
+void emul_set_keep_layers(void* h, int on, uint64_t cache_entries) {
+    Emul* e = (Emul*)h;
+    e->P.tmode = on ? 1 : 0;
+    e->P.cache_cap = 0;
+    e->P.cache_tab = nullptr;
+    if (on && cache_entries) {
+        uint64_t cap = 1024;
+        while (cap < cache_entries) cap <<= 1;
+        e->P.cache_stride = 3 + e->wsT;
+        e->cache_tab.assign(cap * (size_t)e->P.cache_stride, 0);
+        e->P.cache_tab = e->cache_tab.data();
+        e->P.cache_cap = cap;
+        e->cache_stats[0] = e->cache_stats[1] = 0;
+        e->P.cache_stats = e->cache_stats;
+    }
+}
+uint64_t emul_cache_used(void* h) { return ((Emul*)h)->cache_stats[0]; }
 void emul_destroy(void* h) { delete (Emul*)h; }
 int emul_state_words(void* h) { return ((Emul*)h)->wsT; }
 uint64_t emul_lds_bytes(void* h) { return ((Emul*)h)->lds.size(); }
@@ -235,7 +276,7 @@ int emul_compile(void* h, const DDInput* in, DDResult* res2, const uint8_t** are
     Emul* e = (Emul*)h;
     e->arena_head = 0;
     std::memset(res2, 0, 2 * sizeof(DDResult));
-    if (in->width + 2 > e->P.capN) return -3;
+    if (in->width + 2 > e->P.capN && !e->P.tier) return -3;
     switch (e->wsT) {
         case 1: run<1>(*e, *in, res2); break;
         case 2: run<2>(*e, *in, res2); break;

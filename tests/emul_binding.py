@@ -16,7 +16,8 @@ ROOT = os.path.dirname(HERE)
 def build_emul():
     src = os.path.join(HERE, "emul", "emul_capi.cpp")
     out = os.path.join(HERE, "emul", "libddo_emul.so")
-    deps = [src] + [os.path.join(ROOT, "ddo_amd", "csrc", f) for f in ("misp_dd_core.hpp", "misp_dd_inplace.hpp", "dd_types.h", "engine.hpp")]
+    deps = [src] + [os.path.join(ROOT, "ddo_amd", "csrc", f) for f in ("misp_dd_core.hpp", "misp_dd_inplace.hpp", "dd_types.h", "engine.hpp",
+                                                                          "dd_thresholds.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", out, src],
                        check=True)
@@ -51,6 +52,16 @@ class Emul:
             self.L.emul_destroy(self.h)
         except Exception:
             pass
+
+    def keep_layers(self, on=True, cache_entries=0):
+        """every layer kept (frontier cut-set, thresholds); cache_entries > 0: a fresh, empty SimpleCache table"""
+        self.L.emul_set_keep_layers.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        self.L.emul_set_keep_layers(self.h, 1 if on else 0, int(cache_entries))
+
+    def cache_used(self):
+        self.L.emul_cache_used.restype = C.c_uint64
+        self.L.emul_cache_used.argtypes = [C.c_void_p]
+        return self.L.emul_cache_used(self.h)
 
     def compile(self, comp_type, width, best_lb, state, value, depth, flags=4):
         inp = DDInput()

@@ -161,9 +161,21 @@ class Oracle:
         for fn in ("oracle_max2sat_trace_solve", "oracle_mcp_trace_solve"):
             getattr(L, fn).restype = C.c_void_p
             getattr(L, fn).argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(SolveOut)]
+        L.oracle_trace_solve_ex.restype = C.c_void_p
+        L.oracle_trace_solve_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(SolveOut)]
         L.oracle_trace_state_words.restype = C.c_uint64
         L.oracle_trace_state_words.argtypes = [C.c_void_p]
         self.L = L
+
+    def trace_ex(self, kind, path, width=0, max_compiles=0, frontier=False, cache=False):
+        """Traced SEQUENTIAL solve of an instance file ("misp" | "knapsack" | "max2sat" | "mcp") with a last-exact-layer or
+        frontier cut-set and the Empty / Simple cache: (summary, canonical records in compile order)."""
+        out = SolveOut()
+        t = self.L.oracle_trace_solve_ex(kind.encode(), path.encode(), width, max_compiles, 1 if frontier else 0, 1 if cache else 0, C.byref(out))
+        if not t:
+            raise RuntimeError(f"oracle_trace_solve_ex failed on {kind} {path}")
+        ws = int(self.L.oracle_trace_state_words(t))
+        return out.asdict(), read_trace(self.L, t, ws)
 
     def vector_trace(self, kind, path, width=0, max_compiles=0):
         """Traced sequential solve of a signed-vector model ("max2sat" | "mcp"): (summary, canonical records); states

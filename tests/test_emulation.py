@@ -110,3 +110,24 @@ def test_emulation_matches_golden(oracle, case, engine):
     for k in ["is_exact", "best_value", "best_exact_value", "nodes_expanded", "arcs", "layers"]:
         assert g[k] == case[k], (k, g[k], case[k])
     assert len(g["cutset"]) == case["n_cutset"] and cutset_digest(g["cutset"]) == case["cutset_digest"]
+
+
+@pytest.mark.parametrize("cap,nthreads", [(8, 64), (32, 64), (64, 128)])
+def test_emulation_of_a_capacity_tier(oracle, monkeypatch, cap, nthreads):
+    """A capacity tier (host_solver.cpp: dispatch; Engine::create_tier) = the in-place engine with node slots for layers of
+    at most `cap` nodes, asked for widths far above that: every compile either ends with ST_RETRY (the DD outgrew the
+    tier: the host moves it up) or equals the oracle's record."""
+    monkeypatch.setenv("DDO_EMUL_TIER", "1")
+    inst = oracle.misp(data_path("misp", "brock200_2.clq"))
+    _, recs = inst.trace_solve(100, 300)
+    e = Emul(inst.n, inst.rows, inst.weights, cap, nthreads=nthreads, engine=2)
+    done = retry = 0
+    for i, r in enumerate(recs):
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"])[0]
+        if g["status"] == 78:   # ST_RETRY
+            retry += 1
+            continue
+        assert g["status"] == 0
+        assert diff(r, g) is None, f"cap {cap} compile #{i}: {diff(r, g)}"
+        done += 1
+    assert done > 0 and retry > 0
