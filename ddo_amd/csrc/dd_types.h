@@ -13,7 +13,8 @@
 
 namespace ddo_hip {
 
-constexpr int MAX_WS = 32;               // 64-bit words per state at the wire (MISP uses up to 16: n <= 1024; MAX2SAT n <= 62)
+constexpr int MAX_WS = 72;               // 64-bit words per state at the wire (MISP uses up to 16: n <= 1024; signed-vector models n <= 142: 71 pair words + depth)
+constexpr int MAX_VEC_VARS = 2 * (MAX_WS - 1);   // variables of a signed-vector state (two 32-bit benefits per word)
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
 // comp_type values follow include/ddo_hip.h (== mdd.rs:41-48 order)

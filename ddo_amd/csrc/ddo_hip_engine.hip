@@ -26,7 +26,7 @@
 namespace ddo_hip {
 
 static int pick_ws(int ws) {
-    const int opts[] = {1, 2, 4, 7, 8, 16, 32};
+    const int opts[] = {1, 2, 4, 7, 8, 16, 32, 72};
     for (int o : opts)
         if (ws <= o) return o;
     return -1;
@@ -870,6 +870,7 @@ static int cache_probe(const CacheTable* t, int wsT, const uint64_t* state, int 
         case 8: hipLaunchKernelGGL(cache_probe_kernel<8>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
         case 16: hipLaunchKernelGGL(cache_probe_kernel<16>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
         case 32: hipLaunchKernelGGL(cache_probe_kernel<32>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
+        case 72: hipLaunchKernelGGL(cache_probe_kernel<72>, dim3(1), dim3(64), 0, 0, v, d_state, depth, op, packed_in, d_out); break;
         default: set_error("cache_probe: unsupported state width"); return DDO_ERR_UNSUPPORTED;
     }
     HIP_TRY(hipGetLastError());
@@ -990,7 +991,7 @@ ddo_model* ddo_model_create_knapsack(int n, int64_t capacity, const int64_t* pro
 ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix) {
     const int ws = (n + 1) / 2 + 1;   // two benefits per word + the depth word
     if (n < 1 || !adj_matrix || ws > MAX_WS) {
-        set_error("ddo_model_create_mcp: 1 <= n <= 62 vertices are supported (two benefits per word, 32 words per state)");
+        set_error("ddo_model_create_mcp: 1 <= n <= 142 vertices are supported (two benefits per word, 72 words per state)");
         return nullptr;
     }
     int64_t abs_sum = 0;
@@ -1042,7 +1043,7 @@ ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix) {
 ddo_model* ddo_model_create_max2sat(int n, size_t nb_clauses, const int64_t* lit_a, const int64_t* lit_b, const int64_t* weight) {
     const int ws = (n + 1) / 2 + 1;   // two benefits per word + the depth word
     if (n < 1 || ws > MAX_WS || (nb_clauses && (!lit_a || !lit_b || !weight))) {
-        set_error("ddo_model_create_max2sat: 1 <= n <= 62 variables are supported (two benefits per word, 32 words per state)");
+        set_error("ddo_model_create_max2sat: 1 <= n <= 142 variables are supported (two benefits per word, 72 words per state)");
         return nullptr;
     }
     // data.rs:31-46 + FxHashMap::insert: clause = (min literal, max literal); a repeated clause keeps its LAST weight

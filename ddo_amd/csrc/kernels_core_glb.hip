@@ -31,6 +31,7 @@ kernel_fn pick_kernel_glb(int wsT) {
         case 8: return misp_compile_kernel<8, false>;
         case 16: return misp_compile_kernel<16, false>;
         case 32: return misp_compile_kernel<32, false>;   // signed-vector models only (MAX2SAT n <= 62)
+        case 72: return misp_compile_kernel<72, false>;   // signed-vector models up to n = 142 (frb15-9-x: n = 135)
         default: return nullptr;
     }
 }

@@ -31,6 +31,7 @@ kernel_fn pick_kernel_lds(int wsT) {
         case 8: return misp_compile_kernel<8, true>;
         case 16: return misp_compile_kernel<16, true>;
         case 32: return misp_compile_kernel<32, true>;   // signed-vector models only (MAX2SAT n <= 62)
+        case 72: return misp_compile_kernel<72, true>;   // signed-vector models up to n = 142 (frb15-9-x: n = 135)
         default: return nullptr;
     }
 }

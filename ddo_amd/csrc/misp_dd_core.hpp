@@ -164,8 +164,8 @@ struct DDShared {
     uint32_t cache_hits;
     int32_t xcand[64];   // per-lane partial results of the recycled-merge search
     // signed-vector models (MCP): per-variable reductions of a merge (relax.rs:141-176) and the merged node's rank
-    uint32_t vmin[64];
-    uint64_t vposmask, vnegmask;
+    uint32_t vmin[MAX_VEC_VARS];
+    uint64_t vposmask[(MAX_VEC_VARS + 63) / 64], vnegmask[(MAX_VEC_VARS + 63) / 64];
     int32_t mrank, xdelta;
 };
 
@@ -759,9 +759,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (tid == 0) {
             sh->mergedKey = 0;
             for (int k = 0; k < WS; ++k) sh->merged[k] = 0;
-            for (int v = 0; v < 64; ++v) sh->vmin[v] = 0xFFFFFFFFu;
-            sh->vposmask = 0;
-            sh->vnegmask = 0;
+            if (dd_is_vec(c.kind)) {
+                for (int v = 0; v < MAX_VEC_VARS; ++v) sh->vmin[v] = 0xFFFFFFFFu;
+                for (int q = 0; q < (MAX_VEC_VARS + 63) / 64; ++q) sh->vposmask[q] = sh->vnegmask[q] = 0;
+            }
             sh->mrank = 0;
             sh->xdelta = 0;
             sh->recycled = 0;
@@ -798,23 +799,29 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                             // McpRelax::merge (relax.rs:141-176): per variable the signs seen and the smallest |benefit|;
                             // relax (relax.rs:115-121) adds rank(victim) - rank(merged) to every redirected arc, so the
                             // merged node's value is max(value + rank) over the victims minus its own rank
-                            uint64_t pm = 0, nm = 0;
+                            constexpr int NMW = (2 * WS + 63) / 64;
+                            uint64_t pm[NMW], nm[NMW];
+#pragma unroll
+                            for (int q = 0; q < NMW; ++q) pm[q] = nm[q] = 0;
 #pragma unroll
                             for (int k = 0; k < WS; ++k) {
                                 const int32_t a0 = (int32_t)(uint32_t)s[k], a1 = (int32_t)(uint32_t)(s[k] >> 32);
                                 if (2 * k < c.n) {
                                     LDS_MIN_U32(&sh->vmin[2 * k], (uint32_t)iabs32(a0));
-                                    if (a0 > 0) pm |= 1ULL << (2 * k);
-                                    if (a0 < 0) nm |= 1ULL << (2 * k);
+                                    if (a0 > 0) pm[(2 * k) >> 6] |= 1ULL << ((2 * k) & 63);
+                                    if (a0 < 0) nm[(2 * k) >> 6] |= 1ULL << ((2 * k) & 63);
                                 }
                                 if (2 * k + 1 < c.n) {
                                     LDS_MIN_U32(&sh->vmin[2 * k + 1], (uint32_t)iabs32(a1));
-                                    if (a1 > 0) pm |= 1ULL << (2 * k + 1);
-                                    if (a1 < 0) nm |= 1ULL << (2 * k + 1);
+                                    if (a1 > 0) pm[(2 * k + 1) >> 6] |= 1ULL << ((2 * k + 1) & 63);
+                                    if (a1 < 0) nm[(2 * k + 1) >> 6] |= 1ULL << ((2 * k + 1) & 63);
                                 }
                             }
-                            if (pm) LDS_OR_U64(&sh->vposmask, pm);
-                            if (nm) LDS_OR_U64(&sh->vnegmask, nm);
+#pragma unroll
+                            for (int q = 0; q < (2 * WS + 63) / 64; ++q) {
+                                if (pm[q]) LDS_OR_U64(&sh->vposmask[q], pm[q]);
+                                if (nm[q]) LDS_OR_U64(&sh->vnegmask[q], nm[q]);
+                            }
                             const int32_t adj = unbias32((uint32_t)(key >> 32)) + (int32_t)c.cpop[cur][cd];
                             const uint64_t akey = ((uint64_t)bias32(adj) << 32) | (uint32_t)key;
                             if (akey > mkey) mkey = akey;
@@ -888,7 +895,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                         for (int hsel = 0; hsel < 2; ++hsel) {
                             const int v = 2 * k + hsel;
                             if (v >= c.n) continue;
-                            const bool posi = (sh->vposmask >> v) & 1ULL, nega = (sh->vnegmask >> v) & 1ULL;
+                            const bool posi = (sh->vposmask[v >> 6] >> (v & 63)) & 1ULL, nega = (sh->vnegmask[v >> 6] >> (v & 63)) & 1ULL;
                             int32_t b = 0;
                             if (posi && !nega) b = (int32_t)sh->vmin[v];
                             else if (nega && !posi) b = -(int32_t)sh->vmin[v];

@@ -125,7 +125,7 @@ ddo_model* ddo_model_create_knapsack(int n, int64_t capacity, const int64_t* pro
 ddo_model* ddo_model_read_knapsack(const char* path);
 /** Maximum cut (examples/mcp/{graph,model,relax}.rs: `Mcp`, `McpRelax`, `McpRanking`).  `adj_matrix`: n x n symmetric
  *  edge weights (graph.rs:30-46).  The state is `McpState { benef, depth }` (model.rs:27-31): n signed 32-bit benefits,
- *  two per word (variable v in half v & 1 of word v / 2), followed by one word holding the depth; n <= 62.  Variables in
+ *  two per word (variable v in half v & 1 of word v / 2), followed by one word holding the depth; n <= 142.  Variables in
  *  natural order (model.rs:88-96); decision +1 = side S, -1 = side T (model.rs:33-35). */
 ddo_model* ddo_model_create_mcp(int n, const int64_t* adj_matrix);
 /** Reads an instance exactly as examples/mcp/graph.rs:48-79 does ("c " comments, "<vertices> <edges>", "<src> <dst> <w>"). */
@@ -133,7 +133,7 @@ ddo_model* ddo_model_read_mcp(const char* path);
 /** Weighted MAX2SAT (examples/max2sat/{data,model,relax,heuristics}.rs: `Max2Sat`, `Max2SatRelax`, `Max2SatRanking`).
  *  Clause k is (lit_a[k] OR lit_b[k]) with weight[k]; literals are +-(1 + variable); a unit clause has lit_a == lit_b; a clause
  *  listed twice keeps its last weight (data.rs:31-62, 96-110).  State as for max-cut: `State { depth, substates }`
- *  (model.rs:55-60) = n signed 32-bit benefits, two per word, then one depth word; n <= 62.  Variables are branched from
+ *  (model.rs:55-60) = n signed 32-bit benefits, two per word, then one depth word; n <= 142 (frb15-9-x: n = 135).  Variables are branched from
  *  the end of `vars_by_sum_of_clause_weights` (model.rs:138-140, 330-346); decision +1 = true, -1 = false. */
 ddo_model* ddo_model_create_max2sat(int n, size_t nb_clauses, const int64_t* lit_a, const int64_t* lit_b, const int64_t* weight);
 /** Reads a .wcnf file exactly as examples/max2sat/data.rs:67-116 does. */

@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-MAX_WS = 32
+MAX_WS = 72
 CT_EXACT, CT_RELAXED, CT_RESTRICTED = 0, 1, 2
 IN_FUSED, IN_FILTER_CUTSET, IN_WANT_PATHS = 1, 2, 4
 IN_FRONTIER, IN_CACHE, IN_MUST_EXPLORE = 16, 32, 64

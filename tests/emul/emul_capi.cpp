@@ -48,7 +48,7 @@ T* carve(unsigned char*& p, size_t count) {
 }
 
 int pick_ws(int ws) {
-    const int opts[] = {1, 2, 4, 7, 8, 16, 32};
+    const int opts[] = {1, 2, 4, 7, 8, 16, 32, 72};
     for (int o : opts)
         if (ws <= o) return o;
     return -1;
@@ -285,6 +285,7 @@ int emul_compile(void* h, const DDInput* in, DDResult* res2, const uint8_t** are
         case 8: run<8>(*e, *in, res2); break;
         case 16: run<16>(*e, *in, res2); break;
         case 32: run<32>(*e, *in, res2); break;
+        case 72: run<72>(*e, *in, res2); break;
         default: return -2;
     }
     *arena_out = e->arena.data();

@@ -165,7 +165,7 @@ def test_max2sat_model_host_side(tmp_path):
     with pytest.raises(ddo_amd.DdoError):
         ddo_amd.Max2Sat.from_clauses(2, [(3, 1, 1)])            # literal outside [-n, n]
     with pytest.raises(ddo_amd.DdoError):
-        ddo_amd.Max2Sat.from_clauses(63, [])                      # more than 62 variables
+        ddo_amd.Max2Sat.from_clauses(143, [])                     # more than 142 variables
 
 
 def test_mcp_model_host_side(tmp_path):
@@ -178,4 +178,4 @@ def test_mcp_model_host_side(tmp_path):
     with pytest.raises(ddo_amd.DdoError):
         ddo_amd.Mcp.from_matrix(np.array([[0, 1], [2, 0]]))    # not symmetric
     with pytest.raises(ddo_amd.DdoError):
-        ddo_amd.Mcp.from_matrix(np.zeros((63, 63), dtype=np.int64))      # more than 62 vertices
+        ddo_amd.Mcp.from_matrix(np.zeros((143, 143), dtype=np.int64))    # more than 142 vertices

@@ -109,6 +109,7 @@ VEC_CASES = [
     ("max2sat", "frb10-6-1.wcnf", 8, 40), ("max2sat", "frb10-6-2.wcnf", 25, 30), ("max2sat", "frb10-6-3.wcnf", 0, 30),
     ("mcp", "mcp_n30_p0.1_000.mcp", 3, 60), ("mcp", "mcp_n30_p0.1_001.mcp", 10, 60), ("mcp", "mcp_n30_p0.1_004.mcp", 0, 60),
     ("mcp", "mcp_n30_p0.1_007.mcp", 2, 80),
+    ("max2sat", "frb15-9-1.wcnf", 6, 14),     # n = 135: 69 state words, the 72-word template (BASELINE config C3's stress instance)
 ]
 
 

@@ -39,6 +39,7 @@ def have_gpu():
     ("max2sat", "frb10-6-4.wcnf", 300, 60), ("max2sat", "frb10-6-1.wcnf", 5000, 8),
     ("mcp", "mcp_n30_p0.1_000.mcp", 3, 300), ("mcp", "mcp_n30_p0.1_001.mcp", 10, 300), ("mcp", "mcp_n30_p0.1_004.mcp", 0, 300),
     ("mcp", "mcp_n30_p0.1_007.mcp", 2, 300), ("mcp", "mcp_n30_p0.1_008.mcp", 100, 200), ("mcp", "mcp_n30_p0.1_003.mcp", 1000, 60),
+    ("max2sat", "frb15-9-1.wcnf", 6, 40), ("max2sat", "frb15-9-1.wcnf", 500, 8), ("max2sat", "frb15-9-1.wcnf", 5000, 4),   # n = 135: 69 words
 ])
 def test_replay_of_oracle_trace(have_gpu, oracle, kind, fname, width, max_compiles):
     path = data_path(kind, fname)
@@ -93,3 +94,24 @@ def test_golden_compile(have_gpu, case):
     # possible without the model's transition on the host, but their count must be the node's depth
     for n in got["cutset_nodes"]:
         assert len(n.path) == n.depth - case["depth"]
+
+
+def test_frb15_stress_instance_bounds(have_gpu):
+    """BASELINE config C3's stress instance frb15-9-1 (n = 135, 2648 clauses, optimum 341783 -- examples/max2sat/tests.rs:107-110,
+    ignored there as too slow): 69-word states on the 72-word template.  Under a time budget the search stops with
+    incumbent <= optimum <= best open bound, and the incumbent is a real assignment of that weight."""
+    import ctypes as C
+    from tests.oracle_binding import Oracle
+    import os
+    from tests.conftest import ROOT
+    path = data_path("max2sat", "frb15-9-1.wcnf")
+    model = ddo_amd.Max2Sat.read_instance(path)
+    assert model.n == 135 and model.ws == 69
+    s = ParallelSolver(model, FixedWidth(1000), ddo_amd.TimeBudget(8.0), nb_threads=64, fringe="nodup")
+    c = s.maximize()
+    assert c.best_value is not None and s.best_lower_bound() <= 341783 <= s.best_upper_bound()
+    values = np.zeros(model.n, dtype=np.int64)
+    for d in s.best_solution():
+        values[d.variable] = d.value
+    o = Oracle(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+    assert o.L.oracle_max2sat_evaluate(path.encode(), values.ctypes.data_as(C.c_void_p)) == c.best_value
