@@ -578,6 +578,11 @@ struct ddo_solver {
         std::vector<int> order(r.n_cutset);
         for (int j = 0; j < r.n_cutset; ++j) order[j] = j;
         const bool deal = cfg.world_size > 1 && it.depth == 0 && it.block->parent == nullptr;
+        if (!b->row_len.empty() && !deal)
+            // frontier cut-set: the reference collects it bottom-up (clean.rs:586-606), so the deepest nodes reach the fringe
+            // first -- and the NoDupFringe keeps the FIRST of two copies of a state with equal values (no_duplicate.rs:110).
+            // MISP nodes keep their state from layer to layer, so one cut-set can hold the same state at two depths.
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->row_len[(size_t)x] > b->row_len[(size_t)y]; });
         if (deal) {
             std::sort(order.begin(), order.end(), [&](int x, int y) {
                 int64_t ux = std::min<int64_t>(it.ub, r.cs_ub[x]), uy = std::min<int64_t>(it.ub, r.cs_ub[y]);

@@ -1533,6 +1533,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             int64_t bk64 = best_lb;
             if (has_best_exact && (int64_t)exact_value > bk64) bk64 = exact_value;
             const int32_t bk = bk64 < -(1 << 30) ? -(1 << 30) : (int32_t)bk64;   // values are far above: same comparisons
+            const bool bk_min = bk64 <= -((int64_t)1 << 39);                      // no bound known: best_known == isize::MIN
             if (has_best_exact && T >= 0 && nT > 0) {
                 PAR_BEGIN
                 for (int pos = tid; pos < nT; pos += NT) {
@@ -1550,12 +1551,15 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     const bool nex = !(w & (NI_INEXACT | NI_RELAXED));
                     const int32_t val = c.lval[li], rub = c.lrub[li];
                     int32_t th = LD_I32(&c.lth[li]);
-                    if (rub != INT32_MAX && (int64_t)val + rub <= (int64_t)bk) {
+                    if (rub != INT32_MAX && !bk_min && (int64_t)val + rub <= (int64_t)bk) {
                         th = bk - rub;
                     } else if (w & NI_CUTSET) {
                         const int32_t vb = LD_I32(&c.lvb[li]);
-                        if (vb == VB_UNMARKED || (int64_t)val + vb <= (int64_t)bk) {
-                            const int32_t cand = vb == VB_UNMARKED ? TH_INF : bk - vb;   // best_known - isize::MIN saturates
+                        // value_bot of an unmarked node is isize::MIN: value_top (+sat) MIN <= best_known unless there is no
+                        // bound at all (best_known == isize::MIN) and value_top > 0; best_known (-sat) MIN is then 0, else huge
+                        const bool locb_le = vb == VB_UNMARKED ? (!bk_min || val <= 0) : (!bk_min && (int64_t)val + vb <= (int64_t)bk);
+                        if (locb_le) {
+                            const int32_t cand = vb == VB_UNMARKED ? (bk_min ? 0 : TH_INF) : bk - vb;
                             const int32_t old = th == TH_NONE ? TH_INF : th;
                             th = cand < old ? cand : old;
                         } else {
