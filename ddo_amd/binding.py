@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time",
     "ddo_solver_bench_freeze", "ddo_solver_bench_step", "ddo_solver_bench_frozen",
     "ddo_solver_export_subproblems", "ddo_solver_import_subproblems",
-    "ddo_cache_create", "ddo_cache_destroy", "ddo_cache_clear", "ddo_cache_stats", "ddo_cache_get_threshold", "ddo_cache_update_threshold",
+    "ddo_dominance_create", "ddo_dominance_destroy", "ddo_dominance_clear", "ddo_cache_create", "ddo_cache_destroy", "ddo_cache_clear", "ddo_cache_stats", "ddo_cache_get_threshold", "ddo_cache_update_threshold",
 ]
 
 DDO_OK, DDO_CUTOFF = 0, 2
@@ -50,7 +50,7 @@ class _SubProblem(C.Structure):
 
 class _CompileInput(C.Structure):
     _fields_ = [("comp_type", C.c_int), ("max_width", C.c_size_t), ("best_lb", C.c_int64), ("residual", _SubProblem),
-                ("cutoff", C.POINTER(C.c_int)), ("cache", C.c_void_p)]
+                ("cutoff", C.POINTER(C.c_int)), ("cache", C.c_void_p), ("dominance", C.c_void_p)]
 
 
 class _Completion(C.Structure):
@@ -64,7 +64,7 @@ class _Counters(C.Structure):
 class _SolverConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("width_policy", C.c_int), ("width", C.c_size_t), ("nb_concurrent", C.c_int),
                 ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int), ("fringe", C.c_int),
-                ("sequential", C.c_int), ("cutset_type", C.c_int), ("cache_entries", C.c_size_t)]
+                ("sequential", C.c_int), ("cutset_type", C.c_int), ("cache_entries", C.c_size_t), ("dominance_entries", C.c_size_t)]
 
 
 _CUTSET_CB = C.CFUNCTYPE(None, C.POINTER(_SubProblem), C.c_void_p)
@@ -111,6 +111,10 @@ def lib():
     L.ddo_model_initial_value.argtypes = [C.c_void_p]
     L.ddo_model_compare_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ddo_model_export_misp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ddo_dominance_create.restype = C.c_void_p
+    L.ddo_dominance_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.ddo_dominance_destroy.argtypes = [C.c_void_p]
+    L.ddo_dominance_clear.argtypes = [C.c_void_p]
     L.ddo_cache_create.restype = C.c_void_p
     L.ddo_cache_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     L.ddo_cache_destroy.argtypes = [C.c_void_p]
@@ -270,7 +274,7 @@ class Misp:
         return SubProblem(state=self.initial_state(), value=self.initial_value(), path=[], depth=0)
 
 
-def _fill_input(model, comp_type, max_width, residual, best_lb, keep, cutoff=None, cache=None):
+def _fill_input(model, comp_type, max_width, residual, best_lb, keep, cutoff=None, cache=None, dominance=None):
     ci = _CompileInput()
     ci.comp_type = comp_type
     ci.max_width = int(max_width)
@@ -289,6 +293,7 @@ def _fill_input(model, comp_type, max_width, residual, best_lb, keep, cutoff=Non
     ci.residual.path_len = len(residual.path)
     ci.cutoff = cutoff   # None, or a ctypes c_int polled like Cutoff::must_stop (clean.rs:352)
     ci.cache = cache._h if cache is not None else None
+    ci.dominance = dominance._h if dominance is not None else None
     return ci
 
 
@@ -406,6 +411,27 @@ class SimpleCache:
             raise DdoError(f"ddo_cache_update_threshold rc={rc}: {_err()}")
 
 
+class SimpleDominanceChecker:
+    """`SimpleDominanceChecker::new(KPDominance, nb_variables)` (dominance/simple.rs:37-117, examples/knapsack/main.rs:198-218,
+    325) in device memory: knapsack models only (the relation is keyed by the depth, one coordinate + the value)."""
+
+    def __init__(self, model, capacity_per_depth=1 << 14, device=0):
+        self.model = model
+        self._h = lib().ddo_dominance_create(model._h, device, int(capacity_per_depth))
+        if not self._h:
+            raise DdoError("ddo_dominance_create failed: " + _err())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ddo_dominance_destroy(self._h)
+        except Exception:
+            pass
+
+    def clear(self):
+        lib().ddo_dominance_clear(self._h)
+
+
 class Mdd:
     """`impl DecisionDiagram for Mdd<T, CUTSET_TYPE>` (mdd.rs:75-114) on the device: LAST_EXACT_LAYER or FRONTIER cut-set;
     caching=True lets compile() take a SimpleCache."""
@@ -423,10 +449,10 @@ class Mdd:
         except Exception:
             pass
 
-    def compile(self, comp_type, max_width, residual, best_lb, cutoff=None, cache=None):
+    def compile(self, comp_type, max_width, residual, best_lb, cutoff=None, cache=None, dominance=None):
         keep = []
         ci = _fill_input(self.model, comp_type, max_width, residual, best_lb, keep,
-                         C.pointer(cutoff) if cutoff is not None else None, cache)   # cutoff: ctypes.c_int
+                         C.pointer(cutoff) if cutoff is not None else None, cache, dominance)   # cutoff: ctypes.c_int
         out = _Completion()
         rc = lib().ddo_mdd_compile(self._h, C.byref(ci), C.byref(out))
         if rc == DDO_CUTOFF:
@@ -515,7 +541,7 @@ class ParallelSolver:
     the fringe is the NoDupFringe<MaxUB>.  `nb_threads` = sub-problems compiled concurrently on the GPU."""
 
     def __init__(self, problem, width, cutoff=None, nb_threads=256, device=0, rank=0, world_size=1, fringe="nodup",
-                 sequential=False, cutset_type=LAST_EXACT_LAYER, cache_entries=0):
+                 sequential=False, cutset_type=LAST_EXACT_LAYER, cache_entries=0, dominance_entries=0):
         self.problem = problem
         cfg = _SolverConfig()
         cfg.device = device
@@ -532,6 +558,7 @@ class ParallelSolver:
         cfg.sequential = 1 if sequential else 0
         cfg.cutset_type = int(cutset_type)          # the `D` of ParallelSolver<State, D, C>: DefaultMDDLEL | DefaultMDDFC
         cfg.cache_entries = int(cache_entries)      # the `C`: 0 = EmptyCache, else SimpleCache with that many entries on the device
+        cfg.dominance_entries = int(dominance_entries)   # 0 = EmptyDominanceChecker, else SimpleDominanceChecker (knapsack models)
         self._h = lib().ddo_solver_create(problem._h, C.byref(cfg))
         if not self._h:
             raise DdoError("ddo_solver_create failed: " + _err())
@@ -679,7 +706,7 @@ def DefaultCachingSolver(problem, width, cutoff=None, nb_threads=256, device=0, 
 class SequentialSolver(ParallelSolver):
     """SequentialSolver (sequential.rs:202-527): one sub-problem at a time, NoDupFringe, and its `explored` bookkeeping."""
 
-    def __init__(self, problem, width, cutoff=None, device=0, cutset_type=LAST_EXACT_LAYER, cache_entries=0):
+    def __init__(self, problem, width, cutoff=None, device=0, cutset_type=LAST_EXACT_LAYER, cache_entries=0, dominance_entries=0):
         super().__init__(problem, width, cutoff=cutoff, nb_threads=1, device=device, fringe="nodup", sequential=True,
-                         cutset_type=cutset_type, cache_entries=cache_entries)
+                         cutset_type=cutset_type, cache_entries=cache_entries, dominance_entries=dominance_entries)
   # solver/mod.rs:28

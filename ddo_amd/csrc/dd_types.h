@@ -31,6 +31,7 @@ constexpr uint32_t IN_POOL_OUT = 8u;       // keep the cut-set in the device nod
 constexpr uint32_t IN_FRONTIER = 16u;      // CUTSET_TYPE == FRONTIER (clean.rs:586-606) instead of the last exact layer
 constexpr uint32_t IN_CACHE = 32u;         // SimpleCache behind the compile: _filter_with_cache, thresholds, cache updates
 constexpr uint32_t IN_MUST_EXPLORE = 64u;  // solver pop: Cache::must_explore first (sequential.rs:341, parallel.rs:537); ST_SKIPPED when it says no
+constexpr uint32_t IN_DOMINANCE = 256u;     // SimpleDominanceChecker behind the compile: _filter_with_dominance (clean.rs:689-708)
 constexpr uint32_t IN_MARK_EXPLORED = 128u; // ... and update_threshold(state, depth, value, true) when it says yes (parallel.rs:538 only)
 constexpr uint64_t NO_POOL_SRC = ~0ULL;    // DDInput.src_off: the residual state is inline (not a pool row)
 
@@ -217,16 +218,28 @@ struct EngineParams {
     int32_t cache_stride;      // u64 words per entry
     int32_t pad4;
     unsigned long long* cache_stats;   // [0] entries in use, [1] insertions refused (table full)
+    // SimpleDominanceChecker (dominance/simple.rs:37-117) for models whose dominance key is the depth and whose states have
+    // ONE coordinate besides the value (knapsack: KPDominance, examples/knapsack/main.rs:198-218): per depth the set of
+    // non-dominated (coordinate, value) pairs -- a Pareto front kept sorted by coordinate -- in HBM, one spin lock per depth
+    uint64_t* dom_coord;       // [max_layers][dom_cap]
+    int32_t* dom_value;        // [max_layers][dom_cap]
+    uint32_t* dom_count;       // [max_layers]
+    uint32_t* dom_lock;        // [max_layers]
+    uint32_t dom_cap;          // entries per depth; 0: EmptyDominanceChecker
+    uint32_t pad5;
+    unsigned long long* dom_stats;     // [0] insertions dropped (front full)
 };
 
 // node flag bits (node_flags.rs:48-185 restricted to what the device needs)
 constexpr uint32_t NF_INEXACT = 1u;   // !F_EXACT
 constexpr uint32_t NF_RELAXED = 2u;   // F_RELAXED
 constexpr uint32_t NF_CACHE = 8u;     // F_CACHE
+constexpr uint32_t NF_DOM = 16u;      // dominated (dominance/simple.rs:67-111)
 constexpr uint32_t NF_OKPATH = 4u;    // signed-vector models: the best arc comes from a node with an exact best path
-// ninfo word: bits 0..25 best arc (parent position << 1 | decision), 26 pruned by the cache, 27 frontier cut-set,
+// ninfo word: bits 0..24 best arc (parent position << 1 | decision), 25 dominated, 26 pruned by the cache, 27 frontier cut-set,
 // 28 = no arc (root), 29 ok best path, 30/31 flags
-constexpr uint32_t NI_ARC_MASK = 0x03FFFFFFu;
+constexpr uint32_t NI_ARC_MASK = 0x01FFFFFFu;
+constexpr uint32_t NI_DOM = 0x02000000u;      // removed by _filter_with_dominance (kept in the layer with its threshold, never expanded)
 constexpr uint32_t NI_CACHE = 0x04000000u;    // F_CACHE: pruned by _filter_with_cache (kept in the layer, never expanded)
 constexpr uint32_t NI_CUTSET = 0x08000000u;   // F_CUTSET of a frontier cut-set
 constexpr uint32_t NI_NOARC = 0x10000000u;

@@ -570,6 +570,43 @@ int Engine::read_pool(uint64_t off, void* dst, size_t bytes) {
     return DDO_OK;
 }
 
+DominanceTable* DominanceTable::create(const Model* model, int device, size_t capacity_per_depth) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error("ddo_dominance_create: no such HIP device (the checker lives in device memory: there is no CPU fallback)");
+        return nullptr;
+    }
+    if (model->kind != MODEL_KNAPSACK) {
+        set_error("ddo_dominance_create: the device checker covers dominance relations keyed by the depth with one coordinate (knapsack)");
+        return nullptr;
+    }
+    DominanceTable* t = new DominanceTable();
+    t->device = device;
+    t->cap = (uint32_t)std::max<size_t>(64, capacity_per_depth);
+    t->depths = model->n + 2;
+    const size_t nd = (size_t)t->depths;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&t->coord, nd * t->cap * 8) != hipSuccess ||
+        hipMalloc((void**)&t->value, nd * t->cap * 4) != hipSuccess || hipMalloc((void**)&t->count, nd * 4) != hipSuccess ||
+        hipMalloc((void**)&t->lock, nd * 4) != hipSuccess || hipMalloc((void**)&t->stats, 64) != hipSuccess || t->clear() != DDO_OK) {
+        set_error("ddo_dominance_create: could not allocate device memory");
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+DominanceTable::~DominanceTable() {
+    (void)hipSetDevice(device);
+    for (void* p : {(void*)coord, (void*)value, (void*)count, (void*)lock, (void*)stats})
+        if (p) (void)hipFree(p);
+}
+int DominanceTable::clear() {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemset(count, 0, (size_t)depths * 4));
+    HIP_TRY(hipMemset(lock, 0, (size_t)depths * 4));
+    HIP_TRY(hipMemset(stats, 0, 64));
+    return DDO_OK;
+}
+
 CacheTable* CacheTable::create(const Model* model, int device, size_t capacity_entries) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -652,7 +689,7 @@ void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) co
     }
 }
 
-int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache) {
+int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache, const DominanceTable* dom) {
     results.resize((size_t)std::max(count, 0) * 2);
     if (count <= 0) return DDO_OK;
     // One engine is shared by every ddo_mdd of a (model, device, width) and has a single launch in flight: the three
@@ -660,12 +697,12 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
     // parallel.rs:576-602).  The asynchronous launch()/wait()/fetch() path belongs to the lazy solver, which owns a
     // private engine.
     std::lock_guard<std::mutex> batch_guard(batch_mtx_);
-    int rc = launch(inputs, count, cache);
+    int rc = launch(inputs, count, cache, dom);
     if (rc != DDO_OK) return rc;
     return collect(results);
 }
 
-int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache) {
+int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, const DominanceTable* dom) {
     std::lock_guard<std::mutex> g(mtx_);
     if (pending_ > 0) {
         set_error("Engine::launch: a batch is already in flight");
@@ -729,6 +766,15 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache) {
     } else {
         P.cache_tab = nullptr;
         P.cache_cap = 0;
+    }
+    P.dom_cap = 0;
+    if (dom && P_.tmode && dom->device == device_ && dom->depths >= P_.max_layers - 1) {
+        P.dom_coord = dom->coord;
+        P.dom_value = dom->value;
+        P.dom_count = dom->count;
+        P.dom_lock = dom->lock;
+        P.dom_stats = dom->stats;
+        P.dom_cap = dom->cap;
     }
     const int grid = std::min(count, nslots_);
     kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT, threads_)
@@ -891,6 +937,12 @@ struct ddo_cache {
     CacheTable* t = nullptr;
     Model* model = nullptr;
     ~ddo_cache() { delete t; }
+};
+
+struct ddo_dominance {
+    DominanceTable* t = nullptr;
+    Model* model = nullptr;
+    ~ddo_dominance() { delete t; }
 };
 
 struct ddo_mdd {
@@ -1232,9 +1284,14 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
     std::vector<size_t> active;
     din.reserve(count);
     const ddo_cache* cache = inputs[0].cache;
+    const ddo_dominance* dom = inputs[0].dominance;
     for (size_t i = 0; i < count; ++i) {
         if (!mdds[i] || mdds[i]->engine.get() != eng) {
             set_error("ddo_mdd_compile_batch: all mdds must come from the same model, device and max_width");
+            return DDO_ERR_INVALID;
+        }
+        if (inputs[i].dominance != dom || (dom && (!mdds[i]->caching || dom->model != mdds[i]->model))) {
+            set_error("ddo_mdd_compile_batch: one ddo_dominance (of the same model) per batch, and only for mdds created with DDO_MDD_CACHING");
             return DDO_ERR_INVALID;
         }
         if (inputs[i].cache != cache || (cache && (!mdds[i]->caching || cache->model != mdds[i]->model))) {
@@ -1250,7 +1307,7 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
         }
         DDInput di;
         int rc = fill_input(*mdds[i]->model, &inputs[i], di,
-                            IN_WANT_PATHS | (mdds[i]->cutset_type == DDO_FRONTIER ? IN_FRONTIER : 0u) | (cache ? IN_CACHE : 0u));
+                            IN_WANT_PATHS | (mdds[i]->cutset_type == DDO_FRONTIER ? IN_FRONTIER : 0u) | (cache ? IN_CACHE : 0u) | (dom ? IN_DOMINANCE : 0u));
         if (rc != DDO_OK) {
             set_error("ddo_mdd_compile: invalid compile input");
             return rc;
@@ -1264,7 +1321,7 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
         active.push_back(i);
     }
     std::vector<HostResult> res;
-    int rc = eng->run_batch(din.data(), (int)din.size(), res, cache ? cache->t : nullptr);
+    int rc = eng->run_batch(din.data(), (int)din.size(), res, cache ? cache->t : nullptr, dom ? dom->t : nullptr);
     if (rc != DDO_OK) return rc;
     int worst = DDO_OK;
     for (size_t a = 0; a < active.size(); ++a) {
@@ -1355,6 +1412,21 @@ int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
     }
     return DDO_OK;
 }
+ddo_dominance* ddo_dominance_create(const ddo_model* model, int device, size_t capacity_per_depth) {
+    if (!model) {
+        set_error("ddo_dominance_create: null model");
+        return nullptr;
+    }
+    DominanceTable* t = DominanceTable::create(&model->m, device, capacity_per_depth);
+    if (!t) return nullptr;
+    ddo_dominance* d = new ddo_dominance();
+    d->t = t;
+    d->model = const_cast<Model*>(&model->m);
+    return d;
+}
+void ddo_dominance_destroy(ddo_dominance* d) { delete d; }
+int ddo_dominance_clear(ddo_dominance* d) { return d ? d->t->clear() : DDO_ERR_INVALID; }
+
 ddo_cache* ddo_cache_create(const ddo_model* model, int device, size_t capacity_entries) {
     if (!model || capacity_entries < 1) {
         set_error("ddo_cache_create: invalid arguments");

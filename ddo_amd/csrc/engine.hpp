@@ -67,6 +67,21 @@ struct CacheTable {
     int read_stats(uint64_t* used, uint64_t* dropped) const;
 };
 
+/// SimpleDominanceChecker (dominance/simple.rs:37-117) on the device, for models whose dominance key is the depth and whose
+/// states carry one coordinate besides the value (knapsack): per depth a sorted Pareto front in HBM (misp_dd_core.hpp).
+struct DominanceTable {
+    int device = 0;
+    uint64_t* coord = nullptr;
+    int32_t* value = nullptr;
+    uint32_t *count = nullptr, *lock = nullptr;
+    unsigned long long* stats = nullptr;
+    uint32_t cap = 0;
+    int depths = 0;
+    ~DominanceTable();
+    static DominanceTable* create(const Model* model, int device, size_t capacity_per_depth);
+    int clear();
+};
+
 /// One decoded compile() result living on the host.
 struct HostResult {
     DDResult hdr{};
@@ -112,10 +127,11 @@ class Engine {
 
     /// Runs `count` work items in one launch.  results: 2 per item ([1] used by IN_FUSED).
     /// Returns DDO_OK or a negative error.  Thread-safe (serialised internally).
-    int run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache = nullptr);
+    int run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache = nullptr,
+                  const DominanceTable* dom = nullptr);
     /// The two halves of run_batch: launch() enqueues upload + kernel + download of the result headers and
     /// returns at once; collect() waits, fetches the arena and decodes.  One launch may be in flight.
-    int launch(const DDInput* inputs, int count, const CacheTable* cache = nullptr);
+    int launch(const DDInput* inputs, int count, const CacheTable* cache = nullptr, const DominanceTable* dom = nullptr);
     int collect(std::vector<HostResult>& results);   // == wait() + fetch()
     /// wait(): the launch in flight has left the device (its result headers are on the host).  After it a new
     /// launch() may be issued at once -- it uses the other buffer set -- and fetch() then downloads and decodes

@@ -426,6 +426,7 @@ struct ddo_solver {
     ddo_solver_config cfg{};
     std::shared_ptr<Engine> engine;
     CacheTable* cache = nullptr;         // SimpleCache in device memory (cfg.cache_entries > 0)
+    DominanceTable* dominance = nullptr; // SimpleDominanceChecker in device memory (cfg.dominance_entries > 0)
     NoDupFringe* fringe = nullptr;
     LazyFringe* lazy = nullptr;          // DDO_FRINGE_LAZY
     std::vector<LazyItem> litems, flight;   // flight: the batch currently on the device
@@ -513,6 +514,7 @@ struct ddo_solver {
         delete fringe;
         delete lazy;
         delete cache;
+        delete dominance;
     }
 
     long engine_width() const {
@@ -1244,6 +1246,7 @@ struct ddo_solver {
             // DefaultCachingSolver: must_explore at the pop (sequential.rs:341 / parallel.rs:537-549; the parallel solver
             // also marks the node explored), thresholds and cache filter inside the compiles
             if (cache) in.flags |= IN_CACHE | IN_MUST_EXPLORE | (cfg.sequential ? 0u : IN_MARK_EXPLORED);
+            if (dominance) in.flags |= IN_DOMINANCE;
             in.width = width_of(items[i]);
             in.value = (int32_t)items[i].value;
             in.depth = items[i].depth;
@@ -1252,7 +1255,7 @@ struct ddo_solver {
             std::memcpy(in.state, items[i].block->state(items[i].row), (size_t)model->ws * 8);
         }
         auto t_run0 = std::chrono::steady_clock::now();
-        int rc = engine->run_batch(inputs.data(), (int)inputs.size(), results, cache);
+        int rc = engine->run_batch(inputs.data(), (int)inputs.size(), results, cache, dominance);
         auto t_run1 = std::chrono::steady_clock::now();
         st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
         if (rc != DDO_OK) {
@@ -1265,7 +1268,7 @@ struct ddo_solver {
                 results[2 * i].hdr.status <= -100 || results[2 * i + 1].hdr.status <= -100) {
                 // the shared output arena overflowed: redo this sub-problem on its own
                 std::vector<HostResult> solo;
-                int rc2 = engine->run_batch(&inputs[i], 1, solo, cache);
+                int rc2 = engine->run_batch(&inputs[i], 1, solo, cache, dominance);
                 if (rc2 != DDO_OK || solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY) {
                     set_error("device compile failed: output arena too small for one sub-problem");
                     err = DDO_ERR_CAPACITY;
@@ -1326,7 +1329,7 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
     if (s->cfg.world_size < 1) s->cfg.world_size = 1;
     if (s->cfg.rank < 0 || s->cfg.rank >= s->cfg.world_size) s->cfg.rank = 0;
     if (s->cfg.cutset_type == 0) s->cfg.cutset_type = DDO_LAST_EXACT_LAYER;
-    const bool keep_layers = s->cfg.cutset_type == DDO_FRONTIER || s->cfg.cache_entries > 0;
+    const bool keep_layers = s->cfg.cutset_type == DDO_FRONTIER || s->cfg.cache_entries > 0 || s->cfg.dominance_entries > 0;
     if ((s->cfg.cutset_type != DDO_LAST_EXACT_LAYER && s->cfg.cutset_type != DDO_FRONTIER) || (keep_layers && cfg->fringe == DDO_FRINGE_LAZY)) {
         set_error("ddo_solver_create: cutset_type must be LAST_EXACT_LAYER or FRONTIER; a frontier cut-set or a cache need DDO_FRINGE_NODUP");
         delete s;
@@ -1340,6 +1343,10 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
         return nullptr;
     }
     if (s->cfg.cache_entries > 0 && !(s->cache = CacheTable::create(s->model, cfg->device, s->cfg.cache_entries))) {
+        delete s;
+        return nullptr;
+    }
+    if (s->cfg.dominance_entries > 0 && !(s->dominance = DominanceTable::create(s->model, cfg->device, s->cfg.dominance_entries))) {
         delete s;
         return nullptr;
     }

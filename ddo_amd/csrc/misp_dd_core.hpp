@@ -227,6 +227,11 @@ struct DDCtx {
     uint64_t cache_cap;
     int cache_stride;
     unsigned long long* cache_stats;
+    uint64_t* dom_coord;
+    int32_t* dom_value;
+    uint32_t *dom_count, *dom_lock;
+    uint32_t dom_cap;
+    unsigned long long* dom_stats;
     // output
     uint8_t* arena;
     uint64_t arena_cap;
@@ -351,7 +356,7 @@ DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth
 /// a candidate that is in `curr_l`: unique (it won the dedup) and not removed by _filter_with_cache (clean.rs:710-726)
 template <class Ctx>
 DDO_DEV bool cand_live(const Ctx& c, int cur, int cd) {
-    return c.ctarget[cd] == (uint32_t)cd && !(c.tmode && (c.cflags[cur][cd] & NF_CACHE));
+    return c.ctarget[cd] == (uint32_t)cd && !(c.tmode && (c.cflags[cur][cd] & (NF_CACHE | NF_DOM)));
 }
 
 /// candidate numbering: NO-children of parent position p live at p, YES-children at capN + p,
@@ -606,6 +611,111 @@ DDO_DEV int table_size_for(int ncand_max, int cap) {
     return h;
 }
 
+/// _filter_with_dominance (clean.rs:689-708) with SimpleDominanceChecker (dominance/simple.rs:67-111) for a dominance whose
+/// key is the depth and whose states have one coordinate (state word 0) besides the value -- KPDominance.  The set of
+/// non-dominated (coordinate, value) pairs of a depth is a Pareto front; kept sorted by coordinate (values then strictly
+/// decrease), `is_dominated_or_insert` is a binary search, one walk over the dominating run (its smallest value is the
+/// threshold; an entry that differs in value only contributes value - 1) or one splice that drops what the new pair
+/// dominates.  The reference processes curr_l in dominance order (value, then coordinate, descending): ranks by counting,
+/// then ONE thread replays that order under the depth's lock -- the data structure is shared by all compiles in flight.
+template <int WS, class Ctx>
+DDO_DEV void dominance_filter(Ctx& c, int cur, int nprev, int depth) {
+    DD_TID_SETUP(c)
+    auto* sh = c.sh;
+    const int capN = c.capN;
+    const int ncl = 2 * nprev;
+    uint32_t* order = c.keep;                 // free until the positions are assigned (capC1 entries with kept layers)
+    PAR_BEGIN
+    if (tid == 0) sh->scan_total = 0;
+    PAR_END
+    PAR_BEGIN   // rank of every exact node of curr_l in (value, coordinate) descending order
+    for (int j = tid; j < ncl; j += NT) {
+        const int cd = lin2cand(j, nprev, capN);
+        if (!cand_live(c, cur, cd) || (LD_U32(&c.cflags[cur][cd]) & (NF_INEXACT | NF_RELAXED))) continue;
+        const int32_t v = unbias32((uint32_t)(LD_U64(&c.ckey[cur][cd]) >> 32));
+        const uint64_t co = c.cstate[cur][cd];
+        int rank = 0;
+        for (int j2 = 0; j2 < ncl; ++j2) {
+            const int c2 = lin2cand(j2, nprev, capN);
+            if (c2 == cd || !cand_live(c, cur, c2) || (LD_U32(&c.cflags[cur][c2]) & (NF_INEXACT | NF_RELAXED))) continue;
+            const int32_t v2 = unbias32((uint32_t)(LD_U64(&c.ckey[cur][c2]) >> 32));
+            const uint64_t co2 = c.cstate[cur][c2];
+            rank += (v2 > v || (v2 == v && co2 > co)) ? 1 : 0;
+        }
+        order[rank] = (uint32_t)cd;
+        LDS_ADD_I32(&sh->scan_total, 1);
+    }
+    PAR_END
+    const int m = sh->scan_total;
+    DD_SYNC();
+    PAR_BEGIN
+    if (tid == 0 && m > 0) {
+        uint64_t* fc = c.dom_coord + (size_t)depth * c.dom_cap;
+        int32_t* fv = c.dom_value + (size_t)depth * c.dom_cap;
+#if !defined(DDO_HOST_EMULATION)
+        while (atomicCAS(&c.dom_lock[depth], 0u, 1u) != 0u) {}
+        __threadfence();
+#endif
+        int F = (int)CT_LD(&c.dom_count[depth]);
+        for (int q = 0; q < m; ++q) {
+            const int cd = (int)order[q];
+            const int32_t v = unbias32((uint32_t)(LD_U64(&c.ckey[cur][cd]) >> 32));
+            const uint64_t co = c.cstate[cur][cd];
+            int lo = 0, hi = F;                       // first entry with coordinate >= co
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (CT_LD(&fc[mid]) < co) lo = mid + 1; else hi = mid;
+            }
+            const int idx = lo;
+            bool dominated = false;
+            int32_t th = TH_INF;
+            if (!(idx < F && CT_LD(&fc[idx]) == co && CT_LD(&fv[idx]) == v)) {   // an equal pair is replaced, it does not dominate
+                for (int k = idx; k < F; ++k) {
+                    const int32_t ov = CT_LD(&fv[k]);
+                    if (ov < v) break;
+                    dominated = true;
+                    const int32_t t = CT_LD(&fc[k]) == co ? ov - 1 : ov;   // only the value differs: threshold value - 1
+                    th = t < th ? t : th;
+                }
+            }
+            if (dominated) {
+                c.cflags[cur][cd] = LD_U32(&c.cflags[cur][cd]) | NF_DOM;
+                c.cth[cd] = th;
+                sh->ncache += 1;
+                continue;
+            }
+            int first = idx;                           // entries the new pair dominates or equals: a run ending at idx
+            while (first > 0 && CT_LD(&fv[first - 1]) <= v) --first;
+            const int last = idx + ((idx < F && CT_LD(&fc[idx]) == co) ? 1 : 0);
+            const int removed = last - first;
+            if (F - removed + 1 > (int)c.dom_cap) {   // front full: the pair is not recorded (sound: less pruning later)
+                CT_ADD(&c.dom_stats[0], 1ULL);
+                continue;
+            }
+            if (removed == 0) {
+                for (int k = F; k > first; --k) {
+                    CT_ST(&fc[k], CT_LD(&fc[k - 1]));
+                    CT_ST(&fv[k], CT_LD(&fv[k - 1]));
+                }
+            } else if (removed > 1) {
+                for (int k = last; k < F; ++k) {
+                    CT_ST(&fc[k - removed + 1], CT_LD(&fc[k]));
+                    CT_ST(&fv[k - removed + 1], CT_LD(&fv[k]));
+                }
+            }
+            CT_ST(&fc[first], co);
+            CT_ST(&fv[first], v);
+            F = F - removed + 1;
+        }
+        CT_ST(&c.dom_count[depth], (uint32_t)F);
+#if !defined(DDO_HOST_EMULATION)
+        __threadfence();
+        atomicExch(&c.dom_lock[depth], 0u);
+#endif
+    }
+    PAR_END
+}
+
 /// One compile() -- clean.rs:345-381 -- of the sub-problem `in` with the given type.
 template <int WS>
 DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
@@ -619,6 +729,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     const int LS = c.tmode ? c.lstride : capN;                        // nodes per layer in the per-layer arrays
     const bool frontier = c.tmode && (in.flags & IN_FRONTIER) != 0;   // CUTSET_TYPE == FRONTIER
     const bool use_cache = c.tmode && (in.flags & IN_CACHE) != 0 && c.cache_cap != 0;
+    const bool use_dom = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dom_cap != 0 && c.kind == MODEL_KNAPSACK;
 
     // ---------------------------------------------------------------- _clear + _initialize
     int cur = 0;
@@ -719,8 +830,24 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             }
             PAR_END
         }
-        const int ncache = (use_cache && L >= 1) ? sh->ncache : 0;
-        const int nU = sh->nU - ncache;                               // |curr_l| after the filter
+        int ncache = (use_cache && L >= 1) ? sh->ncache : 0;
+        // ------------------------------------------------------------ _filter_with_dominance (clean.rs:689-708)
+        // every layer, the root's too: the exact nodes of curr_l, best (value, coordinate) first, are checked against -- and
+        // added to -- the set of non-dominated states of this depth (dominance/simple.rs:67-111); a dominated node leaves
+        // curr_l with the threshold the checker returns
+        if (use_dom) {
+            if (ncache == 0) {
+                PAR_BEGIN
+                if (tid == 0) sh->ncache = 0;
+                PAR_END
+            }
+            const int before = sh->ncache;
+            DD_SYNC();
+            dominance_filter<WS>(c, cur, nprev, c.depth0 + L);
+            ncache = sh->ncache;
+            (void)before;
+        }
+        const int nU = sh->nU - ncache;                               // |curr_l| after the filters
 
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
         const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
@@ -782,8 +909,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         for (int j = lo; j < hi; ++j) {
             int cd = lin2cand(j, nprev, capN);
             uint8_t cl = 0;
-            if (c.ctarget[cd] == (uint32_t)cd && c.tmode && (c.cflags[cur][cd] & NF_CACHE)) {
-                cl = 3;   // pruned by the cache: a node of the layer, not of curr_l
+            if (c.ctarget[cd] == (uint32_t)cd && c.tmode && (c.cflags[cur][cd] & (NF_CACHE | NF_DOM))) {
+                cl = 3;   // pruned by the cache / dominated: a node of the layer, not of curr_l
             } else if (c.ctarget[cd] == (uint32_t)cd) {
                 cl = 1;
                 if (squash) {
@@ -997,7 +1124,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     ++pos;
                 }
             }
-            if (tid == 0) sh->cache_hits += (uint32_t)ncache;
+            if (tid == 0) sh->cache_hits += (uint32_t)ncache;   // (nodes removed by the cache or by dominance)
             PAR_END
             ntot = n + ncache;
         }
@@ -1038,7 +1165,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (fl & NF_INEXACT) w |= NI_INEXACT;
             if (fl & NF_RELAXED) w |= NI_RELAXED;
             if (fl & NF_OKPATH) w |= NI_OKPATH;
-            if (pos >= n) w |= NI_CACHE;
+            if (pos >= n) w |= (fl & NF_DOM) ? NI_DOM : NI_CACHE;
             ni[pos] = w;
         }
         // arcs entering this layer, translated to node positions (needed by the backward pass)
@@ -1992,6 +2119,12 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.cache_cap = P.tmode ? P.cache_cap : 0;
     c.cache_stride = P.cache_stride;
     c.cache_stats = P.cache_stats;
+    c.dom_coord = P.dom_coord;
+    c.dom_value = P.dom_value;
+    c.dom_count = P.dom_count;
+    c.dom_lock = P.dom_lock;
+    c.dom_cap = P.tmode ? P.dom_cap : 0;
+    c.dom_stats = P.dom_stats;
     unsigned char* p = lds;
     if (TLDS) {
         c.table = (uint32_t*)p;

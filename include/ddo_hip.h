@@ -69,6 +69,7 @@ typedef struct ddo_subproblem {
 } ddo_subproblem;
 
 typedef struct ddo_cache ddo_cache;
+typedef struct ddo_dominance ddo_dominance;
 
 /** mdd.rs:51-71  struct CompilationInput.  problem / relaxation / ranking are
  *  fixed by the ddo_model the mdd was created from (the device cannot call
@@ -84,6 +85,7 @@ typedef struct ddo_compile_input {
     ddo_subproblem residual;
     const volatile int* cutoff;
     ddo_cache* cache;
+    ddo_dominance* dominance; /* NULL == EmptyDominanceChecker (dominance/empty.rs); else see ddo_dominance_create */
 } ddo_compile_input;
 
 /** common.rs:115-121  struct Completion { is_exact, best_value: Option<isize> } */
@@ -165,6 +167,17 @@ int ddo_cache_stats(const ddo_cache* cache, uint64_t* used, uint64_t* dropped);
 int ddo_cache_get_threshold(const ddo_cache* cache, const uint64_t* state, size_t depth, int64_t* value, int* explored);
 int ddo_cache_update_threshold(ddo_cache* cache, const uint64_t* state, size_t depth, int64_t value, int explored);
 
+/* ---- DominanceChecker (abstraction/dominance.rs:100-124; implementation/dominance/simple.rs:37-117) ---------------- */
+/** SimpleDominanceChecker in device memory for the dominance relation of `model`.  The device checker covers relations
+ *  whose key is the depth and whose states have one coordinate besides the value (use_value = true): the knapsack's
+ *  KPDominance (examples/knapsack/main.rs:198-218: more remaining capacity and more value dominate).  Per depth it keeps
+ *  the non-dominated (capacity, value) pairs, at most `capacity_per_depth` of them (a full set drops new pairs: sound).
+ *  Handed to compile() through ddo_compile_input.dominance (the mdd must have been created with DDO_MDD_CACHING: dominated
+ *  nodes keep their threshold in the kept layers) or owned by a solver (ddo_solver_config.dominance). */
+ddo_dominance* ddo_dominance_create(const ddo_model* model, int device, size_t capacity_per_depth);
+void ddo_dominance_destroy(ddo_dominance* dominance);
+int ddo_dominance_clear(ddo_dominance* dominance);
+
 /* ---- DecisionDiagram (mdd.rs:75-114) -------------------------------------------------------- */
 /** == `D::default()` bound to a model and a device.  `max_width` is the largest width any
  *  compile() on this object will ask for (sizes the HBM workspace). */
@@ -220,6 +233,8 @@ typedef struct ddo_solver_config {
                               (DefaultMDDLEL / DefaultMDDFC, mdd/mod.rs:42-49); DDO_FRONTIER needs DDO_FRINGE_NODUP */
     size_t cache_entries;  /* 0: EmptyCache; else a SimpleCache of at least that many entries in device memory
                               (the `C` of the solver: DefaultCachingSolver, solver/mod.rs); needs DDO_FRINGE_NODUP */
+    size_t dominance_entries; /* 0: EmptyDominanceChecker; else a SimpleDominanceChecker with that many pairs per depth
+                              (knapsack models: KPDominance, knapsack/main.rs:325); needs DDO_FRINGE_NODUP */
 } ddo_solver_config;
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg);

@@ -359,6 +359,17 @@ struct KPRanking : StateRanking<KnapsackState> {
 
 /// main.rs:267-303: lines starting with 'c' skipped; first line "n capacity";
 /// then n lines "profit weight".
+/// examples/knapsack/main.rs:198-218: states of one depth are comparable; more capacity and more value dominate
+struct KPDominance {
+    using Key = size_t;
+    struct KeyHash { size_t operator()(const Key& k) const { return std::hash<size_t>()(k); } };
+    struct KeyEq { bool operator()(const Key& a, const Key& b) const { return a == b; } };
+    std::optional<Key> get_key(std::shared_ptr<const KnapsackState> s) const { return s->depth; }
+    size_t nb_dimensions(const KnapsackState&) const { return 1; }
+    isize get_coordinate(const KnapsackState& s, size_t) const { return (isize)s.capacity; }
+    bool use_value() const { return true; }
+};
+
 inline Knapsack read_knapsack_instance(const std::string& fname) {
     std::ifstream f(fname);
     if (!f) throw std::runtime_error("io error: cannot open " + fname);

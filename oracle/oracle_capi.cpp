@@ -295,11 +295,12 @@ namespace {
 /// traced sequential solve with any decision-diagram type D (last exact layer / frontier cut-set) and cache type C
 template <class T, class D, class C, class PB, class RELAX, class RANK>
 Trace* traced_solve_dc(PB& pb, RELAX& relax, RANK& rank, size_t nvars, size_t ws, uint64_t width, uint64_t max_compiles,
-                       oracle_solve_out* out) {
+                       oracle_solve_out* out, DominanceChecker<T>* domx = nullptr) {
     FixedWidth<T> fixed(width);
     NbUnassignedWidth<T> unassigned(nvars);
     const WidthHeuristic<T>& w = width ? (const WidthHeuristic<T>&)fixed : unassigned;
-    EmptyDominanceChecker<T> dom;
+    EmptyDominanceChecker<T> dom0;
+    DominanceChecker<T>& dom = domx ? *domx : (DominanceChecker<T>&)dom0;
     struct CountCutoff : Cutoff {
         const Trace* tr;
         uint64_t max;
@@ -335,11 +336,11 @@ Trace* traced_solve_dc(PB& pb, RELAX& relax, RANK& rank, size_t nvars, size_t ws
 }
 template <class T, class PB, class RELAX, class RANK>
 Trace* traced_solve_any(PB& pb, RELAX& relax, RANK& rank, size_t nvars, size_t ws, uint64_t width, uint64_t max_compiles, int frontier,
-                        int cache, oracle_solve_out* out) {
-    if (frontier && cache) return traced_solve_dc<T, DefaultMDDFC<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out);
-    if (frontier) return traced_solve_dc<T, DefaultMDDFC<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out);
-    if (cache) return traced_solve_dc<T, DefaultMDDLEL<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out);
-    return traced_solve_dc<T, DefaultMDDLEL<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out);
+                        int cache, oracle_solve_out* out, DominanceChecker<T>* dom = nullptr) {
+    if (frontier && cache) return traced_solve_dc<T, DefaultMDDFC<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom);
+    if (frontier) return traced_solve_dc<T, DefaultMDDFC<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom);
+    if (cache) return traced_solve_dc<T, DefaultMDDLEL<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom);
+    return traced_solve_dc<T, DefaultMDDLEL<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom);
 }
 }  // namespace
 
@@ -357,11 +358,13 @@ void* oracle_trace_solve_ex(const char* kind, const char* path, uint64_t width, 
             MispRanking rank;
             return traced_solve_any<BitSet>(pb, relax, rank, pb.nb_vars, (pb.nb_vars + 63) / 64, width, max_compiles, frontier, cache, out);
         }
-        if (k == "knapsack") {
+        if (k == "knapsack" || k == "knapsack+dominance") {   // "+dominance": SimpleDominanceChecker(KPDominance), knapsack/main.rs:325
             Knapsack pb = read_knapsack_instance(path);
             KPRelax relax(pb);
             KPRanking rank;
-            return traced_solve_any<KnapsackState>(pb, relax, rank, pb.nb_variables(), 2, width, max_compiles, frontier, cache, out);
+            SimpleDominanceChecker<KnapsackState, KPDominance> dom(KPDominance{}, pb.nb_variables());
+            return traced_solve_any<KnapsackState>(pb, relax, rank, pb.nb_variables(), 2, width, max_compiles, frontier, cache, out,
+                                                   k == "knapsack" ? nullptr : &dom);
         }
         if (k == "max2sat") {
             Weighed2Sat inst = read_max2sat_instance(path);

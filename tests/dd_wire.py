@@ -7,7 +7,7 @@ import numpy as np
 MAX_WS = 72
 CT_EXACT, CT_RELAXED, CT_RESTRICTED = 0, 1, 2
 IN_FUSED, IN_FILTER_CUTSET, IN_WANT_PATHS = 1, 2, 4
-IN_FRONTIER, IN_CACHE, IN_MUST_EXPLORE = 16, 32, 64
+IN_FRONTIER, IN_CACHE, IN_MUST_EXPLORE, IN_MARK_EXPLORED, IN_DOMINANCE = 16, 32, 64, 128, 256
 ST_OK, ST_CUTOFF, ST_NOT_RUN = 0, 1, 77
 
 

@@ -37,6 +37,10 @@ struct Emul {
     std::vector<int32_t> aux[2], lddelta;   // knapsack tables, per-layer relax deltas
     std::vector<unsigned char> mem3;         // kept layers (frontier cut-set / thresholds / cache)
     std::vector<uint64_t> cache_tab;
+    std::vector<uint64_t> dom_coord;
+    std::vector<int32_t> dom_value;
+    std::vector<uint32_t> dom_count, dom_lock;
+    unsigned long long dom_stats[8] = {0};
     unsigned long long cache_stats[8] = {0};
 };
 
@@ -266,6 +270,23 @@ void emul_set_keep_layers(void* h, int on, uint64_t cache_entries) {
     }
 }
 uint64_t emul_cache_used(void* h) { return ((Emul*)h)->cache_stats[0]; }
+/// a fresh, empty SimpleDominanceChecker (per depth `cap` pairs); cap 0 removes it
+void emul_set_dominance(void* h, uint32_t cap) {
+    Emul* e = (Emul*)h;
+    e->P.dom_cap = cap;
+    if (!cap) return;
+    const size_t nd = (size_t)e->P.max_layers;
+    e->dom_coord.assign(nd * cap, 0);
+    e->dom_value.assign(nd * cap, 0);
+    e->dom_count.assign(nd, 0);
+    e->dom_lock.assign(nd, 0);
+    e->P.dom_coord = e->dom_coord.data();
+    e->P.dom_value = e->dom_value.data();
+    e->P.dom_count = e->dom_count.data();
+    e->P.dom_lock = e->dom_lock.data();
+    e->dom_stats[0] = 0;
+    e->P.dom_stats = e->dom_stats;
+}
 void emul_destroy(void* h) { delete (Emul*)h; }
 int emul_state_words(void* h) { return ((Emul*)h)->wsT; }
 uint64_t emul_lds_bytes(void* h) { return ((Emul*)h)->lds.size(); }

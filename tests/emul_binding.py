@@ -58,6 +58,11 @@ class Emul:
         self.L.emul_set_keep_layers.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         self.L.emul_set_keep_layers(self.h, 1 if on else 0, int(cache_entries))
 
+    def dominance(self, cap):
+        """a fresh SimpleDominanceChecker with `cap` pairs per depth (0: none); needs keep_layers(True)"""
+        self.L.emul_set_dominance.argtypes = [C.c_void_p, C.c_uint32]
+        self.L.emul_set_dominance(self.h, int(cap))
+
     def cache_used(self):
         self.L.emul_cache_used.restype = C.c_uint64
         self.L.emul_cache_used.argtypes = [C.c_void_p]

@@ -10,7 +10,7 @@ import pytest
 
 import ddo_amd
 from tests.conftest import data_path
-from tests.dd_wire import IN_CACHE, IN_FRONTIER, IN_MUST_EXPLORE, IN_WANT_PATHS
+from tests.dd_wire import IN_CACHE, IN_DOMINANCE, IN_FRONTIER, IN_MUST_EXPLORE, IN_WANT_PATHS
 from tests.emul_binding import ModelEmul
 from tests.parity_util import diff
 
@@ -63,3 +63,35 @@ def test_cache_prunes_and_changes_the_search(oracle):
         assert g["status"] == 0 and diff(r, g) is None
         hits += g["cache_hits"]
     assert hits > 0
+
+
+@pytest.mark.parametrize("frontier,cache", [(False, False), (True, False), (False, True), (True, True)],
+                         ids=["lel", "frontier", "lel+cache", "frontier+cache"])
+@pytest.mark.parametrize("fname,width,max_compiles", [("f1_l-d_kp_10_269", 3, 0), ("f8_l-d_kp_23_10000", 3, 300), ("f8_l-d_kp_23_10000", 20, 200),
+                                                      ("knapPI_1_100_1000_1", 3, 0), ("f10_l-d_kp_20_879", 5, 0), ("f7_l-d_kp_7_50", 2, 0)])
+def test_replay_of_a_knapsack_search_with_dominance(oracle, fname, width, max_compiles, frontier, cache):
+    """SimpleDominanceChecker(KPDominance) (dominance/simple.rs:37-117, examples/knapsack/main.rs:198-218, 325) -- with frontier
+    cut-set and cache this is the reference's own knapsack configuration (SeqCachingSolverFc).  The checker is shared by all
+    compiles of a search, so the replay is stateful like the cache's: _filter_with_dominance (clean.rs:689-708) of compile k
+    sees the non-dominated pairs compiles 0..k-1 left."""
+    path = data_path("knapsack", fname)
+    model = ddo_amd.Knapsack.read_instance(path)
+    plain, _ = oracle.trace_ex("knapsack", path, width, max_compiles, frontier, cache)
+    summary, recs = oracle.trace_ex("knapsack+dominance", path, width, max_compiles, frontier, cache)
+    if max_compiles == 0:
+        assert summary["best_value"] == plain["best_value"] and summary["nodes_expanded"] <= plain["nodes_expanded"]
+    e = ModelEmul(model, max(int(r["width"]) for r in recs))
+    e.keep_layers(True, 1 << 15 if cache else 0)
+    e.dominance(2048)
+    removed = 0
+    for i, r in enumerate(recs):
+        fl = IN_WANT_PATHS | IN_DOMINANCE | (IN_FRONTIER if frontier else 0) | (IN_CACHE if cache else 0)
+        if cache and r["comp_type"] == 2:
+            fl |= IN_MUST_EXPLORE
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=fl)[0]
+        assert g is not None and g["status"] == 0
+        d = diff(r, g)
+        assert d is None, f"{fname} W={width} frontier={frontier} cache={cache} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+        removed += g["cache_hits"]
+    if fname.startswith("f8") and width == 20:
+        assert removed > 0      # nodes did leave layers (dominated, or pruned by the cache)

@@ -133,3 +133,45 @@ def test_cache_thresholds_through_the_host_views(have_gpu):
     assert cache.get_threshold(b, 9) == ((1 << 63) - 1, True)
     cache.clear()
     assert cache.get_threshold(a, 3) is None and cache.stats()["used"] == 0
+
+
+# ---- SimpleDominanceChecker: the reference's knapsack configuration ----------------------------------
+@pytest.mark.parametrize("frontier,cache", [(False, False), (True, True)], ids=["lel", "frontier+cache"])
+@pytest.mark.parametrize("fname,width,max_compiles", [("f8_l-d_kp_23_10000", 3, 300), ("f8_l-d_kp_23_10000", 20, 200), ("knapPI_1_100_1000_1", 3, 0)])
+def test_knapsack_dominance_replayed_in_order(have_gpu, oracle, fname, width, max_compiles, frontier, cache):
+    path = data_path("knapsack", fname)
+    model = ddo_amd.Knapsack.read_instance(path)
+    _, recs = oracle.trace_ex("knapsack+dominance", path, width, max_compiles, frontier, cache)
+    mdd = ddo_amd.Mdd(model, max(int(r["width"]) for r in recs), cutset_type=FRONTIER if frontier else LAST_EXACT_LAYER, caching=True)
+    ch = ddo_amd.SimpleCache(model, 1 << 16) if cache else None
+    dom = ddo_amd.SimpleDominanceChecker(model, 4096)
+    for i, r in enumerate(recs):
+        comp = mdd.compile(r["comp_type"], r["width"], _sub(r), r["best_lb"], cache=ch, dominance=dom)
+        d = diff(r, canon_from_mdd(mdd, comp, model.ws))
+        assert d is None, f"{fname} W={width} frontier={frontier} cache={cache} compile #{i}: {d}"
+
+
+@pytest.mark.parametrize("fname,width", [("f8_l-d_kp_23_10000", 3), ("f8_l-d_kp_23_10000", 20), ("knapPI_1_100_1000_1", 3), ("f1_l-d_kp_10_269", 2),
+                                          ("knapPI_2_100_1000_1", 10)])
+def test_seq_caching_solver_fc_with_dominance(have_gpu, oracle, fname, width):
+    """examples/knapsack/main.rs:320-337: SeqCachingSolverFc (frontier cut-set + SimpleCache) with SimpleDominanceChecker(KPDominance)
+    -- explored sub-problems and counters equal the oracle's, and fewer nodes are expanded than without dominance"""
+    path = data_path("knapsack", fname)
+    model = ddo_amd.Knapsack.read_instance(path)
+    ref, _ = oracle.trace_ex("knapsack+dominance", path, width, 0, True, True)
+    s = SequentialSolver(model, FixedWidth(width), cutset_type=FRONTIER, cache_entries=1 << 18, dominance_entries=1 << 12)
+    c = s.maximize()
+    assert c.is_exact and c.best_value == ref["best_value"]
+    cnt = s.counters()
+    assert (s.explored(), cnt["nodes_expanded"], cnt["arcs"], cnt["layers"], cnt["compiles"]) == \
+           (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
+    plain = SequentialSolver(model, FixedWidth(width), cutset_type=FRONTIER, cache_entries=1 << 18)
+    assert plain.maximize().best_value == c.best_value and plain.counters()["nodes_expanded"] >= cnt["nodes_expanded"]
+    sol = s.best_solution()
+    assert sol is not None and len(sol) == model.n
+
+
+def test_dominance_is_for_knapsack_models(have_gpu):
+    misp = ddo_amd.Misp.read_instance(data_path("misp", "johnson8-2-4.clq"))
+    with pytest.raises(ddo_amd.DdoError):
+        ddo_amd.SimpleDominanceChecker(misp, 64)
