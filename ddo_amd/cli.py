@@ -12,7 +12,7 @@ on the GPU the useful values are hundreds to thousands (tools/fringe_compare.py)
 (`Duration / Objective / Upper Bnd / Lower Bnd / Gap / Aborted / [Cost] / Solution`) so that the outputs can be diffed.
 Like the reference's binaries the solvers use the duplicate-free fringe; `--fringe lazy` selects the device-resident
 block fringe (MISP only).  The knapsack binary of the reference couples a frontier cut-set, a cache and a dominance checker
-(SeqCachingSolverFc); here it runs the plain LEL solver, which proves the same optimum."""
+(SeqCachingSolverFc + SimpleDominanceChecker(KPDominance)): so does this one."""
 import argparse
 import re
 import sys
@@ -58,9 +58,9 @@ def _list(xs):
     return "[" + ", ".join(str(x) for x in xs) + "]"
 
 
-def _solve(model, args, threads, seconds, fringe="nodup"):
+def _solve(model, args, threads, seconds, fringe="nodup", **solver_kw):
     solver = B.ParallelSolver(model, _width(model, args.width), _cutoff(seconds), nb_threads=threads, device=args.device,
-                              fringe=fringe)
+                              fringe=fringe, **solver_kw)
     t0 = time.perf_counter()
     completion = solver.maximize()
     return solver, completion, time.perf_counter() - t0
@@ -81,10 +81,12 @@ def misp(args):
 
 def knapsack(args):
     model = B.Knapsack.read_instance(args.fname)
-    # The reference parses --duration (default 30) but builds its solver with NoCutoff (knapsack/main.rs:326); its
-    # solver also has a dominance checker and a cache, which this one has not: the budget is honoured here so that a
-    # hard instance at the default width of 2 ends with a gap instead of running for hours.
-    solver, completion, dt = _solve(model, args, args.threads, args.duration)
+    # The reference's knapsack binary (main.rs:320-337) is SeqCachingSolverFc: frontier cut-set + SimpleCache, with
+    # SimpleDominanceChecker(KPDominance) -- the same three pieces here, on the device.  It parses --duration (default 30)
+    # but builds its solver with NoCutoff (main.rs:326); the budget is honoured here so that a hard instance at the
+    # default width of 2 ends with a gap instead of running for hours.
+    solver, completion, dt = _solve(model, args, args.threads, args.duration, cutset_type=B.FRONTIER, cache_entries=1 << 20,
+                                    dominance_entries=1 << 14)
     sol = _sorted_solution(solver)
     _report(dt, completion, solver, _list([d.value for d in sol] if sol is not None else []))
 
