@@ -21,7 +21,7 @@ constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr int CT_EXACT = 0, CT_RELAXED = 1, CT_RESTRICTED = 2;
 
 // EngineParams.model_kind
-constexpr int MODEL_MISP = 0, MODEL_KNAPSACK = 1, MODEL_MCP = 2, MODEL_MAX2SAT = 3;
+constexpr int MODEL_MISP = 0, MODEL_KNAPSACK = 1, MODEL_MCP = 2, MODEL_MAX2SAT = 3, MODEL_TSPTW = 4;
 
 // DDInput.flags
 constexpr uint32_t IN_FUSED = 1u;          // restricted, then (if inexact) relaxed: parallel.rs:391-437 on device
@@ -200,6 +200,14 @@ struct EngineParams {
     // ---- capacity tiers (engine.hpp): a tier engine has node slots for narrow decision diagrams only and never
     // squashes (its layer capacity is below every width it is asked for): a DD that outgrows it reports ST_RETRY and is
     // compiled again by the next tier.  hist_bins < 2048 shrinks the LDS area only the squash phases use.
+    // TSPTW (examples/tsptw): distances [n][n], time windows, cheapest entering edge (dd_tsptw.hpp)
+    const int32_t *tw_dist, *tw_early, *tw_late, *tw_cheap;
+    // TSPTW dominance (examples/tsptw/dominance.rs:26-60): best value per (depth, position, must_visit), same table layout as the cache
+    uint64_t* dkey_tab;
+    uint64_t dkey_cap;
+    unsigned long long* dkey_stats;
+    int32_t fan;               // children per node of the layer-rebuilding engine: 0 / 2 binary models, nb_nodes for TSPTW
+    int32_t dbits;             // bits of a decision index in arc words and path words (1 for binary models)
     int32_t hist_bins;         // 0 = 2048
     int32_t tier;              // 0 = full-width engine, 1 = capacity tier
     // ---- frontier cut-set / thresholds / cache (engine 1, dd_thresholds.hpp): every layer of the DD is kept

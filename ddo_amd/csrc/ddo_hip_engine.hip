@@ -59,11 +59,22 @@ int Model::popcount(const uint64_t* a) const {
 void Model::initial_state(uint64_t* out) const {
     for (int k = 0; k < ws; ++k) out[k] = 0;
     if (kind == MODEL_MCP || kind == MODEL_MAX2SAT) return;                     // mcp/model.rs:51-53, max2sat/model.rs:259-264
+    if (kind == MODEL_TSPTW) {   // tsptw/model.rs:36-47: at the depot (node 0) at time 0, every other node still to visit
+        out[1] = n >= 64 ? ~1ULL : (((1ULL << n) - 1) & ~1ULL);
+        return;
+    }
     if (kind == MODEL_KNAPSACK) out[0] = (uint64_t)kp_capacity;                 // knapsack/main.rs:100-102
     else for (int i = 0; i < n; ++i) out[i / 64] |= 1ULL << (i % 64);           // misp/main.rs:69-71
 }
 int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
     if (kind == MODEL_KNAPSACK) return a[0] < b[0] ? -1 : (a[0] > b[0] ? 1 : 0);   // KPRanking (knapsack/main.rs:187-194)
+    if (kind == MODEL_TSPTW) {   // TsptwRanking (tsptw/heuristics.rs:29-36): the depth; ties: packed words (shared tie-break)
+        const uint64_t da = (a[4] >> 32) & 0xFFFF, db = (b[4] >> 32) & 0xFFFF;
+        if (da != db) return da < db ? -1 : 1;
+        for (int k = 0; k < ws; ++k)
+            if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
+        return 0;
+    }
     if (kind == MODEL_MCP || kind == MODEL_MAX2SAT) {              // McpRanking (mcp/model.rs:154-163), Max2SatRanking
         auto rank = [&](const uint64_t* s) {
             int64_t r = 0;
@@ -173,8 +184,11 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     P.npad = (model->n + 63) / 64 * 64;
     // the terminal layer is never squashed (clean.rs:608-618): MISP ends in at most one node, a knapsack DD in up to 2W
     const long slot_width = owner ? (long)cap_width : max_width;   // what the node slots are sized for
-    P.capN = model->kind != MODEL_MISP ? 2 * (int)slot_width + 3 : (int)slot_width + 2;
-    P.capC1 = 2 * P.capN + 1;
+    P.capN = model->kind == MODEL_TSPTW ? std::max((int)slot_width, model->n) + 2      // layers are squashed to the width, the last one has one child per node
+             : model->kind != MODEL_MISP ? 2 * (int)slot_width + 3 : (int)slot_width + 2;
+    P.fan = model->kind == MODEL_TSPTW ? model->n : 2;
+    P.dbits = model->dbits;
+    P.capC1 = P.fan * P.capN + 1;
     P.max_layers = model->n + 2;
     int tc = 1024;
     while (tc * 2 < P.capC1 * 3 || tc < 2 * P.capN) tc <<= 1;
@@ -218,7 +232,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     if (model->kind != MODEL_MISP) engine_kind_ = 1;   // scalar-state models run on the layer-rebuilding engine
     if (features & ENGINE_KEEP_LAYERS) engine_kind_ = 1;   // frontier cut-set / thresholds / cache need every layer of the DD
     P.tmode = (features & ENGINE_KEEP_LAYERS) ? 1 : 0;
-    P.lstride = P.tmode ? P.capC1 + 1 : P.capN;
+    P.lstride = P.tmode ? std::min(P.capC1 + 1, 4 * P.capN + 2) : P.capN;   // kept + cache-pruned + dominated nodes of a layer
     if (owner && engine_kind_ != 2) {
         set_error("Engine::create_tier: the tier does not fit the in-place engine");
         return DDO_ERR_UNSUPPORTED;
@@ -238,7 +252,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers, wsT = model->wsT;
     size_t per_slot = engine_kind_ == 1
                           ? 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capN * 4 + capC1 * 4 + capC1 +
-                                ml * capN * 4 + 2 * ml * 2 * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
+                                ml * capN * 4 + 2 * ml * (size_t)P.fan * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
                                 (table_lds_ ? 0 : (size_t)P.table_cap * 4)
                           : wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 * (((wsT + 8) / 8) * 8 + ((wsT + 7) / 8) * 8) +
                                 (size_t)P.capS * 12 + capN * 4 + P.ev_cap * 4 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
@@ -301,6 +315,19 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         P.vnk = d_k;
         P.vr = (int32_t)model->initial_value;
     }
+    if (model->kind == MODEL_TSPTW) {
+        auto upi = [&](const std::vector<int32_t>& v, const int32_t*& dst) -> int {
+            int32_t* d = nullptr;
+            int r = dev_alloc(allocs_, d, v.size());
+            if (r) return r;
+            if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return DDO_ERR_INTERNAL;
+            dst = d;
+            return DDO_OK;
+        };
+        if ((rc = upi(model->tw_dist, P.tw_dist)) || (rc = upi(model->tw_early, P.tw_early)) || (rc = upi(model->tw_late, P.tw_late)) ||
+            (rc = upi(model->tw_cheap, P.tw_cheap)))
+            return rc;
+    }
     if (model->kind == MODEL_MAX2SAT) {
         auto up = [&](const std::vector<int32_t>& v, const int32_t*& dst) -> int {
             int32_t* d = nullptr;
@@ -323,7 +350,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         if ((rc = dev_alloc(allocs_, P.ckey, S * 2 * capC1))) return rc;
         if ((rc = dev_alloc(allocs_, P.cpop, S * 2 * capC1))) return rc;
         if ((rc = dev_alloc(allocs_, P.cflags, S * 2 * capC1))) return rc;
-        if ((rc = dev_alloc(allocs_, P.ctarget, S * 2 * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.ctarget, S * (size_t)P.fan * capN))) return rc;
         if ((rc = dev_alloc(allocs_, P.keep, S * (P.tmode ? capC1 : capN)))) return rc;
         if ((rc = dev_alloc(allocs_, P.posmap, S * capC1))) return rc;
         if ((rc = dev_alloc(allocs_, P.cls, S * capC1))) return rc;
@@ -336,8 +363,8 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
             if ((rc = dev_alloc(allocs_, P.lvb, lsz))) return rc;
             if ((rc = dev_alloc(allocs_, P.lth, lsz + S * capC1))) return rc;
         }
-        if ((rc = dev_alloc(allocs_, P.arct, S * ml * 2 * capN))) return rc;
-        if ((rc = dev_alloc(allocs_, P.arcc, S * ml * 2 * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.arct, S * ml * (size_t)P.fan * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.arcc, S * ml * (size_t)P.fan * capN))) return rc;
         if ((rc = dev_alloc(allocs_, P.lddelta, S * ml))) return rc;
     } else {
         const size_t capS = P.capS, capW = P.capW;
@@ -576,12 +603,25 @@ DominanceTable* DominanceTable::create(const Model* model, int device, size_t ca
         set_error("ddo_dominance_create: no such HIP device (the checker lives in device memory: there is no CPU fallback)");
         return nullptr;
     }
-    if (model->kind != MODEL_KNAPSACK) {
-        set_error("ddo_dominance_create: the device checker covers dominance relations keyed by the depth with one coordinate (knapsack)");
+    if (model->kind != MODEL_KNAPSACK && model->kind != MODEL_TSPTW) {
+        set_error("ddo_dominance_create: the device checker covers the dominance relations of the knapsack (KPDominance) and TSPTW "
+                  "(TsptwDominance) examples");
         return nullptr;
     }
     DominanceTable* t = new DominanceTable();
     t->device = device;
+    if (model->kind == MODEL_TSPTW) {
+        size_t cap = 1024;
+        while (cap < capacity_per_depth) cap <<= 1;
+        t->dkey_cap = cap;
+        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&t->dkey, cap * 6 * 8) != hipSuccess ||
+            hipMalloc((void**)&t->stats, 64) != hipSuccess || t->clear() != DDO_OK) {
+            set_error("ddo_dominance_create: could not allocate device memory");
+            delete t;
+            return nullptr;
+        }
+        return t;
+    }
     t->cap = (uint32_t)std::max<size_t>(64, capacity_per_depth);
     t->depths = model->n + 2;
     const size_t nd = (size_t)t->depths;
@@ -596,11 +636,16 @@ DominanceTable* DominanceTable::create(const Model* model, int device, size_t ca
 }
 DominanceTable::~DominanceTable() {
     (void)hipSetDevice(device);
-    for (void* p : {(void*)coord, (void*)value, (void*)count, (void*)lock, (void*)stats})
+    for (void* p : {(void*)coord, (void*)value, (void*)count, (void*)lock, (void*)stats, (void*)dkey})
         if (p) (void)hipFree(p);
 }
 int DominanceTable::clear() {
     HIP_TRY(hipSetDevice(device));
+    if (dkey) {
+        HIP_TRY(hipMemset(dkey, 0, dkey_cap * 6 * 8));
+        HIP_TRY(hipMemset(stats, 0, 64));
+        return DDO_OK;
+    }
     HIP_TRY(hipMemset(count, 0, (size_t)depths * 4));
     HIP_TRY(hipMemset(lock, 0, (size_t)depths * 4));
     HIP_TRY(hipMemset(stats, 0, 64));
@@ -768,7 +813,12 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         P.cache_cap = 0;
     }
     P.dom_cap = 0;
-    if (dom && P_.tmode && dom->device == device_ && dom->depths >= P_.max_layers - 1) {
+    P.dkey_cap = 0;
+    if (dom && P_.tmode && dom->device == device_ && dom->dkey) {
+        P.dkey_tab = dom->dkey;
+        P.dkey_cap = dom->dkey_cap;
+        P.dkey_stats = dom->stats;
+    } else if (dom && P_.tmode && dom->device == device_ && dom->depths >= P_.max_layers - 1) {
         P.dom_coord = dom->coord;
         P.dom_value = dom->value;
         P.dom_count = dom->count;
@@ -1184,6 +1234,67 @@ ddo_model* ddo_model_create_max2sat(int n, size_t nb_clauses, const int64_t* lit
     return m;
 }
 
+ddo_model* ddo_model_create_tsptw(int n, const int64_t* distances, const int64_t* earliest, const int64_t* latest) {
+    if (n < 2 || n > 64 || !distances || !earliest || !latest) {
+        set_error("ddo_model_create_tsptw: 2 <= nb_nodes <= 64 (each of the reference's Set256 fields is one state word)");
+        return nullptr;
+    }
+    int64_t worst = 0;
+    for (int i = 0; i < n; ++i) {
+        int64_t row = 0;
+        for (int j = 0; j < n; ++j) {
+            const int64_t d = distances[(size_t)i * n + j];
+            if (d < 0 || d >= (1LL << 29)) {
+                set_error("ddo_model_create_tsptw: distances must be in [0, 2^29)");
+                return nullptr;
+            }
+            row = std::max(row, d);
+        }
+        worst += row;
+        if (earliest[i] < 0 || latest[i] < 0 || latest[i] >= (1LL << 31) || earliest[i] >= (1LL << 31)) {
+            set_error("ddo_model_create_tsptw: time windows must be in [0, 2^31)");
+            return nullptr;
+        }
+        worst = std::max(worst, latest[i]);
+    }
+    if (worst >= (1LL << 30)) {
+        set_error("ddo_model_create_tsptw: tour lengths must stay below 2^30 (device values are int32)");
+        return nullptr;
+    }
+    ddo_model* m = new ddo_model();
+    Model& M = m->m;
+    M.kind = MODEL_TSPTW;
+    M.n = n;
+    M.ws = 5;
+    M.wsT = pick_ws(5);
+    M.dbits = 6;
+    M.unit_weights = false;
+    M.weight.assign(n, 0);
+    M.weight_abs_sum = worst;
+    M.initial_value = 0;
+    M.tw_dist.resize((size_t)n * n);
+    M.tw_early.resize(n);
+    M.tw_late.resize(n);
+    M.tw_cheap.resize(n);
+    for (size_t i = 0; i < M.tw_dist.size(); ++i) M.tw_dist[i] = (int32_t)distances[i];
+    for (int i = 0; i < n; ++i) {
+        M.tw_early[i] = (int32_t)earliest[i];
+        M.tw_late[i] = (int32_t)latest[i];
+        int64_t c = INT32_MAX;                               // relax.rs:50-63: cheapest edge entering node i
+        for (int j = 0; j < n; ++j)
+            if (j != i) c = std::min<int64_t>(c, distances[(size_t)j * n + i]);
+        M.tw_cheap[i] = (int32_t)c;
+    }
+    return m;
+}
+
+ddo_model* ddo_model_read_tsptw(const char* path) {
+    int n = 0;
+    std::vector<int64_t> d, e, l;
+    if (!path || !read_tsptw(path, n, d, e, l)) return nullptr;
+    return ddo_model_create_tsptw(n, d.data(), e.data(), l.data());
+}
+
 ddo_model* ddo_model_read_max2sat(const char* path) {
     int n = 0;
     std::vector<int64_t> a, b, w;
@@ -1374,7 +1485,7 @@ static int emit_path(const ddo_mdd* mdd, const std::vector<uint32_t>& p, ddo_dec
     }
     size_t k = 0;
     for (const ddo_decision& d : mdd->path_to_root) buf[k++] = d;
-    for (uint32_t x : p) buf[k++] = ddo_decision{(int64_t)(x >> 1), mdd->model->decision_value(x & 1)};
+    for (uint32_t x : p) buf[k++] = mdd->model->path_decision(x);
     *len = need;
     return 1;
 }
@@ -1398,7 +1509,7 @@ int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
         const int plen = r.cs_depth.empty() ? r.cs_path_len : r.cs_depth[i];   // frontier cut-set: nodes of several layers
         for (int k = 0; k < plen; ++k) {
             uint32_t x = r.cs_path[(size_t)i * r.cs_path_len + k];
-            path.push_back(ddo_decision{(int64_t)(x >> 1), mdd->model->decision_value(x & 1)});
+            path.push_back(mdd->model->path_decision(x));
         }
         ddo_subproblem sp;
         sp.state = r.cs_state.data() + (size_t)i * ws;

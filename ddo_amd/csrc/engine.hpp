@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/ddo_hip.h"
 #include "dd_types.h"
 
 namespace ddo_hip {
@@ -43,7 +44,16 @@ struct Model {
     std::vector<int32_t> m2_order, m2_rankpos;   // vars_by_sum_of_clause_weights and its inverse
     void initial_state(uint64_t* out) const;   // Problem::initial_state
     /// decision value of the device's decision bit: MISP / knapsack 0 | 1, MCP +1 (side S) | -1 (side T)
-    int64_t decision_value(uint32_t bit) const { return (kind == MODEL_MCP || kind == MODEL_MAX2SAT) ? (bit ? -1 : 1) : (int64_t)bit; }
+    int64_t decision_value(uint32_t bit) const { return (kind == MODEL_MCP || kind == MODEL_MAX2SAT) ? (bit ? -1 : 1) : (int64_t)bit; }   // TSPTW: the node index itself
+    /// decisions on the device wire: (variable << dbits) | decision index (binary models: 1 bit; TSPTW: the node, 6 bits)
+    int dbits = 1;
+    ddo_decision path_decision(uint32_t x) const { return ddo_decision{(int64_t)(x >> dbits), decision_value(x & ((1u << dbits) - 1u))}; }
+    uint32_t path_word(const ddo_decision& d) const {
+        const uint32_t idx = kind == MODEL_TSPTW ? (uint32_t)d.value : (decision_value(1) == d.value ? 1u : 0u);
+        return ((uint32_t)d.variable << dbits) | idx;
+    }
+    // TSPTW (examples/tsptw): distance matrix and time windows in 1/10000 units (instance.rs:87-98), cheapest entering edges
+    std::vector<int32_t> tw_dist, tw_early, tw_late, tw_cheap;
 
     std::mutex mtx;
     std::map<std::pair<int, long>, std::weak_ptr<class Engine>> engines;  // (device, max_width)
@@ -77,6 +87,10 @@ struct DominanceTable {
     unsigned long long* stats = nullptr;
     uint32_t cap = 0;
     int depths = 0;
+    // TSPTW (TsptwDominance, examples/tsptw/dominance.rs:26-60): best value per (depth, position, must_visit) -- a hash table with
+    // the cache's entry layout, 3 key words
+    uint64_t* dkey = nullptr;
+    uint64_t dkey_cap = 0;
     ~DominanceTable();
     static DominanceTable* create(const Model* model, int device, size_t capacity_per_depth);
     int clear();
@@ -240,6 +254,9 @@ bool read_mcp(const std::string& path, int& n, std::vector<int64_t>& adj);
 /// Reads a weighted MAX2SAT instance the way examples/max2sat/data.rs:67-116 does: clause k = (lit_a[k], lit_b[k], weight[k]),
 /// unit clauses with lit_a == lit_b, in file order (a clause listed twice keeps its last weight: the caller applies that).
 bool read_max2sat(const std::string& path, int& n, std::vector<int64_t>& lit_a, std::vector<int64_t>& lit_b, std::vector<int64_t>& weight);
+/// Reads a TSPTW instance the way examples/tsptw/instance.rs:52-109 does: nb_nodes, the distance matrix, one time window per node;
+/// every number is `(f32 * 10000.0) as usize`.
+bool read_tsptw(const std::string& path, int& n, std::vector<int64_t>& dist, std::vector<int64_t>& earliest, std::vector<int64_t>& latest);
 
 }  // namespace ddo_hip
 

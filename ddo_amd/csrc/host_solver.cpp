@@ -75,7 +75,7 @@ void materialize_path(const Model* model, const CutsetBlock* b, int row, std::ve
         const uint32_t* p = blk->paths.data() + (size_t)it->second * blk->path_len;
         const int plen = blk->row_len.empty() ? blk->path_len : blk->row_len[(size_t)it->second];
         // rows are stored node first (towards the parent): a frontier row uses the first plen entries of its stride
-        for (int k = 0; k < plen; ++k) out.push_back(ddo_decision{(int64_t)(p[k] >> 1), model->decision_value(p[k] & 1)});
+        for (int k = 0; k < plen; ++k) out.push_back(model->path_decision(p[k]));
     }
 }
 
@@ -518,11 +518,13 @@ struct ddo_solver {
     }
 
     long engine_width() const {
+        if (cfg.width_policy == DDO_WIDTH_TSPTW) return (long)model->n * (long)model->n * (long)std::max<size_t>(1, cfg.width);
         return cfg.width_policy == DDO_WIDTH_FIXED ? (long)cfg.width : (long)std::max(1, model->n);
     }
     /// WidthHeuristic::max_width (width.rs:168-170 / :399-401; path.len() == depth for MISP)
     int width_of(const Entry& e) const {
         if (cfg.width_policy == DDO_WIDTH_FIXED) return (int)cfg.width;
+        if (cfg.width_policy == DDO_WIDTH_TSPTW) return model->n * (e.depth + 1) * (int)std::max<size_t>(1, cfg.width);   // tsptw/heuristics.rs:48-52
         return std::max(1, model->n - e.depth);
     }
     bool budget_exhausted() const {
@@ -556,7 +558,7 @@ struct ddo_solver {
             best_sol.clear();
             materialize_path(model, it.block, it.row, best_sol);
             const std::vector<uint32_t>& p = r.hdr.exact_same_as_best ? r.best_path : r.exact_path;
-            for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), model->decision_value(x & 1)});
+            for (uint32_t x : p) best_sol.push_back(model->path_decision(x));
             has_sol = true;
         }
     }
@@ -766,8 +768,7 @@ struct ddo_solver {
                 b->paths.resize((size_t)b->path_len);
                 for (int k = 0; k < b->path_len; ++k) {
                     const ddo_decision& d = paths[path_off[i] + (size_t)k];
-                    const uint32_t bit = model->decision_value(1) == d.value ? 1u : 0u;
-                    b->paths[(size_t)k] = ((uint32_t)d.variable << 1) | bit;
+                    b->paths[(size_t)k] = model->path_word(d);
                 }
                 block_ref(b);
                 fringe->push(Entry{b, 0, b->depth, value[i], ub[i], hash_words(b->states.data(), ws)});
@@ -832,7 +833,7 @@ struct ddo_solver {
                     best_sol.clear();
                     if ((err = materialize_pool_path(its[i].block, its[i].row, best_sol)) != DDO_OK) break;
                     const std::vector<uint32_t>& p = r->hdr.exact_same_as_best ? r->best_path : r->exact_path;
-                    for (uint32_t x : p) best_sol.push_back(ddo_decision{(int64_t)(x >> 1), model->decision_value(x & 1)});
+                    for (uint32_t x : p) best_sol.push_back(model->path_decision(x));
                     has_sol = true;
                 }
                 const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;

@@ -123,6 +123,7 @@ __device__ __forceinline__ uint64_t dd_brev(uint64_t x) { return __brevll(x); }
 #endif
 
 #include "dd_thresholds.hpp"
+#include "dd_tsptw.hpp"
 
 namespace ddo_hip {
 
@@ -191,6 +192,11 @@ struct DDCtx {
     const int32_t *m2_wtt, *m2_wtf, *m2_wft, *m2_wff, *m2_order, *m2_rankpos;
     // capacity
     int capN, capC1, max_layers;
+    TwModel tw;          // TSPTW tables (kind == MODEL_TSPTW)
+    uint64_t* dkey_tab;  // TSPTW dominance: (depth, position, must_visit) -> best value
+    uint64_t dkey_cap;
+    unsigned long long* dkey_stats;
+    int fan, dbits;      // children per node (2; TSPTW: nb_nodes) and the bits a decision index takes in arc / path words
     // slot workspace
     uint64_t* cstate[2];
     uint64_t* ckey[2];
@@ -315,6 +321,8 @@ DDO_DEV int32_t vec_rank(const uint64_t* s, int n, int from) {
 /// items in ratio order; the only floating point on the path: cap/weight * profit, floored)
 template <int WS>
 DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth) {
+    if constexpr (WS >= 5)
+        if (c.kind == MODEL_TSPTW) return tw_rub(c.tw, s);
     if (c.kind == MODEL_MCP)   // mcp/relax.rs:123-130
         return vec_rank<WS>(s, c.n, depth) + c.vest[depth] - c.vr + c.vnk[depth];
     if (c.kind == MODEL_MAX2SAT) {   // max2sat/model.rs:231-240; a complete assignment (depth n) has nothing left to gain
@@ -359,9 +367,9 @@ DDO_DEV bool cand_live(const Ctx& c, int cur, int cd) {
     return c.ctarget[cd] == (uint32_t)cd && !(c.tmode && (c.cflags[cur][cd] & (NF_CACHE | NF_DOM)));
 }
 
-/// candidate numbering: NO-children of parent position p live at p, YES-children at capN + p,
-/// the merged node of a relaxed layer at 2*capN.
-DDO_DEV int lin2cand(int j, int nprev, int capN) { return j < nprev ? j : capN + (j - nprev); }
+/// candidate numbering: the child of parent position p under decision index d lives at d * capN + p (binary models:
+/// NO-children at p, YES-children at capN + p), the merged node of a relaxed layer at fan * capN.
+DDO_DEV int lin2cand(int j, int nprev, int capN) { return (j / nprev) * capN + (j % nprev); }
 
 /// 64-bit primary ranking key: (value_top, secondary rank) -- clean.rs:803-808, then the model's StateRanking where it is a
 /// number: MispRanking's len() (popcount), 0 for knapsack, later the 32-bit rank of the signed-vector models.
@@ -407,7 +415,7 @@ template <int WS>
 DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
     DD_TID_SETUP(c)
     DDShared* sh = c.sh;
-    const int ncl = 2 * nprev;
+    const int ncl = c.fan * nprev;
     const int q = (ncl + NT - 1) / NT;
     const uint64_t* key = c.ckey[cur];
     const uint32_t* pop = c.cpop[cur];
@@ -623,7 +631,7 @@ DDO_DEV void dominance_filter(Ctx& c, int cur, int nprev, int depth) {
     DD_TID_SETUP(c)
     auto* sh = c.sh;
     const int capN = c.capN;
-    const int ncl = 2 * nprev;
+    const int ncl = c.fan * nprev;
     uint32_t* order = c.keep;                 // free until the positions are assigned (capC1 entries with kept layers)
     PAR_BEGIN
     if (tid == 0) sh->scan_total = 0;
@@ -723,17 +731,19 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     DDShared* sh = c.sh;
     const int capN = c.capN, capC1 = c.capC1;
     const int W = in.width;
-    const int MERGED = 2 * capN;
+    const int MERGED = c.fan * capN;
     const bool relaxed = comp_type == CT_RELAXED;
     const bool restricted = comp_type == CT_RESTRICTED;
+    const uint32_t dmask = (1u << c.dbits) - 1u;
     const int LS = c.tmode ? c.lstride : capN;                        // nodes per layer in the per-layer arrays
     const bool frontier = c.tmode && (in.flags & IN_FRONTIER) != 0;   // CUTSET_TYPE == FRONTIER
     const bool use_cache = c.tmode && (in.flags & IN_CACHE) != 0 && c.cache_cap != 0;
     const bool use_dom = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dom_cap != 0 && c.kind == MODEL_KNAPSACK;
+    const bool use_dkey = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dkey_cap != 0 && c.kind == MODEL_TSPTW;
 
     // ---------------------------------------------------------------- _clear + _initialize
     int cur = 0;
-    const int hsize = table_size_for(2 * (W + 2) + 1, c.table_cap);
+    const int hsize = table_size_for(c.fan * (W + 2) + 1, c.table_cap);
     const int hmask = hsize - 1;
     PAR_BEGIN
     for (int i = tid; i < c.npad; i += NT) c.cnt[i] = 0;
@@ -756,7 +766,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         c.cpop[0][0] = (uint32_t)pop;
         c.cflags[0][0] = 0;
         c.ctarget[0] = 0;        // the root is its own "winner"
-        c.ctarget[capN] = NONE32;
+        for (int d = 1; d < c.fan; ++d) c.ctarget[(size_t)d * capN] = NONE32;
     }
     PAR_END
     PAR_BEGIN
@@ -782,7 +792,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         PAR_BEGIN
         if (c.kind != MODEL_MISP) {   // static order (knapsack/main.rs:118-125, mcp/model.rs:88-96); an empty layer ends the DD
             if (tid == 0 && c.depth0 + L < c.n && sh->nU > 0)
-                sh->varkey = c.kind == MODEL_MCP       ? (uint32_t)(c.depth0 + L)
+                sh->varkey = (c.kind == MODEL_MCP || c.kind == MODEL_TSPTW) ? (uint32_t)(c.depth0 + L)   // tsptw/model.rs:140-147
                              : c.kind == MODEL_MAX2SAT ? (uint32_t)c.m2_order[c.n - (c.depth0 + L) - 1]   // model.rs:330-346
                                                        : (uint32_t)c.kp_order[c.depth0 + L];
         } else {
@@ -811,7 +821,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (tid == 0) sh->ncache = 0;
             PAR_END
             PAR_BEGIN
-            const int nclx = 2 * nprev;
+            const int nclx = c.fan * nprev;
             for (int j = tid; j < nclx; j += NT) {
                 const int cd = lin2cand(j, nprev, capN);
                 if (c.ctarget[cd] != (uint32_t)cd) continue;
@@ -847,6 +857,46 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             ncache = sh->ncache;
             (void)before;
         }
+        if (use_dkey) {
+            // TsptwDominance (examples/tsptw/dominance.rs:26-60): states with the same (position, must_visit) compare on their
+            // value alone.  The reference walks curr_l best value first, so a node is dominated exactly when the best value
+            // recorded for its key -- by earlier compiles or by this layer -- is larger than its own: record all, then test.
+            if (ncache == 0) {
+                PAR_BEGIN
+                if (tid == 0) sh->ncache = 0;
+                PAR_END
+            }
+            struct { uint64_t* cache_tab; uint64_t cache_cap; int cache_stride; unsigned long long* cache_stats; } dk{c.dkey_tab, c.dkey_cap, 6, c.dkey_stats};
+            const int nclx = c.fan * nprev;
+            PAR_BEGIN
+            for (int j = tid; j < nclx; j += NT) {
+                const int cd = lin2cand(j, nprev, capN);
+                if (!cand_live(c, cur, cd) || (LD_U32(&c.cflags[cur][cd]) & (NF_INEXACT | NF_RELAXED))) continue;
+                const uint64_t w4 = c.cstate[cur][(size_t)4 * capC1 + cd];
+                const uint64_t key3[3] = {(w4 & TW_VIRTUAL) ? c.cstate[cur][cd] : (w4 & 0xFFFF), (w4 & TW_VIRTUAL) ? 1ULL : 0ULL,
+                                          c.cstate[cur][(size_t)1 * capC1 + cd]};
+                cache_update<3>(dk, key3, c.depth0 + L, th_pack(unbias32((uint32_t)(LD_U64(&c.ckey[cur][cd]) >> 32)), false));
+            }
+            PAR_END
+            PAR_BEGIN
+            for (int j = tid; j < nclx; j += NT) {
+                const int cd = lin2cand(j, nprev, capN);
+                if (!cand_live(c, cur, cd) || (LD_U32(&c.cflags[cur][cd]) & (NF_INEXACT | NF_RELAXED))) continue;
+                const uint64_t w4 = c.cstate[cur][(size_t)4 * capC1 + cd];
+                const uint64_t key3[3] = {(w4 & TW_VIRTUAL) ? c.cstate[cur][cd] : (w4 & 0xFFFF), (w4 & TW_VIRTUAL) ? 1ULL : 0ULL,
+                                          c.cstate[cur][(size_t)1 * capC1 + cd]};
+                int64_t packed = 0;
+                if (!cache_get<3>(dk, key3, c.depth0 + L, &packed)) continue;
+                const int32_t best = th_value(packed), val = unbias32((uint32_t)(LD_U64(&c.ckey[cur][cd]) >> 32));
+                if (best > val) {                                   // dominated: only the value differs -> threshold value - 1
+                    c.cflags[cur][cd] = LD_U32(&c.cflags[cur][cd]) | NF_DOM;
+                    c.cth[cd] = best - 1;
+                    LDS_ADD_I32(&sh->ncache, 1);
+                }
+            }
+            PAR_END
+            ncache = sh->ncache;
+        }
         const int nU = sh->nU - ncache;                               // |curr_l| after the filters
 
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
@@ -858,7 +908,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             failed = true;
             break;
         }
-        const int ncl = 2 * nprev;
+        const int ncl = c.fan * nprev;
         const int q = (ncl + NT - 1) / NT;
         int K = 0;
         if (squash) {
@@ -886,6 +936,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (tid == 0) {
             sh->mergedKey = 0;
             for (int k = 0; k < WS; ++k) sh->merged[k] = 0;
+            if (c.kind == MODEL_TSPTW) {
+                sh->merged[1] = ~0ULL;      // intersection of the must-visit sets
+                sh->vmin[0] = 0xFFFFFFFFu;  // earliest elapsed time
+            }
             if (dd_is_vec(c.kind)) {
                 for (int v = 0; v < MAX_VEC_VARS; ++v) sh->vmin[v] = 0xFFFFFFFFu;
                 for (int q = 0; q < (MAX_VEC_VARS + 63) / 64; ++q) sh->vposmask[q] = sh->vnegmask[q] = 0;
@@ -953,6 +1007,19 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                             const uint64_t akey = ((uint64_t)bias32(adj) << 32) | (uint32_t)key;
                             if (akey > mkey) mkey = akey;
                             anydel = true;
+                        } else if (relaxed && c.kind == MODEL_TSPTW) {
+                            // TsptwRelax::merge (relax.rs:65-191): union of the positions, intersection / union of the must-visit
+                            // sets, union of the maybe-visit sets, earliest and latest elapsed time
+                            if constexpr (WS >= 5) {
+                                LDS_OR_U64(&sh->merged[0], (s[4] & TW_VIRTUAL) ? s[0] : (1ULL << (s[4] & 0xFFFF)));
+                                LDS_AND_U64(&sh->merged[1], s[1]);
+                                LDS_OR_U64(&sh->merged[2], s[1]);
+                                if (s[4] & TW_MAYBE) LDS_OR_U64(&sh->merged[3], s[2]);
+                                LDS_MIN_U32(&sh->vmin[0], tw_earliest(s));
+                                LDS_MAX_I32(&sh->mrank, (int32_t)tw_latest(s));
+                            }
+                            if (key > mkey) mkey = key;
+                            anydel = true;
                         } else if (relaxed) {
                             if (c.kind == MODEL_KNAPSACK) {   // KPRelax::merge: the largest capacity (main.rs:150-152)
 #pragma unroll
@@ -973,7 +1040,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         c.tcount[tid] = kept;
         if (anydel) {
-            if (dd_is_vec(c.kind)) {
+            if (dd_is_vec(c.kind) || c.kind == MODEL_TSPTW) {
                 // reductions already done per victim
             } else if (c.kind == MODEL_KNAPSACK) {
 #pragma unroll
@@ -1014,6 +1081,20 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (tid == 0) {
                 uint64_t ms[WS];
                 for (int k = 0; k < WS; ++k) ms[k] = sh->merged[k];
+                if (c.kind == MODEL_TSPTW) {   // RelaxHelper::get_* (relax.rs:120-166)
+                    const uint64_t pos = sh->merged[0], agree = sh->merged[1], all_must = sh->merged[2], all_maybe = sh->merged[3];
+                    const uint32_t e = sh->vmin[0], l = (uint32_t)sh->mrank;
+                    const uint64_t maybe = (all_maybe | all_must) & ~agree;
+                    for (int k = 0; k < WS; ++k) ms[k] = 0;
+                    if constexpr (WS >= 5) {
+                        ms[0] = pos;
+                        ms[1] = agree;
+                        ms[2] = maybe;
+                        ms[3] = (uint64_t)e | ((uint64_t)(e != l ? l : e) << 32);
+                        ms[4] = TW_VIRTUAL | (e != l ? TW_FUZZY : 0) | (maybe ? TW_MAYBE : 0) | ((uint64_t)(c.depth0 + L) << 32);
+                    }
+                    sh->mrank = 0;
+                }
                 if (dd_is_vec(c.kind)) {
                     // merged benefit: all signs agree -> the value closest to zero, else 0 (relax.rs:141-176)
                     int32_t mrank = 0;
@@ -1158,9 +1239,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             uint32_t w;
             if (arc == NONE32) w = NI_NOARC;
             else {
-                uint32_t d = arc >= (uint32_t)capN ? 1u : 0u;
+                uint32_t d = arc / (uint32_t)capN;            // decision index of the best arc, parent position
                 uint32_t pp = arc - d * (uint32_t)capN;
-                w = (pp << 1) | d;
+                w = (pp << c.dbits) | d;
             }
             if (fl & NF_INEXACT) w |= NI_INEXACT;
             if (fl & NF_RELAXED) w |= NI_RELAXED;
@@ -1170,8 +1251,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         // arcs entering this layer, translated to node positions (needed by the backward pass)
         if (((relaxed && lel >= 0) || c.tmode) && L >= 1) {
-            uint32_t* at = c.arct + (size_t)L * 2 * capN;
-            int32_t* ac = c.arcc + (size_t)L * 2 * capN;
+            uint32_t* at = c.arct + (size_t)L * c.fan * capN;
+            int32_t* ac = c.arcc + (size_t)L * c.fan * capN;
             for (int j = tid; j < ncl; j += NT) {
                 int cd = lin2cand(j, nprev, capN);
                 uint32_t t = c.ctarget[cd];
@@ -1204,7 +1285,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         const uint64_t vbit = 1ULL << (var & 63);
         const int32_t wv = c.weight[var];
         const uint64_t kpw = kp ? (uint64_t)c.kp_weight[var] : 0;
-        int32_t* ac_next = c.arcc + (size_t)(L + 1) * 2 * capN;   // costs of the arcs entering layer L + 1
+        int32_t* ac_next = c.arcc + (size_t)(L + 1) * c.fan * capN;   // costs of the arcs entering layer L + 1
         int myarcs = 0, myuniq = 0;
         for (int pos = tid; pos < n; pos += NT) {
             const uint32_t p = c.keep[pos];
@@ -1220,10 +1301,43 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             const uint32_t pok = (!inexact || (!(pfl & NF_RELAXED) && (uint32_t)pkey != NONE32 && ((uint32_t)pkey & KEY_OK))) ? KEY_OK : 0u;
             const int32_t rub = rub_of<WS>(c, s, pop, c.depth0 + L);
             if (c.tmode) c.lrub[(size_t)L * LS + pos] = rub;   // node.rub (clean.rs:363), read again by _compute_thresholds
-            if ((int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded
+            if (rub == RUB_NEG_INF || (int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded (isize::MIN + value saturates)
                 if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);
-                c.ctarget[pos] = NONE32;
-                c.ctarget[capN + pos] = NONE32;
+                for (int d = 0; d < c.fan; ++d) c.ctarget[(size_t)d * capN + pos] = NONE32;
+                continue;
+            }
+            if (WS >= 5 && c.kind == MODEL_TSPTW) {
+                // examples/tsptw/model.rs:65-139: one child per node the salesman may visit next; decision index = node
+                uint64_t dom = 0;
+                if constexpr (WS >= 5) dom = tw_domain(c.tw, s);
+                for (int j = 0; j < c.fan; ++j) {
+                    const uint32_t cd = (uint32_t)((size_t)j * capN + pos);
+                    if (!((dom >> j) & 1ULL)) {
+                        c.ctarget[cd] = NONE32;
+                        continue;
+                    }
+                    uint64_t y[WS];
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) y[k] = 0;
+                    int32_t cost = 0;
+                    if constexpr (WS >= 5) tw_transition(c.tw, s, j, y, &cost);
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
+                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
+                    c.ckey[nxt][cd] = mykey;
+                    ac_next[cd] = cost;
+                    c.cpop[nxt][cd] = 0;                       // TsptwRanking compares depths: equal within a layer
+                    c.cflags[nxt][cd] = inexact;
+                    FENCE_BLOCK();
+                    const uint32_t w = dedup_insert<WS>(c, nxt, cd, y, hmask);
+                    c.ctarget[cd] = w;
+                    ++myarcs;
+                    if (w == cd) ++myuniq;
+                    else {
+                        GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
+                        if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
+                    }
+                }
                 continue;
             }
             if (c.kind == MODEL_MAX2SAT) {
@@ -1453,7 +1567,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     int n_layers = L;
     int nT = 0;          // nodes of the terminal layer
     const int nU = sh->nU;
-    const int ncl = 2 * nprev;
+    const int ncl = c.fan * nprev;
     const int q = (ncl + NT - 1) / NT;
     if (!failed && nU > (c.tmode ? LS : capN)) {
         PAR_BEGIN
@@ -1519,8 +1633,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             uint32_t w;
             if (arc == NONE32) w = NI_NOARC;
             else {
-                uint32_t d = arc >= (uint32_t)capN ? 1u : 0u;
-                w = ((arc - d * (uint32_t)capN) << 1) | d;
+                uint32_t d = arc / (uint32_t)capN;
+                w = ((arc - d * (uint32_t)capN) << c.dbits) | d;
             }
             if (fl & NF_INEXACT) w |= NI_INEXACT;
             if (fl & NF_RELAXED) w |= NI_RELAXED;
@@ -1534,7 +1648,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (!(fl & (NF_INEXACT | NF_RELAXED))) LDS_MAX_U64(&sh->bestExactKey, bk + 1);
         }
         if (((relaxed && lel >= 0) || c.tmode) && L >= 1) {
-            uint32_t* at = c.arct + (size_t)L * 2 * capN;
+            uint32_t* at = c.arct + (size_t)L * c.fan * capN;
             for (int j = tid; j < ncl; j += NT) {
                 int cd = lin2cand(j, nprev, capN);
                 uint32_t t = c.ctarget[cd];
@@ -1613,11 +1727,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             for (int Lc = T; Lc >= 1; --Lc) {
                 const int nP = c.nlayer[Lc - 1];
                 PAR_BEGIN
-                const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
-                const int32_t* ac = c.arcc + (size_t)Lc * 2 * capN;
+                const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
+                const int32_t* ac = c.arcc + (size_t)Lc * c.fan * capN;
                 const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
-                for (int j = tid; j < 2 * nP; j += NT) {
-                    const int d = j >= nP ? 1 : 0;
+                for (int j = tid; j < c.fan * nP; j += NT) {
+                    const int d = j / nP;
                     const int pp = j - d * nP;
                     const uint32_t t = at[d * capN + pp];
                     if (t == NONE32) continue;
@@ -1641,10 +1755,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             } else {
                 for (int Lc = 1; Lc <= T; ++Lc) {
                     const int nP = c.nlayer[Lc - 1];
-                    const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
+                    const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
                     const int dfrom = c.ldup[2 * Lc];
-                    for (int j = tid; j < 2 * nP; j += NT) {
-                        const int d = j >= nP ? 1 : 0;
+                    for (int j = tid; j < c.fan * nP; j += NT) {
+                        const int d = j / nP;
                         const int pp = j - d * nP;
                         const uint32_t t = at[d * capN + pp];
                         if (t == NONE32) continue;
@@ -1678,7 +1792,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     const bool nex = !(w & (NI_INEXACT | NI_RELAXED));
                     const int32_t val = c.lval[li], rub = c.lrub[li];
                     int32_t th = LD_I32(&c.lth[li]);
-                    if (rub != INT32_MAX && !bk_min && (int64_t)val + rub <= (int64_t)bk) {
+                    if (rub == RUB_NEG_INF) {
+                        th = TH_INF;                                   // value (+sat) isize::MIN <= anything; best_known (-sat) MIN is huge
+                    } else if (rub != INT32_MAX && !bk_min && (int64_t)val + rub <= (int64_t)bk) {
                         th = bk - rub;
                     } else if (w & NI_CUTSET) {
                         const int32_t vb = LD_I32(&c.lvb[li]);
@@ -1708,11 +1824,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 if (Lc == 0) break;
                 const int nP = c.nlayer[Lc - 1];
                 PAR_BEGIN
-                const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
-                const int32_t* ac = c.arcc + (size_t)Lc * 2 * capN;
+                const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
+                const int32_t* ac = c.arcc + (size_t)Lc * c.fan * capN;
                 const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
-                for (int j = tid; j < 2 * nP; j += NT) {
-                    const int d = j >= nP ? 1 : 0;
+                for (int j = tid; j < c.fan * nP; j += NT) {
+                    const int d = j / nP;
                     const int pp = j - d * nP;
                     const uint32_t t = at[d * capN + pp];
                     if (t == NONE32) continue;
@@ -1739,11 +1855,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             for (int pos = tid; pos < nP; pos += NT) vbB[pos] = VB_UNMARKED;
             PAR_END
             PAR_BEGIN
-            const uint32_t* at = c.arct + (size_t)Lc * 2 * capN;
-            const int32_t* ac = c.arcc + (size_t)Lc * 2 * capN;
+            const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
+            const int32_t* ac = c.arcc + (size_t)Lc * c.fan * capN;
             const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
-            for (int j = tid; j < 2 * nP; j += NT) {
-                const int d = j >= nP ? 1 : 0;
+            for (int j = tid; j < c.fan * nP; j += NT) {
+                const int d = j / nP;
                 const int pp = j - d * nP;
                 const uint32_t t = at[d * capN + pp];
                 if (t == NONE32) continue;
@@ -1863,8 +1979,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             for (int Lc = n_layers - 1, i = 0; Lc >= 1; --Lc, ++i) {
                 uint32_t w = c.ninfo[(size_t)Lc * LS + p];
                 uint32_t arc = w & NI_ARC_MASK;
-                out[i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
-                p = (int)(arc >> 1);
+                out[i] = ((uint32_t)c.lvar[Lc - 1] << c.dbits) | (arc & dmask);
+                p = (int)(arc >> c.dbits);
             }
         }
         if (tid == 64 % NT && exact_len) {
@@ -1873,8 +1989,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             for (int Lc = n_layers - 1, i = 0; Lc >= 1; --Lc, ++i) {
                 uint32_t w = c.ninfo[(size_t)Lc * LS + p];
                 uint32_t arc = w & NI_ARC_MASK;
-                out[i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
-                p = (int)(arc >> 1);
+                out[i] = ((uint32_t)c.lvar[Lc - 1] << c.dbits) | (arc & dmask);
+                p = (int)(arc >> c.dbits);
             }
         }
         // cut-set nodes (clean.rs:421-443)
@@ -1904,8 +2020,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     int p = pos;
                     for (int Lw = Lc, i = 0; Lw >= 1; --Lw, ++i) {
                         const uint32_t arc = c.ninfo[(size_t)Lw * LS + p] & NI_ARC_MASK;
-                        o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lw - 1] << 1) | (arc & 1u);
-                        p = (int)(arc >> 1);
+                        o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lw - 1] << c.dbits) | (arc & dmask);
+                        p = (int)(arc >> c.dbits);
                     }
                 }
         } else if (want_cutset && ncut) {
@@ -1933,8 +2049,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int Lc = lel, i = 0; Lc >= 1; --Lc, ++i) {
                     uint32_t w = c.ninfo[(size_t)Lc * LS + p];
                     uint32_t arc = w & NI_ARC_MASK;
-                    o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lc - 1] << 1) | (arc & 1u);
-                    p = (int)(arc >> 1);
+                    o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lc - 1] << c.dbits) | (arc & dmask);
+                    p = (int)(arc >> c.dbits);
                 }
             }
         }
@@ -2085,13 +2201,15 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
         c.cpop[b] = P.cpop + (s * 2 + b) * capC1;
         c.cflags[b] = P.cflags + (s * 2 + b) * capC1;
     }
-    c.ctarget = P.ctarget + s * 2 * capN;
+    c.fan = P.fan > 2 ? P.fan : 2;
+    c.dbits = P.fan > 2 ? P.dbits : 1;
+    c.ctarget = P.ctarget + s * (size_t)c.fan * capN;
     c.keep = P.keep + s * capN;
     c.posmap = P.posmap + s * capC1;
     c.cls = P.cls + s * capC1;
     c.ninfo = P.ninfo + s * ml * capN;
-    c.arct = P.arct + s * ml * 2 * capN;
-    c.arcc = P.arcc + s * ml * 2 * capN;
+    c.arct = P.arct + s * ml * (size_t)c.fan * capN;
+    c.arcc = P.arcc + s * ml * (size_t)c.fan * capN;
     c.nlayer = P.nlayer + s * ml;
     c.lvar = P.lvar + s * ml;
     c.ldup = P.ldup + s * ml * 2;
@@ -2125,6 +2243,10 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.dom_lock = P.dom_lock;
     c.dom_cap = P.tmode ? P.dom_cap : 0;
     c.dom_stats = P.dom_stats;
+    c.tw = TwModel{P.n, P.tw_dist, P.tw_early, P.tw_late, P.tw_cheap};
+    c.dkey_tab = P.dkey_tab;
+    c.dkey_cap = P.tmode ? P.dkey_cap : 0;
+    c.dkey_stats = P.dkey_stats;
     unsigned char* p = lds;
     if (TLDS) {
         c.table = (uint32_t*)p;

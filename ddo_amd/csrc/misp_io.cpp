@@ -259,4 +259,62 @@ bool read_max2sat(const std::string& path, int& n, std::vector<int64_t>& lit_a, 
     return true;
 }
 
+/// examples/tsptw/instance.rs:52-109.  Lines are trimmed; empty lines and lines starting with '#' are skipped; the first
+/// remaining line starts with the number of nodes, the next nb_nodes lines are the rows of the distance matrix, every later
+/// line is "earliest latest".  A number x becomes `(x as f32 * 10000.0) as usize`: single-precision product, truncated
+/// towards zero, negative or NaN -> 0.
+static int64_t tsptw_fixed(const std::string& tok) {
+    const float v = std::strtof(tok.c_str(), nullptr);
+    const float m = v * 10000.0f;
+    if (!(m > 0.0f)) return 0;
+    return (int64_t)m;
+}
+bool read_tsptw(const std::string& path, int& n, std::vector<int64_t>& dist, std::vector<int64_t>& earliest, std::vector<int64_t>& latest) {
+    std::ifstream f(path);
+    if (!f) {
+        set_error("cannot open " + path);
+        return false;
+    }
+    n = 0;
+    dist.clear();
+    earliest.clear();
+    latest.clear();
+    long lc = 0;
+    std::string line;
+    while (std::getline(f, line)) {
+        const size_t b = line.find_first_not_of(" \t\r\n"), e = line.find_last_not_of(" \t\r\n");
+        if (b == std::string::npos) continue;
+        line = line.substr(b, e - b + 1);
+        if (line[0] == '#') continue;
+        std::istringstream ss(line);
+        std::string tok;
+        if (lc == 0) {
+            ss >> tok;
+            n = (int)std::strtol(tok.c_str(), nullptr, 10);
+            if (n < 1 || n > 65535) {
+                set_error("malformed tsptw instance " + path);
+                return false;
+            }
+            dist.assign((size_t)n * n, 0);
+        } else if (lc <= n) {
+            int j = 0;
+            while (ss >> tok) {
+                if (j < n) dist[(size_t)(lc - 1) * n + j] = tsptw_fixed(tok);
+                ++j;
+            }
+        } else {
+            std::string a, c;
+            ss >> a >> c;
+            earliest.push_back(tsptw_fixed(a));
+            latest.push_back(tsptw_fixed(c));
+        }
+        lc += 1;
+    }
+    if (n < 1 || (int)earliest.size() < n) {
+        set_error("malformed tsptw instance " + path);
+        return false;
+    }
+    return true;
+}
+
 }  // namespace ddo_hip

@@ -140,6 +140,18 @@ ddo_model* ddo_model_read_mcp(const char* path);
 ddo_model* ddo_model_create_max2sat(int n, size_t nb_clauses, const int64_t* lit_a, const int64_t* lit_b, const int64_t* weight);
 /** Reads a .wcnf file exactly as examples/max2sat/data.rs:67-116 does. */
 ddo_model* ddo_model_read_max2sat(const char* path);
+/** TSPTW (examples/tsptw/{instance,state,model,relax,heuristics,dominance}.rs: `Tsptw`, `TsptwRelax`, `TsptwRanking`).
+ *  `distances`: nb_nodes x nb_nodes travel times, `earliest` / `latest`: one time window per node, all in the reference's
+ *  fixed-point unit (1/10000, instance.rs:87-98); node 0 is the depot; 2 <= nb_nodes <= 64.  Variable k is the k-th move of
+ *  the tour, its decision value the node visited (up to nb_nodes children per DD node; the last move returns to 0); the
+ *  objective is MINUS the arrival time back at the depot (travel + waiting).  The state is `TsptwState { position,
+ *  elapsed, must_visit, maybe_visit, depth }` (state.rs:34-69) in 5 words:
+ *    [0] Position::Virtual(set) as a node bit mask (0 for Position::Node)   [1] must_visit   [2] maybe_visit (0 when None)
+ *    [3] elapsed: earliest | latest << 32 (ElapsedTime::FixedAt(d): both d)
+ *    [4] node of Position::Node | bit 16 position is virtual | bit 17 elapsed is fuzzy | bit 18 maybe_visit is Some | depth << 32 */
+ddo_model* ddo_model_create_tsptw(int nb_nodes, const int64_t* distances, const int64_t* earliest, const int64_t* latest);
+/** Reads an instance exactly as examples/tsptw/instance.rs:52-109 does (`(f32 * 10000.0) as usize` per number). */
+ddo_model* ddo_model_read_tsptw(const char* path);
 void ddo_model_destroy(ddo_model* model);
 int ddo_model_nb_variables(const ddo_model* model);
 int ddo_model_state_words(const ddo_model* model);
@@ -172,6 +184,8 @@ int ddo_cache_update_threshold(ddo_cache* cache, const uint64_t* state, size_t d
  *  whose key is the depth and whose states have one coordinate besides the value (use_value = true): the knapsack's
  *  KPDominance (examples/knapsack/main.rs:198-218: more remaining capacity and more value dominate).  Per depth it keeps
  *  the non-dominated (capacity, value) pairs, at most `capacity_per_depth` of them (a full set drops new pairs: sound).
+ *  For a TSPTW model it is TsptwDominance (examples/tsptw/dominance.rs:26-60: same position and must_visit set, larger
+ *  value dominates): one hash table of `capacity_per_depth` (depth, position, must_visit) keys in all.
  *  Handed to compile() through ddo_compile_input.dominance (the mdd must have been created with DDO_MDD_CACHING: dominated
  *  nodes keep their threshold in the kept layers) or owned by a solver (ddo_solver_config.dominance). */
 ddo_dominance* ddo_dominance_create(const ddo_model* model, int device, size_t capacity_per_depth);
@@ -210,6 +224,8 @@ int ddo_mdd_last_counters(const ddo_mdd* mdd, ddo_counters* out);
 /* ---- Solver (solver.rs:32-97; parallel.rs:287-641) ------------------------------------------ */
 #define DDO_WIDTH_FIXED 0         /* width.rs:166-171 FixedWidth(w)            */
 #define DDO_WIDTH_NB_UNASSIGNED 1 /* width.rs:397-402 NbUnassignedWidth(n)     */
+#define DDO_WIDTH_TSPTW 2         /* examples/tsptw/heuristics.rs:38-52 TsptwWidth: nb_vars * (depth + 1) * factor,
+                                     factor = ddo_solver_config.width */
 
 /* Fringe implementations (abstraction/fringe.rs:26-45) */
 #define DDO_FRINGE_NODUP 0 /* fringe/no_duplicate.rs:52-324: one entry per state, host resident (exact ddo order) */

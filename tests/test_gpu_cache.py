@@ -75,10 +75,15 @@ def test_cached_search_replayed_in_order(have_gpu, oracle, kind, fname, width, m
     assert st["used"] > 0 and st["dropped"] == 0
 
 
-@pytest.mark.parametrize("frontier,cache", [(True, False), (False, True), (True, True)], ids=["frontier", "lel+cache", "frontier+cache"])
-@pytest.mark.parametrize("kind,fname,width", [("misp", "johnson8-4-4.clq", 4), ("misp", "keller4.clq", 30), ("misp", "brock200_2.clq", 60),
-                                               ("knapsack", "f8_l-d_kp_23_10000", 5), ("max2sat", "pass.wcnf", 2), ("max2sat", "frb10-6-3.wcnf", 0),
-                                               ("mcp", "mcp_n30_p0.1_002.mcp", 4)])
+# sequential searches of a few thousand sub-problems at most (one launch per compile: about a millisecond each)
+SEQ_CASES = [("misp", "johnson8-4-4.clq", 4, True, False), ("misp", "johnson8-4-4.clq", 4, False, True), ("misp", "johnson8-4-4.clq", 4, True, True),
+             ("misp", "MANN_a9.clq", 3, True, True), ("misp", "hamming6-4.clq", 6, True, True),
+             ("knapsack", "f8_l-d_kp_23_10000", 5, False, True), ("knapsack", "f8_l-d_kp_23_10000", 5, True, True),
+             ("max2sat", "pass.wcnf", 2, True, False), ("max2sat", "pass.wcnf", 2, True, True), ("max2sat", "frb10-6-3.wcnf", 0, False, True),
+             ("mcp", "mcp_n30_p0.1_002.mcp", 4, True, False), ("mcp", "mcp_n30_p0.1_002.mcp", 4, False, True), ("mcp", "mcp_n30_p0.1_002.mcp", 4, True, True)]
+
+
+@pytest.mark.parametrize("kind,fname,width,frontier,cache", SEQ_CASES)
 def test_sequential_solver_matches_the_oracle(have_gpu, oracle, kind, fname, width, frontier, cache):
     path = data_path(kind, fname)
     model = MODELS[kind].read_instance(path)
@@ -93,8 +98,8 @@ def test_sequential_solver_matches_the_oracle(have_gpu, oracle, kind, fname, wid
 
 
 @pytest.mark.parametrize("kind,fname,expected,width,threads", [
-    ("misp", "brock200_2.clq", 12, 100, 64), ("misp", "keller4.clq", 11, 50, 32), ("misp", "hamming8-4.clq", 16, 0, 64), ("knapsack", "knapPI_1_100_1000_1", 9147, 30, 16),
-    ("max2sat", "frb10-6-4.wcnf", 38928, 0, 32), ("mcp", "mcp_n30_p0.1_003.mcp", None, 20, 32),
+    ("misp", "brock200_2.clq", 12, 100, 64), ("misp", "johnson8-4-4.clq", 14, 6, 16), ("knapsack", "knapPI_1_100_1000_1", 9147, 30, 16),
+    ("knapsack", "f8_l-d_kp_23_10000", 9767, 5, 32), ("max2sat", "frb10-6-4.wcnf", 38928, 0, 64), ("mcp", "mcp_n30_p0.1_003.mcp", None, 20, 32),
 ])
 def test_default_caching_solver_proves_the_optimum(have_gpu, oracle, kind, fname, expected, width, threads):
     """DefaultCachingSolver = ParallelSolver<DefaultMDDFC, SimpleCache> (solver/mod.rs) with many sub-problems in flight"""
