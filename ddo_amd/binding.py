@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ABI_SYMBOLS = [
     "ddo_last_error", "ddo_device_count", "ddo_model_create_misp", "ddo_model_read_misp", "ddo_model_create_knapsack",
     "ddo_model_read_knapsack", "ddo_model_create_mcp", "ddo_model_read_mcp", "ddo_model_create_max2sat",
-    "ddo_model_read_max2sat", "ddo_model_destroy",
+    "ddo_model_read_max2sat", "ddo_model_create_tsptw", "ddo_model_read_tsptw", "ddo_model_destroy",
     "ddo_model_nb_variables", "ddo_model_state_words", "ddo_model_initial_state", "ddo_model_initial_value",
     "ddo_model_compare_states", "ddo_model_export_misp", "ddo_mdd_create", "ddo_mdd_destroy", "ddo_mdd_compile",
     "ddo_mdd_compile_batch", "ddo_mdd_is_exact", "ddo_mdd_best_value", "ddo_mdd_best_exact_value",
@@ -103,6 +103,10 @@ def lib():
     L.ddo_model_create_max2sat.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ddo_model_read_max2sat.restype = C.c_void_p
     L.ddo_model_read_max2sat.argtypes = [C.c_char_p]
+    L.ddo_model_create_tsptw.restype = C.c_void_p
+    L.ddo_model_create_tsptw.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ddo_model_read_tsptw.restype = C.c_void_p
+    L.ddo_model_read_tsptw.argtypes = [C.c_char_p]
     L.ddo_model_destroy.argtypes = [C.c_void_p]
     L.ddo_model_nb_variables.argtypes = [C.c_void_p]
     L.ddo_model_state_words.argtypes = [C.c_void_p]
@@ -411,6 +415,36 @@ class SimpleCache:
             raise DdoError(f"ddo_cache_update_threshold rc={rc}: {_err()}")
 
 
+class Tsptw(Misp):
+    """TSPTW model == `Tsptw` + `TsptwRelax` + `TsptwRanking` (examples/tsptw); 5-word states (include/ddo_hip.h); variable k is the
+    k-th move of the tour, its value the node visited; values are MINUS the elapsed time in 1/10000 units."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise DdoError("could not create the TSPTW model: " + _err())
+        self._h = handle
+        L = lib()
+        self.n = L.ddo_model_nb_variables(handle)
+        self.ws = L.ddo_model_state_words(handle)
+
+    @classmethod
+    def read_instance(cls, path):  # instance.rs:52-109
+        return cls(lib().ddo_model_read_tsptw(os.fspath(path).encode()))
+
+    @classmethod
+    def from_arrays(cls, distances, earliest, latest):
+        d = np.ascontiguousarray(distances, dtype=np.int64)
+        e = np.ascontiguousarray(earliest, dtype=np.int64)
+        l = np.ascontiguousarray(latest, dtype=np.int64)
+        assert d.ndim == 2 and d.shape[0] == d.shape[1] == len(e) == len(l)
+        return cls(lib().ddo_model_create_tsptw(d.shape[0], d.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p)))
+
+
+class TsptwWidth:  # examples/tsptw/heuristics.rs:38-52: nb_vars * (depth + 1) * factor
+    def __init__(self, factor=1):
+        self.factor = int(factor)
+
+
 class SimpleDominanceChecker:
     """`SimpleDominanceChecker::new(KPDominance, nb_variables)` (dominance/simple.rs:37-117, examples/knapsack/main.rs:198-218,
     325) in device memory: knapsack models only (the relation is keyed by the depth, one coordinate + the value)."""
@@ -549,6 +583,8 @@ class ParallelSolver:
             cfg.width_policy, cfg.width = 0, width.w
         elif isinstance(width, NbUnassignedWidth):
             cfg.width_policy, cfg.width = 1, 0
+        elif isinstance(width, TsptwWidth):
+            cfg.width_policy, cfg.width = 2, width.factor
         else:
             raise TypeError("width must be FixedWidth or NbUnassignedWidth")
         cfg.nb_concurrent = int(nb_threads)

@@ -5,6 +5,7 @@ the GPU engine:
     python -m ddo_amd.cli knapsack <file> [-t N] [-d SECONDS] [-w WIDTH]      (examples/knapsack/main.rs:230-246, 308-358)
     python -m ddo_amd.cli max2sat  -f <file> [-w WIDTH] [-t SECONDS]          (examples/max2sat/main.rs:19-72)
     python -m ddo_amd.cli mcp      -f <file> [-w WIDTH] [-t SECONDS]          (examples/mcp/main.rs:19-66)
+    python -m ddo_amd.cli tsptw    <file> [-w FACTOR] [-t N] [-d SECONDS]     (examples/tsptw/main.rs:49-101)
 
 `-t/--threads` of misp / knapsack is the number of sub-problems compiled concurrently (the reference's worker threads);
 on the GPU the useful values are hundreds to thousands (tools/fringe_compare.py), so the default is 8192 for misp (brock400_1 / W = 10 000 is proved in 183 / 169 / 146 / 143 / 138 s with
@@ -147,6 +148,35 @@ def mcp(args):
     _report(dt, completion, solver, _list(f"Decision {{ variable: Variable({d.variable}), value: {d.value} }}" for d in sol))
 
 
+def tsptw(args):
+    """examples/tsptw/main.rs:70-128: DefaultCachingSolver (frontier cut-set + SimpleCache), SimpleDominanceChecker(TsptwDominance),
+    TsptwWidth(nb_vars, -w); the six report lines of print_solution"""
+    import os
+    import numpy as np
+    model = B.Tsptw.read_instance(args.instance)
+    solver = B.ParallelSolver(model, B.TsptwWidth(args.width or 1), _cutoff(args.duration), nb_threads=args.threads, device=args.device,
+                              fringe="nodup", cutset_type=B.FRONTIER, cache_entries=1 << 22, dominance_entries=1 << 22)
+    t0 = time.perf_counter()
+    completion = solver.maximize()
+    dt = time.perf_counter() - t0
+
+    def objective(x):   # main.rs:109-115
+        if x <= -(1 << 63):
+            return "+inf"
+        if x >= (1 << 63) - 1:
+            return "-inf"
+        return f"{-(np.float32(x) / np.float32(10000.0)):.2f}"
+
+    sol = _sorted_solution(solver)
+    path = os.path.abspath(args.instance)
+    print(f"instance : {os.path.basename(os.path.dirname(path))}/{os.path.basename(path)}")
+    print(f"status   : {'Proved' if completion.is_exact else 'Timeout'}")
+    print(f"lower bnd: {objective(solver.best_lower_bound())}")
+    print(f"upper bnd: {objective(solver.best_upper_bound())}")
+    print(f"duration : {dt}")
+    print("solution : " + ("No feasible solution found" if sol is None else "".join(f" {d.value}" for d in sol)))   # main.rs:130-146: every entry preceded by a space
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="ddo_amd.cli", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -161,6 +191,13 @@ def main(argv=None):
         p.add_argument("--fringe", choices=("nodup", "lazy"), default="nodup")
         p.add_argument("--device", type=int, default=0)
         p.set_defaults(fn=fn)
+    p = sub.add_parser("tsptw")
+    p.add_argument("instance", help="the path to the TSP+TW instance")
+    p.add_argument("-w", "--width", type=int, default=None, help="multiplier of the default width nb_vars * (depth + 1)")
+    p.add_argument("-t", "--threads", type=int, default=64, help="sub-problems compiled concurrently")
+    p.add_argument("-d", "--duration", type=int, default=None, help="time budget in seconds")
+    p.add_argument("--device", type=int, default=0)
+    p.set_defaults(fn=tsptw)
     for name, fn in (("max2sat", max2sat), ("mcp", mcp)):
         p = sub.add_parser(name)
         p.add_argument("-f", "--file", required=True, help="the instance file")

@@ -245,6 +245,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     if (owner)   // tier kernel: 3 waves per SIMD = 12 waves per CU (kernels_inplace_tier.hip)
         blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(12 / (threads_ / 64))));
     int nslots = prop.multiProcessorCount * blocks_per_cu;
+    if (P.tmode) nslots = std::min(nslots, 64);   // every layer of every DD in flight is kept: hundreds of MB per slot at large widths
     if (const char* env = std::getenv(owner ? "DDO_HIP_TIER_SLOTS" : "DDO_HIP_SLOTS")) {
         int s = std::atoi(env);
         if (s > 0) nslots = s;

@@ -1181,10 +1181,26 @@ struct TsptwRelax : Relaxation<TsptwState> {
     }
 };
 
-/// heuristics.rs:26-51
+/// TsptwState on the device wire (include/ddo_hip.h, ddo_model_create_tsptw): 5 words; instances of at most 64 nodes
+inline void pack_tsptw_state(const TsptwState& s, uint64_t* out) {
+    out[0] = s.pos_virtual ? s.pos_set.w[0] : 0;
+    out[1] = s.must_visit.w[0];
+    out[2] = s.has_maybe ? s.maybe_visit.w[0] : 0;
+    out[3] = (uint64_t)(uint32_t)s.t_earliest | ((uint64_t)(uint32_t)(s.fuzzy ? s.t_latest : s.t_earliest) << 32);
+    out[4] = (s.pos_virtual ? 0ULL : (uint64_t)s.pos_node) | (s.pos_virtual ? 1ULL << 16 : 0) | (s.fuzzy ? 1ULL << 17 : 0) |
+             (s.has_maybe ? 1ULL << 18 : 0) | ((uint64_t)s.depth << 32);
+}
+/// heuristics.rs:26-51: the depth; ties (every pair of one layer) fall to the packed state words like for the other models
+/// whose ranking is not a total order (compare_signed_vectors): the reference leaves them to its hash map's order
 struct TsptwRanking : StateRanking<TsptwState> {
     int compare(const TsptwState& a, const TsptwState& b) const override {
-        return a.depth < b.depth ? -1 : (a.depth > b.depth ? 1 : 0);
+        if (a.depth != b.depth) return a.depth < b.depth ? -1 : 1;
+        uint64_t x[5], y[5];
+        pack_tsptw_state(a, x);
+        pack_tsptw_state(b, y);
+        for (int k = 0; k < 5; ++k)
+            if (x[k] != y[k]) return x[k] < y[k] ? -1 : 1;
+        return 0;
     }
 };
 struct TsptwWidth : WidthHeuristic<TsptwState> {

@@ -57,6 +57,7 @@ void state_to_words(const KnapsackState& s, size_t, uint64_t* out) {   // device
     out[1] = (uint64_t)s.depth;
 }
 void state_to_words(const Max2SatState& s, size_t, uint64_t* out) { pack_signed_vector(s.substates, s.depth, out); }
+void state_to_words(const TsptwState& s, size_t, uint64_t* out) { pack_tsptw_state(s, out); }
 void state_to_words(const McpState& s, size_t, uint64_t* out) { pack_signed_vector(s.benef, s.depth, out); }
 
 template <class T, class D>
@@ -295,10 +296,10 @@ namespace {
 /// traced sequential solve with any decision-diagram type D (last exact layer / frontier cut-set) and cache type C
 template <class T, class D, class C, class PB, class RELAX, class RANK>
 Trace* traced_solve_dc(PB& pb, RELAX& relax, RANK& rank, size_t nvars, size_t ws, uint64_t width, uint64_t max_compiles,
-                       oracle_solve_out* out, DominanceChecker<T>* domx = nullptr) {
+                       oracle_solve_out* out, DominanceChecker<T>* domx = nullptr, const WidthHeuristic<T>* wx = nullptr) {
     FixedWidth<T> fixed(width);
     NbUnassignedWidth<T> unassigned(nvars);
-    const WidthHeuristic<T>& w = width ? (const WidthHeuristic<T>&)fixed : unassigned;
+    const WidthHeuristic<T>& w = wx ? *wx : (width ? (const WidthHeuristic<T>&)fixed : unassigned);
     EmptyDominanceChecker<T> dom0;
     DominanceChecker<T>& dom = domx ? *domx : (DominanceChecker<T>&)dom0;
     struct CountCutoff : Cutoff {
@@ -336,11 +337,11 @@ Trace* traced_solve_dc(PB& pb, RELAX& relax, RANK& rank, size_t nvars, size_t ws
 }
 template <class T, class PB, class RELAX, class RANK>
 Trace* traced_solve_any(PB& pb, RELAX& relax, RANK& rank, size_t nvars, size_t ws, uint64_t width, uint64_t max_compiles, int frontier,
-                        int cache, oracle_solve_out* out, DominanceChecker<T>* dom = nullptr) {
-    if (frontier && cache) return traced_solve_dc<T, DefaultMDDFC<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom);
-    if (frontier) return traced_solve_dc<T, DefaultMDDFC<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom);
-    if (cache) return traced_solve_dc<T, DefaultMDDLEL<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom);
-    return traced_solve_dc<T, DefaultMDDLEL<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom);
+                        int cache, oracle_solve_out* out, DominanceChecker<T>* dom = nullptr, const WidthHeuristic<T>* wx = nullptr) {
+    if (frontier && cache) return traced_solve_dc<T, DefaultMDDFC<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom, wx);
+    if (frontier) return traced_solve_dc<T, DefaultMDDFC<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom, wx);
+    if (cache) return traced_solve_dc<T, DefaultMDDLEL<T>, SimpleCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom, wx);
+    return traced_solve_dc<T, DefaultMDDLEL<T>, EmptyCache<T>>(pb, relax, rank, nvars, ws, width, max_compiles, out, dom, wx);
 }
 }  // namespace
 
@@ -380,6 +381,16 @@ void* oracle_trace_solve_ex(const char* kind, const char* path, uint64_t width, 
             McpRanking rank;
             return traced_solve_any<McpState>(pb, relax, rank, pb.nb_variables(), (pb.nb_variables() + 1) / 2 + 1, width, max_compiles, frontier,
                                               cache, out);
+        }
+        if (k == "tsptw" || k == "tsptw+dominance") {   // width 0: TsptwWidth(nb_vars, 1) as in examples/tsptw/tests.rs:42; else FixedWidth
+            Tsptw pb(read_tsptw_instance(path));
+            if (pb.nb_variables() > 64) throw std::runtime_error("tsptw traces pack states for at most 64 nodes");
+            TsptwRelax relax(pb);
+            TsptwRanking rank;
+            TsptwWidth tw(pb.nb_variables(), 1);
+            SimpleDominanceChecker<TsptwState, TsptwDominance> dom(TsptwDominance(), pb.nb_variables());
+            return traced_solve_any<TsptwState>(pb, relax, rank, pb.nb_variables(), 5, width, max_compiles, frontier, cache, out,
+                                                k == "tsptw" ? nullptr : &dom, width ? nullptr : &tw);
         }
         std::fprintf(stderr, "oracle_trace_solve_ex: unknown kind %s\n", kind);
         return nullptr;

@@ -73,7 +73,7 @@ void run(Emul& e, const DDInput& in, DDResult* res2) {
 }  // namespace
 
 static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int nthreads, uint64_t arena_bytes, int capN_,
-                         const int64_t* weights);
+                         const int64_t* weights, int fan = 2);
 
 extern "C" {
 
@@ -105,7 +105,7 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
 }  // extern "C"
 
 static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int nthreads, uint64_t arena_bytes, int capN_,
-                         const int64_t* weights) {
+                         const int64_t* weights, int fan) {
     EngineParams& P = e->P;
     P.n = n;
     P.ws = wsT;
@@ -114,7 +114,9 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
     P.adj = e->adj.data();
     P.weight = e->weight.data();
     P.capN = capN_;
-    P.capC1 = 2 * P.capN + 1;
+    P.fan = fan;
+    P.dbits = fan > 2 ? 6 : 1;
+    P.capC1 = fan * P.capN + 1;
     P.max_layers = n + 2;
     int tc = 1024;
     while (tc * 2 < P.capC1 * 3 || tc < 2 * P.capN) tc <<= 1;
@@ -122,22 +124,22 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
     P.table_in_lds = 1;
     P.nslots = 1;
     const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers;
-    const size_t LSm = capC1 + 1;   // nodes per kept layer (emul_set_keep_layers switches P.tmode / P.lstride on)
-    size_t bytes = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + 2 * capN * 4 + capC1 * 4 + capC1 * 4 + capC1 +
-                   ml * LSm * 4 + 2 * ml * 2 * capN * 4 + ml * 5 * 4 + wsT * capN * 8 + capN * 8 + 64 * 32;
+    const size_t LSm = std::min<size_t>(capC1 + 1, 4 * (size_t)P.capN + 2);   // nodes per kept layer (emul_set_keep_layers switches P.tmode / P.lstride on)
+    size_t bytes = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + (size_t)fan * capN * 4 + capC1 * 4 + capC1 * 4 + capC1 +
+                   ml * LSm * 4 + 2 * ml * (size_t)fan * capN * 4 + ml * 5 * 4 + wsT * capN * 8 + capN * 8 + 64 * 32;
     e->mem.assign(bytes, 0xCD);  // poison
     unsigned char* p = e->mem.data();
     P.cstate = carve<uint64_t>(p, 2 * wsT * capC1);
     P.ckey = carve<uint64_t>(p, 2 * capC1);
     P.cpop = carve<uint32_t>(p, 2 * capC1);
     P.cflags = carve<uint32_t>(p, 2 * capC1);
-    P.ctarget = carve<uint32_t>(p, 2 * capN);
+    P.ctarget = carve<uint32_t>(p, (size_t)fan * capN);
     P.keep = carve<uint32_t>(p, capC1);
     P.posmap = carve<uint32_t>(p, capC1);
     P.cls = carve<uint8_t>(p, capC1);
     P.ninfo = carve<uint32_t>(p, ml * LSm);
-    P.arct = carve<uint32_t>(p, ml * 2 * capN);
-    P.arcc = carve<int32_t>(p, ml * 2 * capN);
+    P.arct = carve<uint32_t>(p, ml * (size_t)fan * capN);
+    P.arcc = carve<int32_t>(p, ml * (size_t)fan * capN);
     P.nlayer = carve<int32_t>(p, ml);
     P.lntot = carve<int32_t>(p, ml);
     P.lvar = carve<int32_t>(p, ml);
@@ -239,6 +241,12 @@ void* emul_create_model(const void* model_handle, int max_width, int nthreads, u
         P.vr = (int32_t)M.initial_value;
     }
     if (M.kind == MODEL_MCP) P.vgraph = M.vgraph.data();
+    if (M.kind == MODEL_TSPTW) {
+        P.tw_dist = M.tw_dist.data();
+        P.tw_early = M.tw_early.data();
+        P.tw_late = M.tw_late.data();
+        P.tw_cheap = M.tw_cheap.data();
+    }
     if (M.kind == MODEL_MAX2SAT) {
         P.m2_wtt = M.m2_w[0].data();
         P.m2_wtf = M.m2_w[1].data();
@@ -249,8 +257,9 @@ void* emul_create_model(const void* model_handle, int max_width, int nthreads, u
     }
     e->lddelta.assign((size_t)M.n + 2, 0);
     P.lddelta = e->lddelta.data();
-    const int capN = M.kind != MODEL_MISP ? 2 * max_width + 3 : max_width + 2;   // the terminal layer is never squashed
-    return emul_finish(e, M.n, M.wsT, M.unit_weights, max_width, nthreads, arena_bytes, capN, M.weight.data());
+    const int capN = M.kind == MODEL_TSPTW ? std::max(max_width, M.n) + 2
+                     : M.kind != MODEL_MISP ? 2 * max_width + 3 : max_width + 2;   // the terminal layer is never squashed
+    return emul_finish(e, M.n, M.wsT, M.unit_weights, max_width, nthreads, arena_bytes, capN, M.weight.data(), M.kind == MODEL_TSPTW ? M.n : 2);
 }
 /// keep every layer (frontier cut-set, thresholds, cache) on / off; cache_entries > 0 (re)creates an EMPTY cache table
 void emul_set_keep_layers(void* h, int on, uint64_t cache_entries) {
@@ -273,8 +282,20 @@ uint64_t emul_cache_used(void* h) { return ((Emul*)h)->cache_stats[0]; }
 /// a fresh, empty SimpleDominanceChecker (per depth `cap` pairs); cap 0 removes it
 void emul_set_dominance(void* h, uint32_t cap) {
     Emul* e = (Emul*)h;
-    e->P.dom_cap = cap;
+    e->P.dom_cap = 0;
+    e->P.dkey_cap = 0;
     if (!cap) return;
+    if (e->P.model_kind == MODEL_TSPTW) {   // TsptwDominance: one hash table of (depth, position, must_visit) keys
+        uint64_t c2 = 1024;
+        while (c2 < cap) c2 <<= 1;
+        e->dom_coord.assign(c2 * 6, 0);
+        e->P.dkey_tab = e->dom_coord.data();
+        e->P.dkey_cap = c2;
+        e->dom_stats[0] = e->dom_stats[1] = 0;
+        e->P.dkey_stats = e->dom_stats;
+        return;
+    }
+    e->P.dom_cap = cap;
     const size_t nd = (size_t)e->P.max_layers;
     e->dom_coord.assign(nd * cap, 0);
     e->dom_value.assign(nd * cap, 0);

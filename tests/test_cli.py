@@ -79,3 +79,16 @@ def test_mcp_report():
     rc, kv, _ = run(["mcp", "-f", os.path.join(DATA, "mcp", "mcp_n30_p0.1_000.mcp"), "-w", "100"])
     assert rc == 0 and kv["Aborted"] == "false" and kv["Gap"] == "0.000"
     assert kv["Solution"].startswith("[Decision { variable: Variable(") and kv["Solution"].count("Decision") == 30
+
+
+@pytest.mark.gpu
+def test_tsptw_report():
+    """examples/tsptw/main.rs:102-146: six lines, bounds as tour lengths with two decimals, the tour as a permutation"""
+    rc, kv, lines = run(["tsptw", os.path.join(DATA, "tsptw", "Langevin", "N40ft201.dat"), "-t", "16"])
+    assert rc == 0
+    kv = {k.strip(): v for k, v in kv.items()}
+    assert [ln.split(":")[0].strip() for ln in lines] == ["instance", "status", "lower bnd", "upper bnd", "duration", "solution"]
+    assert kv["instance"] == "Langevin/N40ft201.dat" and kv["status"] == "Proved"
+    assert kv["lower bnd"] == "1109.30" and kv["upper bnd"] == "1109.30"
+    tour = [int(x) for x in kv["solution"].split()]
+    assert len(tour) == 40 and tour[-1] == 0 and sorted(tour) == list(range(40))

@@ -1,0 +1,102 @@
+"""TSPTW on the device (`-m gpu`, through the C ABI): BASELINE config C5 (Langevin N40ft*, 40 nodes) and its neighbours.
+
+  (1) the reference's own test configuration (examples/tsptw/tests.rs:33-63: DefaultCachingSolver = frontier cut-set +
+      SimpleCache, SimpleDominanceChecker(TsptwDominance), TsptwWidth(nb_vars, 1)) proves the known optima of
+      tests.rs:81-499; every tour is re-evaluated independently (time windows, each node once, length);
+  (2) config C5 as worded -- FixedWidth(20000) -- on N40 instances;
+  (3) traced oracle searches at small widths replayed compile by compile, in order, against one device cache and one device
+      dominance checker; sequential searches reproduce the oracle's explored count and counters."""
+import numpy as np
+import pytest
+
+import ddo_amd
+from ddo_amd import FRONTIER, LAST_EXACT_LAYER, FixedWidth, ParallelSolver, SequentialSolver, SubProblem, TsptwWidth
+from tests.conftest import data_path
+from tests.parity_util import canon_from_mdd, diff
+
+pytestmark = pytest.mark.gpu
+
+N20 = [("N20ft301", 661.6), ("N20ft304", 817.0), ("N20ft308", 788.2), ("N20ft402", 701.0), ("N20ft408", 786.1), ("N20ft410", 693.8)]
+N40 = [("N40ft201", 1109.3), ("N40ft202", 1017.4), ("N40ft203", 903.1), ("N40ft204", 897.4), ("N40ft205", 983.6), ("N40ft206", 1081.9),
+       ("N40ft207", 884.9), ("N40ft208", 1051.6), ("N40ft209", 1027.5), ("N40ft210", 1035.3), ("N40ft401", 1105.2), ("N40ft402", 1016.4),
+       ("N40ft403", 903.1), ("N40ft404", 897.4), ("N40ft405", 982.6), ("N40ft406", 1081.9), ("N40ft407", 872.2), ("N40ft408", 1043.5),
+       ("N40ft409", 1025.5), ("N40ft410", 1034.3)]
+N60 = [("N60ft201", 1375.4), ("N60ft204", 1283.6), ("N60ft308", 1168.8), ("N60ft408", 1150.0)]
+
+
+@pytest.fixture(scope="module")
+def have_gpu():
+    if ddo_amd.device_count() < 1:
+        pytest.fail("no HIP device: the gpu-marked tests must run on an MI355X box")
+    return True
+
+
+def _solve(oracle, name, expected, width, threads):
+    path = data_path("tsptw", "Langevin", name + ".dat")
+    model = ddo_amd.Tsptw.read_instance(path)
+    s = ParallelSolver(model, width, nb_threads=threads, fringe="nodup", cutset_type=FRONTIER, cache_entries=1 << 20, dominance_entries=1 << 20)
+    c = s.maximize()
+    assert c.is_exact and c.best_value is not None
+    assert np.float32(-c.best_value) / np.float32(10000.0) == np.float32(expected)      # compared in f32 like tests.rs:49-52
+    assert s.best_upper_bound() == s.best_lower_bound() == c.best_value
+    tour = np.full(model.n, -1, dtype=np.int64)
+    for d in s.best_solution():
+        tour[d.variable] = d.value                                                         # variable k = k-th move of the tour
+    import ctypes as C
+    assert oracle.L.oracle_tsptw_tour_length(path.encode(), tour.ctypes.data_as(C.c_void_p), None) == -c.best_value
+    return model, s
+
+
+@pytest.mark.parametrize("name,expected", N20 + N40 + N60)
+def test_langevin_known_optima_reference_configuration(have_gpu, oracle, name, expected):
+    _solve(oracle, name, expected, TsptwWidth(1), 16)
+
+
+@pytest.mark.parametrize("name,expected", [N40[0], N40[6], N40[12], N40[19]])
+def test_config_c5_fixed_width_20000(have_gpu, oracle, name, expected):
+    """BASELINE config C5: TSPTW n = 40, width 20000 (realised as FixedWidth(20000): the reference CLI's -w is a factor)"""
+    _solve(oracle, name, expected, FixedWidth(20000), 4)
+
+
+@pytest.mark.parametrize("name,expected,width", [("N20ft405", 724.7, 3), ("N40ft403", 903.1, 4), ("N40ft207", 884.9, 2), ("N60ft204", 1283.6, 2)])
+def test_small_widths_force_real_branch_and_bound(have_gpu, oracle, name, expected, width):
+    _, s = _solve(oracle, name, expected, FixedWidth(width), 32)
+    assert s.explored() > 1
+
+
+def _sub(r):
+    return SubProblem(state=np.array(r["state"], dtype=np.uint64), value=r["value"], path=[], depth=r["depth"])
+
+
+@pytest.mark.parametrize("kind,frontier,cache", [("tsptw", False, False), ("tsptw", True, False), ("tsptw+dominance", True, True)],
+                         ids=["lel", "frontier", "frontier+cache+dominance"])
+@pytest.mark.parametrize("name,width,max_compiles", [("N20ft405", 3, 0), ("N40ft403", 3, 150), ("N60ft204", 2, 100), ("N40ft207", 2, 100), ("N40ft201", 0, 0)])
+def test_replay_of_oracle_search(have_gpu, oracle, name, width, max_compiles, kind, frontier, cache):
+    path = data_path("tsptw", "Langevin", name + ".dat")
+    model = ddo_amd.Tsptw.read_instance(path)
+    _, recs = oracle.trace_ex(kind, path, width, max_compiles, frontier, cache)
+    mdd = ddo_amd.Mdd(model, max(int(r["width"]) for r in recs), cutset_type=FRONTIER if frontier else LAST_EXACT_LAYER, caching=True)
+    ch = ddo_amd.SimpleCache(model, 1 << 16) if cache else None
+    dom = ddo_amd.SimpleDominanceChecker(model, 1 << 16) if "dominance" in kind else None
+    for i, r in enumerate(recs):
+        comp = mdd.compile(r["comp_type"], r["width"], _sub(r), r["best_lb"], cache=ch, dominance=dom)
+        got = canon_from_mdd(mdd, comp, model.ws)
+        d = diff(r, got)
+        assert d is None, f"{name} W={width} {kind} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+        for n in got["cutset_nodes"]:
+            assert len(n.path) == n.depth - r["depth"] and all(0 <= dd.value < model.n for dd in n.path)
+
+
+@pytest.mark.parametrize("name,width", [("N20ft405", 3), ("N20ft301", 2), ("N40ft403", 6), ("N40ft207", 4)])
+def test_sequential_solver_matches_the_oracle(have_gpu, oracle, name, width):
+    """SeqCachingSolverFc-like configuration (frontier + cache + dominance), one sub-problem at a time: explored count and
+    counters equal the oracle's"""
+    path = data_path("tsptw", "Langevin", name + ".dat")
+    model = ddo_amd.Tsptw.read_instance(path)
+    ref, _ = oracle.trace_ex("tsptw+dominance", path, width, 0, True, True)
+    s = SequentialSolver(model, FixedWidth(width), cutset_type=FRONTIER, cache_entries=1 << 18, dominance_entries=1 << 18)
+    c = s.maximize()
+    assert c.is_exact and c.best_value == ref["best_value"]
+    cnt = s.counters()
+    assert (s.explored(), cnt["nodes_expanded"], cnt["arcs"], cnt["layers"], cnt["compiles"]) == \
+           (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
