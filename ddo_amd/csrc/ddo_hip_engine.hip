@@ -194,7 +194,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     while (tc * 2 < P.capC1 * 3 || tc < 2 * P.capN) tc <<= 1;
     P.table_cap = tc;
     threads_ = max_width >= 2048 ? 1024 : 256;
+    if (const char* env = std::getenv("DDO_HIP_DENSE")) dense_ = !owner && std::atoi(env) != 0 && model->kind == MODEL_MISP;
     if (owner) threads_ = tier_threads;
+    else if (dense_) threads_ = 512;
     else if (const char* env = std::getenv("DDO_HIP_THREADS")) {
         int t = std::atoi(env);
         if (t >= 256 && t <= 1024 && t % 64 == 0) threads_ = t;
@@ -242,6 +244,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     // ---- how many DDs in flight: residency of the kernel, then HBM
     int blocks_per_cu = (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(2048 / threads_));
     blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+    if (dense_ && engine_kind_ == 2) blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, 2));   // 2 x 8 waves at 128 VGPRs
     if (owner)   // tier kernel: 3 waves per SIMD = 12 waves per CU (kernels_inplace_tier.hip)
         blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(12 / (threads_ / 64))));
     int nslots = prop.multiProcessorCount * blocks_per_cu;
@@ -465,6 +468,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     ev1_ = e1;
 
     kernel_fn fn = owner ? pick_kernel2_tier(model->wsT)
+                   : (dense_ && engine_kind_ == 2) ? pick_kernel2_dense(model->wsT)
                    : engine_kind_ == 2 ? pick_kernel2(model->wsT, threads_)
                                        : pick_kernel(model->wsT, table_lds_);
     if (!fn) {

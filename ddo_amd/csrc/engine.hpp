@@ -188,6 +188,7 @@ class Engine {
     Engine* pool_owner() { return owner_ ? owner_ : this; }
     Engine* owner_ = nullptr;        // capacity tier: the engine whose node pool / cutoff flag this one shares
     int cap_width_ = 0;              // capacity tier: layer capacity (0 = full-width engine)
+    bool dense_ = false;             // two 512-thread workgroups per CU (kernels_inplace_tier.hip: misp_compile_kernel2_dense)
     void decode(const DDResult& r, const uint8_t* arena, HostResult& out) const;
 
     Model* model_ = nullptr;

@@ -25,6 +25,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
 }
 
+// Two decision diagrams per CU at full width: 512 threads each, 4 waves per SIMD (128 VGPRs like the 1024-thread kernel), so
+// that two workgroups -- 16 waves -- share a CU and overlap each other's memory latency (Engine: "dense" configuration).
+template <int WS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) misp_compile_kernel2_dense(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    DD2Ctx<WS> c;
+    dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
+    c.tid_ = (int)threadIdx.x;
+    for (;;) {
+        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
+        __syncthreads();
+        const int w = c.sh->work;
+        __syncthreads();
+        if (w >= P.nbatch) break;
+        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+    }
+}
+
+kernel_fn pick_kernel2_dense(int wsT) {
+    switch (wsT) {
+        case 1: return misp_compile_kernel2_dense<1>;
+        case 2: return misp_compile_kernel2_dense<2>;
+        case 4: return misp_compile_kernel2_dense<4>;
+        case 7: return misp_compile_kernel2_dense<7>;
+        case 8: return misp_compile_kernel2_dense<8>;
+        case 16: return misp_compile_kernel2_dense<16>;
+        default: return nullptr;
+    }
+}
+
 kernel_fn pick_kernel2_tier(int wsT) {
     switch (wsT) {
         case 1: return misp_compile_kernel2_tier<1>;
