@@ -167,6 +167,7 @@ def main():
                     help="after the timed steps (N = 1 only), run the whole search to the PROVED optimum under this time budget and report "
                          "time_to_proved_optimum_s, the second half of BASELINE.json's metric (0 = skip)")
     ap.add_argument("--prove-concurrent", type=int, default=8192, help="sub-problems in flight during the proof search")
+    ap.add_argument("--freeze-stride", type=int, default=0, help="experiments only: take every k-th root cut-set node (default 8 // world)")
     ap.add_argument("--instance", default=INSTANCE)
     ap.add_argument("--width", type=int, default=WIDTH)
     args = ap.parse_args()
@@ -233,7 +234,7 @@ def main():
         solver.step()
         exchange()
     barrier()
-    stride = max(1, 8 // world)
+    stride = args.freeze_stride or max(1, 8 // world)
     nfrozen = solver.bench_freeze(args.batches, stride)
     if nfrozen < 1:
         raise SystemExit("bench.py: the fringe ran dry before the workload could be frozen")
@@ -247,6 +248,7 @@ def main():
     barrier()
     c0 = solver.counters()
     k0, l0 = solver.device_time()
+    ts0 = solver.tier_stats()
     e0 = solver.explored()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -255,6 +257,7 @@ def main():
     t1 = time.perf_counter()
     c1 = solver.counters()
     k1, l1 = solver.device_time()
+    ts1 = solver.tier_stats()
     e1 = solver.explored()
     done_steps = args.steps
 
@@ -268,10 +271,23 @@ def main():
         my_arcs = c1["arcs"] - c0["arcs"]
         c_mean = my_arcs / max(1, my_nodes)                       # mean children per expanded node
         bytes_per_node = (ws_bytes + 8) + c_mean * (ws_bytes + 16)
-        launches = max(1, l1 - l0)
-        kernel_s = (k1 - k0) / 1e3
         ws_t = next(w for w in (1, 2, 4, 7, 8, 16) if w >= (model.n + 63) // 64)
-        achieved = my_nodes * bytes_per_node / max(kernel_s, 1e-12) / 1e9   # GB/s over the kernel's own time
+        # the sub-problems of a step run on the engine tier that fits them (host_solver.cpp: dispatch): the DOMINANT kernel is
+        # the tier with the most kernel time over the timed region; its roofline uses the nodes IT expanded and ITS launches
+        tiers = []
+        for a, b in zip(ts0, ts1):
+            name = (f"ddo_hip::misp_compile_kernel2_dense<{ws_t}> (512 threads, two decision diagrams per CU)" if b["dense"]
+                    else f"ddo_hip::misp_compile_kernel2<{ws_t}, {b['threads']}>" if b is ts1[-1]
+                    else f"ddo_hip::misp_compile_kernel2_tier<{ws_t}> ({b['threads']} threads, layer capacity {b['layer_capacity']})")
+            tiers.append({"kernel": name, "kernel_ms": b["kernel_ms"] - a["kernel_ms"], "launches": b["launches"] - a["launches"],
+                          "subproblems": b["subproblems"] - a["subproblems"], "handed_up": b["retried"] - a["retried"],
+                          "nodes_expanded": b["nodes_expanded"] - a["nodes_expanded"], "slots": b["slots"], "lds_bytes": b["lds_bytes"]})
+        dom = max(tiers, key=lambda t: t["kernel_ms"]) if tiers else None
+        if dom and dom["kernel_ms"] > 0 and dom["launches"] > 0:
+            launches, kernel_s, dom_nodes, dom_name = dom["launches"], dom["kernel_ms"] / 1e3, dom["nodes_expanded"], dom["kernel"]
+        else:
+            launches, kernel_s, dom_nodes, dom_name = max(1, l1 - l0), (k1 - k0) / 1e3, my_nodes, f"ddo_hip::misp_compile_kernel2<{ws_t}, 1024>"
+        achieved = dom_nodes * bytes_per_node / max(kernel_s, 1e-12) / 1e9   # GB/s over the kernel's own time
         # HBM traffic: PMC counters cannot be read from inside this process; the committed rocprofv3 passes of this very
         # command and workload (tools/profile_round.sh -> profiles/<round>/pmc_summary.json; the workload is frozen, so
         # the profiled launches ARE these launches) give bytes per expanded node, scaled by the nodes of one launch.
@@ -283,7 +299,7 @@ def main():
                 try:
                     tj = json.load(open(pj)).get("traffic")
                     if tj and tj.get("hbm_bytes_per_node"):
-                        traffic = tj["hbm_bytes_per_node"] * my_nodes / launches
+                        traffic = tj["hbm_bytes_per_node"] * dom_nodes / launches
                         traffic_src = f"profiles/{rnd}/pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per node, same frozen workload) x nodes per launch"
                         break
                 except (ValueError, OSError):
@@ -314,9 +330,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "kernel": f"ddo_hip::misp_compile_kernel2<{ws_t}, 1024>", "kernel_ms_avg": 1e3 * kernel_s / launches, "launches": launches,
-                "bytes_per_node": bytes_per_node, "children_per_node": c_mean, "nodes_per_launch": my_nodes / launches,
-                "kernel_nodes_per_s": my_nodes / max(kernel_s, 1e-12),
+                "kernel": dom_name, "kernel_ms_avg": 1e3 * kernel_s / launches, "launches": launches,
+                "bytes_per_node": bytes_per_node, "children_per_node": c_mean, "nodes_per_launch": dom_nodes / launches,
+                "kernel_nodes_per_s": dom_nodes / max(kernel_s, 1e-12),
+                "all_kernels": {"kernel_ms": k1 - k0, "nodes_expanded": my_nodes, "GBps": my_nodes * bytes_per_node / max((k1 - k0) / 1e3, 1e-12) / 1e9},
+                "tiers": tiers,
             },
         }
         if world == 1 and not args.no_cpu:

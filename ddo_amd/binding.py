@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "ddo_solver_create", "ddo_solver_destroy", "ddo_solver_maximize", "ddo_solver_best_value",
     "ddo_solver_best_solution", "ddo_solver_best_lower_bound", "ddo_solver_best_upper_bound", "ddo_solver_set_primal",
     "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_flush",
-    "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time",
+    "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time", "ddo_solver_tier_count", "ddo_solver_tier_stats",
     "ddo_solver_bench_freeze", "ddo_solver_bench_step", "ddo_solver_bench_frozen",
     "ddo_solver_export_subproblems", "ddo_solver_import_subproblems",
     "ddo_dominance_create", "ddo_dominance_destroy", "ddo_dominance_clear", "ddo_cache_create", "ddo_cache_destroy", "ddo_cache_clear", "ddo_cache_stats", "ddo_cache_get_threshold", "ddo_cache_update_threshold",
@@ -59,6 +59,12 @@ class _Completion(C.Structure):
 
 class _Counters(C.Structure):
     _fields_ = [("nodes_expanded", C.c_uint64), ("arcs", C.c_uint64), ("layers", C.c_uint64), ("compiles", C.c_uint64)]
+
+
+class _TierStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_uint64), ("subproblems", C.c_uint64), ("retried", C.c_uint64),
+                ("nodes_expanded", C.c_uint64), ("lds_bytes", C.c_uint64), ("layer_capacity", C.c_int32), ("threads", C.c_int32),
+                ("slots", C.c_int32), ("dense", C.c_int32)]
 
 
 class _SolverConfig(C.Structure):
@@ -171,6 +177,8 @@ def lib():
     L.ddo_solver_fringe_best_ub.restype = C.c_int64
     L.ddo_solver_fringe_best_ub.argtypes = [C.c_void_p]
     L.ddo_solver_device_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.ddo_solver_tier_count.argtypes = [C.c_void_p]
+    L.ddo_solver_tier_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(_TierStats)]
     _lib = L
     return L
 
@@ -723,6 +731,15 @@ class ParallelSolver:
         c = _Counters()
         lib().ddo_solver_counters(self._h, C.byref(c))
         return {"nodes_expanded": c.nodes_expanded, "arcs": c.arcs, "layers": c.layers, "compiles": c.compiles}
+
+    def tier_stats(self):
+        """per-tier accounting (`ddo_tier_stats`): capacity tiers first, then the dense tier, the full-width engine last"""
+        out = []
+        for t in range(lib().ddo_solver_tier_count(self._h)):
+            ts = _TierStats()
+            if lib().ddo_solver_tier_stats(self._h, t, C.byref(ts)) == 0:
+                out.append({name: getattr(ts, name) for name, _ in _TierStats._fields_})
+        return out
 
     def device_time(self):
         ms = C.c_double()

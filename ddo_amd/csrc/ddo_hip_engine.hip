@@ -129,9 +129,12 @@ std::shared_ptr<Engine> Engine::create_private(Model* model, int device, long ma
 }
 
 std::shared_ptr<Engine> Engine::create_tier(Model* model, int device, Engine* owner, int cap_width, int threads) {
-    if (!owner || owner->engine_kind() != 2 || !owner->has_pool() || cap_width < 8 || 2 * (long)cap_width > owner->max_width() ||
-        threads < 64 || threads > 256 || threads % 64) {
-        set_error("Engine::create_tier: needs an in-place owner engine with a node pool, 8 <= cap_width <= max_width / 2, 64..256 threads");
+    // cap_width == max_width: the DENSE tier -- full layer capacity (it squashes like the owner), half the dedup table, 512
+    // threads, two workgroups per CU; a layer whose table would overflow hands the DD to the owner (ST_RETRY)
+    const bool dense = owner && (long)cap_width == owner->max_width() && threads == 512;
+    if (!owner || owner->engine_kind() != 2 || !owner->has_pool() || cap_width < 8 ||
+        (!dense && (2 * (long)cap_width > owner->max_width() || threads < 64 || threads > 256 || threads % 64))) {
+        set_error("Engine::create_tier: needs an in-place owner engine with a node pool, 8 <= cap_width <= max_width / 2, 64..256 threads (or cap_width == max_width with 512 threads: dense tier)");
         return nullptr;
     }
     std::shared_ptr<Engine> e(new Engine());
@@ -194,9 +197,8 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     while (tc * 2 < P.capC1 * 3 || tc < 2 * P.capN) tc <<= 1;
     P.table_cap = tc;
     threads_ = max_width >= 2048 ? 1024 : 256;
-    if (const char* env = std::getenv("DDO_HIP_DENSE")) dense_ = !owner && std::atoi(env) != 0 && model->kind == MODEL_MISP;
+    dense_ = owner && (long)cap_width == max_width && tier_threads == 512;
     if (owner) threads_ = tier_threads;
-    else if (dense_) threads_ = 512;
     else if (const char* env = std::getenv("DDO_HIP_THREADS")) {
         int t = std::atoi(env);
         if (t >= 256 && t <= 1024 && t % 64 == 0) threads_ = t;
@@ -208,12 +210,16 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     P.table_in_lds = table_lds_ ? 1 : 0;
     // ---- engine 2 (in-place layers) when its LDS footprint fits and values fit the packed 21-bit key
     P.capS = 2 * (int)slot_width + 8;
-    P.tier = owner ? 1 : 0;
-    P.hist_bins = owner ? 64 : 2048;   // a tier never squashes: the histogram / tie-break area of LDS is not needed
+    P.tier = dense_ ? 2 : owner ? 1 : 0;
+    P.hist_bins = dense_ ? 256 : owner ? 64 : 2048;   // a capacity tier never squashes: the histogram / tie-break area of LDS is not needed
     P.capW = P.capN;
     int t2 = 1024;
     while (t2 < 3 * P.capW) t2 <<= 1;
     P.tab2_cap = t2;
+    if (dense_) {   // the largest table that leaves room for two workgroups per CU
+        const char* env = std::getenv("DDO_HIP_DENSE_TABLE");
+        P.tab2_cap = std::min(t2, env ? std::max(1024, std::atoi(env)) : 16384);
+    }
     long long neg = 0;
     for (int i = 0; i < model->n; ++i)
         if (model->weight[i] < 0) neg += model->weight[i];
@@ -221,31 +227,38 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     P.phase_clocks = std::getenv("DDO_HIP_STATS") ? 1 : 0;
     P.lex_cap = 1024;
     if (const char* env = std::getenv("DDO_HIP_LEX_CAP")) P.lex_cap = std::max(1, std::min(1024, std::atoi(env)));   // tests: force the radix path
+    P.lex_cap = std::max(1, std::min(P.lex_cap, P.hist_bins / 2));   // the tie-break keys (8 bytes each) share the histogram area
     P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 3) & ~3ull;   // 16-byte event records stay aligned per slot
     engine_kind_ = 2;
     if (const char* env = std::getenv("DDO_HIP_ENGINE")) engine_kind_ = std::atoi(env) == 1 ? 1 : 2;
-    size_t lds2 = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, true, P.hist_bins);
-    const size_t lds2g = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, false, P.hist_bins);
+    size_t lds2 = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, true, P.hist_bins, P.lex_cap, model->wsT);
+    const size_t lds2g = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, false, P.hist_bins, P.lex_cap, model->wsT);
     // the dedup table always lives in LDS; the ranking keys join it when both fit, else they stay in HBM (L2-hot)
-    keys_global_ = lds2 > lds_max;
+    keys_global_ = lds2 > (dense_ ? lds_max / 2 : lds_max);
     if (const char* env = std::getenv("DDO_HIP_KEYS_GLOBAL")) keys_global_ = std::atoi(env) != 0;
     if (keys_global_) lds2 = lds2g;
     if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
     if (model->kind != MODEL_MISP) engine_kind_ = 1;   // scalar-state models run on the layer-rebuilding engine
     if (features & ENGINE_KEEP_LAYERS) engine_kind_ = 1;   // frontier cut-set / thresholds / cache need every layer of the DD
     P.tmode = (features & ENGINE_KEEP_LAYERS) ? 1 : 0;
-    P.lstride = P.tmode ? std::min(P.capC1 + 1, 4 * P.capN + 2) : P.capN;   // kept + cache-pruned + dominated nodes of a layer
+    // a kept layer holds its surviving nodes AND the cache-pruned / dominated ones (their thresholds flow to the parents):
+    // up to every distinct child of the layer above
+    P.lstride = P.tmode ? P.capC1 + 1 : P.capN;
     if (owner && engine_kind_ != 2) {
         set_error("Engine::create_tier: the tier does not fit the in-place engine");
         return DDO_ERR_UNSUPPORTED;
     }
     if (engine_kind_ == 2) lds_bytes_ = lds2;
+    if (dense_ && (lds_bytes_ > lds_max / 2 || (long)P.tab2_cap * 7 / 8 < P.capW + 8)) {   // (the sweep alone inserts up to capW nodes)
+        set_error("Engine::create_tier: the dense tier does not fit two workgroups per CU at this width");
+        return DDO_ERR_UNSUPPORTED;
+    }
 
     // ---- how many DDs in flight: residency of the kernel, then HBM
     int blocks_per_cu = (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(2048 / threads_));
     blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
-    if (dense_ && engine_kind_ == 2) blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, 2));   // 2 x 8 waves at 128 VGPRs
-    if (owner)   // tier kernel: 3 waves per SIMD = 12 waves per CU (kernels_inplace_tier.hip)
+    if (dense_) blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, 2));   // 2 x 8 waves at 128 VGPRs
+    else if (owner)   // tier kernel: 3 waves per SIMD = 12 waves per CU (kernels_inplace_tier.hip)
         blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(12 / (threads_ / 64))));
     int nslots = prop.multiProcessorCount * blocks_per_cu;
     if (P.tmode) nslots = std::min(nslots, 64);   // every layer of every DD in flight is kept: hundreds of MB per slot at large widths
@@ -260,12 +273,15 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
                                 (table_lds_ ? 0 : (size_t)P.table_cap * 4)
                           : wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 * (((wsT + 8) / 8) * 8 + ((wsT + 7) / 8) * 8) +
                                 (size_t)P.capS * 12 + capN * 4 + P.ev_cap * 4 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
-    if (P.tmode) per_slot += ml * (size_t)P.lstride * (wsT * 8 + 5 * 4) + capC1 * 8;
+    if (P.tmode) {
+        per_slot += ml * (size_t)P.lstride * (wsT * 8 + 6 * 4) + capC1 * 8;
+        nslots = std::min(nslots, (int)std::max<size_t>(4, (8ull << 30) / per_slot));   // D-ary models: up to a GB per slot
+    }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     // output arena: restricted/relaxed results of one batch (cut-set rows + paths), sized by the slots that can run
     size_t arena_mb = std::min<size_t>(1024, std::max<size_t>(64, ((size_t)nslots * (size_t)P.capN * 256) >> 20));
-    if (owner) arena_mb = std::min<size_t>(arena_mb, 256);
+    if (owner && !dense_) arena_mb = std::min<size_t>(arena_mb, 256);
     if (const char* env = std::getenv("DDO_HIP_ARENA_MB")) arena_mb = (size_t)std::max(16, std::atoi(env));
     arena_cap_ = arena_mb << 20;
     size_t budget = free_b > (arena_cap_ + (2ull << 30)) ? (size_t)((free_b - arena_cap_ - (1ull << 30)) * 0.8) : 0;
@@ -467,14 +483,15 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     ev0_ = e0;
     ev1_ = e1;
 
-    kernel_fn fn = owner ? pick_kernel2_tier(model->wsT)
-                   : (dense_ && engine_kind_ == 2) ? pick_kernel2_dense(model->wsT)
+    kernel_fn fn = dense_ ? pick_kernel2_dense(model->wsT)
+                   : owner ? pick_kernel2_tier(model->wsT)
                    : engine_kind_ == 2 ? pick_kernel2(model->wsT, threads_)
                                        : pick_kernel(model->wsT, table_lds_);
     if (!fn) {
         set_error("unsupported state width");
         return DDO_ERR_UNSUPPORTED;
     }
+    kernel_ = (void*)fn;
     {   // several engines (tiers, widths) share a kernel: the attribute must cover the largest of them
         static std::mutex attr_mtx;
         static std::map<std::pair<int, const void*>, size_t> attr_max;
@@ -698,6 +715,25 @@ int CacheTable::read_stats(uint64_t* used, uint64_t* dropped) const {
     return DDO_OK;
 }
 
+int Engine::grow_arena(size_t bytes) {
+    std::lock_guard<std::mutex> g(mtx_);
+    if (pending_ > 0 || fetch_set_ >= 0) {
+        set_error("Engine::grow_arena: a launch is in flight");
+        return DDO_ERR_INVALID;
+    }
+    if (bytes <= arena_cap_) return DDO_OK;
+    HIP_TRY(hipSetDevice(device_));
+    for (int k = 0; k < 2; ++k)
+        if (io_[k].h_arena) {
+            HIP_TRY(hipHostFree(io_[k].h_arena));
+            io_[k].h_arena = nullptr;
+            io_[k].h_arena_cap = 0;
+        }
+    arena_cap_ = bytes;
+    P_.arena_cap = arena_cap_;
+    return DDO_OK;
+}
+
 void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) const {
     out.clear();
     out.hdr = r;
@@ -784,7 +820,7 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     }
     for (int i = 0; i < count; ++i) {
         if ((!owner_ && inputs[i].width + 2 > P_.capN) || inputs[i].width < 1 || inputs[i].width > max_width_ ||
-            (owner_ && inputs[i].width <= P_.capW)) {   // a tier never squashes: its layer capacity must be below the width
+            (owner_ && !dense_ && inputs[i].width <= P_.capW)) {   // a capacity tier never squashes: its layer capacity must be below the width
             set_error("compile width exceeds the max_width the mdd was created with (or is < 1)");
             return DDO_ERR_CAPACITY;
         }
@@ -832,8 +868,7 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         P.dom_cap = dom->cap;
     }
     const int grid = std::min(count, nslots_);
-    kernel_fn fn = engine_kind_ == 2 ? pick_kernel2(model_->wsT, threads_)
-                                     : pick_kernel(model_->wsT, table_lds_);
+    kernel_fn fn = (kernel_fn)kernel_;
     if (rewind_ >= 0) {   // bench: the frozen batch overwrites the blocks of its previous run
         rewind_val_ = (unsigned long long)rewind_;
         rewind_ = -1;

@@ -159,6 +159,7 @@ class Engine {
     int nslots() const { return nslots_; }
     int cap_width() const { return cap_width_; }
     bool is_tier() const { return owner_ != nullptr; }
+    bool is_dense() const { return dense_; }
     int threads() const { return threads_; }
     int engine_kind() const { return engine_kind_; }
     size_t lds_bytes() const { return lds_bytes_; }
@@ -188,8 +189,14 @@ class Engine {
     Engine* pool_owner() { return owner_ ? owner_ : this; }
     Engine* owner_ = nullptr;        // capacity tier: the engine whose node pool / cutoff flag this one shares
     int cap_width_ = 0;              // capacity tier: layer capacity (0 = full-width engine)
+    void* kernel_ = nullptr;         // the __global__ entry picked in init(): launch() must use the very same one
     bool dense_ = false;             // two 512-thread workgroups per CU (kernels_inplace_tier.hip: misp_compile_kernel2_dense)
     void decode(const DDResult& r, const uint8_t* arena, HostResult& out) const;
+  public:
+    /// Enlarge the output arena (no launch may be in flight): one sub-problem's cut-set did not fit.
+    int grow_arena(size_t bytes);
+    size_t arena_capacity() const { return arena_cap_; }
+  private:
 
     Model* model_ = nullptr;
     int device_ = 0;

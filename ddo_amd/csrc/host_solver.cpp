@@ -900,10 +900,10 @@ struct ddo_solver {
     int flight_tier = -1;                          // engine of the launch in flight (flight = its items)
     std::vector<std::pair<std::vector<LazyItem>, std::vector<HostResult>>> todo;   // finished, not folded in yet
     static constexpr int HINT_DEPTHS = 1024;
-    struct TierHint { uint32_t tried[3] = {0, 0, 0}, retried[3] = {0, 0, 0}; };
+    struct TierHint { uint32_t tried[4] = {0, 0, 0, 0}, retried[4] = {0, 0, 0, 0}; };
     std::vector<TierHint> hints;
     uint64_t probe_ctr = 0;
-    uint64_t st_tier_items[4] = {0, 0, 0, 0}, st_tier_retry[4] = {0, 0, 0, 0}, st_tier_launch[4] = {0, 0, 0, 0};
+    uint64_t st_tier_items[5] = {0, 0, 0, 0, 0}, st_tier_retry[5] = {0, 0, 0, 0, 0}, st_tier_launch[5] = {0, 0, 0, 0, 0}, st_tier_nodes[5] = {0, 0, 0, 0, 0};
 
     bool pending() const { return !flight.empty() || !todo.empty(); }
 
@@ -1018,6 +1018,7 @@ struct ddo_solver {
                     lists[(size_t)t + 1].push_back(cur[i]);
                 } else {
                     done.push_back(cur[i]);
+                    st_tier_nodes[t] += res[2 * i].hdr.nodes_expanded + res[2 * i + 1].hdr.nodes_expanded;
                     done_res.push_back(std::move(res[2 * i]));
                     done_res.push_back(std::move(res[2 * i + 1]));
                 }
@@ -1270,6 +1271,14 @@ struct ddo_solver {
                 // the shared output arena overflowed: redo this sub-problem on its own
                 std::vector<HostResult> solo;
                 int rc2 = engine->run_batch(&inputs[i], 1, solo, cache, dominance);
+                // ... and if even one sub-problem's cut-set (a frontier cut-set holds nodes of every layer) does not
+                // fit, enlarge the arena: 4x per attempt up to 8 GB
+                while (rc2 == DDO_OK && (solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY) &&
+                       engine->arena_capacity() < (8ull << 30)) {
+                    if ((rc2 = engine->grow_arena(engine->arena_capacity() * 4)) != DDO_OK) break;
+                    solo.clear();
+                    rc2 = engine->run_batch(&inputs[i], 1, solo, cache, dominance);
+                }
                 if (rc2 != DDO_OK || solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY) {
                     set_error("device compile failed: output arena too small for one sub-problem");
                     err = DDO_ERR_CAPACITY;
@@ -1387,6 +1396,13 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
                 return nullptr;
             }
             s->tiers.push_back(t);
+        }
+        // the dense tier: full layer capacity, two decision diagrams per CU (DDO_HIP_DENSE=0 switches it off); it exists only
+        // where its LDS footprint fits twice -- not a failure otherwise
+        const char* denv = std::getenv("DDO_HIP_DENSE");
+        if (s->cfg.width_policy == DDO_WIDTH_FIXED && s->engine->engine_kind() == 2 && (denv ? std::atoi(denv) != 0 : s->cfg.width >= 2048)) {
+            auto t = Engine::create_tier(s->model, cfg->device, s->engine.get(), (int)s->cfg.width, 512);
+            if (t) s->tiers.push_back(t);
         }
     }
     s->tiers.push_back(s->engine);
@@ -1506,6 +1522,29 @@ int64_t ddo_solver_fringe_best_ub(const ddo_solver* s) {
     const Entry* top = s->fringe->peek();
     return top ? top->ub : I64_MIN;
 }
+int ddo_solver_tier_count(const ddo_solver* s) { return s ? (int)s->tiers.size() : 0; }
+int ddo_solver_tier_stats(const ddo_solver* s, int t, ddo_tier_stats* out) {
+    if (!s || !out || t < 0 || t >= (int)s->tiers.size()) return DDO_ERR_INVALID;
+    const auto& e = s->tiers[(size_t)t];
+    std::memset(out, 0, sizeof(*out));
+    out->kernel_ms = e->kernel_ms();
+    out->launches = e->launches();
+    out->subproblems = s->st_tier_items[t];
+    out->retried = s->st_tier_retry[t];
+    if (t + 1 < (int)s->tiers.size()) out->nodes_expanded = s->st_tier_nodes[t];
+    else {   // the last tier's results are folded in by the pipeline: everything the lower tiers did not finish
+        uint64_t lower = 0;
+        for (int k = 0; k + 1 < (int)s->tiers.size(); ++k) lower += s->st_tier_nodes[k];
+        out->nodes_expanded = s->counters.nodes_expanded > lower ? s->counters.nodes_expanded - lower : 0;
+    }
+    out->layer_capacity = e->is_tier() ? e->cap_width() : (int32_t)e->max_width();
+    out->threads = e->threads();
+    out->slots = e->nslots();
+    out->dense = e->is_dense() ? 1 : 0;
+    out->lds_bytes = e->lds_bytes();
+    return DDO_OK;
+}
+
 int ddo_solver_device_time(const ddo_solver* s, double* kernel_ms, uint64_t* launches) {
     if (!s) return DDO_ERR_INVALID;
     double ms = 0;

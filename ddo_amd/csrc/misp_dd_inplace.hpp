@@ -28,6 +28,7 @@
 // host emulation.
 // =============================================================================
 #pragma once
+#include <cstddef>
 #include "misp_dd_core.hpp"
 
 namespace ddo_hip {
@@ -97,8 +98,7 @@ struct DD2Shared {
     uint32_t kand, kor, pivKey;
     uint64_t land, lor;
     uint32_t gs[64];
-    uint64_t pivLex[MAX_WS];
-    uint64_t merged[MAX_WS];
+    uint64_t pivLex[1];
     uint64_t mergedKey;     // key32 << 32 | slot of the best victim
     uint64_t bestKey, bestExactKey;
     uint64_t nodes, arcs;
@@ -108,7 +108,11 @@ struct DD2Shared {
     uint64_t clk_last;
     uint64_t mk[24];        // statistics and auxiliary tick slots (DD2_STAT, DD2_TICK2), [16..24): DD2_PROBE
     int32_t xcand[64];
+    uint64_t merged[MAX_WS];   // LAST: a workgroup only allocates the WS words it uses (dd2_shared_bytes)
 };
+
+/// LDS bytes of the shared block of a WS-word engine
+inline size_t dd2_shared_bytes(int ws) { return (offsetof(DD2Shared, merged) + (size_t)ws * 8 + 15) & ~(size_t)15; }
 
 // DD2_STAT(k, v): profiling statistics (DDO_HIP_STATS) accumulated next to the code marks; workgroup-uniform context
 #define DD2_STAT(k, v)                                      \
@@ -206,6 +210,8 @@ struct DD2Ctx {
     int vbase_off;
     int NT;
     int lex_cap;
+    int hist_bins;   // bins of the select histogram: 2048 = digits of 10/11/11 bits, less = 8-bit digits
+    int tab_limit;   // entries the dedup table may hold (a dense tier's table is smaller than 3 x the layer capacity)
     int clocks;        // per-phase shader-clock accounting (DDO_HIP_STATS): costs one barrier per phase
     int tier;          // capacity tier: no squash phases (their LDS is not there), capacity errors mean ST_RETRY
 #if !defined(DDO_HOST_EMULATION)
@@ -462,9 +468,12 @@ DDO_DEV void select_key2(DD2Ctx<WS>& c, int K) {
     const uint32_t diff = sh->kand ^ sh->kor;
     uint32_t piv = 0;
     // digits of key32, most significant first: bits 22..31, 11..21, 0..10
-    const int dshift[3] = {22, 11, 0};
-    const int dbits[3] = {10, 11, 11};
-    for (int d = 0; d < 3 && !done; ++d) {
+    // (a dense tier has 256 bins: four 8-bit digits)
+    const bool wide_digits = c.hist_bins >= 2048;
+    const int nd = wide_digits ? 3 : 4;
+    const int dshift[4] = {wide_digits ? 22 : 24, wide_digits ? 11 : 16, wide_digits ? 0 : 8, 0};
+    const int dbits[4] = {wide_digits ? 10 : 8, wide_digits ? 11 : 8, wide_digits ? 11 : 8, 8};
+    for (int d = 0; d < nd && !done; ++d) {
         const int shift = dshift[d];
         const uint32_t dmask = (1u << dbits[d]) - 1;
         if (((diff >> shift) & dmask) == 0) {
@@ -853,7 +862,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         int merged_slot = -1, dup_from = -1, dup_to = -1;
         const uint64_t del_off = DD_UNIFORM64(sh->ev_pos);
         int n_del = 0;
-        if (squash && c.tier) {   // cannot happen: a tier's layer capacity is below the width (the host guarantees it)
+        if (squash && c.tier == 1) {   // cannot happen: a tier's layer capacity is below the width (the host guarantees it)
             PAR_BEGIN
             if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 11;
             PAR_END
@@ -1245,10 +1254,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_END
         const int nwl = DD_UNIFORM(sh->nwl);      // nodes containing the variable
         const int nwl2 = DD_UNIFORM(sh->nwl2);    // fresh nodes that do not
-        if (nwl + nwl2 > c.capW || n > c.capW || sh->ev_pos + 4ull * (uint64_t)(nwl + nwl2) + 12 > c.ev_cap) {
+        // (n + nwl bounds the entries of the next layer's dedup table: every node of this layer and one YES-child per branching node)
+        if (nwl + nwl2 > c.capW || n > c.capW || n + nwl > c.tab_limit || sh->ev_pos + 4ull * (uint64_t)(nwl + nwl2) + 12 > c.ev_cap) {
             PAR_BEGIN
             if (tid == 0) {
-                sh->status = ST_ERR_CAPACITY - 100 * (nwl + nwl2 > c.capW ? 41 : (n > c.capW ? 42 : 43));
+                sh->status = ST_ERR_CAPACITY - 100 * (nwl + nwl2 > c.capW ? 41 : (n > c.capW ? 42 : (n + nwl > c.tab_limit ? 44 : 43)));
                 sh->bestKey = ((uint64_t)(uint32_t)nwl << 32) | (uint32_t)n;   // debugging aid: reported as best_value fields
                 sh->nodes = sh->ev_pos;
                 sh->arcs = (uint64_t)L;
@@ -1954,7 +1964,13 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
 }
 
 /// LDS bytes of one in-place workgroup
-inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool keys_in_lds = true, int hist_bins = 2048) {
+/// entries of the rank-counting scratch (lex_split2: partial counts of a tie list of m <= lex_cap nodes with 2 m <= threads)
+DD_HD inline int dd2_tcount_len(int nthreads, int lex_cap) {
+    const int m = nthreads / 2 < lex_cap ? nthreads / 2 : lex_cap;
+    return m < 64 ? 64 : m;
+}
+
+inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool keys_in_lds = true, int hist_bins = 2048, int lex_cap = 1024, int ws = MAX_WS) {
     const size_t nbw = ((size_t)capS + 31) / 32;
     size_t b = keys_in_lds ? (size_t)capS * 4 : 0;   // key32 / value_bot
     b = (b + 15) & ~(size_t)15;
@@ -1963,8 +1979,8 @@ inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool 
     b = (b + 15) & ~(size_t)15;
     b += (size_t)npad * 4;                 // cnt
     b += (size_t)(hist_bins > 0 ? hist_bins : 2048) * 4;   // hist (squash phases only)
-    b += (size_t)nthreads * 4 * 2;         // scan scratch
-    b += (sizeof(DD2Shared) + 15) & ~(size_t)15;
+    b += (size_t)dd2_tcount_len(nthreads, lex_cap) * 4 * 2;   // rank-counting scratch
+    b += dd2_shared_bytes(ws);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -2022,10 +2038,11 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     p += (size_t)(P.hist_bins > 0 ? P.hist_bins : 2048) * 4;
     c.wl = P.s_wl + s * 2 * capW;          // work lists live in HBM (written and read once per layer, coalesced)
     c.fl = c.wl + capW;
+    c.lex_cap = P.lex_cap > 0 && P.lex_cap <= 1024 ? P.lex_cap : 1024;
     c.tcount = (LDS_PTR(int32_t))p;
-    p += (size_t)nthreads * 4;
+    p += (size_t)dd2_tcount_len(nthreads, c.lex_cap) * 4;
     c.tcount2 = (LDS_PTR(int32_t))p;
-    p += (size_t)nthreads * 4;
+    p += (size_t)dd2_tcount_len(nthreads, c.lex_cap) * 4;
     c.sh = (LDS_PTR(DD2Shared))p;
     c.arena = P.arena;
     c.arena_cap = P.arena_cap;
@@ -2036,7 +2053,8 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.pool_head = P.pool_head;
     c.vbase_off = P.vbase_off;
     c.clocks = P.phase_clocks;
-    c.lex_cap = P.lex_cap > 0 && P.lex_cap <= 1024 ? P.lex_cap : 1024;
+    c.hist_bins = P.hist_bins > 0 ? P.hist_bins : 2048;
+    c.tab_limit = P.tab2_cap >= 3 * P.capW ? 0x7FFFFFFF : (int)((long)P.tab2_cap * 7 / 8);
     c.tier = P.tier;
     c.NT = nthreads;
 }

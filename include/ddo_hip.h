@@ -302,6 +302,16 @@ uint64_t ddo_solver_fringe_len(const ddo_solver* s);
 int64_t ddo_solver_fringe_best_ub(const ddo_solver* s);
 /** Milliseconds spent inside device compile launches so far (HIP events on the engine's stream)
  *  and the number of launches. */
+/* Per-tier accounting of the lazy solver (no reference counterpart: the reference has one engine).  Tier 0.. are the
+ * capacity tiers (narrow decision diagrams, several per CU), then the dense tier (full width, two per CU) when it fits, the
+ * last tier is the full-width engine.  kernel_ms = HIP-event time of the tier's launches. */
+typedef struct ddo_tier_stats {
+    double kernel_ms;
+    uint64_t launches, subproblems, retried, nodes_expanded, lds_bytes;
+    int32_t layer_capacity, threads, slots, dense;
+} ddo_tier_stats;
+int ddo_solver_tier_count(const ddo_solver* s);
+int ddo_solver_tier_stats(const ddo_solver* s, int tier, ddo_tier_stats* out);
 int ddo_solver_device_time(const ddo_solver* s, double* kernel_ms, uint64_t* launches);
 
 #ifdef __cplusplus

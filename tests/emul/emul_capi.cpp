@@ -97,7 +97,7 @@ void* emul_create(int n, const uint64_t* adj_rows, const int64_t* weights, int m
         unit &= weights[i] == 1;
     }
     void* h = emul_finish(e, n, wsT, unit, max_width, nthreads, arena_bytes, max_width + 2, weights);
-    if (h && engine == 2 && std::getenv("DDO_EMUL_TIER")) e->P.tier = 1;   // capacity tier: max_width is the layer capacity, widths above it are accepted
+    if (h && engine == 2 && std::getenv("DDO_EMUL_TIER") && !std::getenv("DDO_EMUL_DENSE")) e->P.tier = 1;   // capacity tier: max_width is the layer capacity, widths above it are accepted
     return h;
 }
 
@@ -124,7 +124,7 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
     P.table_in_lds = 1;
     P.nslots = 1;
     const size_t capC1 = P.capC1, capN = P.capN, ml = P.max_layers;
-    const size_t LSm = std::min<size_t>(capC1 + 1, 4 * (size_t)P.capN + 2);   // nodes per kept layer (emul_set_keep_layers switches P.tmode / P.lstride on)
+    const size_t LSm = capC1 + 1;   // nodes per kept layer (emul_set_keep_layers switches P.tmode / P.lstride on)
     size_t bytes = 2 * wsT * capC1 * 8 + 2 * capC1 * 8 + 2 * capC1 * 4 * 2 + (size_t)fan * capN * 4 + capC1 * 4 + capC1 * 4 + capC1 +
                    ml * LSm * 4 + 2 * ml * (size_t)fan * capN * 4 + ml * 5 * 4 + wsT * capN * 8 + capN * 8 + 64 * 32;
     e->mem.assign(bytes, 0xCD);  // poison
@@ -185,6 +185,17 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
     P.vbase_off = (int32_t)neg;
     P.lex_cap = 1024;
     if (const char* env = std::getenv("DDO_EMUL_LEX_CAP")) P.lex_cap = std::max(1, std::min(1024, std::atoi(env)));
+    P.hist_bins = 2048;
+    if (const char* env = std::getenv("DDO_EMUL_DENSE")) {   // dense tier (two workgroups per CU): small table, 8-bit select digits, short tie lists in LDS
+        P.tier = 2;
+        P.hist_bins = 256;
+        P.lex_cap = std::min(P.lex_cap, 128);
+        P.tab2_cap = std::min(P.tab2_cap, std::max(64, std::atoi(env)));
+        if ((long)P.tab2_cap * 7 / 8 < P.capW + 8) {
+            std::fprintf(stderr, "emul: dense table too small for the layer capacity\n");
+            std::abort();
+        }
+    }
     P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 3) & ~3ull;
     {
         const size_t capS = P.capS, capW = P.capW, mlz = P.max_layers;
@@ -206,7 +217,7 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
             std::fprintf(stderr, "emul: workspace2 overflow\n");
             std::abort();
         }
-        e->lds2.assign(dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, nthreads), 0xEE);
+        e->lds2.assign(dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, nthreads, true, P.hist_bins, P.lex_cap, wsT), 0xEE);
     }
     return e;
 }

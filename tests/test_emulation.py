@@ -131,3 +131,40 @@ def test_emulation_of_a_capacity_tier(oracle, monkeypatch, cap, nthreads):
         assert diff(r, g) is None, f"cap {cap} compile #{i}: {diff(r, g)}"
         done += 1
     assert done > 0 and retry > 0
+
+
+@pytest.mark.parametrize("table,nthreads,expect_retry", [(1 << 20, 512, False), (128, 512, True), (128, 256, True)])
+def test_emulation_of_the_dense_tier(oracle, monkeypatch, table, nthreads, expect_retry):
+    """The dense tier (Engine::create_tier with cap_width == max_width, 512 threads, two workgroups per CU) = the in-place
+    engine at full layer capacity with a SMALLER dedup table, 8-bit select digits and at most 128 tie-break keys in LDS.  A
+    layer whose table could overflow ends the compile with ST_RETRY (the host hands it to the full-width engine); every
+    other compile equals the oracle's record -- including the squashed layers (the capacity tiers never squash)."""
+    monkeypatch.setenv("DDO_EMUL_DENSE", str(table))
+    inst = oracle.misp(data_path("misp", "brock200_2.clq"))
+    _, recs = inst.trace_solve(100, 300)
+    e = Emul(inst.n, inst.rows, inst.weights, 100, nthreads=nthreads, engine=2)
+    done = retry = squashed = 0
+    for i, r in enumerate(recs):
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"])[0]
+        if g["status"] == 78:   # ST_RETRY
+            retry += 1
+            continue
+        assert g["status"] == 0
+        assert diff(r, g) is None, f"table {table} compile #{i}: {diff(r, g)}"
+        done += 1
+        squashed += 0 if g["is_exact"] else 1
+    assert done > 0 and squashed > 0
+    assert (retry > 0) == expect_retry
+
+
+@pytest.mark.parametrize("case", [c for c in _golden_small() if c["width"] >= 100][:6], ids=lambda c: c["id"])
+def test_dense_tier_emulation_matches_golden(oracle, monkeypatch, case):
+    """8-bit select digits and the 128-key tie-break limit of the dense tier on the golden compiles (widths up to 1000)"""
+    monkeypatch.setenv("DDO_EMUL_DENSE", str(1 << 20))
+    inst = oracle.misp(data_path("misp", case["instance"] + ".clq"))
+    e = Emul(inst.n, inst.rows, inst.weights, case["width"], nthreads=512, engine=2)
+    state = np.array([int(x) for x in case["state"]], dtype=np.uint64)
+    g = e.compile(case["comp_type"], case["width"], case["best_lb"], state, case["value"], case["depth"])[0]
+    for k in ["is_exact", "best_value", "best_exact_value", "nodes_expanded", "arcs", "layers"]:
+        assert g[k] == case[k], (k, g[k], case[k])
+    assert len(g["cutset"]) == case["n_cutset"] and cutset_digest(g["cutset"]) == case["cutset_digest"]

@@ -177,6 +177,39 @@ def test_capacity_tiers_do_not_change_the_search(have_gpu, monkeypatch, name, ex
         assert abs(tiered[0] - base[0]) <= 0.2 * base[0] + 8
 
 
+@pytest.mark.parametrize("name,expected,width,table,threads", [
+    ("brock200_2", 12, 100, 128, 1), ("brock200_2", 12, 100, 1 << 20, 64), ("keller4", 11, 64, 128, 1),
+    ("p_hat300-1", 8, 128, 256, 300), ("brock200_4", 17, 300, 512, 256), ("brock200_2", 12, 3000, 4096, 600),
+])
+def test_the_dense_tier_does_not_change_the_search(have_gpu, monkeypatch, name, expected, width, table, threads):
+    """The dense tier (two full-width decision diagrams per CU, half-size dedup table; host_solver.cpp: ddo_solver_create,
+    Engine::create_tier) hands a DD whose table could overflow to the full-width engine (ST_RETRY).  Whatever it completes
+    is what the full-width engine produces (tests/test_emulation.py replays oracle traces through the dense configuration
+    compile by compile); here: same proved optimum, a feasible solution of that value, about the same amount of work."""
+    model = ddo_amd.Misp.read_instance(data_path("misp", name + ".clq"))
+    monkeypatch.setenv("DDO_HIP_TIERS", "0")
+
+    def run(dense):
+        monkeypatch.setenv("DDO_HIP_DENSE", "1" if dense else "0")
+        monkeypatch.setenv("DDO_HIP_DENSE_TABLE", str(table))
+        s = ParallelSolver(model, FixedWidth(width), nb_threads=threads, fringe="lazy")
+        c = s.maximize()
+        assert c.is_exact and c.best_value == expected
+        sol = [d.variable for d in s.best_solution() if d.value == 1]
+        rows, w = model.export()
+        assert len(sol) == expected and is_independent_set(rows, model.ws, sol)
+        return s.explored(), s.tier_stats()
+
+    base = run(False)
+    dense = run(True)
+    assert len(base[1]) == 1 and len(dense[1]) == 2 and dense[1][0]["dense"] == 1 and dense[1][0]["threads"] == 512
+    assert dense[1][0]["subproblems"] > 0 and dense[1][0]["nodes_expanded"] > 0
+    if table <= 4096:
+        assert dense[1][0]["retried"] > 0 and dense[1][1]["subproblems"] == dense[1][0]["retried"]
+    if threads == 1:
+        assert abs(dense[0] - base[0]) <= 0.2 * base[0] + 8
+
+
 # ---- (3) golden fixtures (generated by tests/golden/make_golden.py from the oracle) ----------------
 def _golden_cases():
     with open(GOLDEN) as f:
