@@ -218,7 +218,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     P.tab2_cap = t2;
     if (dense_) {   // the largest table that leaves room for two workgroups per CU
         const char* env = std::getenv("DDO_HIP_DENSE_TABLE");
-        P.tab2_cap = std::min(t2, env ? std::max(1024, std::atoi(env)) : 16384);
+        P.tab2_cap = std::min(t2, env ? std::max(64, std::atoi(env)) : 16384);
     }
     long long neg = 0;
     for (int i = 0; i < model->n; ++i)
@@ -876,15 +876,17 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         pool_owner()->pool_head_bound_ = rewind_val_;
     }
     HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
-    if (vm_base_) {
+    if (Engine* po = pool_owner(); po->vm_base_) {
         // the kernel allocates blocks with one atomic on the pool head: back everything the launches that are not
-        // fetched yet (the previous one may still run) and this one can possibly take
+        // fetched yet (the previous one may still run) and this one can possibly take.  The pool belongs to the owner
+        // engine; a tier's launches are accounted there as well (fetch() takes them off again).
         const size_t worst = (size_t)count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
-        const size_t need = (size_t)pool_head_bound_ + pool_unfetched_worst_ + worst;
-        if (need > vm_mapped_) pool_grow(need + 2 * vm_chunk_);
-        pool_unfetched_worst_ += worst;
-        P_.pool_cap = vm_mapped_;
-        P.pool_cap = vm_mapped_;
+        const size_t need = (size_t)po->pool_head_bound_ + po->pool_unfetched_worst_ + worst;
+        if (need > po->vm_mapped_) po->pool_grow(need + 2 * po->vm_chunk_);
+        po->pool_unfetched_worst_ += worst;
+        po->P_.pool_cap = po->vm_mapped_;
+        P_.pool_cap = po->vm_mapped_;
+        P.pool_cap = po->vm_mapped_;
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);
     HIP_TRY(hipGetLastError());
