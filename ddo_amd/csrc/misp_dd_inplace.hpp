@@ -1190,7 +1190,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // other node stays unchanged in the next layer and enters the dedup table right away with its cached hash
         // (fresh survivors follow in expand 1, changed / new nodes in expand 2).  Word `var/64` of every slot and
         // the hashes are contiguous streams; the loads of a batch are in flight before the first is used.
+#if defined(DDO_KS)   // experiment knob: slots fetched per thread and batch by the work-list sweep
+        constexpr int KS = DDO_KS;
+#else
         constexpr int KS = DEEP ? 8 : 4;
+#endif
         PAR_BEGIN
         {
             const uint64_t* row = c.st + (size_t)vw * capS;
