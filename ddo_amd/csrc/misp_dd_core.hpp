@@ -492,9 +492,47 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
     uint64_t pivLex[WS];
 #pragma unroll
     for (int k = 0; k < WS; ++k) pivLex[k] = 0;
+    uint64_t ldiff = 0, land = 0;   // bits of word wj in which the nodes still tied differ / agree on 1
     for (int qd = 0; qd < 8 * WS && !done; ++qd) {
         const int wj = qd >> 3;
         const int shift = 8 * (7 - (qd & 7));
+        if ((qd & 7) == 0) {
+            // one sweep per word: AND / OR of the word over the nodes still tied.  Bytes that are the same for all of them
+            // decide nothing -- with 31-word signed-vector states most of the 248 digit rounds would be such bytes
+            PAR_BEGIN
+            if (tid == 0) {
+                sh->k1and = ~0ULL;
+                sh->k1or = 0;
+            }
+            PAR_END
+            PAR_BEGIN
+            uint64_t a = ~0ULL, o = 0;
+            int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+            for (int j = lo; j < hi; ++j) {
+                int cd = lin2cand(j, nprev, c.capN);
+                if (!cand_live(c, cur, cd)) continue;
+                if (k1_of(LD_U64(&key[cd]), pop[cd]) != pivK1) continue;
+                bool active = true;
+                for (int k = 0; k < wj && active; ++k)
+                    active = lexkey(c, st[(size_t)k * capC1 + cd]) == pivLex[k];
+                if (!active) continue;
+                const uint64_t lw = lexkey(c, st[(size_t)wj * capC1 + cd]);
+                a &= lw;
+                o |= lw;
+            }
+            if (a != ~0ULL || o != 0) {
+                LDS_AND_U64(&sh->k1and, a);
+                LDS_OR_U64(&sh->k1or, o);
+            }
+            PAR_END
+            land = sh->k1and;
+            ldiff = land ^ sh->k1or;
+            DD_SYNC();   // every thread has its copy before thread 0 resets the pair for the next word
+        }
+        if (((ldiff >> shift) & 0xFF) == 0) {   // the same byte in every tied node
+            pivLex[wj] |= land & (0xFFULL << shift);
+            continue;
+        }
         PAR_BEGIN
         if (tid < 256) c.hist[tid] = 0;
         PAR_END
