@@ -140,6 +140,12 @@ DDO_DEV uint32_t key_arc(uint64_t key) {   // candidate index of the best arc, N
 constexpr int32_t VB_UNMARKED = INT32_MIN;  // value_bot = isize::MIN  <=> !MARKED (clean.rs:392, 464)
 
 /// Workgroup-shared scalars (one per workgroup, lives in LDS).
+#if defined(DDO_HOST_EMULATION)
+DDO_DEV uint64_t dd_clock() { return 0; }
+#else
+DDO_DEV uint64_t dd_clock() { return (uint64_t)__builtin_readcyclecounter(); }
+#endif
+
 struct DDShared {
     int32_t work;
     uint32_t varkey;
@@ -153,6 +159,7 @@ struct DDShared {
     int32_t xbest;       // recycled merge: candidate re-added to the layer (clean.rs:868-872)
     uint32_t recycled_merges;
     int32_t maxn;
+    uint64_t clk[8], clk_last;   // shader-clock ticks per phase (DDO_HIP_STATS): DD1_TICK
     uint64_t k1and, k1or;
     uint64_t pivK1;
     uint64_t pivLex[MAX_WS];
@@ -169,6 +176,19 @@ struct DDShared {
     uint64_t vposmask[(MAX_VEC_VARS + 63) / 64], vnegmask[(MAX_VEC_VARS + 63) / 64];
     int32_t mrank, xdelta;
 };
+
+// DD1_TICK(ph): shader-clock ticks since the previous mark are charged to phase ph (DDO_HIP_STATS; workgroup-uniform context)
+#define DD1_TICK(ph)                                        \
+    if (c.clocks) {                                         \
+        PAR_BEGIN                                           \
+        if (tid == 0) {                                     \
+            const uint64_t _t = dd_clock();                 \
+            sh->clk[ph] += _t - sh->clk_last;               \
+            sh->clk_last = _t;                              \
+        }                                                   \
+        PAR_END                                             \
+    }
+
 
 /// Everything one workgroup needs: model, slot-local workspace and LDS carve-up.
 template <int WS>
@@ -225,6 +245,7 @@ struct DDCtx {
     DDShared* sh;
     // frontier cut-set / thresholds / cache (dd_thresholds.hpp): every layer is kept
     int tmode, lstride;
+    int clocks;          // DDO_HIP_STATS: phase clocks on
     uint64_t* lstate;
     int32_t *lval, *lrub, *lvb, *lth;
     int32_t* cth;        // [capC1] theta of the candidates the cache pruned in the layer being built
@@ -793,6 +814,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         sh->recycled_merges = 0;
         sh->maxn = 0;
         sh->cutoff = 0;
+        for (int k = 0; k < 8; ++k) sh->clk[k] = 0;
+        sh->clk_last = dd_clock();
         sh->ncache = 0;
         sh->cache_hits = 0;
         for (int k = 0; k < WS; ++k) c.cstate[0][(size_t)k * capC1] = in.state[k];
@@ -937,6 +960,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         const int nU = sh->nU - ncache;                               // |curr_l| after the filters
 
+        DD1_TICK(0)   // next_variable, cache / dominance filters
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
         const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
         if ((!squash && nU > capN) || (c.tmode && nU + ncache + 1 > LS)) {  // Exact DD wider than the workspace
@@ -968,6 +992,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             K = restricted ? W : W - 1;
             if (K > 0) select_pivot<WS>(c, cur, nprev, K);
         }
+        DD1_TICK(1)   // exact top-K pivot: radix select on the key, tie-break on the state words
 
         // ------------------------------------------------------------ classify + count (pass 1)
         PAR_BEGIN
@@ -1248,6 +1273,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             ntot = n + ncache;
         }
 
+        DD1_TICK(3)   // classify, positions, merged node
         // ------------------------------------------------------------ layers.push (clean.rs:678-684)
         PAR_BEGIN
         if (tid == 0) {
@@ -1308,6 +1334,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         PAR_END
 
+        DD1_TICK(5)   // layer bookkeeping (kept layers, arcs)
         // ------------------------------------------------------------ expand (clean.rs:360-370, 728-776)
         const int nxt = cur ^ 1;
         PAR_BEGIN
@@ -1601,6 +1628,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         L += 1;
     }
 
+    DD1_TICK(4)
     // ==================================================================== _finalize (clean.rs:407-414)
     int n_layers = L;
     int nT = 0;          // nodes of the terminal layer
@@ -1704,6 +1732,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         PAR_END
     }
 
+    DD1_TICK(6)   // _finalize: terminal layer, best node
     // ---------------------------------------------------------------- results
     const bool is_exact = lel < 0;                                     // clean.rs:635
     const bool has_best = !failed && sh->bestKey != 0;
@@ -2125,7 +2154,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         r.cs_value_off = cs_value_off;
         r.cs_ub_off = cs_ub_off;
         r.cs_path_off = cs_path_off;
-        for (int k = 0; k < 32; ++k) r.phase_clk[k] = 0;
+        for (int k = 0; k < 32; ++k) r.phase_clk[k] = k < 8 && c.clocks ? sh->clk[k] : 0;
         r.pool_off = NO_POOL_SRC;
         r.cs_depth_off = c.tmode ? cs_depth_off : 0;
         r.cs_path_stride = cs_path_len;
@@ -2256,6 +2285,7 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.cs_pop = P.cs_pop + s * capN;
     c.table_cap = P.table_cap;
     c.tmode = P.tmode;
+    c.clocks = P.phase_clocks;
     c.lstride = P.tmode ? P.lstride : P.capN;
     c.lstate = nullptr;
     c.lval = c.lrub = c.lvb = c.lth = c.cth = nullptr;

@@ -52,11 +52,9 @@ constexpr uint32_t KEY_POP_MASK = (1u << KEY_POP_BITS) - 1;
 #endif
 
 #if defined(DDO_HOST_EMULATION)
-DDO_DEV uint64_t dd_clock() { return 0; }
 #define DD_UNIFORM(x) (x)
 #define DD_UNIFORM64(x) (x)
 #else
-DDO_DEV uint64_t dd_clock() { return (uint64_t)__builtin_readcyclecounter(); }
 // Workgroup-uniform scalars read from LDS land in VGPRs; at the 128-VGPR cap of 1024-thread workgroups every
 // long-lived one costs a spill somewhere.  readfirstlane moves them to SGPRs (and makes the loads they index scalar).
 #define DD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)

