@@ -510,14 +510,15 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         if (need == sh->sel_bucket) done = true;  // the whole bucket is kept: stop refining
     }
     // ---- tie-break: lexicographic member order; digit = byte of brev(~word), MSB first
-    uint64_t pivLex[WS];
-#pragma unroll
-    for (int k = 0; k < WS; ++k) pivLex[k] = 0;
+    // The pivot words live in LDS (sh->pivLex, zeroed above); only the word in progress is a register: a local array
+    // indexed by the running word number would sit in scratch memory (31- and 69-word states).
+    uint64_t pw = 0;
     uint64_t ldiff = 0, land = 0;   // bits of word wj in which the nodes still tied differ / agree on 1
     for (int qd = 0; qd < 8 * WS && !done; ++qd) {
         const int wj = qd >> 3;
         const int shift = 8 * (7 - (qd & 7));
         if ((qd & 7) == 0) {
+            pw = 0;
             // one sweep per word: AND / OR of the word over the nodes still tied.  Bytes that are the same for all of them
             // decide nothing -- with 31-word signed-vector states most of the 248 digit rounds would be such bytes
             PAR_BEGIN
@@ -535,7 +536,7 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
                 if (k1_of(LD_U64(&key[cd]), pop[cd]) != pivK1) continue;
                 bool active = true;
                 for (int k = 0; k < wj && active; ++k)
-                    active = lexkey(c, st[(size_t)k * capC1 + cd]) == pivLex[k];
+                    active = lexkey(c, st[(size_t)k * capC1 + cd]) == sh->pivLex[k];
                 if (!active) continue;
                 const uint64_t lw = lexkey(c, st[(size_t)wj * capC1 + cd]);
                 a &= lw;
@@ -550,10 +551,9 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
             ldiff = land ^ sh->k1or;
             DD_SYNC();   // every thread has its copy before thread 0 resets the pair for the next word
         }
-        if (((ldiff >> shift) & 0xFF) == 0) {   // the same byte in every tied node
-            pivLex[wj] |= land & (0xFFULL << shift);
-            continue;
-        }
+        const bool same_byte = ((ldiff >> shift) & 0xFF) == 0;   // the same byte in every tied node
+        if (same_byte) pw |= land & (0xFFULL << shift);
+        else {
         PAR_BEGIN
         if (tid < 256) c.hist[tid] = 0;
         PAR_END
@@ -565,10 +565,10 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
             if (k1_of(LD_U64(&key[cd]), pop[cd]) != pivK1) continue;
             bool active = true;
             for (int k = 0; k < wj && active; ++k)
-                active = lexkey(c, st[(size_t)k * capC1 + cd]) == pivLex[k];
+                active = lexkey(c, st[(size_t)k * capC1 + cd]) == sh->pivLex[k];
             if (!active) continue;
             uint64_t lw = lexkey(c, st[(size_t)wj * capC1 + cd]);
-            if (shift + 8 < 64 && (lw >> (shift + 8)) != (pivLex[wj] >> (shift + 8))) continue;
+            if (shift + 8 < 64 && (lw >> (shift + 8)) != (pw >> (shift + 8))) continue;
             LDS_ADD_U32(&c.hist[(lw >> shift) & 0xFF], 1u);
         }
         PAR_END
@@ -584,15 +584,18 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
             }
         }
         PAR_END
-        pivLex[wj] |= (uint64_t)sh->sel_digit << shift;
+        pw |= (uint64_t)sh->sel_digit << shift;
         need -= sh->sel_above;
         if (need == sh->sel_bucket) done = true;
+        }
+        if (done || (qd & 7) == 7) {   // the word is finished (or the selection is): publish it
+            PAR_BEGIN
+            if (tid == 0) sh->pivLex[wj] = pw;
+            PAR_END
+        }
     }
     PAR_BEGIN
-    if (tid == 0) {
-        sh->pivK1 = pivK1;
-        for (int k = 0; k < WS; ++k) sh->pivLex[k] = pivLex[k];
-    }
+    if (tid == 0) sh->pivK1 = pivK1;
     PAR_END
 }
 
