@@ -907,19 +907,31 @@ struct ddo_solver {
 
     bool pending() const { return !flight.empty() || !todo.empty(); }
 
+    // how wide a DD gets depends on its depth and on how far its bound lies above the incumbent (everything whose rough upper
+    // bound does not beat the incumbent is pruned): the retry statistics are kept per (depth, ub - incumbent) cell
+    static constexpr int HINT_SLACKS = 16;
+    int64_t hint_lb = 0;
+    int tier_skip_pct = 90;   // a tier is skipped by the cells in which more than this share of its DDs outgrew it
+    bool hint_by_slack = true;
+    size_t hint_cell(const LazyItem& e) const {
+        const size_t d = (size_t)std::min(std::max(e.depth, 0), HINT_DEPTHS - 1);
+        if (!hint_by_slack) return d * HINT_SLACKS;
+        const int64_t sl = e.ub - hint_lb;
+        return d * HINT_SLACKS + (size_t)std::min<int64_t>(std::max<int64_t>(sl, 0), HINT_SLACKS - 1);
+    }
     int start_tier(const LazyItem& e) {
         const int T = (int)tiers.size();
         if (T <= 1) return 0;
-        if (hints.empty()) hints.resize(HINT_DEPTHS);
-        const TierHint& h = hints[std::min(std::max(e.depth, 0), HINT_DEPTHS - 1)];
+        if (hints.empty()) hints.resize((size_t)HINT_DEPTHS * HINT_SLACKS);
+        const TierHint& h = hints[hint_cell(e)];
         const bool probe = !bench_mode && (++probe_ctr & 63) == 0;   // keep sampling the lower tiers: the search moves on (a frozen bench batch does not)
         for (int t = 0; t + 1 < T; ++t)
-            if (probe || h.tried[t] < 32 || (uint64_t)h.retried[t] * 10 < (uint64_t)h.tried[t] * 9) return t;
+            if (probe || h.tried[t] < 32 || (uint64_t)h.retried[t] * 100 < (uint64_t)h.tried[t] * (uint64_t)tier_skip_pct) return t;
         return T - 1;
     }
     void note_tier(const LazyItem& e, int t, bool retried) {
         if (t + 1 >= (int)tiers.size()) return;
-        TierHint& h = hints[std::min(std::max(e.depth, 0), HINT_DEPTHS - 1)];
+        TierHint& h = hints[hint_cell(e)];
         h.tried[t] += 1;
         h.retried[t] += retried ? 1 : 0;
         if (h.tried[t] >= 8192) {
@@ -948,6 +960,7 @@ struct ddo_solver {
     int dispatch(std::vector<LazyItem>& batch, int64_t lb, bool rewind) {
         const int T = (int)tiers.size();
         std::vector<std::vector<LazyItem>> lists((size_t)T);
+        hint_lb = lb > -((int64_t)1 << 40) ? lb : 0;
         for (LazyItem& e : batch) lists[(size_t)start_tier(e)].push_back(e);
         batch.clear();
         auto fail = [&](int rc) {
@@ -1407,6 +1420,8 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
     }
     s->tiers.push_back(s->engine);
     s->want_stats = std::getenv("DDO_HIP_STATS") != nullptr;
+    if (const char* env = std::getenv("DDO_HIP_TIER_SKIP")) s->tier_skip_pct = std::max(1, std::min(100, std::atoi(env)));
+    if (const char* env = std::getenv("DDO_HIP_HINT_SLACK")) s->hint_by_slack = std::atoi(env) != 0;   // 0: per-depth cells only (A/B)
     return s;
 }
 void ddo_solver_destroy(ddo_solver* s) { delete s; }
