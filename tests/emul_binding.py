@@ -17,10 +17,19 @@ def build_emul():
     src = os.path.join(HERE, "emul", "emul_capi.cpp")
     out = os.path.join(HERE, "emul", "libddo_emul.so")
     deps = [src] + [os.path.join(ROOT, "ddo_amd", "csrc", f) for f in ("misp_dd_core.hpp", "misp_dd_inplace.hpp", "dd_types.h", "engine.hpp",
-                                                                          "dd_thresholds.hpp")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", out, src],
-                       check=True)
+                                                                          "dd_thresholds.hpp", "dd_tsptw.hpp")]
+    def stale():
+        return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+    if stale():
+        import fcntl
+        with open(out + ".lock", "w") as lk:   # pytest-xdist workers: one of them builds, the others wait and find it fresh
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                tmp = out + ".%d.tmp" % os.getpid()
+                subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", tmp, src],
+                               check=True)
+                os.replace(tmp, out)
     return out
 
 
