@@ -916,6 +916,17 @@ int Engine::wait() {
     return DDO_OK;
 }
 
+int Engine::peek_retry(std::vector<uint8_t>& retry) {
+    std::lock_guard<std::mutex> g(mtx_);
+    retry.clear();
+    if (fetch_set_ < 0) return DDO_OK;
+    const IoSet& io = io_[fetch_set_];
+    retry.resize((size_t)io.count);
+    for (int i = 0; i < io.count; ++i)
+        retry[(size_t)i] = io.h_results[(size_t)i * 2].status == ST_RETRY || io.h_results[(size_t)i * 2 + 1].status == ST_RETRY;
+    return DDO_OK;
+}
+
 int Engine::fetch(std::vector<HostResult>& results) {
     std::lock_guard<std::mutex> g(mtx_);
     if (fetch_set_ < 0) {

@@ -193,6 +193,11 @@ class Engine {
     bool dense_ = false;             // two 512-thread workgroups per CU (kernels_inplace_tier.hip: misp_compile_kernel2_dense)
     void decode(const DDResult& r, const uint8_t* arena, HostResult& out) const;
   public:
+    /// After wait(), before fetch(): which sub-problems of the finished launch ended with ST_RETRY (a capacity tier hands them
+    /// up).  Lets the host launch the next tier before it decodes this one.
+    int peek_retry(std::vector<uint8_t>& retry);
+  private:
+  public:
     /// Enlarge the output arena (no launch may be in flight): one sub-problem's cut-set did not fit.
     int grow_arena(size_t bytes);
     size_t arena_capacity() const { return arena_cap_; }

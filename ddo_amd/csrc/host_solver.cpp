@@ -963,11 +963,43 @@ struct ddo_solver {
         hint_lb = lb > -((int64_t)1 << 40) ? lb : 0;
         for (LazyItem& e : batch) lists[(size_t)start_tier(e)].push_back(e);
         batch.clear();
+        int rc;
+        // a finished lower tier is split by status first (who is handed up?), the next tier is launched, and only then are
+        // its results decoded: the decode of 8192 result records is host work the device does not have to wait for
+        struct Deferred { int t; std::vector<LazyItem> items; std::vector<uint8_t> retry; };
+        std::vector<Deferred> deferred;
+        auto decode_deferred = [&]() -> int {
+            int err = DDO_OK;
+            for (Deferred& d : deferred) {
+                std::vector<HostResult> res;
+                int r2 = err == DDO_OK ? tiers[(size_t)d.t]->fetch(res) : DDO_ERR_INTERNAL;
+                if (r2 != DDO_OK || res.size() != 2 * d.items.size()) {
+                    if (err == DDO_OK) err = r2 != DDO_OK ? r2 : DDO_ERR_INTERNAL;
+                    for (size_t i = 0; i < d.items.size(); ++i)
+                        if (!d.retry[i]) dev_unref(d.items[i].block);
+                    continue;
+                }
+                std::vector<LazyItem> done;
+                std::vector<HostResult> done_res;
+                done.reserve(d.items.size());
+                done_res.reserve(2 * d.items.size());
+                for (size_t i = 0; i < d.items.size(); ++i) {
+                    if (d.retry[i]) continue;
+                    done.push_back(d.items[i]);
+                    st_tier_nodes[d.t] += res[2 * i].hdr.nodes_expanded + res[2 * i + 1].hdr.nodes_expanded;
+                    done_res.push_back(std::move(res[2 * i]));
+                    done_res.push_back(std::move(res[2 * i + 1]));
+                }
+                if (!done.empty()) todo.emplace_back(std::move(done), std::move(done_res));
+            }
+            deferred.clear();
+            return err;
+        };
         auto fail = [&](int rc) {
+            (void)decode_deferred();   // finished results are kept (or their references released)
             for (auto& l : lists) drop_items(l);
             return rc;
         };
-        int rc;
         auto t_run0 = std::chrono::steady_clock::now();
         // tiers run one after the other (a full-width workgroup owns a whole CU): the launch in flight must have left
         if (flight_tier >= 0 && (rc = tiers[(size_t)flight_tier]->wait()) != DDO_OK) {
@@ -1002,8 +1034,9 @@ struct ddo_solver {
                 todo.emplace_back(std::move(flight), std::move(res));
                 flight.clear();
             }
+            if (rc == DDO_OK) rc = decode_deferred();
             st_host_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
-            rc = absorb_todo();
+            if (rc == DDO_OK) rc = absorb_todo();
             st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
             if (rc != DDO_OK) {
                 tiers[(size_t)t]->wait();
@@ -1017,30 +1050,25 @@ struct ddo_solver {
                 flight_tier = t;
                 break;
             }
-            std::vector<HostResult> res;
-            if ((rc = tiers[(size_t)t]->collect(res)) != DDO_OK) return fail(rc);
-            std::vector<LazyItem> done;
-            std::vector<HostResult> done_res;
-            done.reserve(cur.size());
-            done_res.reserve(2 * cur.size());
+            Deferred d;
+            d.t = t;
+            if ((rc = tiers[(size_t)t]->wait()) != DDO_OK || (rc = tiers[(size_t)t]->peek_retry(d.retry)) != DDO_OK || d.retry.size() != cur.size()) {
+                return fail(rc != DDO_OK ? rc : DDO_ERR_INTERNAL);
+            }
             for (size_t i = 0; i < cur.size(); ++i) {
-                const bool retry = res[2 * i].hdr.status == ST_RETRY || res[2 * i + 1].hdr.status == ST_RETRY;
-                note_tier(cur[i], t, retry);
-                if (retry) {
+                note_tier(cur[i], t, d.retry[i] != 0);
+                if (d.retry[i]) {
                     st_tier_retry[t] += 1;
                     lists[(size_t)t + 1].push_back(cur[i]);
-                } else {
-                    done.push_back(cur[i]);
-                    st_tier_nodes[t] += res[2 * i].hdr.nodes_expanded + res[2 * i + 1].hdr.nodes_expanded;
-                    done_res.push_back(std::move(res[2 * i]));
-                    done_res.push_back(std::move(res[2 * i + 1]));
                 }
             }
+            d.items.swap(cur);
             cur.clear();
-            if (!done.empty()) todo.emplace_back(std::move(done), std::move(done_res));
+            deferred.push_back(std::move(d));
         }
+        rc = decode_deferred();   // (whatever no later launch of this call covered)
         st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
-        return DDO_OK;
+        return rc;
     }
 
     /// waits for the launch in flight (if any) and folds every finished result into the fringe
