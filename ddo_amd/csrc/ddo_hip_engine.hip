@@ -1487,6 +1487,20 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
     std::vector<HostResult> res;
     int rc = eng->run_batch(din.data(), (int)din.size(), res, cache ? cache->t : nullptr, dom ? dom->t : nullptr);
     if (rc != DDO_OK) return rc;
+    // The output arena is shared by the compiles of a launch: one that found it full is compiled again on its own, and if
+    // its cut-set alone does not fit, the arena grows (4x per attempt up to 8 GB) -- as the solver host does.
+    for (size_t a = 0; a < active.size(); ++a) {
+        auto capacity = [](const HostResult& r) { return r.hdr.status == ST_ERR_CAPACITY || r.hdr.status <= -100; };
+        if (!capacity(res[2 * a])) continue;
+        std::vector<HostResult> solo;
+        int rc2 = eng->run_batch(&din[a], 1, solo, cache ? cache->t : nullptr, dom ? dom->t : nullptr);
+        while (rc2 == DDO_OK && solo.size() >= 1 && capacity(solo[0]) && eng->arena_capacity() < (8ull << 30)) {
+            if ((rc2 = eng->grow_arena(eng->arena_capacity() * 4)) != DDO_OK) break;
+            solo.clear();
+            rc2 = eng->run_batch(&din[a], 1, solo, cache ? cache->t : nullptr, dom ? dom->t : nullptr);
+        }
+        if (rc2 == DDO_OK && solo.size() >= 1) res[2 * a] = std::move(solo[0]);
+    }
     int worst = DDO_OK;
     for (size_t a = 0; a < active.size(); ++a) {
         const size_t i = active[a];

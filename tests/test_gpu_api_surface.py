@@ -142,3 +142,25 @@ def test_concurrent_compiles_on_distinct_mdds(brock, oracle):
     for th in ths:
         th.join()
     assert not errors, errors[:3]
+
+
+def test_compile_batch_survives_a_full_output_arena(brock, oracle, monkeypatch):
+    """The compiles of one launch share the output arena.  With a 16 MB arena a batch of 128 relaxed compiles at width 3001 (about 40 MB of cut-sets)
+    overflows it: ddo_mdd_compile_batch compiles the ones that found it full again on their own (growing the arena when a
+    single cut-set does not fit) -- every result must equal the oracle's, as without the squeeze."""
+    from tests.parity_util import canon_from_mdd, diff
+
+    monkeypatch.setenv("DDO_HIP_ARENA_MB", "16")
+    inst = oracle.misp(data_path("misp", "brock200_2.clq"))
+    W = 3001   # (a width no other test uses: the engine of this (model, width) is created under the small arena)
+    _, recs = inst.trace_solve(W, 2)
+    relaxed = [r for r in recs if r["comp_type"] == CompilationType.Relaxed and len(r["cutset"]) > 500]
+    assert relaxed
+    r = relaxed[0]
+    B = 128
+    mdds = [ddo_amd.Mdd(brock, W) for _ in range(B)]
+    sub = ddo_amd.SubProblem(state=np.array(r["state"], dtype=np.uint64), value=r["value"], path=[], depth=r["depth"])
+    comps = ddo_amd.Mdd.compile_batch(mdds, [r["comp_type"]] * B, [r["width"]] * B, [sub] * B, [r["best_lb"]] * B)
+    for j in range(B):
+        d = diff(r, canon_from_mdd(mdds[j], comps[j], brock.ws))
+        assert d is None, f"compile #{j}: {d}"

@@ -10,7 +10,7 @@ each one gets a RESTRICTED and a RELAXED compile through ddo_mdd_compile_batch (
 Reported per cell: nodes expanded per second of kernel... of wall time of the batch call, the algorithmic GB/s
 ((S + 8) + c (S + 16) bytes per node, S = 8 ceil(n / 64)) and its fraction of the 8 TB/s HBM roofline, and which device
 engine served the width (in-place layers up to W = 32 767, the layer-rebuilding engine above: its dedup table does not fit
-the LDS).  One JSON line per cell; `--quick` runs one seed and skips W = 100 000 x B = 256."""
+the LDS).  One JSON line per cell; `--quick` runs one seed; W = 100 000 x B = 256 only with --huge."""
 import argparse
 import json
 import os
@@ -54,6 +54,7 @@ def random_states(n, count, seed=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--huge", action="store_true", help="also W = 100 000 x B = 256")
     args = ap.parse_args()
     seeds = [1] if args.quick else [1, 2, 3]
     for n in (200, 400):
@@ -62,8 +63,9 @@ def main():
                 model = ddo_amd.Misp.from_rows(n, gnp_rows(n, p, seed), np.ones(n, dtype=np.int64))
                 for W in (1000, 10000, 100000):
                     for B in (1, 16, 256):
-                        if W == 100000 and B == 256 and (args.quick or n == 400):
-                            continue          # 256 x 2 x 100 002 node layers of the rebuilding engine: minutes per cell
+                        if W == 100000 and B == 256 and not args.huge:
+                            continue          # 256 cut-sets of 100 000 nodes overflow the shared 1 GB output arena: the compiles are
+                                              # repeated one by one (minutes per cell); --huge runs the cell anyway
                         states = random_states(n, B)
                         try:
                             mdds = [ddo_amd.Mdd(model, W) for _ in range(B)]
