@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "ddo_model_compare_states", "ddo_model_export_misp", "ddo_mdd_create", "ddo_mdd_destroy", "ddo_mdd_compile",
     "ddo_mdd_compile_batch", "ddo_mdd_is_exact", "ddo_mdd_best_value", "ddo_mdd_best_exact_value",
     "ddo_mdd_best_solution", "ddo_mdd_best_exact_solution", "ddo_mdd_drain_cutset", "ddo_mdd_last_counters",
-    "ddo_solver_create", "ddo_solver_destroy", "ddo_solver_maximize", "ddo_solver_best_value",
+    "ddo_solver_create", "ddo_width_heuristic", "ddo_solver_destroy", "ddo_solver_maximize", "ddo_solver_best_value",
     "ddo_solver_best_solution", "ddo_solver_best_lower_bound", "ddo_solver_best_upper_bound", "ddo_solver_set_primal",
     "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_flush",
     "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time", "ddo_solver_tier_count", "ddo_solver_tier_stats",
@@ -29,6 +29,18 @@ ABI_SYMBOLS = [
 DDO_OK, DDO_CUTOFF = 0, 2
 LAST_EXACT_LAYER, FRONTIER = 1, 2
 MDD_CACHING = 0x10
+DDO_HANDED_UP = 3
+MDD_ENGINES = {"full": 0, "dense": 0x100, "tier0": 0x200, "tier1": 0x300}   # DDO_MDD_ENGINE_* (include/ddo_hip.h)
+
+
+class _HandedUp:
+    """ddo_mdd_compile answered DDO_HANDED_UP: the decision diagram does not fit the capacity tier the mdd is bound to."""
+
+    def __repr__(self):
+        return "HANDED_UP"
+
+
+HANDED_UP = _HandedUp()
 
 
 class DdoError(RuntimeError):
@@ -70,7 +82,8 @@ class _TierStats(C.Structure):
 class _SolverConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("width_policy", C.c_int), ("width", C.c_size_t), ("nb_concurrent", C.c_int),
                 ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int), ("fringe", C.c_int),
-                ("sequential", C.c_int), ("cutset_type", C.c_int), ("cache_entries", C.c_size_t), ("dominance_entries", C.c_size_t)]
+                ("sequential", C.c_int), ("cutset_type", C.c_int), ("cache_entries", C.c_size_t), ("dominance_entries", C.c_size_t),
+                ("width_times", C.c_size_t), ("width_div_by", C.c_size_t)]
 
 
 _CUTSET_CB = C.CFUNCTYPE(None, C.POINTER(_SubProblem), C.c_void_p)
@@ -147,6 +160,8 @@ def lib():
     L.ddo_mdd_last_counters.argtypes = [C.c_void_p, C.POINTER(_Counters)]
     L.ddo_solver_create.restype = C.c_void_p
     L.ddo_solver_create.argtypes = [C.c_void_p, C.POINTER(_SolverConfig)]
+    L.ddo_width_heuristic.restype = C.c_size_t
+    L.ddo_width_heuristic.argtypes = [C.POINTER(_SolverConfig), C.c_size_t, C.c_size_t]
     L.ddo_solver_destroy.argtypes = [C.c_void_p]
     L.ddo_solver_maximize.argtypes = [C.c_void_p, C.POINTER(_Completion)]
     L.ddo_solver_best_value.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -216,6 +231,46 @@ class Completion:  # common.rs:115-121
 class FixedWidth:  # width.rs:166-171
     def __init__(self, w):
         self.w = int(w)
+
+
+class Times:  # width.rs:636-642: max(1, k * inner)
+    def __init__(self, k, inner):
+        self.k, self.inner = int(k), inner
+
+
+class DivBy:  # width.rs:875-881: max(1, inner / k)
+    def __init__(self, k, inner):
+        if int(k) < 1:
+            raise ZeroDivisionError("DivBy(0, ..) divides by zero (width.rs:1073 panics)")
+        self.k, self.inner = int(k), inner
+
+
+def _width_config(cfg, width):
+    """Fills width_policy / width / width_times / width_div_by of a _SolverConfig from a WidthHeuristic object:
+    FixedWidth, NbUnassignedWidth, TsptwWidth, optionally wrapped as Times(k, inner), DivBy(k, inner) or DivBy(k, Times(j, inner))."""
+    cfg.width_times = cfg.width_div_by = 0
+    if isinstance(width, DivBy):
+        cfg.width_div_by, width = width.k, width.inner
+    if isinstance(width, Times):
+        if width.k == 0:   # Times(0, inner) is the constant 1
+            width = FixedWidth(1)
+        else:
+            cfg.width_times, width = width.k, width.inner
+    if isinstance(width, FixedWidth):
+        cfg.width_policy, cfg.width = 0, width.w
+    elif isinstance(width, NbUnassignedWidth):
+        cfg.width_policy, cfg.width = 1, 0
+    elif isinstance(width, TsptwWidth):
+        cfg.width_policy, cfg.width = 2, width.factor
+    else:
+        raise TypeError("width must be FixedWidth, NbUnassignedWidth or TsptwWidth, optionally inside Times(k, ..) / DivBy(k, ..) / DivBy(k, Times(j, ..))")
+    return cfg
+
+
+def width_heuristic(width, nb_vars, depth):
+    """WidthHeuristic::max_width as the solver host evaluates it (ddo_width_heuristic; no device needed)."""
+    cfg = _width_config(_SolverConfig(), width)
+    return int(lib().ddo_width_heuristic(C.byref(cfg), int(nb_vars), int(depth)))
 
 
 class NbUnassignedWidth:  # width.rs:397-402
@@ -478,9 +533,9 @@ class Mdd:
     """`impl DecisionDiagram for Mdd<T, CUTSET_TYPE>` (mdd.rs:75-114) on the device: LAST_EXACT_LAYER or FRONTIER cut-set;
     caching=True lets compile() take a SimpleCache."""
 
-    def __init__(self, model, max_width, device=0, cutset_type=LAST_EXACT_LAYER, caching=False):
+    def __init__(self, model, max_width, device=0, cutset_type=LAST_EXACT_LAYER, caching=False, engine="full"):
         self.model = model
-        self._h = lib().ddo_mdd_create(model._h, device, cutset_type | (MDD_CACHING if caching else 0), int(max_width))
+        self._h = lib().ddo_mdd_create(model._h, device, cutset_type | (MDD_CACHING if caching else 0) | MDD_ENGINES[engine], int(max_width))
         if not self._h:
             raise DdoError("ddo_mdd_create failed: " + _err())
 
@@ -499,6 +554,8 @@ class Mdd:
         rc = lib().ddo_mdd_compile(self._h, C.byref(ci), C.byref(out))
         if rc == DDO_CUTOFF:
             return None  # Err(Reason::CutoffOccurred)
+        if rc == DDO_HANDED_UP:
+            return HANDED_UP
         if rc != DDO_OK:
             raise DdoError(f"ddo_mdd_compile rc={rc}: {_err()}")
         return Completion(bool(out.is_exact), out.best_value if out.has_best_value else None)
@@ -516,7 +573,8 @@ class Mdd:
         rc = lib().ddo_mdd_compile_batch(hs, cis, outs, sts, n)
         if rc < 0:
             raise DdoError(f"ddo_mdd_compile_batch rc={rc}: {_err()} statuses={list(sts)}")
-        return [Completion(bool(o.is_exact), o.best_value if o.has_best_value else None) for o in outs]
+        return [HANDED_UP if sts[i] == DDO_HANDED_UP else Completion(bool(o.is_exact), o.best_value if o.has_best_value else None)
+                for i, o in enumerate(outs)]
 
     def is_exact(self):
         return bool(lib().ddo_mdd_is_exact(self._h))
@@ -587,14 +645,7 @@ class ParallelSolver:
         self.problem = problem
         cfg = _SolverConfig()
         cfg.device = device
-        if isinstance(width, FixedWidth):
-            cfg.width_policy, cfg.width = 0, width.w
-        elif isinstance(width, NbUnassignedWidth):
-            cfg.width_policy, cfg.width = 1, 0
-        elif isinstance(width, TsptwWidth):
-            cfg.width_policy, cfg.width = 2, width.factor
-        else:
-            raise TypeError("width must be FixedWidth or NbUnassignedWidth")
+        _width_config(cfg, width)
         cfg.nb_concurrent = int(nb_threads)
         cfg.time_budget_s = float(getattr(cutoff, "seconds", 0.0) or 0.0)
         cfg.rank, cfg.world_size = int(rank), int(world_size)

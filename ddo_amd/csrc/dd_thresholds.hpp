@@ -16,6 +16,7 @@ namespace ddo_hip {
 constexpr int32_t TH_NONE = INT32_MAX;        // theta: None
 constexpr int32_t TH_INF = INT32_MAX - 1;     // theta: isize::MAX and everything derived from it by saturating arithmetic
 constexpr int64_t TH_INF64 = (int64_t)1 << 40;
+constexpr uint64_t CACHE_MAX_PROBES = 4096;     // an entry lives at most this many slots from its home slot (update and get agree)
 constexpr uint64_t CT_EMPTY = 0ULL, CT_LOCKED = 2ULL;   // tag word: 0 empty, 2 being written, (hash | 1) ready
 
 DD_HD inline int64_t th_pack(int32_t theta, bool explored) {
@@ -73,11 +74,14 @@ DDO_DEV bool cache_get(const Ctx& c, const uint64_t* s, int depth, int64_t* pack
     const uint64_t tag = h | 1ULL;
     const uint64_t mask = c.cache_cap - 1;
     uint64_t slot = (h >> 1) & mask;
-    for (uint64_t probes = 0; probes <= mask; ++probes) {
+    // cache_update never stores an entry more than CACHE_MAX_PROBES slots from its home slot, so a look-up that has gone
+    // that far without a hit is a miss: a full or heavily clustered table costs a bounded scan per candidate
+    for (uint64_t probes = 0; probes <= mask && probes < CACHE_MAX_PROBES; ++probes) {
         uint64_t* e = c.cache_tab + slot * (uint64_t)c.cache_stride;
         uint64_t t = CT_LD(&e[0]);
         while (t == CT_LOCKED) t = CT_LD(&e[0]);   // another compile is writing this entry right now
         if (t == CT_EMPTY) return false;
+        CT_FENCE();   // acquire: the writer stores payload, fence, tag -- the payload loads below must not move above the tag load
         if (t == tag && CT_LD(&e[2]) == (uint64_t)depth) {
             bool eq = true;
 #pragma unroll
@@ -102,7 +106,7 @@ DDO_DEV void cache_update(const Ctx& c, const uint64_t* s, int depth, int64_t pa
     const uint64_t tag = h | 1ULL;
     const uint64_t mask = c.cache_cap - 1;
     uint64_t slot = (h >> 1) & mask;
-    for (uint64_t probes = 0; probes <= mask && probes < 4096; ++probes) {
+    for (uint64_t probes = 0; probes <= mask && probes < CACHE_MAX_PROBES; ++probes) {
         uint64_t* e = c.cache_tab + slot * (uint64_t)c.cache_stride;
         bool done = false, next = false;
         while (!done && !next) {   // the winner of the claim finishes inside one iteration: lanes of a wave cannot starve each other

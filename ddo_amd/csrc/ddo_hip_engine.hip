@@ -11,6 +11,8 @@
 // compile needs no host round trip and no inter-workgroup synchronisation.
 // =============================================================================
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <thread>
 
 #include <algorithm>
 #include <cstdio>
@@ -139,6 +141,35 @@ std::shared_ptr<Engine> Engine::create_tier(Model* model, int device, Engine* ow
     }
     std::shared_ptr<Engine> e(new Engine());
     if (e->init(model, device, owner->max_width(), false, owner, cap_width, threads) != DDO_OK) return nullptr;
+    return e;
+}
+
+std::shared_ptr<Engine> Engine::get_selected(Model* model, int device, long max_width, int selector) {
+    std::lock_guard<std::mutex> g(model->mtx);
+    auto key = std::make_pair(device, max_width * 8 + (long)(4 + (selector >> 8)));   // (features of Engine::get stay below 4)
+    auto it = model->engines.find(key);
+    if (it != model->engines.end()) {
+        if (auto sp = it->second.lock()) return sp;
+    }
+    int cap = 0, threads = 0;
+    if (selector == DDO_MDD_ENGINE_DENSE && max_width < 8) max_width = 8;   // (the smallest layer capacity a tier is built for)
+    if (selector == DDO_MDD_ENGINE_DENSE) cap = (int)max_width, threads = 512;
+    else if (selector == DDO_MDD_ENGINE_TIER0) cap = 256, threads = 64;
+    else if (selector == DDO_MDD_ENGINE_TIER1) cap = 1024, threads = 128;
+    else {
+        set_error("ddo_mdd_create: unknown DDO_MDD_ENGINE_* selector");
+        return nullptr;
+    }
+    if (model->kind != MODEL_MISP || (selector != DDO_MDD_ENGINE_DENSE && 2 * (long)cap > max_width)) {
+        set_error("ddo_mdd_create: DDO_MDD_ENGINE_* needs a MISP model; TIER0 / TIER1 need max_width >= 512 / 2048");
+        return nullptr;
+    }
+    std::shared_ptr<Engine> owner(new Engine());
+    if (owner->init(model, device, max_width, true) != DDO_OK) return nullptr;
+    auto e = create_tier(model, device, owner.get(), cap, threads);
+    if (!e) return nullptr;
+    e->owner_ref_ = owner;
+    model->engines[key] = e;
     return e;
 }
 
@@ -284,6 +315,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     if (owner && !dense_) arena_mb = std::min<size_t>(arena_mb, 256);
     if (const char* env = std::getenv("DDO_HIP_ARENA_MB")) arena_mb = (size_t)std::max(16, std::atoi(env));
     arena_cap_ = arena_mb << 20;
+    if (const char* env = std::getenv("DDO_HIP_ARENA_KB")) arena_cap_ = (size_t)std::max(1, std::atoi(env)) << 10;   // tests: force the overflow paths
     size_t budget = free_b > (arena_cap_ + (2ull << 30)) ? (size_t)((free_b - arena_cap_ - (1ull << 30)) * 0.8) : 0;
     if (budget / per_slot < (size_t)nslots) nslots = (int)(budget / per_slot);
     if (nslots < 1) {
@@ -775,7 +807,15 @@ void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) co
     }
 }
 
-int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache, const DominanceTable* dom) {
+bool Engine::kernel_done() {
+    std::lock_guard<std::mutex> g(mtx_);
+    if (pending_ <= 0) return true;
+    (void)hipSetDevice(device_);
+    return hipEventQuery((hipEvent_t)ev1_) != hipErrorNotReady;
+}
+
+int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache, const DominanceTable* dom,
+                      const volatile int* const* stop_flags, int nflags) {
     results.resize((size_t)std::max(count, 0) * 2);
     if (count <= 0) return DDO_OK;
     // One engine is shared by every ddo_mdd of a (model, device, width) and has a single launch in flight: the three
@@ -785,7 +825,33 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
     std::lock_guard<std::mutex> batch_guard(batch_mtx_);
     int rc = launch(inputs, count, cache, dom);
     if (rc != DDO_OK) return rc;
-    return collect(results);
+    bool raised = false;
+    if (stop_flags && nflags > 0) {
+        bool any = false;
+        for (int i = 0; i < nflags; ++i) any |= stop_flags[i] != nullptr;
+        while (any && !raised && !kernel_done()) {
+            for (int i = 0; i < nflags && !raised; ++i)
+                if (stop_flags[i] && *stop_flags[i]) raised = true;
+            if (raised) pool_owner()->set_cutoff(true);
+            else std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    rc = collect(results);
+    if (raised) pool_owner()->set_cutoff(false);
+    return rc;
+}
+
+int Engine::run_solo_growing(const DDInput& input, std::vector<HostResult>& results, const CacheTable* cache, const DominanceTable* dom) {
+    auto capacity = [](const HostResult& r) { return r.hdr.status == ST_ERR_CAPACITY || r.hdr.status <= -100; };
+    std::lock_guard<std::mutex> batch_guard(batch_mtx_);
+    for (;;) {
+        results.assign(2, HostResult());
+        int rc = launch(&input, 1, cache, dom);
+        if (rc == DDO_OK) rc = collect(results);
+        if (rc != DDO_OK) return rc;
+        if (!(capacity(results[0]) || capacity(results[1])) || arena_cap_ >= (8ull << 30)) return DDO_OK;
+        if ((rc = grow_arena(arena_cap_ * 4)) != DDO_OK) return rc;
+    }
 }
 
 int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, const DominanceTable* dom) {
@@ -819,8 +885,8 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         io.in_cap = cap;
     }
     for (int i = 0; i < count; ++i) {
-        if ((!owner_ && inputs[i].width + 2 > P_.capN) || inputs[i].width < 1 || inputs[i].width > max_width_ ||
-            (owner_ && !dense_ && inputs[i].width <= P_.capW)) {   // a capacity tier never squashes: its layer capacity must be below the width
+        // (a capacity tier never squashes: a DD whose width is below the tier's layer capacity and that needs a squash is handed up)
+        if ((!owner_ && inputs[i].width + 2 > P_.capN) || inputs[i].width < 1 || inputs[i].width > max_width_) {
             set_error("compile width exceeds the max_width the mdd was created with (or is < 1)");
             return DDO_ERR_CAPACITY;
         }
@@ -1403,14 +1469,20 @@ ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, siz
         return nullptr;
     }
     const bool caching = (cutset_type & DDO_MDD_CACHING) != 0;
-    cutset_type &= ~DDO_MDD_CACHING;
+    const int selector = cutset_type & DDO_MDD_ENGINE_MASK;
+    cutset_type &= ~(DDO_MDD_CACHING | DDO_MDD_ENGINE_MASK);
     if (cutset_type != DDO_LAST_EXACT_LAYER && cutset_type != DDO_FRONTIER) {
         set_error("ddo_mdd_create: cutset_type must be DDO_LAST_EXACT_LAYER or DDO_FRONTIER (optionally | DDO_MDD_CACHING)");
         return nullptr;
     }
     Model* m = const_cast<Model*>(&model->m);
     const bool keep = caching || cutset_type == DDO_FRONTIER;   // both need every layer of the DD on the device
-    auto eng = Engine::get(m, device, (long)max_width, keep ? Engine::ENGINE_KEEP_LAYERS : 0);
+    if (selector && keep) {
+        set_error("ddo_mdd_create: DDO_MDD_ENGINE_* selects a kernel of the in-place engine (DDO_LAST_EXACT_LAYER, no DDO_MDD_CACHING)");
+        return nullptr;
+    }
+    auto eng = selector ? Engine::get_selected(m, device, (long)max_width, selector)
+                        : Engine::get(m, device, (long)max_width, keep ? Engine::ENGINE_KEEP_LAYERS : 0);
     if (!eng) return nullptr;
     ddo_mdd* d = new ddo_mdd();
     d->model = m;
@@ -1485,21 +1557,19 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
         active.push_back(i);
     }
     std::vector<HostResult> res;
-    int rc = eng->run_batch(din.data(), (int)din.size(), res, cache ? cache->t : nullptr, dom ? dom->t : nullptr);
+    std::vector<const volatile int*> stops;
+    for (size_t a : active) stops.push_back(inputs[a].cutoff);
+    int rc = eng->run_batch(din.data(), (int)din.size(), res, cache ? cache->t : nullptr, dom ? dom->t : nullptr, stops.data(), (int)stops.size());
     if (rc != DDO_OK) return rc;
     // The output arena is shared by the compiles of a launch: one that found it full is compiled again on its own, and if
-    // its cut-set alone does not fit, the arena grows (4x per attempt up to 8 GB) -- as the solver host does.
+    // its cut-set alone does not fit, the arena grows -- as the solver host does (Engine::run_solo_growing; a compile that
+    // failed on the arena wrote nothing to the cache).
     for (size_t a = 0; a < active.size(); ++a) {
         auto capacity = [](const HostResult& r) { return r.hdr.status == ST_ERR_CAPACITY || r.hdr.status <= -100; };
         if (!capacity(res[2 * a])) continue;
         std::vector<HostResult> solo;
-        int rc2 = eng->run_batch(&din[a], 1, solo, cache ? cache->t : nullptr, dom ? dom->t : nullptr);
-        while (rc2 == DDO_OK && solo.size() >= 1 && capacity(solo[0]) && eng->arena_capacity() < (8ull << 30)) {
-            if ((rc2 = eng->grow_arena(eng->arena_capacity() * 4)) != DDO_OK) break;
-            solo.clear();
-            rc2 = eng->run_batch(&din[a], 1, solo, cache ? cache->t : nullptr, dom ? dom->t : nullptr);
-        }
-        if (rc2 == DDO_OK && solo.size() >= 1) res[2 * a] = std::move(solo[0]);
+        if (eng->run_solo_growing(din[a], solo, cache ? cache->t : nullptr, dom ? dom->t : nullptr) == DDO_OK && solo.size() >= 1)
+            res[2 * a] = std::move(solo[0]);
     }
     int worst = DDO_OK;
     for (size_t a = 0; a < active.size(); ++a) {
@@ -1509,7 +1579,7 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
         d->depth = inputs[i].residual.depth;
         d->path_to_root.assign(inputs[i].residual.path, inputs[i].residual.path + inputs[i].residual.path_len);
         int st = d->res.hdr.status;
-        int code = st == ST_OK ? DDO_OK : (st == ST_CUTOFF ? DDO_CUTOFF : (st <= -100 ? DDO_ERR_CAPACITY : st));
+        int code = st == ST_OK ? DDO_OK : (st == ST_CUTOFF ? DDO_CUTOFF : (st == ST_RETRY ? DDO_HANDED_UP : (st <= -100 ? DDO_ERR_CAPACITY : st)));
         if (statuses) statuses[i] = code;
         if (code < 0 && worst >= 0) worst = code;
         if (code != DDO_OK) d->res.valid = false;

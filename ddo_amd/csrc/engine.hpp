@@ -137,12 +137,28 @@ class Engine {
     /// same width semantics (widths up to owner->max_width()) out of the owner's node pool, never squashes, and reports
     /// ST_RETRY for a DD that outgrows it.  The owner must outlive the tier.
     static std::shared_ptr<Engine> create_tier(Model* model, int device, Engine* owner, int cap_width, int threads);
+    /// The engine behind an mdd created with DDO_MDD_ENGINE_* (`selector` = that flag): a tier (DENSE: max_width / 512 threads,
+    /// TIER0: 256 / 64, TIER1: 1024 / 128) of a private full-width owner, which the tier keeps alive.  Shared per
+    /// (model, device, max_width, selector) like Engine::get.
+    static std::shared_ptr<Engine> get_selected(Model* model, int device, long max_width, int selector);
     ~Engine();
 
     /// Runs `count` work items in one launch.  results: 2 per item ([1] used by IN_FUSED).
     /// Returns DDO_OK or a negative error.  Thread-safe (serialised internally).
+    /// `stop_flags` (optional, `nflags` of them, entries may be null): host flags of the callers' Cutoff objects
+    /// (`ddo_compile_input.cutoff`).  While the launch runs they are polled; when one is raised the device-visible cutoff flag
+    /// goes up and the running compiles end with ST_CUTOFF at their next layer -- Cutoff::must_stop inside the layer loop
+    /// (clean.rs:352) for a TimeBudget that expires mid-compile.
     int run_batch(const DDInput* inputs, int count, std::vector<HostResult>& results, const CacheTable* cache = nullptr,
-                  const DominanceTable* dom = nullptr);
+                  const DominanceTable* dom = nullptr, const volatile int* const* stop_flags = nullptr, int nflags = 0);
+    /// the kernel of the launch in flight has finished (non-blocking)
+    bool kernel_done();
+    /// One work item on its own, for a compile that found the shared output arena of its batch full: runs it, and while its
+    /// own output does not fit, enlarges the arena (4x per attempt up to 8 GB) and runs it again -- all under the batch lock,
+    /// so that no other host thread's launch gets between the growth and the retry.  A compile that fails on the arena
+    /// leaves nothing in the cache (misp_dd_core.hpp: thresholds follow the reservation), so repeating it is sound.
+    int run_solo_growing(const DDInput& input, std::vector<HostResult>& results, const CacheTable* cache = nullptr,
+                         const DominanceTable* dom = nullptr);
     /// The two halves of run_batch: launch() enqueues upload + kernel + download of the result headers and
     /// returns at once; collect() waits, fetches the arena and decodes.  One launch may be in flight.
     int launch(const DDInput* inputs, int count, const CacheTable* cache = nullptr, const DominanceTable* dom = nullptr);
@@ -188,6 +204,7 @@ class Engine {
              int features = 0);
     Engine* pool_owner() { return owner_ ? owner_ : this; }
     Engine* owner_ = nullptr;        // capacity tier: the engine whose node pool / cutoff flag this one shares
+    std::shared_ptr<Engine> owner_ref_;   // get_selected: the tier owns its owner
     int cap_width_ = 0;              // capacity tier: layer capacity (0 = full-width engine)
     void* kernel_ = nullptr;         // the __global__ entry picked in init(): launch() must use the very same one
     bool dense_ = false;             // two 512-thread workgroups per CU (kernels_inplace_tier.hip: misp_compile_kernel2_dense)

@@ -517,16 +517,13 @@ struct ddo_solver {
         delete dominance;
     }
 
-    long engine_width() const {
-        if (cfg.width_policy == DDO_WIDTH_TSPTW) return (long)model->n * (long)model->n * (long)std::max<size_t>(1, cfg.width);
-        return cfg.width_policy == DDO_WIDTH_FIXED ? (long)cfg.width : (long)std::max(1, model->n);
+    long engine_width() const {   // the largest width any sub-problem can be given: sizes the device workspace
+        size_t w = 1;
+        for (int d = 0; d <= model->n; ++d) w = std::max(w, ddo_width_heuristic(&cfg, (size_t)model->n, (size_t)d));
+        return (long)w;
     }
     /// WidthHeuristic::max_width (width.rs:168-170 / :399-401; path.len() == depth for MISP)
-    int width_of(const Entry& e) const {
-        if (cfg.width_policy == DDO_WIDTH_FIXED) return (int)cfg.width;
-        if (cfg.width_policy == DDO_WIDTH_TSPTW) return model->n * (e.depth + 1) * (int)std::max<size_t>(1, cfg.width);   // tsptw/heuristics.rs:48-52
-        return std::max(1, model->n - e.depth);
-    }
+    int width_of(const Entry& e) const { return (int)ddo_width_heuristic(&cfg, (size_t)model->n, (size_t)std::max(e.depth, 0)); }
     bool budget_exhausted() const {
         if (cfg.time_budget_s <= 0) return false;
         double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
@@ -592,7 +589,12 @@ struct ddo_solver {
                 int64_t ux = std::min<int64_t>(it.ub, r.cs_ub[x]), uy = std::min<int64_t>(it.ub, r.cs_ub[y]);
                 if (ux != uy) return ux > uy;
                 if (b->values[x] != b->values[y]) return b->values[x] > b->values[y];
-                return model->compare_states(b->state(x), b->state(y)) > 0;
+                const int cs = model->compare_states(b->state(x), b->state(y));
+                if (cs != 0) return cs > 0;
+                // a frontier cut-set can hold one state at two depths with equal bound and value: the depth makes the order
+                // strict and total, so that every rank sorts the rows alike and a row is owned by exactly one of them
+                const int dx = b->row_len.empty() ? 0 : b->row_len[(size_t)x], dy = b->row_len.empty() ? 0 : b->row_len[(size_t)y];
+                return dx > dy;
             });
         }
         for (int k = 0; k < r.n_cutset; ++k) {
@@ -1101,7 +1103,7 @@ struct ddo_solver {
             std::memset(&in, 0, sizeof(in));
             in.comp_type = CT_RESTRICTED;
             in.flags = IN_FUSED | IN_FILTER_CUTSET | IN_POOL_OUT;
-            in.width = cfg.width_policy == DDO_WIDTH_FIXED ? (int)cfg.width : std::max(1, model->n - its[i].depth);
+            in.width = (int)ddo_width_heuristic(&cfg, (size_t)model->n, (size_t)std::max(its[i].depth, 0));
             in.value = (int32_t)its[i].value;
             in.depth = its[i].depth;
             in.best_lb = std::max(-lim, std::min(lim, lb));
@@ -1309,18 +1311,16 @@ struct ddo_solver {
         for (size_t i = 0; i < items.size() && err == DDO_OK; ++i) {
             if (results[2 * i].hdr.status == ST_ERR_CAPACITY || results[2 * i + 1].hdr.status == ST_ERR_CAPACITY ||
                 results[2 * i].hdr.status <= -100 || results[2 * i + 1].hdr.status <= -100) {
-                // the shared output arena overflowed: redo this sub-problem on its own
+                // the shared output arena overflowed: redo this sub-problem on its own (and if even one sub-problem's cut-set
+                // -- a frontier cut-set holds nodes of every layer -- does not fit, the arena grows).  The failed run left no
+                // thresholds in the cache (misp_dd_core.hpp), but it did answer Cache::must_explore and mark the node explored
+                // at the pop: the second run must not ask again (it would be told "already explored" and dropped).
                 std::vector<HostResult> solo;
-                int rc2 = engine->run_batch(&inputs[i], 1, solo, cache, dominance);
-                // ... and if even one sub-problem's cut-set (a frontier cut-set holds nodes of every layer) does not
-                // fit, enlarge the arena: 4x per attempt up to 8 GB
-                while (rc2 == DDO_OK && (solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY) &&
-                       engine->arena_capacity() < (8ull << 30)) {
-                    if ((rc2 = engine->grow_arena(engine->arena_capacity() * 4)) != DDO_OK) break;
-                    solo.clear();
-                    rc2 = engine->run_batch(&inputs[i], 1, solo, cache, dominance);
-                }
-                if (rc2 != DDO_OK || solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY) {
+                DDInput again = inputs[i];
+                again.flags &= ~(IN_MUST_EXPLORE | IN_MARK_EXPLORED);
+                int rc2 = engine->run_solo_growing(again, solo, cache, dominance);
+                if (rc2 != DDO_OK || solo.size() < 2 || solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY ||
+                    solo[0].hdr.status <= -100 || solo[1].hdr.status <= -100) {
                     set_error("device compile failed: output arena too small for one sub-problem");
                     err = DDO_ERR_CAPACITY;
                     break;
@@ -1364,6 +1364,17 @@ struct ddo_solver {
 };
 
 extern "C" {
+
+size_t ddo_width_heuristic(const ddo_solver_config* cfg, size_t nb_vars, size_t depth) {
+    if (!cfg) return 0;
+    size_t w;
+    if (cfg->width_policy == DDO_WIDTH_FIXED) w = cfg->width;                                             // width.rs:168-170
+    else if (cfg->width_policy == DDO_WIDTH_TSPTW) w = nb_vars * (depth + 1) * std::max<size_t>(1, cfg->width);   // tsptw/heuristics.rs:48-52
+    else w = std::max<size_t>(1, nb_vars > depth ? nb_vars - depth : 0);                                   // width.rs:399-401 (never 0 here: a DD has a root)
+    if (cfg->width_times > 0) w = std::max<size_t>(1, cfg->width_times * w);                               // Times, width.rs:638-641
+    if (cfg->width_div_by > 0) w = std::max<size_t>(1, w / cfg->width_div_by);                             // DivBy, width.rs:877-880
+    return w;
+}
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg) {
     if (!model || !cfg) {

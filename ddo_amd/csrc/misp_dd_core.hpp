@@ -1840,78 +1840,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 }
             }
             PAR_END
-            // ---- _compute_thresholds (clean.rs:478-532) + _maybe_update_cache (:534-545)
-            int64_t bk64 = best_lb;
-            if (has_best_exact && (int64_t)exact_value > bk64) bk64 = exact_value;
-            const int32_t bk = bk64 < -(1 << 30) ? -(1 << 30) : (int32_t)bk64;   // values are far above: same comparisons
-            const bool bk_min = bk64 <= -((int64_t)1 << 39);                      // no bound known: best_known == isize::MIN
-            if (has_best_exact && T >= 0 && nT > 0) {
-                PAR_BEGIN
-                for (int pos = tid; pos < nT; pos += NT) {
-                    const bool nex = !(c.ninfo[(size_t)T * LS + pos] & (NI_INEXACT | NI_RELAXED));
-                    if ((!frontier && is_exact) || (frontier && nex)) c.lth[(size_t)T * LS + pos] = bk;
-                }
-                PAR_END
-            }
-            for (int Lc = T; Lc >= 0; --Lc) {
-                PAR_BEGIN
-                for (int pos = tid; pos < c.lntot[Lc]; pos += NT) {
-                    const size_t li = (size_t)Lc * LS + pos;
-                    const uint32_t w = LD_U32(&c.ninfo[li]);
-                    if (w & NI_CACHE) continue;                       // its theta is the cached threshold: only propagated
-                    const bool nex = !(w & (NI_INEXACT | NI_RELAXED));
-                    const int32_t val = c.lval[li], rub = c.lrub[li];
-                    int32_t th = LD_I32(&c.lth[li]);
-                    if (rub == RUB_NEG_INF) {
-                        th = TH_INF;                                   // value (+sat) isize::MIN <= anything; best_known (-sat) MIN is huge
-                    } else if (rub != INT32_MAX && !bk_min && (int64_t)val + rub <= (int64_t)bk) {
-                        th = bk - rub;
-                    } else if (w & NI_CUTSET) {
-                        const int32_t vb = LD_I32(&c.lvb[li]);
-                        // value_bot of an unmarked node is isize::MIN: value_top (+sat) MIN <= best_known unless there is no
-                        // bound at all (best_known == isize::MIN) and value_top > 0; best_known (-sat) MIN is then 0, else huge
-                        const bool locb_le = vb == VB_UNMARKED ? (!bk_min || val <= 0) : (!bk_min && (int64_t)val + vb <= (int64_t)bk);
-                        if (locb_le) {
-                            const int32_t cand = vb == VB_UNMARKED ? (bk_min ? 0 : TH_INF) : bk - vb;
-                            const int32_t old = th == TH_NONE ? TH_INF : th;
-                            th = cand < old ? cand : old;
-                        } else {
-                            th = val;
-                        }
-                    } else if (nex && th == TH_NONE) {
-                        th = TH_INF;                                   // large theta for dangling nodes
-                    }
-                    c.lth[li] = th;
-                    const bool above = frontier ? nex : Lc <= lel_eff;
-                    if (use_cache && th != TH_NONE && above) {
-                        uint64_t st[WS];
-#pragma unroll
-                        for (int k = 0; k < WS; ++k) st[k] = c.lstate[((size_t)Lc * WS + k) * LS + pos];
-                        cache_update<WS>(c, st, c.depth0 + Lc, th_pack(th, !(w & NI_CUTSET)));
-                    }
-                }
-                PAR_END
-                if (Lc == 0) break;
-                const int nP = c.nlayer[Lc - 1];
-                PAR_BEGIN
-                const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
-                const int32_t* ac = c.arcc + (size_t)Lc * c.fan * capN;
-                const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
-                for (int j = tid; j < c.fan * nP; j += NT) {
-                    const int d = j / nP;
-                    const int pp = j - d * nP;
-                    const uint32_t t = at[d * capN + pp];
-                    if (t == NONE32) continue;
-                    const int32_t cost = ac[d * capN + pp];
-                    const int32_t th = LD_I32(&c.lth[(size_t)Lc * LS + t]);
-                    if (th != TH_NONE) GLB_MIN_I32(&c.lth[(size_t)(Lc - 1) * LS + pp], th_sub(th, cost));
-                    if ((int)t == dfrom) {
-                        const int32_t th2 = LD_I32(&c.lth[(size_t)Lc * LS + dto]);
-                        if (th2 != TH_NONE) GLB_MIN_I32(&c.lth[(size_t)(Lc - 1) * LS + pp], th_sub(th2, cost + (c.lddelta ? c.lddelta[Lc] : 0)));
-                    }
-                }
-                PAR_END
-            }
+            // (_compute_thresholds and the cache updates follow the reservation of the output arena, see below)
         }
     }
     if (want_cutset && !c.tmode) {
@@ -2039,6 +1968,88 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     PAR_END
     const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;
     uint8_t* base = c.arena + sh->arena_off;
+
+    // A compile whose output does not fit the shared arena is compiled AGAIN by the host (on its own, arena enlarged): it must
+    // leave no trace in the cache, or the second run would be pruned by the thresholds of the first.  So the thresholds -- and
+    // with them every cache update -- are computed only once the arena space of this DD is reserved.
+    if (c.tmode && !failed && (relaxed || is_exact) && arena_ok) {
+        const int T = n_layers - 1;
+        const int lel_eff = lel < 0 ? n_layers : lel;                       // clean.rs:548-550
+        {
+            // ---- _compute_thresholds (clean.rs:478-532) + _maybe_update_cache (:534-545)
+            int64_t bk64 = best_lb;
+            if (has_best_exact && (int64_t)exact_value > bk64) bk64 = exact_value;
+            const int32_t bk = bk64 < -(1 << 30) ? -(1 << 30) : (int32_t)bk64;   // values are far above: same comparisons
+            const bool bk_min = bk64 <= -((int64_t)1 << 39);                      // no bound known: best_known == isize::MIN
+            if (has_best_exact && T >= 0 && nT > 0) {
+                PAR_BEGIN
+                for (int pos = tid; pos < nT; pos += NT) {
+                    const bool nex = !(c.ninfo[(size_t)T * LS + pos] & (NI_INEXACT | NI_RELAXED));
+                    if ((!frontier && is_exact) || (frontier && nex)) c.lth[(size_t)T * LS + pos] = bk;
+                }
+                PAR_END
+            }
+            for (int Lc = T; Lc >= 0; --Lc) {
+                PAR_BEGIN
+                for (int pos = tid; pos < c.lntot[Lc]; pos += NT) {
+                    const size_t li = (size_t)Lc * LS + pos;
+                    const uint32_t w = LD_U32(&c.ninfo[li]);
+                    if (w & NI_CACHE) continue;                       // its theta is the cached threshold: only propagated
+                    const bool nex = !(w & (NI_INEXACT | NI_RELAXED));
+                    const int32_t val = c.lval[li], rub = c.lrub[li];
+                    int32_t th = LD_I32(&c.lth[li]);
+                    if (rub == RUB_NEG_INF) {
+                        th = TH_INF;                                   // value (+sat) isize::MIN <= anything; best_known (-sat) MIN is huge
+                    } else if (rub != INT32_MAX && !bk_min && (int64_t)val + rub <= (int64_t)bk) {
+                        th = bk - rub;
+                    } else if (w & NI_CUTSET) {
+                        const int32_t vb = LD_I32(&c.lvb[li]);
+                        // value_bot of an unmarked node is isize::MIN: value_top (+sat) MIN <= best_known unless there is no
+                        // bound at all (best_known == isize::MIN) and value_top > 0; best_known (-sat) MIN is then 0, else huge
+                        const bool locb_le = vb == VB_UNMARKED ? (!bk_min || val <= 0) : (!bk_min && (int64_t)val + vb <= (int64_t)bk);
+                        if (locb_le) {
+                            const int32_t cand = vb == VB_UNMARKED ? (bk_min ? 0 : TH_INF) : bk - vb;
+                            const int32_t old = th == TH_NONE ? TH_INF : th;
+                            th = cand < old ? cand : old;
+                        } else {
+                            th = val;
+                        }
+                    } else if (nex && th == TH_NONE) {
+                        th = TH_INF;                                   // large theta for dangling nodes
+                    }
+                    c.lth[li] = th;
+                    const bool above = frontier ? nex : Lc <= lel_eff;
+                    if (use_cache && th != TH_NONE && above) {
+                        uint64_t st[WS];
+#pragma unroll
+                        for (int k = 0; k < WS; ++k) st[k] = c.lstate[((size_t)Lc * WS + k) * LS + pos];
+                        cache_update<WS>(c, st, c.depth0 + Lc, th_pack(th, !(w & NI_CUTSET)));
+                    }
+                }
+                PAR_END
+                if (Lc == 0) break;
+                const int nP = c.nlayer[Lc - 1];
+                PAR_BEGIN
+                const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
+                const int32_t* ac = c.arcc + (size_t)Lc * c.fan * capN;
+                const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
+                for (int j = tid; j < c.fan * nP; j += NT) {
+                    const int d = j / nP;
+                    const int pp = j - d * nP;
+                    const uint32_t t = at[d * capN + pp];
+                    if (t == NONE32) continue;
+                    const int32_t cost = ac[d * capN + pp];
+                    const int32_t th = LD_I32(&c.lth[(size_t)Lc * LS + t]);
+                    if (th != TH_NONE) GLB_MIN_I32(&c.lth[(size_t)(Lc - 1) * LS + pp], th_sub(th, cost));
+                    if ((int)t == dfrom) {
+                        const int32_t th2 = LD_I32(&c.lth[(size_t)Lc * LS + dto]);
+                        if (th2 != TH_NONE) GLB_MIN_I32(&c.lth[(size_t)(Lc - 1) * LS + pp], th_sub(th2, cost + (c.lddelta ? c.lddelta[Lc] : 0)));
+                    }
+                }
+                PAR_END
+            }
+        }
+    }
 
     if (arena_ok && !failed) {
         PAR_BEGIN

@@ -860,7 +860,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         int merged_slot = -1, dup_from = -1, dup_to = -1;
         const uint64_t del_off = DD_UNIFORM64(sh->ev_pos);
         int n_del = 0;
-        if (squash && c.tier == 1) {   // cannot happen: a tier's layer capacity is below the width (the host guarantees it)
+        if (squash && c.tier == 1) {   // a capacity tier has no squash phases (their LDS is not there): the DD is handed up.  The lazy
+                                       // solver never gets here (a tier's layer capacity is below its width); an mdd bound to a tier may
             PAR_BEGIN
             if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 11;
             PAR_END
@@ -1894,7 +1895,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // a capacity tier that ran out of node slots / work-list / event space hands the DD to the next tier (the
         // shared output arena and node pool are not the tier's: those stay errors)
         if (c.tier && (sh->status == ST_ERR_CAPACITY || (sh->status <= ST_ERR_CAPACITY - 100 && sh->status != ST_ERR_CAPACITY - 700 &&
-                                                         sh->status != ST_ERR_CAPACITY - 800 && sh->status != ST_ERR_CAPACITY - 1100)))
+                                                         sh->status != ST_ERR_CAPACITY - 800)))
             r.status = ST_RETRY;
         r.comp_type = comp_type;
         r.is_exact = is_exact ? 1 : 0;

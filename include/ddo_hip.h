@@ -31,6 +31,10 @@ extern "C" {
 /** compile() was interrupted by the cutoff flag == Err(Reason::CutoffOccurred), common.rs:108-111; a solver whose
  *  TimeBudget ran out (parallel.rs:479-489).  Distinct from the 1 that ddo_solver_step returns while work remains. */
 #define DDO_CUTOFF 2
+/** ddo_mdd_compile on an mdd bound to a capacity tier (DDO_MDD_ENGINE_*): the decision diagram outgrew the tier's node slots
+ *  (or, on a capacity tier, needed a squash); nothing was produced -- compile it again on an mdd of the full-width engine.
+ *  This is what the lazy solver does between its tiers (host_solver.cpp: dispatch). */
+#define DDO_HANDED_UP 3
 #define DDO_ERR_NO_DEVICE (-1)   /* no HIP device / HIP runtime error            */
 #define DDO_ERR_INVALID (-2)     /* bad argument                                 */
 #define DDO_ERR_CAPACITY (-3)    /* width / layer / output exceeds the capacity  */
@@ -48,6 +52,17 @@ extern "C" {
 /** OR into the cutset_type of ddo_mdd_create: compile() may be handed a ddo_cache (every layer of the DD is then kept on the
  *  device for _compute_thresholds, clean.rs:478-545; costs memory, not needed with the EmptyCache) */
 #define DDO_MDD_CACHING 0x10
+/** OR into the cutset_type of ddo_mdd_create (MISP, DDO_LAST_EXACT_LAYER, no DDO_MDD_CACHING): binds the mdd to ONE of the
+ *  kernels the lazy solver spreads its sub-problems over, so that each of them can be driven -- and checked against the
+ *  reference's results -- compile by compile.  0 = the engine ddo_mdd_create picks itself (full width, one decision diagram
+ *  per CU).  DENSE = misp_compile_kernel2_dense (full layer capacity, 512 threads, two decision diagrams per CU, the kernel
+ *  the headline benchmark spends its time in); TIER0 / TIER1 = misp_compile_kernel2_tier with layers of at most 256 / 1024
+ *  nodes (64 / 128 threads, 12 / 5 decision diagrams per CU): these never squash and answer DDO_HANDED_UP for a decision
+ *  diagram that does not fit. */
+#define DDO_MDD_ENGINE_DENSE 0x100
+#define DDO_MDD_ENGINE_TIER0 0x200
+#define DDO_MDD_ENGINE_TIER1 0x300
+#define DDO_MDD_ENGINE_MASK 0x300
 
 /** common.rs:58-61  struct Decision { variable: Variable, value: isize } */
 typedef struct ddo_decision {
@@ -251,9 +266,17 @@ typedef struct ddo_solver_config {
                               (the `C` of the solver: DefaultCachingSolver, solver/mod.rs); needs DDO_FRINGE_NODUP */
     size_t dominance_entries; /* 0: EmptyDominanceChecker; else a SimpleDominanceChecker with that many pairs per depth
                               (knapsack models: KPDominance, knapsack/main.rs:325); needs DDO_FRINGE_NODUP */
+    size_t width_times;    /* 0: none; else the decorator Times(k, inner) (width.rs:636-642): max(1, k * inner), inner = the policy
+                              above.  (Times(0, inner) is the constant 1 == FixedWidth(1).)                              */
+    size_t width_div_by;   /* 0: none; else DivBy(k, inner) (width.rs:875-881): max(1, inner / k); with both set the width is
+                              DivBy(div_by, Times(times, inner))                                                         */
 } ddo_solver_config;
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg);
+/** WidthHeuristic::max_width (width.rs:166-171, 397-402, 636-642, 875-881; tsptw/heuristics.rs:38-52) of a sub-problem `depth`
+ *  decisions below the root of a problem with `nb_vars` variables, as the solver evaluates it for `cfg`.  Pure host arithmetic
+ *  (no device needed). */
+size_t ddo_width_heuristic(const ddo_solver_config* cfg, size_t nb_vars, size_t depth);
 void ddo_solver_destroy(ddo_solver* s);
 /** solver.rs:37 maximize() -> Completion */
 int ddo_solver_maximize(ddo_solver* s, ddo_completion* out);

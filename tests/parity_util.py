@@ -52,10 +52,28 @@ def is_independent_set(rows, ws, chosen):
     return True
 
 
-def replay_records(model, recs, device=0, batch=64):
-    """Replays oracle trace records on the GPU through ddo_mdd_compile_batch; yields (i, record, canonical)."""
-    maxw = max(int(r["width"]) for r in recs)
-    mdds = [ddo_amd.Mdd(model, maxw, device=device) for _ in range(min(batch, len(recs)))]
+ENGINES = ["full", "dense", "tier0", "tier1"]   # DDO_MDD_ENGINE_*: the kernels the lazy solver (and bench.py) run
+TIER_CAP = {"tier0": 256, "tier1": 1024}
+
+
+def engine_width(engine, maxw):
+    """max_width an mdd bound to `engine` must be created with to serve compiles of width <= maxw (a capacity tier exists
+    only under a full-width engine at least twice its layer capacity)."""
+    return max(int(maxw), 2 * TIER_CAP.get(engine, 0))
+
+
+def may_hand_up(engine, rec):
+    """A capacity tier hands a DD up when a layer outgrows its node slots or a squash is needed (it has no squash phases);
+    a DD whose layers all fit both the tier and the width must complete.  nodes_expanded bounds every layer from above
+    (is_exact alone does not tell: a squashed relaxed DD whose best path stayed exact reports is_exact too)."""
+    return engine in TIER_CAP and (not rec["is_exact"] or rec["nodes_expanded"] > min(TIER_CAP[engine] // 2, int(rec["width"])))
+
+
+def replay_records(model, recs, device=0, batch=64, engine="full"):
+    """Replays oracle trace records on the GPU through ddo_mdd_compile_batch; yields (i, record, canonical); canonical is
+    ddo_amd.HANDED_UP when the capacity tier the mdds are bound to answered DDO_HANDED_UP."""
+    maxw = engine_width(engine, max(int(r["width"]) for r in recs))
+    mdds = [ddo_amd.Mdd(model, maxw, device=device, engine=engine) for _ in range(min(batch, len(recs)))]
     for base in range(0, len(recs), batch):
         chunk = recs[base:base + batch]
         ms = mdds[:len(chunk)]
@@ -64,4 +82,19 @@ def replay_records(model, recs, device=0, batch=64):
         comps = ddo_amd.Mdd.compile_batch(ms, [r["comp_type"] for r in chunk], [r["width"] for r in chunk], subs,
                                           [r["best_lb"] for r in chunk])
         for j, r in enumerate(chunk):
-            yield base + j, r, canon_from_mdd(ms[j], comps[j], model.ws)
+            yield base + j, r, (comps[j] if comps[j] is ddo_amd.HANDED_UP else canon_from_mdd(ms[j], comps[j], model.ws))
+
+
+def check_replay(model, recs, engine, what, min_completed=1, **kw):
+    """Every record replayed on `engine` equals the oracle's; a capacity tier may hand up only what cannot fit it."""
+    completed = handed = 0
+    for i, r, got in replay_records(model, recs, engine=engine, **kw):
+        if got is ddo_amd.HANDED_UP:
+            assert may_hand_up(engine, r), f"{what} [{engine}] compile #{i}: handed up although exact with {r['nodes_expanded']} nodes"
+            handed += 1
+            continue
+        d = diff(r, got)
+        assert d is None, f"{what} [{engine}] compile #{i} type={r['comp_type']} depth={r['depth']} lb={r['best_lb']}: {d}"
+        completed += 1
+    assert completed + handed == len(recs) and completed >= min_completed, (what, engine, completed, handed)
+    return completed, handed

@@ -179,3 +179,23 @@ def test_mcp_model_host_side(tmp_path):
         ddo_amd.Mcp.from_matrix(np.array([[0, 1], [2, 0]]))    # not symmetric
     with pytest.raises(ddo_amd.DdoError):
         ddo_amd.Mcp.from_matrix(np.zeros((143, 143), dtype=np.int64))    # more than 142 vertices
+
+
+def test_width_heuristics_known_answers():
+    """width.rs:937-1075 (test_fixedwidth, test_adapters) and the doc examples width.rs:492-505, 732-745: Times / DivBy decorate
+    any inner heuristic; both floor at 1."""
+    from ddo_amd import DivBy, FixedWidth, NbUnassignedWidth, Times, TsptwWidth, width_heuristic as w
+    for depth in (0, 1, 5):
+        assert w(FixedWidth(5), 5, depth) == 5                                   # width.rs:954, 966, 985
+    assert [w(Times(k, FixedWidth(5)), 9, 1) for k in (2, 3, 1, 10)] == [10, 15, 5, 50]   # width.rs:1011-1014
+    assert w(DivBy(2, FixedWidth(4)), 9, 1) == 2 and w(DivBy(3, FixedWidth(9)), 9, 1) == 3 and w(DivBy(1, FixedWidth(10)), 9, 1) == 10   # :1032-1034
+    assert w(Times(0, FixedWidth(10)), 9, 1) == 1                                 # width.rs:1053: never below 1
+    assert w(DivBy(9, FixedWidth(4)), 9, 1) == 1
+    assert w(NbUnassignedWidth(5), 5, 1) == 4 and w(NbUnassignedWidth(5), 5, 0) == 5   # width.rs:901, 913
+    assert w(Times(5, NbUnassignedWidth(5)), 5, 3) == 10                         # width.rs:492-505 (three of five variables decided)
+    assert w(DivBy(2, NbUnassignedWidth(5)), 5, 3) == 1                          # width.rs:732-745
+    assert w(DivBy(4, Times(3, NbUnassignedWidth(10))), 10, 2) == 6
+    assert w(TsptwWidth(2), 7, 3) == 7 * 4 * 2                                   # tsptw/heuristics.rs:48-52
+    import pytest
+    with pytest.raises(ZeroDivisionError):                                       # width.rs:1073: DivBy(0, ..) panics
+        DivBy(0, FixedWidth(3))

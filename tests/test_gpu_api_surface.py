@@ -28,6 +28,33 @@ def test_compile_honours_the_cutoff_flag(brock):
     assert c is not None and c.best_value >= 12
 
 
+def test_a_cutoff_raised_mid_compile_interrupts_it():
+    """A TimeBudget (cutoff.rs:302-323) that expires WHILE a compile runs: the reference polls Cutoff::must_stop at every
+    layer (clean.rs:352), here the host watches the caller's flag during the launch and raises the device-visible one, which
+    the layer loop polls.  A wide compile of brock400_1 takes tens of milliseconds; the flag goes up a fraction into it."""
+    import threading
+    import time
+    model = ddo_amd.Misp.read_instance(data_path("misp", "brock400_1.clq"))
+    W = 30000
+    mdd = ddo_amd.Mdd(model, W)
+    flag = C.c_int(0)
+    t0 = time.perf_counter()
+    full = mdd.compile(CompilationType.Relaxed, W, model.root(), -(1 << 62), cutoff=flag)
+    whole = time.perf_counter() - t0
+    assert full is not None and whole > 0.02
+    t = threading.Timer(whole / 10, lambda: setattr(flag, "value", 1))
+    t0 = time.perf_counter()
+    t.start()
+    cut = mdd.compile(CompilationType.Relaxed, W, model.root(), -(1 << 62), cutoff=flag)
+    dt = time.perf_counter() - t0
+    t.join()
+    assert cut is None, "the compile ran to the end although its cutoff flag went up a tenth into it"
+    assert dt < 0.8 * whole
+    flag.value = 0   # the device flag is lowered again: the next compile runs to the end
+    again = mdd.compile(CompilationType.Relaxed, W, model.root(), -(1 << 62), cutoff=flag)
+    assert again is not None and again.best_value == full.best_value
+
+
 def test_best_exact_solution_of_a_relaxed_dd(brock):
     """best_exact_value / best_exact_solution (mdd.rs:96-110): the best terminal reached by an exact path"""
     mdd = ddo_amd.Mdd(brock, 50)

@@ -97,6 +97,30 @@ def test_sequential_solver_matches_the_oracle(have_gpu, oracle, kind, fname, wid
            (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
 
 
+@pytest.mark.parametrize("kind,fname,width,frontier", [("misp", "johnson8-4-4.clq", 4, True), ("misp", "MANN_a9.clq", 3, True),
+                                                       ("knapsack", "f8_l-d_kp_23_10000", 5, False), ("mcp", "mcp_n30_p0.1_002.mcp", 4, True),
+                                                       ("max2sat", "pass.wcnf", 2, True)])
+def test_cached_search_with_an_overflowing_output_arena(have_gpu, oracle, monkeypatch, kind, fname, width, frontier):
+    """A 1 KB output arena: nearly every relaxed compile finds it too small and is compiled AGAIN with the arena enlarged
+    (Engine::run_solo_growing).  A compile that fails on the arena must leave nothing in the cache -- its thresholds would
+    prune the second run (and a node already marked explored would be dropped at the second pop): the search must be the
+    oracle's, sub-problem by sub-problem."""
+    monkeypatch.setenv("DDO_HIP_ARENA_KB", "1")
+    path = data_path(kind, fname)
+    model = MODELS[kind].read_instance(path)
+    ref, _ = oracle.trace_ex(kind, path, width, 0, frontier, True)
+    # (a width no other test uses: the engine of this (model, width, features) must be created under the small arena)
+    s = SequentialSolver(model, FixedWidth(width), cutset_type=FRONTIER if frontier else LAST_EXACT_LAYER, cache_entries=1 << 18)
+    c = s.maximize()
+    assert c.is_exact and c.best_value == ref["best_value"]
+    cnt = s.counters()
+    assert (s.explored(), cnt["nodes_expanded"], cnt["arcs"], cnt["layers"], cnt["compiles"]) == \
+           (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
+    p = DefaultCachingSolver(model, FixedWidth(width), nb_threads=16, cache_entries=1 << 18)   # many in flight + the pop's explored mark
+    c = p.maximize()
+    assert c.is_exact and c.best_value == ref["best_value"] and p.best_upper_bound() == ref["best_value"]
+
+
 @pytest.mark.parametrize("kind,fname,expected,width,threads", [
     ("misp", "brock200_2.clq", 12, 100, 64), ("misp", "johnson8-4-4.clq", 14, 6, 16), ("knapsack", "knapPI_1_100_1000_1", 9147, 30, 16),
     ("knapsack", "f8_l-d_kp_23_10000", 9767, 5, 32), ("max2sat", "pass.wcnf", 54, 2, 8), ("mcp", "mcp_n30_p0.1_003.mcp", None, 20, 32),

@@ -10,7 +10,7 @@ import pytest
 import ddo_amd
 from ddo_amd import CompilationType, FixedWidth, NbUnassignedWidth, ParallelSolver, SubProblem
 from tests.conftest import data_path
-from tests.parity_util import KEYS, canon_from_mdd, cutset_digest, diff, is_independent_set, replay_records
+from tests.parity_util import ENGINES, KEYS, canon_from_mdd, check_replay, cutset_digest, diff, engine_width, is_independent_set, may_hand_up, replay_records
 
 pytestmark = pytest.mark.gpu
 
@@ -40,19 +40,50 @@ def have_gpu():
     ("p_hat300-1", 0, 300),        # n = 300: 5 words padded to 7
     ("c-fat500-1", 0, 0),          # n = 500: 8 words
     ("brock400_1", 500, 120),      # n = 400: 7 words
+    ("keller4", 3000, 500),        # widths far above the capacity tiers' layer capacity: the tiers complete most compiles
+    ("p_hat300-1", 5000, 400),
 ])
-def test_replay_of_oracle_trace(have_gpu, oracle, name, width, max_compiles):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_replay_of_oracle_trace(have_gpu, oracle, name, width, max_compiles, engine):
+    """`engine` binds the mdds to one kernel of the in-place engine (DDO_MDD_ENGINE_*): the full-width kernel, the dense
+    kernel bench.py times (512 threads, 8-bit select digits, 128 tie-break keys in LDS, half-size table) and the two capacity
+    tiers -- every one of them is compared with the oracle compile by compile, on the GPU."""
     path = data_path("misp", name + ".clq")
     inst = oracle.misp(path)
     _, recs = inst.trace_solve(width, max_compiles)
     assert recs
     model = ddo_amd.Misp.read_instance(path)
-    checked = 0
-    for i, r, got in replay_records(model, recs):
+    tier = engine in ("tier0", "tier1")
+    completed, handed = check_replay(model, recs, engine, f"{name} W={width}", min_completed=0 if tier else 1)
+    if not tier:
+        assert handed == 0
+    elif width >= 1000 and max_compiles == 0:   # a whole wide search is made of narrow DDs deep down: those a capacity tier completes
+        assert completed >= 20, (completed, handed)
+    print(f"[{engine}] {name} W={width}: {completed} compiles equal the oracle's, {handed} handed up")
+
+
+@pytest.mark.parametrize("name,width,table,max_compiles", [
+    ("brock200_2", 100, 128, 400), ("keller4", 100, 128, 300), ("brock200_2", 1000, 2048, 60), ("p_hat300-1", 128, 256, 300),
+])
+def test_replay_through_a_shrunk_dense_table(have_gpu, oracle, monkeypatch, name, width, table, max_compiles):
+    """The dense kernel with a dedup table far smaller than 3 x the layer capacity (DDO_HIP_DENSE_TABLE): layers whose nodes
+    plus YES-children would fill more than 7/8 of it hand the DD up (DDO_HANDED_UP), everything it completes is compared
+    with the oracle compile by compile -- long probe chains, a nearly full table."""
+    monkeypatch.setenv("DDO_HIP_DENSE_TABLE", str(table))
+    path = data_path("misp", name + ".clq")
+    _, recs = oracle.misp(path).trace_solve(width, max_compiles)
+    model = ddo_amd.Misp.read_instance(path)
+    completed = handed = 0
+    for i, r, got in replay_records(model, recs, engine="dense"):
+        if got is ddo_amd.HANDED_UP:
+            assert r["nodes_expanded"] > table * 7 // 16, f"{name} compile #{i}: handed up with {r['nodes_expanded']} nodes in all"
+            handed += 1
+            continue
         d = diff(r, got)
-        assert d is None, f"{name} W={width} compile #{i} type={r['comp_type']} depth={r['depth']} lb={r['best_lb']}: {d}"
-        checked += 1
-    assert checked == len(recs)
+        assert d is None, f"{name} W={width} table={table} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+        completed += 1
+    assert completed > 0 and (handed > 0 or table > 128), (completed, handed)
+    print(f"[dense, table {table}] {name} W={width}: {completed} compiles equal the oracle's, {handed} handed up")
 
 
 # ---- (2) whole searches: same optimum / proof / explored count as the oracle -----------------------
@@ -216,16 +247,20 @@ def _golden_cases():
         return json.load(f)["cases"]
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: c["id"])
-def test_golden_compile(have_gpu, case):
+def test_golden_compile(have_gpu, case, engine):
     model = ddo_amd.Misp.read_instance(data_path("misp", case["instance"] + ".clq"))
-    mdd = ddo_amd.Mdd(model, case["width"])
+    mdd = ddo_amd.Mdd(model, engine_width(engine, case["width"]), engine=engine)
     state = np.array([int(x) for x in case["state"]], dtype=np.uint64)
     sub = SubProblem(state=state, value=case["value"], path=[], depth=case["depth"])
     comp = mdd.compile(case["comp_type"], case["width"], sub, case["best_lb"])
+    if comp is ddo_amd.HANDED_UP:
+        assert may_hand_up(engine, case), f"{case['id']} [{engine}]: handed up although it fits the tier"
+        return
     got = canon_from_mdd(mdd, comp, model.ws)
     for k in ["is_exact", "best_value", "best_exact_value", "nodes_expanded", "arcs", "layers"]:
-        assert got[k] == case[k], f"{case['id']}: {k} expected {case[k]} got {got[k]}"
+        assert got[k] == case[k], f"{case['id']} [{engine}]: {k} expected {case[k]} got {got[k]}"
     assert len(got["cutset"]) == case["n_cutset"]
     assert cutset_digest(got["cutset"]) == case["cutset_digest"]
     # paths: every cut-set node's path replays to its state and value (clean.rs:430-441)
@@ -397,7 +432,8 @@ def _write_random_clq(path, n, p_edge, seed, weights=None):
     (1024, 0.5, 64, 10, False),      # the largest model the ABI accepts (MAX_WS = 16 words)
     (1024, 0.9, 300, 6, True),       # weighted: values, rough upper bounds and ranking use the weights
 ])
-def test_replay_at_maximum_state_sizes(have_gpu, oracle, tmp_path, n, p_edge, width, max_compiles, weighted):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_replay_at_maximum_state_sizes(have_gpu, oracle, tmp_path, n, p_edge, width, max_compiles, weighted, engine):
     p = tmp_path / f"rand{n}.clq"
     weights = np.random.RandomState(n).randint(1, 50, size=n) if weighted else None
     _write_random_clq(p, n, p_edge, seed=n + width, weights=weights)
@@ -408,9 +444,7 @@ def test_replay_at_maximum_state_sizes(have_gpu, oracle, tmp_path, n, p_edge, wi
     assert np.array_equal(rows, inst.rows) and np.array_equal(w, inst.weights)
     _, recs = inst.trace_solve(width, max_compiles)
     assert recs
-    for i, r, got in replay_records(model, recs):
-        d = diff(r, got)
-        assert d is None, f"n={n} W={width} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+    check_replay(model, recs, engine, f"n={n} W={width}", min_completed=0 if engine in ("tier0", "tier1") else 1)
 
 
 @pytest.mark.parametrize("fringe", ["nodup", "lazy"])
