@@ -163,7 +163,7 @@ struct EngineParams {
     int32_t tab2_cap;          // dedup table slots (power of two, LDS)
     int32_t vbase_off;         // lowest reachable value relative to the residual value (sum of negative weights)
     int32_t model_kind;        // MODEL_MISP | MODEL_KNAPSACK
-    int32_t pad2;
+    int32_t keys_global;       // in-place engine: 1 = ranking keys live in HBM packed with the hashes (s_hash holds key32 << 32 | h32), 0 = keys in LDS
     const int32_t* kp_weight;  // knapsack: item weights [n]   (`weight` holds the profits)
     const int32_t* kp_order;   // knapsack: items by decreasing profit / weight [n]
     // maximum cut (examples/mcp): states are n signed benefits packed two per word + a depth word
@@ -183,10 +183,10 @@ struct EngineParams {
     int32_t lex_cap;           // tie lists up to this size (<= 1024) are split by rank counting in LDS, longer ones by radix rounds
     int32_t pad1;
     uint64_t* s_state;         // [slot][ws][capS]  node states, word major (streaming scan copy)
-    uint32_t* s_key;           // [slot][capS]      ranking keys when they do not live in LDS (else nullptr)
-    uint64_t* s_rec;           // [slot][capS][RW]  node records: state words + cached hash, RW = 8*ceil((ws+1)/8) words
+    uint64_t* s_rec;           // [slot][capS][RW]  node records: the state words, RW = 8*ceil((ws+1)/8) words (whole 64-byte lines)
     uint64_t* s_path;          // [slot][capS][PR]  best-path bit strings, one bit per layer, PR = 8*ceil(ws/8) words
-    uint64_t* s_hash;          // [slot][capS]      node hashes, contiguous (streamed by the per-layer table rebuild)
+    uint64_t* s_hash;          // [slot][capS]      keys_global: key32 << 32 | h32 per node; else the h32 values as a u32 array (streamed by the
+                               //                   select sweeps and the per-layer table rebuild)
     uint16_t* s_wl;            // [slot][2*capW]    work list + free list
     uint32_t* s_ev;            // [slot][ev_cap]    per-transition event records for the backward pass
     uint32_t* s_evoff;         // [slot][max_layers+1][4] offsets / counts per transition

@@ -421,11 +421,11 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     } else {
         const size_t capS = P.capS, capW = P.capW;
         const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
-        if ((rc = dev_alloc(allocs_, P.s_state, S * wsT * capS))) return rc;
+#if defined(DDO_WORD_MAJOR)
+        if ((rc = dev_alloc(allocs_, P.s_state, S * wsT * capS))) return rc;   // experiment: word-major copy of the states for the work-list sweep
+#endif
         if ((rc = dev_alloc(allocs_, P.s_rec, S * capS * RW))) return rc;
-        if (keys_global_) {
-            if ((rc = dev_alloc(allocs_, P.s_key, S * capS))) return rc;
-        }
+        P.keys_global = keys_global_ ? 1 : 0;
         if ((rc = dev_alloc(allocs_, P.s_path, S * capS * PR))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_hash, S * capS))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_wl, S * 2 * capW))) return rc;

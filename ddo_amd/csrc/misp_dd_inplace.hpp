@@ -68,17 +68,33 @@ DDO_DEV uint64_t dd_uniform64(uint64_t x) {
 constexpr int PH_VAR = 0, PH_SELECT = 1, PH_VICTIMS = 3, PH_WORKLIST = 0, PH_FREELIST = 0, PH_EXPAND = 7, PH_FINAL = 0, PH_BACKWARD = 0;
 constexpr int PH_SELLEX = 2, PH_EXP1 = 4, PH_TABLE = 5, PH_EXP2 = 6;
 
-// ranking keys live in LDS, or -- to fit two workgroups per CU at large widths -- in HBM (L2-resident): all accesses
-// go through these wrappers (agent-scope loads/stores so that L2 atomics and plain accesses never mix in the L1)
+// Ranking key and state hash of a node travel together: key32 = (value - vbase) << 11 | popcount, h32 = the 32 bits of the
+// state hash the dedup table needs (slot and tag).  The keys live in LDS when they fit, else -- to run two workgroups per CU
+// at large widths -- in HBM (L2-resident), PACKED with the hash into one 64-bit word per node (key32 << 32 | h32): a node
+// that is created or changed in place then costs ONE 8-byte store for both (rocprof, round 2: the expand phase is bound by the
+// NUMBER of partial-line write requests, not by bytes), and the atomicMax of a twin's key is a 64-bit one (equal states have
+// equal hashes, so the low half never decides).  With the keys in LDS the hashes are a u32 array in HBM.  All accesses go
+// through the wrappers below (agent-scope loads/stores so that L2 atomics and plain accesses never mix in the L1).
 #if defined(DDO_HOST_EMULATION)
-#define K32(c, i) ((c).key32[(i)])
-#define K32_ST(c, i, v) ((c).key32[(i)] = (v))
-#define K32_MAX(c, i, v) emu_atomic_max<uint32_t>(&(c).key32[(i)], (v))
+#define KH_LD64(p) (*(p))
+#define KH_ST64(p, v) (*(p) = (v))
+#define KH_MAX64(p, v) emu_atomic_max<uint64_t>((p), (v))
+#define KL_LD32(p) (*(p))
+#define KL_ST32(p, v) (*(p) = (v))
+#define KL_MAX32(p, v) emu_atomic_max<uint32_t>((p), (v))
 #else
-#define K32(c, i) __hip_atomic_load(&(c).key32[(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define K32_ST(c, i, v) __hip_atomic_store(&(c).key32[(i)], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define K32_MAX(c, i, v) atomicMax(&(c).key32[(i)], (v))
+#define KH_LD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define KH_ST64(p, v) __hip_atomic_store((p), (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define KH_MAX64(p, v) (uint64_t)atomicMax((unsigned long long*)(p), (unsigned long long)(v))
+#define KL_LD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define KL_ST32(p, v) __hip_atomic_store((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define KL_MAX32(p, v) atomicMax((p), (uint32_t)(v))
 #endif
+#define K32(c, i) k32_ld((c), (i))
+#define KH(c, i) kh_ld((c), (i))
+#define KH_ST(c, i, key, h32v) kh_st((c), (i), (key), (h32v))
+#define K32_ST(c, i, key) k32_st((c), (i), (key))
+#define K32_MAX(c, i, key, h32v) k32_max((c), (i), (key), (h32v))
 
 struct DD2Shared {
     int32_t work, status, cutoff;
@@ -167,10 +183,14 @@ struct DD2Ctx {
     const int32_t* weight;
     int capS, capW, max_layers, nbw;
     // HBM, per engine slot
+#if defined(DDO_WORD_MAJOR)
     uint64_t* st;      // [ws][capS]   word-major copy of the states: only the streaming "who contains v" scan reads it
+#endif
     uint64_t* rec;     // [capS][RW]   node records, one (or two) 64-byte lines each: state words, then the cached hash
     uint64_t* pbr;     // [capS][PR]   best-path bit strings, one line per node
-    uint64_t* hsh;     // [capS]       hash of every node, contiguous: the per-layer table rebuild streams it
+    uint64_t* keyh;    // [capS]       key32 << 32 | h32 of every node when the keys live in HBM (else nullptr): streamed by the
+                       //              select sweeps and by the per-layer table rebuild
+    uint32_t* h32;     // [capS]       h32 of every node when the keys live in LDS (else nullptr)
     int RW, PR;
     LDS_PTR(uint32_t) tab;
     int tab_cap;
@@ -186,7 +206,7 @@ struct DD2Ctx {
     int32_t* cs_value;
     uint32_t* cs_pop;
     // LDS
-    uint32_t* key32;   // capS   (aliased by the value_bot array of the backward pass)
+    uint32_t* key32;   // capS   keys in LDS (nullptr when they are packed into keyh); the backward pass reuses the key storage for value_bot
     LDS_PTR(uint32_t) live;    // nbw
     LDS_PTR(uint32_t) inex;    // nbw
     LDS_PTR(uint32_t) okb;     // nbw
@@ -217,6 +237,31 @@ struct DD2Ctx {
 #endif
 };
 
+template <int WS> DDO_DEV uint32_t k32_ld(const DD2Ctx<WS>& c, int i) {
+    return c.keyh ? (uint32_t)(KH_LD64(&c.keyh[i]) >> 32) : KL_LD32(&c.key32[i]);
+}
+template <int WS> DDO_DEV uint64_t kh_ld(const DD2Ctx<WS>& c, int i) {
+    return c.keyh ? KH_LD64(&c.keyh[i]) : (((uint64_t)KL_LD32(&c.key32[i]) << 32) | (uint64_t)c.h32[i]);
+}
+/// a node is created, or changed in place: key and hash
+template <int WS> DDO_DEV void kh_st(const DD2Ctx<WS>& c, int i, uint32_t key, uint32_t h32v) {
+    if (c.keyh) KH_ST64(&c.keyh[i], ((uint64_t)key << 32) | (uint64_t)h32v);
+    else {
+        KL_ST32(&c.key32[i], key);
+        c.h32[i] = h32v;
+    }
+}
+/// the key of an unchanged state
+template <int WS> DDO_DEV void k32_st(const DD2Ctx<WS>& c, int i, uint32_t key) {
+    if (c.keyh) KH_ST64(&c.keyh[i], ((uint64_t)key << 32) | (KH_LD64(&c.keyh[i]) & 0xFFFFFFFFULL));
+    else KL_ST32(&c.key32[i], key);
+}
+/// a twin arrives at node i (same state, hence same h32): the key keeps the maximum; returns the old key
+template <int WS> DDO_DEV uint32_t k32_max(const DD2Ctx<WS>& c, int i, uint32_t key, uint32_t h32v) {
+    if (c.keyh) return (uint32_t)(KH_MAX64(&c.keyh[i], ((uint64_t)key << 32) | (uint64_t)h32v) >> 32);
+    return KL_MAX32(&c.key32[i], key);
+}
+
 template <class BP> DDO_DEV bool bm_test(BP bm, int s) { return (bm[s >> 5] >> (s & 31)) & 1u; }
 template <class BP> DDO_DEV void bm_set(BP bm, int s) { LDS_OR_U32(&bm[s >> 5], 1u << (s & 31)); }
 template <class BP> DDO_DEV void bm_clr(BP bm, int s) { LDS_AND_U32(&bm[s >> 5], ~(1u << (s & 31))); }
@@ -239,6 +284,10 @@ DDO_DEV uint64_t hash2_state(const uint64_t* s) {
     for (int k = 0; k < WS; ++k) h ^= mixw(s[k], k);
     return h;
 }
+/// the 32 bits of the hash that are kept per node: XOR-linear in H, so a one-word change patches it incrementally
+DDO_DEV uint32_t fold32(uint64_t h) { return (uint32_t)(h ^ (h >> 32)); }
+template <int WS>
+DDO_DEV uint32_t hash32_state(const uint64_t* s) { return fold32(hash2_state<WS>(s)); }
 
 /// Node records are array-of-structures: a random access to a node costs one 64-byte line instead of one line
 /// per state word (rocprof showed the expand phase bound by random 8-byte requests, not by bytes).
@@ -252,49 +301,43 @@ struct alignas(16) U32x4 {
 /// its record with 8-byte loads costs 2.5x more than with 16-byte ones (tools/micro/recload.hip: 22.5 vs 8.9 kcycles
 /// per 1024 records)
 template <int WS>
-DDO_DEV void ld_state_h(const DD2Ctx<WS>& c, int slot, uint64_t* s, uint64_t& h) {
+DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
     const U64x2* r2 = (const U64x2*)(c.rec + (size_t)slot * c.RW);
-    constexpr int NP = (WS + 2) / 2;   // pairs covering the WS state words and the hash
+    constexpr int NP = (WS + 1) / 2;   // pairs covering the WS state words
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const U64x2 v = r2[q];
-        if (2 * q < WS) s[2 * q] = v.a; else if (2 * q == WS) h = v.a;
-        if (2 * q + 1 < WS) s[2 * q + 1] = v.b; else if (2 * q + 1 == WS) h = v.b;
+        s[2 * q] = v.a;
+        if (2 * q + 1 < WS) s[2 * q + 1] = v.b;
     }
-}
-template <int WS>
-DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
-    uint64_t h;
-    ld_state_h<WS>(c, slot, s, h);
-    (void)h;
 }
 template <int WS>
 DDO_DEV uint64_t ld_word(const DD2Ctx<WS>& c, int slot, int k) { return c.rec[(size_t)slot * c.RW + k]; }
 /// full (re)write of a node: record line (16-byte stores: every store instruction of a lane is its own write
 /// request at the L2, so fewer, wider stores matter) + the word-major copy
 template <int WS>
-DDO_DEV void st_node(const DD2Ctx<WS>& c, int slot, const uint64_t* s, uint64_t h) {
+DDO_DEV void st_node(const DD2Ctx<WS>& c, int slot, const uint64_t* s) {
     U64x2* r2 = (U64x2*)(c.rec + (size_t)slot * c.RW);
-    constexpr int NP = (WS + 2) / 2;   // pairs covering the WS state words and the hash
+    constexpr int NP = (WS + 1) / 2;   // pairs covering the WS state words
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         U64x2 v;
-        v.a = 2 * q < WS ? s[2 * q] : (2 * q == WS ? h : 0);
-        v.b = 2 * q + 1 < WS ? s[2 * q + 1] : (2 * q + 1 == WS ? h : 0);
+        v.a = s[2 * q];
+        v.b = 2 * q + 1 < WS ? s[2 * q + 1] : 0;
         r2[q] = v;
     }
+#if defined(DDO_WORD_MAJOR)
 #pragma unroll
     for (int k = 0; k < WS; ++k) c.st[(size_t)k * c.capS + slot] = s[k];
-    c.hsh[slot] = h;
+#endif
 }
-/// one state word changes (NO-child in place)
+/// one state word changes (NO-child in place); the caller stores the new key | hash (KH_ST)
 template <int WS>
-DDO_DEV void st_word(const DD2Ctx<WS>& c, int slot, int k, uint64_t w, uint64_t h) {
-    uint64_t* r = c.rec + (size_t)slot * c.RW;
-    r[k] = w;
-    r[WS] = h;
-    c.hsh[slot] = h;
+DDO_DEV void st_word(const DD2Ctx<WS>& c, int slot, int k, uint64_t w) {
+    c.rec[(size_t)slot * c.RW + k] = w;
+#if defined(DDO_WORD_MAJOR)
     c.st[(size_t)k * c.capS + slot] = w;
+#endif
 }
 /// copies the first `nw` words of a path (the words that can hold decisions up to the current layer)
 template <int WS>
@@ -321,11 +364,11 @@ DDO_DEV void copy_path(const DD2Ctx<WS>& c, int dst, int src, int nw, int setbit
 /// HBM round trip per probe (rocprof: the HBM-resident table accounted for about half of the L2 misses).
 /// insert node `x` (hash h, state s) -> x when new, else the node already holding the same state
 template <int WS>
-DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint64_t h, const uint64_t* s) {
+DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint32_t h, const uint64_t* s) {
     const uint32_t mask = (uint32_t)c.tab_cap - 1;
-    const uint32_t tag = (uint32_t)(h >> 52);
+    const uint32_t tag = h >> 20;
     const uint32_t mine = (tag << 20) | (uint32_t)x;
-    uint32_t slot = (uint32_t)h & mask;
+    uint32_t slot = h & mask;
     for (uint32_t probes = 0; probes <= mask; ++probes) {
         uint32_t e = LD_U32(&c.tab[slot]);
         if (e == T2_EMPTY) {
@@ -349,10 +392,10 @@ DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint64_t h, const uint64_t* 
 }
 /// insert without duplicate check (all unchanged live states are distinct)
 template <int WS>
-DDO_DEV void tab2_insert_unique(const DD2Ctx<WS>& c, int x, uint64_t h) {
+DDO_DEV void tab2_insert_unique(const DD2Ctx<WS>& c, int x, uint32_t h) {
     const uint32_t mask = (uint32_t)c.tab_cap - 1;
-    const uint32_t mine = ((uint32_t)(h >> 52) << 20) | (uint32_t)x;
-    uint32_t slot = (uint32_t)h & mask;
+    const uint32_t mine = ((h >> 20) << 20) | (uint32_t)x;
+    uint32_t slot = h & mask;
     for (uint32_t probes = 0; probes <= mask; ++probes) {
         if (TAB_CAS(&c.tab[slot], T2_EMPTY, mine) == T2_EMPTY) return;
         slot = (slot + 1) & mask;
@@ -361,10 +404,10 @@ DDO_DEV void tab2_insert_unique(const DD2Ctx<WS>& c, int x, uint64_t h) {
 }
 /// node holding state s (hash h), or -1
 template <int WS>
-DDO_DEV int tab2_find(const DD2Ctx<WS>& c, uint64_t h, const uint64_t* s) {
+DDO_DEV int tab2_find(const DD2Ctx<WS>& c, uint32_t h, const uint64_t* s) {
     const uint32_t mask = (uint32_t)c.tab_cap - 1;
-    const uint32_t tag = (uint32_t)(h >> 52);
-    uint32_t slot = (uint32_t)h & mask;
+    const uint32_t tag = h >> 20;
+    uint32_t slot = h & mask;
     for (uint32_t probes = 0; probes <= mask; ++probes) {
         uint32_t e = LD_U32(&c.tab[slot]);
         if (e == T2_EMPTY) return -1;
@@ -793,8 +836,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             c.pbr[k] = 0;
             pop += dd_popc(root[k]);
         }
-        st_node<WS>(c, 0, root, hash2_state<WS>(root));
-        K32_ST(c, 0, ((uint32_t)(in.value - vbase) << KEY_POP_BITS) | (uint32_t)pop);
+        st_node<WS>(c, 0, root);
+        KH_ST(c, 0, ((uint32_t)(in.value - vbase) << KEY_POP_BITS) | (uint32_t)pop, hash32_state<WS>(root));
     }
     PAR_END
     PAR_BEGIN
@@ -983,8 +1026,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 if (tid == 0) {
                     uint64_t ms[WS];
                     for (int k = 0; k < WS; ++k) ms[k] = sh->merged[k];
-                    const uint64_t mh = hash2_state<WS>(ms);
-                    const int r = tab2_find<WS>(c, mh, ms);
+                    const int r = tab2_find<WS>(c, hash32_state<WS>(ms), ms);
                     sh->recycled = (r >= 0 && bm_test(c.live, r)) ? 1 : 0;   // clean.rs:830
                     sh->merged_slot = r;
                 }
@@ -1101,7 +1143,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         const int bestv = (int)(uint32_t)sh->mergedKey;
                         if (tid < WS) {   // one thread per state word: state, best path, vertex counters
                             const uint64_t w = sh->merged[tid];
+#if defined(DDO_WORD_MAJOR)
                             c.st[(size_t)tid * capS + m] = w;
+#endif
                             c.rec[(size_t)m * c.RW + tid] = w;
                             if (tid < npw) c.pbr[(size_t)m * c.PR + tid] = c.pbr[(size_t)bestv * c.PR + tid];
                             uint64_t x = w;
@@ -1119,10 +1163,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                                 pop += dd_popc(ms[k]);
                             }
                             const uint32_t mkey = (uint32_t)(sh->mergedKey >> 32);
-                            K32_ST(c, m, (mkey & ~KEY_POP_MASK) | (uint32_t)pop);
-                            const uint64_t mh = hash2_state<WS>(ms);
-                            c.rec[(size_t)m * c.RW + WS] = mh;
-                            c.hsh[m] = mh;
+                            KH_ST(c, m, (mkey & ~KEY_POP_MASK) | (uint32_t)pop, hash32_state<WS>(ms));
                             bm_set(c.live, m);
                             bm_set(c.inex, m);
                             bm_clr(c.okb, m);
@@ -1196,15 +1237,28 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #endif
         PAR_BEGIN
         {
+#if defined(DDO_WORD_MAJOR)
             const uint64_t* row = c.st + (size_t)vw * capS;
+#else
+            // Word var/64 of every live node comes straight out of its record (one 64-byte sector per node and layer -- the
+            // read the algorithmic byte count allots to a node anyway).  Round 2 kept a word-major copy of the states for this
+            // sweep, a contiguous 8-byte stream, but every YES-child then cost 7 scattered 8-byte stores to keep it up to date,
+            // and partial-line write requests are what the memory system handles worst (tools/micro/expand_patterns.hip: 100 of
+            // the 155 kcycles a workgroup spends per 512 new nodes; the strided sweep adds 6 cycles per node).
+            const uint64_t* row = c.rec + vw;
+#endif
             const int hi = DD_UNIFORM(sh->hiw);
             for (int base = 0; base < hi; base += NT * KS) {
-                uint64_t ww[KS], hh[KS];
+                uint64_t ww[KS], hh[KS];   // hh = key32 << 32 | h32
 #pragma unroll
                 for (int b = 0; b < KS; ++b) {
                     const int s = base + b * NT + tid;
+#if defined(DDO_WORD_MAJOR)
                     ww[b] = s < hi ? row[s] : 0;
-                    hh[b] = s < hi ? c.hsh[s] : 0;
+#else
+                    ww[b] = (s < hi && bm_test(c.live, s)) ? row[(size_t)s * c.RW] : 0;   // (dead slots: no sector fetched)
+#endif
+                    hh[b] = s < hi ? KH(c, s) : 0;
                 }
                 uint32_t pslot[KS], pmine[KS];
                 bool pend[KS];
@@ -1213,7 +1267,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     const int s = base + b * NT + tid;
                     pend[b] = false;
                     pslot[b] = (uint32_t)hh[b] & ((uint32_t)c.tab_cap - 1);
-                    pmine[b] = ((uint32_t)(hh[b] >> 52) << 20) | (uint32_t)s;
+                    pmine[b] = (((uint32_t)hh[b] >> 20) << 20) | (uint32_t)s;
                     if (s >= hi || !bm_test(c.live, s)) continue;
                     if ((ww[b] & vbit) != 0) {
                         const int i = LDS_ADD_I32(&sh->nwl, 1);
@@ -1221,7 +1275,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     } else if (bm_test(c.fresh, s)) {
                         // unit weights: the rough upper bound is the popcount held in the key (main.rs:191-193); a fresh
                         // node that passes the check (clean.rs:362-365) is its own only child and joins the table here
-                        const uint32_t key = c.unit_weights ? K32(c, s) : 0u;
+                        const uint32_t key = (uint32_t)(hh[b] >> 32);
                         if (c.unit_weights && (int64_t)(key & KEY_POP_MASK) + (int64_t)(vbase + (int32_t)(key >> KEY_POP_BITS)) > best_lb) {
                             bm_clr(c.fresh, s);
                             pend[b] = true;
@@ -1313,18 +1367,18 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // popcount held in the key, so the record is not even read.
         for (int j = tid; j < nwl2; j += NT) {
             const int s = c.wl[c.capW - 1 - j];
-            const uint32_t key = K32(c, s);
+            const uint64_t kh = KH(c, s);
+            const uint32_t key = (uint32_t)(kh >> 32);
+            const uint32_t hs = (uint32_t)kh;
             const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
             bm_clr(c.fresh, s);
             bool pruned;
             uint64_t st[WS];
-            uint64_t hs = 0;
             if (c.unit_weights) {
                 pruned = (int64_t)(key & KEY_POP_MASK) + (int64_t)val <= best_lb;
-                if (pruned) ld_state_h<WS>(c, s, st, hs);
-                else hs = c.hsh[s];
+                if (pruned) ld_state<WS>(c, s, st);
             } else {
-                ld_state_h<WS>(c, s, st, hs);
+                ld_state<WS>(c, s, st);
                 pruned = (int64_t)rub2_of<WS>(c, st) + (int64_t)val <= best_lb;
             }
             if (pruned) {
@@ -1356,12 +1410,13 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #endif
         for (int i = tid; i < nwl; i += NT) {
             const int s = c.wl[i];
-            const uint32_t key = K32(c, s);
+            const uint64_t kh = KH(c, s);
+            const uint32_t key = (uint32_t)(kh >> 32);
+            const uint32_t oldh = (uint32_t)kh;
             const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
             const int pop = (int)(key & KEY_POP_MASK);
             uint64_t st[WS];
-            uint64_t oldh = 0;
-            ld_state_h<WS>(c, s, st, oldh);
+            ld_state<WS>(c, s, st);
             DD2_PROBE(0)
             const int32_t rub = c.unit_weights ? pop : rub2_of<WS>(c, st);   // main.rs:191-193
             bm_clr(c.fresh, s);
@@ -1389,15 +1444,15 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     st[k] &= ~vbit;
                     neww = st[k];
                 }
-            const uint64_t newh = oldh ^ mixw(oldw, vw) ^ mixw(neww, vw);
-            st_word<WS>(c, s, vw, neww, newh);
+            const uint32_t newh = oldh ^ fold32(mixw(oldw, vw) ^ mixw(neww, vw));   // (the hash is XOR-linear in the per-word mixes)
+            st_word<WS>(c, s, vw, neww);
             const uint32_t kno = key - 1;  // popcount - 1, same value (cost 0)
-            K32_ST(c, s, kno);   // (cnt[var]: no state of the next layer contains the variable, it is zeroed with the layer)
+            KH_ST(c, s, kno, newh);   // (cnt[var]: no state of the next layer contains the variable, it is zeroed with the layer)
             // ---- decision YES into a free slot (main.rs:95-102)
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
             int ny = -1;
             uint64_t y[WS];
-            uint64_t yh = 0;
+            uint32_t yh = 0;
             uint32_t kyes = 0;
 #pragma unroll
             for (int k = 0; k < WS; ++k) y[k] = 0;
@@ -1412,10 +1467,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 // a DD has at most popcount(root state) layers: only npw path words exist; the child's path is the
                 // parent's plus decision bit L
                 copy_path<WS>(c, ny, s, npw, L);
-                yh = hash2_state<WS>(y);
-                st_node<WS>(c, ny, y, yh);
+                yh = hash32_state<WS>(y);
+                st_node<WS>(c, ny, y);
                 kyes = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop;
-                K32_ST(c, ny, kyes);
+                KH_ST(c, ny, kyes, yh);
                 bm_put(c.inex, ny, bm_test(c.inex, s));
                 bm_put(c.okb, ny, bm_test(c.okb, s));
             } else {
@@ -1429,7 +1484,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             if (t0 == s) {
                 bm_set(c.fresh, s);          // it stays in the layer; its rub shrank: check it again before it is expanded
             } else {                         // the in-place NO-child dissolves into its twin t0
-                const uint32_t old = K32_MAX(c, t0, kno);
+                const uint32_t old = K32_MAX(c, t0, kno, newh);
                 e_no = (uint32_t)t0 | (kno > old ? EV_RAISED : 0u);
                 if (bm_test(c.inex, s)) bm_set(c.inex, t0);
                 add_bits<WS>(c.cnt, st, -1);
@@ -1448,7 +1503,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     LDS_MAX_I32(&sh->hiw, ny + 1);
                     e_yes = (uint32_t)ny | EV_CREATED;
                 } else {
-                    const uint32_t old = K32_MAX(c, t1, kyes);
+                    const uint32_t old = K32_MAX(c, t1, kyes, yh);
                     e_yes = (uint32_t)t1 | (kyes > old ? EV_RAISED : 0u);
                     if (bm_test(c.inex, ny)) bm_set(c.inex, t1);
                 }
@@ -1645,7 +1700,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     DD2_TICK(PH_FINAL)
     // ---------------------------------------------------------------- local bounds (clean.rs:448-475)
     const bool want_cutset = relaxed && !failed && lel >= 0 && has_best;
-    int32_t* vb = (int32_t*)c.key32;       // the ranking keys are dead now: reuse their LDS
+    int32_t* vb = c.keyh ? (int32_t*)c.keyh : (int32_t*)c.key32;   // the ranking keys are dead now: reuse their storage (LDS, or the packed words)
     int32_t* tmp = (int32_t*)c.wl;         // wl + fl = capW x int32
     if (want_cutset) {
         PAR_BEGIN   // terminal layer: value_bot = 0 and MARKED; everything else unmarked
@@ -2001,11 +2056,12 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     const size_t capS = (size_t)P.capS, capW = (size_t)P.capW, ml = (size_t)P.max_layers, s = (size_t)slot;
     c.RW = ((WS + 1 + 7) / 8) * 8;
     c.PR = ((WS + 7) / 8) * 8;
+#if defined(DDO_WORD_MAJOR)
     c.st = P.s_state + s * (size_t)WS * capS;
+#endif
     c.rec = P.s_rec + s * capS * (size_t)c.RW;
     c.pbr = P.s_path + s * capS * (size_t)c.PR;
     c.tab_cap = P.tab2_cap;
-    c.hsh = P.s_hash + s * capS;
     c.ev = P.s_ev + s * P.ev_cap;
     c.ev_cap = P.ev_cap;
     c.evoff = P.s_evoff + s * ml * 8;
@@ -2018,9 +2074,13 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.cs_value = P.cs_value + s * (size_t)P.capN;
     c.cs_pop = P.cs_pop + s * (size_t)P.capN;
     unsigned char* p = lds;
-    if (P.s_key) {
-        c.key32 = P.s_key + s * capS;      // keys in HBM: the LDS footprint halves, two workgroups share a CU
+    if (P.keys_global) {
+        c.keyh = P.s_hash + s * capS;      // keys in HBM, packed with the hashes: the LDS footprint halves, two workgroups share a CU
+        c.key32 = nullptr;
+        c.h32 = nullptr;
     } else {
+        c.keyh = nullptr;
+        c.h32 = (uint32_t*)(P.s_hash + s * capS);
         c.key32 = (uint32_t*)p;
         p += ((size_t)P.capS * 4 + 15) & ~(size_t)15;
     }

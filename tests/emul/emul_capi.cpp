@@ -196,6 +196,7 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
             std::abort();
         }
     }
+    if (const char* env = std::getenv("DDO_EMUL_KEYS_GLOBAL")) P.keys_global = std::atoi(env) != 0;   // keys packed with the hashes in "HBM" (the dense / full-width kernels at large widths)
     P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 3) & ~3ull;
     {
         const size_t capS = P.capS, capW = P.capW, mlz = P.max_layers;

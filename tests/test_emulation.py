@@ -133,13 +133,15 @@ def test_emulation_of_a_capacity_tier(oracle, monkeypatch, cap, nthreads):
     assert done > 0 and retry > 0
 
 
+@pytest.mark.parametrize("packed", [1, 0], ids=["keys-packed-in-hbm", "keys-in-lds"])
 @pytest.mark.parametrize("table,nthreads,expect_retry", [(1 << 20, 512, False), (128, 512, True), (128, 256, True)])
-def test_emulation_of_the_dense_tier(oracle, monkeypatch, table, nthreads, expect_retry):
+def test_emulation_of_the_dense_tier(oracle, monkeypatch, table, nthreads, expect_retry, packed):
     """The dense tier (Engine::create_tier with cap_width == max_width, 512 threads, two workgroups per CU) = the in-place
     engine at full layer capacity with a SMALLER dedup table, 8-bit select digits and at most 128 tie-break keys in LDS.  A
     layer whose table could overflow ends the compile with ST_RETRY (the host hands it to the full-width engine); every
     other compile equals the oracle's record -- including the squashed layers (the capacity tiers never squash)."""
     monkeypatch.setenv("DDO_EMUL_DENSE", str(table))
+    monkeypatch.setenv("DDO_EMUL_KEYS_GLOBAL", str(packed))   # the dense kernel at W = 10 000 keeps key32 << 32 | h32 per node in HBM
     inst = oracle.misp(data_path("misp", "brock200_2.clq"))
     _, recs = inst.trace_solve(100, 300)
     e = Emul(inst.n, inst.rows, inst.weights, 100, nthreads=nthreads, engine=2)
@@ -161,6 +163,7 @@ def test_emulation_of_the_dense_tier(oracle, monkeypatch, table, nthreads, expec
 def test_dense_tier_emulation_matches_golden(oracle, monkeypatch, case):
     """8-bit select digits and the 128-key tie-break limit of the dense tier on the golden compiles (widths up to 1000)"""
     monkeypatch.setenv("DDO_EMUL_DENSE", str(1 << 20))
+    monkeypatch.setenv("DDO_EMUL_KEYS_GLOBAL", "1")
     inst = oracle.misp(data_path("misp", case["instance"] + ".clq"))
     e = Emul(inst.n, inst.rows, inst.weights, case["width"], nthreads=512, engine=2)
     state = np.array([int(x) for x in case["state"]], dtype=np.uint64)
