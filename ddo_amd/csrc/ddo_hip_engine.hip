@@ -303,7 +303,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
                                 ml * capN * 4 + 2 * ml * (size_t)P.fan * capN * 4 + ml * 4 * 4 + wsT * capN * 8 + capN * 8 +
                                 (table_lds_ ? 0 : (size_t)P.table_cap * 4)
                           : wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 * (((wsT + 8) / 8) * 8 + ((wsT + 7) / 8) * 8) +
-                                (size_t)P.capS * 12 + capN * 4 + P.ev_cap * 4 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
+                                (size_t)P.capS * 12 + capN * 4 + P.ev_cap * 4 + P.ev_cap * 2 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
     if (P.tmode) {
         per_slot += ml * (size_t)P.lstride * (wsT * 8 + 6 * 4) + capC1 * 8;
         nslots = std::min(nslots, (int)std::max<size_t>(4, (8ull << 30) / per_slot));   // D-ary models: up to a GB per slot
@@ -420,13 +420,13 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         if ((rc = dev_alloc(allocs_, P.lddelta, S * ml))) return rc;
     } else {
         const size_t capS = P.capS, capW = P.capW;
-        const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
+        const size_t RW = ((wsT + 1 + 7) / 8) * 8;
 #if defined(DDO_WORD_MAJOR)
         if ((rc = dev_alloc(allocs_, P.s_state, S * wsT * capS))) return rc;   // experiment: word-major copy of the states for the work-list sweep
 #endif
         if ((rc = dev_alloc(allocs_, P.s_rec, S * capS * RW))) return rc;
         P.keys_global = keys_global_ ? 1 : 0;
-        if ((rc = dev_alloc(allocs_, P.s_path, S * capS * PR))) return rc;
+        if ((rc = dev_alloc(allocs_, P.s_ptree, S * (size_t)(P.ev_cap / 4)))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_hash, S * capS))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_wl, S * 2 * capW))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_ev, S * P.ev_cap))) return rc;

@@ -489,10 +489,10 @@ struct ddo_solver {
                          (double)st_clk[8] / tl, (double)st_clk[9] / tl, (double)st_clk[10] / tl, (double)st_clk[11] / tl, (double)st_clk[16] / tl,
                          (double)st_clk[12] / tl, (double)st_clk[15] / tl, (double)st_clk[13] / tl, (double)st_clk[14] / tl, (double)st_clk[17] / tl);
             for (int q = 18; q < 24; ++q) std::fprintf(stderr, " aux%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
-            if (st_clk[29]) {   // thread 0's own node in expand: the dependent chain, cycles per probed node
-                const double np = (double)st_clk[29];
-                std::fprintf(stderr, " | expand chain per node (thread 0, %.0f probes): loads %.0f, children + stores + fence %.0f, insert NO %.0f, insert YES %.0f, record %.0f",
-                             np, st_clk[24] / np, st_clk[25] / np, st_clk[26] / np, st_clk[27] / np, st_clk[28] / np);
+            if (st_clk[31]) {   // thread 0's own node in expand (make PROBES=1): the dependent chain, cycles per probed node
+                const double np = (double)st_clk[31];
+                std::fprintf(stderr, " | expand chain per node (thread 0, %.0f probes): loads %.0f, children + stores + fence %.0f, table insert NO %.0f + its bookkeeping %.0f, table insert YES %.0f + its bookkeeping %.0f, record %.0f",
+                             np, st_clk[24] / np, st_clk[25] / np, st_clk[26] / np, st_clk[29] / np, st_clk[27] / np, st_clk[30] / np, st_clk[28] / np);
             }
             std::fprintf(stderr, " | recycled merges per layer %.4f", (double)st_recycled / tl);
             std::fprintf(stderr, "\n");

@@ -187,11 +187,11 @@ struct DD2Ctx {
     uint64_t* st;      // [ws][capS]   word-major copy of the states: only the streaming "who contains v" scan reads it
 #endif
     uint64_t* rec;     // [capS][RW]   node records, one (or two) 64-byte lines each: state words, then the cached hash
-    uint64_t* pbr;     // [capS][PR]   best-path bit strings, one line per node
+    uint64_t* pt;      // [ev_cap / 4]  path tree: one entry per event record, parent path id | layer << 32 (see PID_NONE)
     uint64_t* keyh;    // [capS]       key32 << 32 | h32 of every node when the keys live in HBM (else nullptr): streamed by the
                        //              select sweeps and by the per-layer table rebuild
     uint32_t* h32;     // [capS]       h32 of every node when the keys live in LDS (else nullptr)
-    int RW, PR;
+    int RW;
     LDS_PTR(uint32_t) tab;
     int tab_cap;
     uint32_t* ev;
@@ -202,7 +202,7 @@ struct DD2Ctx {
     int32_t* lmerge;   // [max_layers]   merged slot (-1 none)
     uint32_t* cs_slot;
     uint64_t* cs_state;
-    uint64_t* cs_path;
+    uint32_t* cs_pid;  // [capW]        path ids of the snapshot's nodes
     int32_t* cs_value;
     uint32_t* cs_pop;
     // LDS
@@ -300,6 +300,45 @@ struct alignas(16) U32x4 {
 /// state words (+ the cached hash) of a node with 16-byte loads: records are 64-byte aligned, and one thread reading
 /// its record with 8-byte loads costs 2.5x more than with 16-byte ones (tools/micro/recload.hip: 22.5 vs 8.9 kcycles
 /// per 1024 records)
+/// Best paths are kept BY REFERENCE.  In-place layers make a path a very regular thing: a node that stays (the NO-child) keeps
+/// its path, a new node (the YES-child created by the arc of event record e) has its parent's path plus decision 1 at the
+/// layer of e.  So a path is a chain of event records -- the layers at which its 1-decisions were taken -- and a node only
+/// stores the id of the last one, in the spare word of its record line: `pt[e]` = (path id of the parent when e was written)
+/// | layer << 32.  Event records are append-only within a DD, so a chain is never overwritten.  Creating a child, or handing
+/// a better path over to a twin, costs 4 bytes that travel with stores made anyway; round 2 copied a 64-byte bit string per
+/// child and per hand-over (a line read plus a line written: a third of the expand phase's memory time,
+/// tools/micro/expand_parts.hip).  Bit strings are built only for what leaves the DD: the best terminal node(s) and the
+/// cut-set nodes that survive the local bounds.  A MISP path has at most value-many 1-decisions, so chains are short.
+constexpr uint32_t PID_NONE = 0xFFFFFFFFu;   // the empty path (the DD's root)
+template <int WS>
+DDO_DEV uint32_t pid_ld(const DD2Ctx<WS>& c, int slot) { return (uint32_t)c.rec[(size_t)slot * c.RW + WS]; }
+template <int WS>
+DDO_DEV void pid_st(const DD2Ctx<WS>& c, int slot, uint32_t pid) { c.rec[(size_t)slot * c.RW + WS] = (uint64_t)pid; }
+/// ORs the 1-decisions of path `pid` into bits[] (bit L = the decision taken at layer L of this DD)
+template <int WS>
+DDO_DEV void path_bits(const DD2Ctx<WS>& c, uint32_t pid, uint64_t* bits) {
+    int guard = c.max_layers + 1;
+    while (pid != PID_NONE && guard-- > 0) {
+        const uint64_t e = c.pt[pid];
+        const int L = (int)(e >> 32);
+#pragma unroll
+        for (int k = 0; k < WS; ++k)
+            if (k == (L >> 6)) bits[k] |= 1ULL << (L & 63);
+        pid = (uint32_t)e;
+    }
+}
+
+template <int WS>
+DDO_DEV void ld_state_p(const DD2Ctx<WS>& c, int slot, uint64_t* s, uint32_t& pid) {
+    const U64x2* r2 = (const U64x2*)(c.rec + (size_t)slot * c.RW);
+    constexpr int NP = (WS + 2) / 2;   // pairs covering the WS state words and the path id
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const U64x2 v = r2[q];
+        if (2 * q < WS) s[2 * q] = v.a; else if (2 * q == WS) pid = (uint32_t)v.a;
+        if (2 * q + 1 < WS) s[2 * q + 1] = v.b; else if (2 * q + 1 == WS) pid = (uint32_t)v.b;
+    }
+}
 template <int WS>
 DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
     const U64x2* r2 = (const U64x2*)(c.rec + (size_t)slot * c.RW);
@@ -313,50 +352,20 @@ DDO_DEV void ld_state(const DD2Ctx<WS>& c, int slot, uint64_t* s) {
 }
 template <int WS>
 DDO_DEV uint64_t ld_word(const DD2Ctx<WS>& c, int slot, int k) { return c.rec[(size_t)slot * c.RW + k]; }
-/// full (re)write of a node: record line (16-byte stores: every store instruction of a lane is its own write
-/// request at the L2, so fewer, wider stores matter) + the word-major copy
+/// full (re)write of a node's record line -- state words and path id -- with 16-byte stores.  Also used for the NO-child
+/// that changes ONE word in place: a store that covers its whole 64-byte line is cheaper for the memory system than an
+/// 8-byte one into a line that is not cached (tools/micro/expand_parts.hip: 8.4 vs 14.0 kcycles per 512 nodes).
 template <int WS>
-DDO_DEV void st_node(const DD2Ctx<WS>& c, int slot, const uint64_t* s) {
+DDO_DEV void st_node(const DD2Ctx<WS>& c, int slot, const uint64_t* s, uint32_t pid) {
     U64x2* r2 = (U64x2*)(c.rec + (size_t)slot * c.RW);
-    constexpr int NP = (WS + 1) / 2;   // pairs covering the WS state words
+    constexpr int NP = (WS + 2) / 2;   // pairs covering the WS state words and the path id
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         U64x2 v;
-        v.a = s[2 * q];
-        v.b = 2 * q + 1 < WS ? s[2 * q + 1] : 0;
+        v.a = 2 * q < WS ? s[2 * q] : (2 * q == WS ? (uint64_t)pid : 0);
+        v.b = 2 * q + 1 < WS ? s[2 * q + 1] : (2 * q + 1 == WS ? (uint64_t)pid : 0);
         r2[q] = v;
     }
-#if defined(DDO_WORD_MAJOR)
-#pragma unroll
-    for (int k = 0; k < WS; ++k) c.st[(size_t)k * c.capS + slot] = s[k];
-#endif
-}
-/// one state word changes (NO-child in place); the caller stores the new key | hash (KH_ST)
-template <int WS>
-DDO_DEV void st_word(const DD2Ctx<WS>& c, int slot, int k, uint64_t w) {
-    c.rec[(size_t)slot * c.RW + k] = w;
-#if defined(DDO_WORD_MAJOR)
-    c.st[(size_t)k * c.capS + slot] = w;
-#endif
-}
-/// copies the first `nw` words of a path (the words that can hold decisions up to the current layer)
-template <int WS>
-DDO_DEV void copy_path(const DD2Ctx<WS>& c, int dst, int src, int nw, int setbit = -1) {
-    // 16-byte accesses (path lines are 64-byte aligned): half the memory requests of word-wise copies; the word
-    // behind an odd nw is copied along (it is never read)
-    const U64x2* a = (const U64x2*)(c.pbr + (size_t)src * c.PR);
-    U64x2* b = (U64x2*)(c.pbr + (size_t)dst * c.PR);
-    constexpr int NP = (WS + 1) / 2;
-    U64x2 tmp[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) tmp[q] = 2 * q < nw ? a[q] : U64x2{0, 0};
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-        if (2 * q < nw) {
-            if (setbit >= 0 && (setbit >> 6) == 2 * q) tmp[q].a |= 1ULL << (setbit & 63);
-            if (setbit >= 0 && (setbit >> 6) == 2 * q + 1) tmp[q].b |= 1ULL << (setbit & 63);
-            b[q] = tmp[q];
-        }
 }
 
 /// The dedup table lives in LDS and is rebuilt for every layer (clear, stream all unchanged live nodes in by their
@@ -425,6 +434,76 @@ DDO_DEV int tab2_find(const DD2Ctx<WS>& c, uint32_t h, const uint64_t* s) {
     return -1;
 }
 
+
+/// Inserts the two children of one node together: x1 (hash h1, state s1) and -- when x2 >= 0 -- x2 (h2, s2); r1 / r2 receive
+/// the node that holds each state (the child itself when it is new).  The probing runs in two alternating phases: an LDS phase
+/// that walks both probe sequences up to a claimed empty entry or the first entry with a matching tag, and a global phase that
+/// compares BOTH candidates' records at once.  A wave whose lanes meet their twins after different numbers of probes then
+/// pays one memory round trip per phase instead of one per probe step (thread-0 probes, round 3: the two separate inserts
+/// took 7.5 + 10.8 kcycles of a 46 kcycle chain, nearly all of it waves waiting for a few lanes' twin compares, one after
+/// the other).
+template <int WS>
+DDO_DEV void tab2_insert2(const DD2Ctx<WS>& c, int x1, uint32_t h1, const uint64_t* s1, int x2, uint32_t h2, const uint64_t* s2, int& r1, int& r2) {
+    const uint32_t mask = (uint32_t)c.tab_cap - 1;
+    const uint32_t tag1 = h1 >> 20, tag2 = h2 >> 20;
+    const uint32_t mine1 = (tag1 << 20) | (uint32_t)x1, mine2 = (tag2 << 20) | (uint32_t)x2;
+    uint32_t p1 = h1 & mask, p2 = h2 & mask;
+    r1 = -1;
+    r2 = x2 >= 0 ? -1 : -2;   // -2: there is no second child
+    uint32_t probes = 0;
+    for (;;) {
+        int c1 = -1, c2 = -1;   // holders whose tag matches: to be compared
+        while (r1 == -1 && c1 < 0 && probes <= 2 * mask + 2) {
+            const uint32_t e = TAB_CAS(&c.tab[p1], T2_EMPTY, mine1);   // (one LDS round trip: the old entry comes back either way)
+            if (e == T2_EMPTY) {
+                r1 = x1;
+                break;
+            }
+            if ((e >> 20) == tag1) c1 = (int)(e & 0xFFFFFu);
+            else p1 = (p1 + 1) & mask;
+            ++probes;
+        }
+        while (r2 == -1 && c2 < 0 && probes <= 2 * mask + 2) {
+            const uint32_t e = TAB_CAS(&c.tab[p2], T2_EMPTY, mine2);   // (one LDS round trip: the old entry comes back either way)
+            if (e == T2_EMPTY) {
+                r2 = x2;
+                break;
+            }
+            if ((e >> 20) == tag2) c2 = (int)(e & 0xFFFFFu);
+            else p2 = (p2 + 1) & mask;
+            ++probes;
+        }
+        if (c1 < 0 && c2 < 0) break;
+        // the holders may have been written by other waves a moment ago (a node is published right after it is stored):
+        // agent-scope loads bypass this CU's vector L1, which other waves' stores do not refresh
+        const uint64_t* o1 = c.rec + (size_t)(c1 >= 0 ? c1 : 0) * c.RW;
+        const uint64_t* o2 = c.rec + (size_t)(c2 >= 0 ? c2 : 0) * c.RW;
+        uint64_t a[WS], b[WS];
+#pragma unroll
+        for (int k = 0; k < WS; ++k) a[k] = c1 >= 0 ? LD_U64(&o1[k]) : 0;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) b[k] = c2 >= 0 ? LD_U64(&o2[k]) : 0;
+        if (c1 >= 0) {
+            bool eq = true;
+#pragma unroll
+            for (int k = 0; k < WS; ++k) eq &= a[k] == s1[k];
+            if (eq) r1 = c1;
+            else p1 = (p1 + 1) & mask;
+        }
+        if (c2 >= 0) {
+            bool eq = true;
+#pragma unroll
+            for (int k = 0; k < WS; ++k) eq &= b[k] == s2[k];
+            if (eq) r2 = c2;
+            else p2 = (p2 + 1) & mask;
+        }
+    }
+    if (r1 == -1 || r2 == -1) {   // probe budget exhausted: the table is full (cannot happen: tab_limit)
+        c.sh->status = ST_ERR_INTERNAL;
+        if (r1 == -1) r1 = x1;
+        if (r2 == -1) r2 = x2;
+    }
+}
 
 /// OR / MAX over the lanes of a wave (every lane of the wave must call; lanes without a value pass 0)
 #if defined(DDO_HOST_EMULATION)
@@ -832,11 +911,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         } else {
             for (int k = 0; k < WS; ++k) root[k] = in.state[k];
         }
-        for (int k = 0; k < WS; ++k) {
-            c.pbr[k] = 0;
-            pop += dd_popc(root[k]);
-        }
-        st_node<WS>(c, 0, root);
+        for (int k = 0; k < WS; ++k) pop += dd_popc(root[k]);
+        st_node<WS>(c, 0, root, PID_NONE);
         KH_ST(c, 0, ((uint32_t)(in.value - vbase) << KEY_POP_BITS) | (uint32_t)pop, hash32_state<WS>(root));
     }
     PAR_END
@@ -850,11 +926,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         c.fresh[0] = 1u;
     }
     PAR_END
-
-    // every transition branches on a vertex of the root state, so a DD has at most popcount(root) layers: the best
-    // paths need that many bits, not n
-    const int root_pop = DD_UNIFORM((int)(K32(c, 0) & KEY_POP_MASK));
-    const int npw = root_pop == 0 ? 1 : ((root_pop + 63) / 64 < WS ? (root_pop + 63) / 64 : WS);
 
     int lel = -1;
     int snapL = -1;  // layer whose snapshot sits in the cut-set buffers
@@ -1107,7 +1178,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         const int bestv = (int)(uint32_t)sh->mergedKey;
                         if ((mkey >> KEY_POP_BITS) > (K32(c, r) >> KEY_POP_BITS)) {   // the best redirected arc wins
                             K32_ST(c, r, (mkey & ~KEY_POP_MASK) | (K32(c, r) & KEY_POP_MASK));
-                            copy_path<WS>(c, r, bestv, npw);
+                            pid_st<WS>(c, r, pid_ld<WS>(c, bestv));
                         }
                         bm_set(c.inex, r);
                         bm_clr(c.okb, r);       // F_RELAXED: best paths through r are not exact
@@ -1147,7 +1218,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                             c.st[(size_t)tid * capS + m] = w;
 #endif
                             c.rec[(size_t)m * c.RW + tid] = w;
-                            if (tid < npw) c.pbr[(size_t)m * c.PR + tid] = c.pbr[(size_t)bestv * c.PR + tid];
+                            if (tid == 0) pid_st<WS>(c, m, pid_ld<WS>(c, bestv));
                             uint64_t x = w;
                             while (x) {
                                 int b = dd_ctz(x);
@@ -1195,9 +1266,13 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 int i = LDS_ADD_I32(&sh->ncut, 1);
                 if (i >= c.capW) continue;
                 c.cs_slot[i] = (uint32_t)s;
-                for (int k = 0; k < WS; ++k) {
-                    c.cs_state[(size_t)k * c.capW + i] = ld_word<WS>(c, s, k);
-                    c.cs_path[(size_t)k * c.capW + i] = c.pbr[(size_t)s * c.PR + k];
+                {
+                    uint64_t ss[WS];
+                    uint32_t spid = PID_NONE;
+                    ld_state_p<WS>(c, s, ss, spid);
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) c.cs_state[(size_t)k * c.capW + i] = ss[k];
+                    c.cs_pid[i] = spid;
                 }
                 const uint32_t key = K32(c, s);
                 c.cs_value[i] = vbase + (int32_t)(key >> KEY_POP_BITS);
@@ -1405,7 +1480,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         const int32_t wv = c.weight[var];
 #if defined(DDO_HIP_PROBES)
         const bool probing = c.clocks && tid == 0;
-        uint64_t probe[5] = {0, 0, 0, 0, 0};
+        uint64_t probe[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t probe_t = probing ? dd_clock() : 0;
 #endif
         for (int i = tid; i < nwl; i += NT) {
@@ -1416,7 +1491,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
             const int pop = (int)(key & KEY_POP_MASK);
             uint64_t st[WS];
-            ld_state<WS>(c, s, st);
+            uint32_t ppid = PID_NONE;   // the parent's best path: it stays the NO-child's, the YES-child extends it
+            ld_state_p<WS>(c, s, st, ppid);
             DD2_PROBE(0)
             const int32_t rub = c.unit_weights ? pop : rub2_of<WS>(c, st);   // main.rs:191-193
             bm_clr(c.fresh, s);
@@ -1445,10 +1521,12 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     neww = st[k];
                 }
             const uint32_t newh = oldh ^ fold32(mixw(oldw, vw) ^ mixw(neww, vw));   // (the hash is XOR-linear in the per-word mixes)
-            st_word<WS>(c, s, vw, neww);
+            st_node<WS>(c, s, st, ppid);   // (one word changed: the whole line goes out, see st_node)
             const uint32_t kno = key - 1;  // popcount - 1, same value (cost 0)
             KH_ST(c, s, kno, newh);   // (cnt[var]: no state of the next layer contains the variable, it is zeroed with the layer)
             // ---- decision YES into a free slot (main.rs:95-102)
+            const int r = LDS_ADD_I32(&sh->nrec, 1);                       // this node's event record ...
+            const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;   // ... is also the path-tree node of its YES arc
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
             int ny = -1;
             uint64_t y[WS];
@@ -1464,11 +1542,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     y[k] = st[k] & adjv[k];
                     ypop += dd_popc(y[k]);
                 }
-                // a DD has at most popcount(root state) layers: only npw path words exist; the child's path is the
-                // parent's plus decision bit L
-                copy_path<WS>(c, ny, s, npw, L);
+                // the child's best path is the parent's plus decision 1 at layer L: path-tree node eid
+                c.pt[eid] = (uint64_t)ppid | ((uint64_t)(uint32_t)L << 32);
                 yh = hash32_state<WS>(y);
-                st_node<WS>(c, ny, y);
+                st_node<WS>(c, ny, y, eid);
                 kyes = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop;
                 KH_ST(c, ny, kyes, yh);
                 bm_put(c.inex, ny, bm_test(c.inex, s));
@@ -1478,23 +1555,25 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             }
             FENCE_BLOCK();   // both records are visible to the workgroup before the table publishes their slots
             DD2_PROBE(1)
-            // ---- dedup: NO-child (append_edge_to!, clean.rs:199-220)
+            // ---- dedup of both children (append_edge_to!, clean.rs:199-220)
             uint32_t e_no = (uint32_t)s, e_yes = NONE32;
-            const int t0 = tab2_insert<WS>(c, s, newh, st);
+            int t0, t1;
+            tab2_insert2<WS>(c, s, newh, st, ny, yh, y, t0, t1);
+            DD2_PROBE(2)
+            // twins: both keys' atomics are in flight together, their results are needed for the event record only
+            uint32_t old0 = 0, old1 = 0;
+            if (t0 != s) old0 = K32_MAX(c, t0, kno, newh);
+            if (ny >= 0 && t1 != ny) old1 = K32_MAX(c, t1, kyes, yh);
             if (t0 == s) {
                 bm_set(c.fresh, s);          // it stays in the layer; its rub shrank: check it again before it is expanded
             } else {                         // the in-place NO-child dissolves into its twin t0
-                const uint32_t old = K32_MAX(c, t0, kno, newh);
-                e_no = (uint32_t)t0 | (kno > old ? EV_RAISED : 0u);
                 if (bm_test(c.inex, s)) bm_set(c.inex, t0);
                 add_bits<WS>(c.cnt, st, -1);
                 bm_clr(c.live, s);
                 LDS_ADD_I32(&sh->nlive, -1);
             }
-            DD2_PROBE(2)
-            // ---- dedup: YES-child
+            DD2_PROBE(5)
             if (ny >= 0) {
-                const int t1 = tab2_insert<WS>(c, ny, yh, y);
                 if (t1 == ny) {              // a new node enters the layer
                     bm_set(c.live, ny);
                     bm_set(c.fresh, ny);
@@ -1503,21 +1582,20 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     LDS_MAX_I32(&sh->hiw, ny + 1);
                     e_yes = (uint32_t)ny | EV_CREATED;
                 } else {
-                    const uint32_t old = K32_MAX(c, t1, kyes, yh);
-                    e_yes = (uint32_t)t1 | (kyes > old ? EV_RAISED : 0u);
                     if (bm_test(c.inex, ny)) bm_set(c.inex, t1);
                 }
             }
-            DD2_PROBE(3)
-            const int r = LDS_ADD_I32(&sh->nrec, 1);
+            if (t0 != s) e_no = (uint32_t)t0 | (kno > old0 ? EV_RAISED : 0u);
+            if (ny >= 0 && t1 != ny) e_yes = (uint32_t)t1 | (kyes > old1 ? EV_RAISED : 0u);
+            DD2_PROBE(6)
             U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
             // parent | NO target | YES target | slot allocated for the YES-child
             *rec4 = U32x4{(uint32_t)s, e_no, e_yes, ny >= 0 ? (uint32_t)ny : NONE32};
             DD2_PROBE(4)
 #if defined(DDO_HIP_PROBES)
             if (probing && i == tid) {   // thread 0's first node went the whole way: charge its chain
-                for (int q = 0; q < 5; ++q) sh->mk[16 + q] += probe[q];
-                sh->mk[21] += 1;
+                for (int q = 0; q < 7; ++q) sh->mk[16 + q] += probe[q];
+                sh->mk[23] += 1;
             }
 #endif
         }
@@ -1546,7 +1624,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const int t = (int)(w & EV_SLOT_MASK);
                 const int x = which == 0 ? (int)rec[0] : (int)rec[3];
                 if (K32(c, t) == K32(c, x)) {
-                    copy_path<WS>(c, t, x, npw);
+                    // the NO arc carries the parent's path as it was when the record was written, the YES arc that plus its own node
+                    const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;
+                    pid_st<WS>(c, t, which == 0 ? (uint32_t)c.pt[eid] : eid);
                     bm_put(c.okb, t, bm_test(c.okb, x));
                 }
                 rec[1 + which] = w & ~EV_RAISED;
@@ -1605,7 +1685,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     if (K32(c, t) == K32(c, x) && bm_test(c.okb, x) && !bm_test(c.okb, t)) {
                         const uint32_t bit = 1u << (t & 31);
                         const uint32_t old = LDS_OR_U32(&c.okb[t >> 5], bit);
-                        if (!(old & bit)) copy_path<WS>(c, t, x, npw);
+                        if (!(old & bit)) {
+                            const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;
+                            pid_st<WS>(c, t, which == 0 ? (uint32_t)c.pt[eid] : eid);
+                        }
                     }
                 }
             }
@@ -1849,22 +1932,41 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     uint8_t* base = c.arena + sh->arena_off;
 
     if (arena_ok && !failed) {
+        // the two best paths as bit strings (LDS scratch: the merged-state words and the candidate list are free now)
+        LDS_PTR(uint64_t) bbits = (LDS_PTR(uint64_t))sh->merged;
+        LDS_PTR(uint64_t) xbits = (LDS_PTR(uint64_t))sh->xcand;   // 64 x int32 = 32 words >= WS
+        PAR_BEGIN
+        if (tid == 0 && best_len) {
+            uint64_t b[WS];
+#pragma unroll
+            for (int k = 0; k < WS; ++k) b[k] = 0;
+            path_bits<WS>(c, pid_ld<WS>(c, best_slot), b);
+#pragma unroll
+            for (int k = 0; k < WS; ++k) bbits[k] = b[k];
+        }
+        if (tid == 64 % NT && exact_len) {
+            uint64_t b[WS];
+#pragma unroll
+            for (int k = 0; k < WS; ++k) b[k] = 0;
+            path_bits<WS>(c, pid_ld<WS>(c, exact_slot), b);
+#pragma unroll
+            for (int k = 0; k < WS; ++k) xbits[k] = b[k];
+        }
+        PAR_END
         PAR_BEGIN
         // best paths (clean.rs:329-343): one decision per transition, terminal first
         if (best_len) {
             uint32_t* out = (uint32_t*)(base + path_off);
             for (int i = tid; i < best_len; i += NT) {
                 const int tr = path_len - 1 - i;
-                const uint64_t w = c.pbr[(size_t)best_slot * c.PR + (tr >> 6)];
-                out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
+                out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((bbits[tr >> 6] >> (tr & 63)) & 1ULL);
             }
         }
         if (exact_len) {
             uint32_t* out = (uint32_t*)(base + exact_off);
             for (int i = tid; i < exact_len; i += NT) {
                 const int tr = path_len - 1 - i;
-                const uint64_t w = c.pbr[(size_t)exact_slot * c.PR + (tr >> 6)];
-                out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
+                out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((xbits[tr >> 6] >> (tr & 63)) & 1ULL);
             }
         }
         if (want_cutset && ncut && pblock) {
@@ -1906,7 +2008,15 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const int idx = LDS_ADD_I32(&sh->ncut2, 1);
 #pragma unroll
                 for (int k = 0; k < WS; ++k) p_state[(size_t)k * ncut + idx] = s[k];
-                for (uint32_t k = 0; k < pw; ++k) p_path[(size_t)k * ncut + idx] = c.cs_path[(size_t)k * c.capW + i];
+                {   // the path of a node that stays in the cut-set is built now, from its chain in the path tree
+                    uint64_t pb[WS];
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) pb[k] = 0;
+                    path_bits<WS>(c, c.cs_pid[i], pb);
+#pragma unroll
+                    for (int k = 0; k < WS; ++k)
+                        if ((uint32_t)k < pw) p_path[(size_t)k * ncut + idx] = pb[k];
+                }
                 p_value[idx] = (int32_t)v;
                 p_ub[idx] = (int32_t)ub;
                 o_value[idx] = (int32_t)v;
@@ -1933,9 +2043,16 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 for (int k = 0; k < WS; ++k) o_state[(size_t)idx * WS + k] = s[k];
                 o_value[idx] = (int32_t)v;
                 o_ub[idx] = (int32_t)ub;
+                uint64_t pb[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) pb[k] = 0;
+                path_bits<WS>(c, c.cs_pid[i], pb);
                 for (int j = 0; j < cs_path_len; ++j) {
                     const int tr = cs_path_len - 1 - j;
-                    const uint64_t w = c.cs_path[(size_t)(tr >> 6) * c.capW + i];
+                    uint64_t w = 0;
+#pragma unroll
+                    for (int k = 0; k < WS; ++k)
+                        if (k == (tr >> 6)) w = pb[k];
                     o_path[(size_t)idx * cs_path_len + j] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((w >> (tr & 63)) & 1ULL);
                 }
             }
@@ -2055,12 +2172,11 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.nbw = (P.capS + 31) / 32;
     const size_t capS = (size_t)P.capS, capW = (size_t)P.capW, ml = (size_t)P.max_layers, s = (size_t)slot;
     c.RW = ((WS + 1 + 7) / 8) * 8;
-    c.PR = ((WS + 7) / 8) * 8;
 #if defined(DDO_WORD_MAJOR)
     c.st = P.s_state + s * (size_t)WS * capS;
 #endif
     c.rec = P.s_rec + s * capS * (size_t)c.RW;
-    c.pbr = P.s_path + s * capS * (size_t)c.PR;
+    c.pt = P.s_ptree + s * (P.ev_cap / 4);
     c.tab_cap = P.tab2_cap;
     c.ev = P.s_ev + s * P.ev_cap;
     c.ev_cap = P.ev_cap;
@@ -2070,7 +2186,7 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.lmerge = P.nlayer + s * ml;          // the per-layer node counts of engine 1 are not needed here
     c.cs_slot = P.s_cs_slot + s * capW;
     c.cs_state = P.cs_state + s * (size_t)WS * (size_t)P.capN;   // capN >= capW words per row are reserved
-    c.cs_path = P.s_cs_path + s * (size_t)WS * capW;
+    c.cs_pid = (uint32_t*)(P.s_cs_path + s * (size_t)WS * capW);
     c.cs_value = P.cs_value + s * (size_t)P.capN;
     c.cs_pop = P.cs_pop + s * (size_t)P.capN;
     unsigned char* p = lds;

@@ -201,13 +201,13 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
     {
         const size_t capS = P.capS, capW = P.capW, mlz = P.max_layers;
         const size_t RW = ((wsT + 1 + 7) / 8) * 8, PR = ((wsT + 7) / 8) * 8;
-        size_t b2 = wsT * capS * 8 + capS * (RW + PR + 1) * 8 + capW * 4 + P.ev_cap * 4 + mlz * 8 * 4 + capW * 4 +
+        size_t b2 = wsT * capS * 8 + capS * (RW + PR + 1) * 8 + capW * 4 + P.ev_cap * 4 + P.ev_cap * 2 + 64 + mlz * 8 * 4 + capW * 4 +
                     wsT * capW * 8 + 64 * 16;
         e->mem2.assign(b2, 0xCD);
         unsigned char* q = e->mem2.data();
         P.s_state = carve<uint64_t>(q, wsT * capS);
         P.s_rec = carve<uint64_t>(q, capS * RW);
-        P.s_path = carve<uint64_t>(q, capS * PR);
+        P.s_ptree = carve<uint64_t>(q, P.ev_cap / 4 + 1);
         P.s_hash = carve<uint64_t>(q, capS);
         P.s_wl = carve<uint16_t>(q, 2 * capW);
         P.s_ev = carve<uint32_t>(q, P.ev_cap);
