@@ -258,7 +258,18 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     P.phase_clocks = std::getenv("DDO_HIP_STATS") ? 1 : 0;
     P.lex_cap = 1024;
     if (const char* env = std::getenv("DDO_HIP_LEX_CAP")) P.lex_cap = std::max(1, std::min(1024, std::atoi(env)));   // tests: force the radix path
-    P.lex_cap = std::max(1, std::min(P.lex_cap, P.hist_bins / 2));   // the tie-break keys (8 bytes each) share the histogram area
+    if (!dense_) P.lex_cap = std::max(1, std::min(P.lex_cap, P.hist_bins / 2));   // the tie-break keys (8 bytes each) share the histogram area
+    if (dense_) {
+        // A dense-tier DD whose layer would hold more than 7/8 of the table's entries is handed up, so no layer ever needs more
+        // node slots than that: fewer slots = smaller LDS bitmaps, and the room goes to the tie-break keys -- ties of a few
+        // hundred nodes are the rule at width 10 000, and ranking them out of LDS costs a fraction of the radix rounds through
+        // HBM scratch (round 3: 95 of the 320 kcycles a squashed layer spends on its squash).
+        P.capS = std::min(P.capS, (int)((long)P.tab2_cap * 7 / 8) + 16);
+        const char* lenv = std::getenv("DDO_HIP_LEX_CAP");
+        int lc = lenv ? P.lex_cap : 1024;
+        while (lc > 128 && dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, false, P.hist_bins, lc, model->wsT) > lds_max / 2) lc -= 32;
+        P.lex_cap = std::max(1, std::min(lc, lenv ? P.lex_cap : 1024));
+    }
     P.ev_cap = ((uint64_t)P.max_layers * (uint64_t)(5 * P.capW + 16) + 2ull * P.capW + 64 + 3) & ~3ull;   // 16-byte event records stay aligned per slot
     engine_kind_ = 2;
     if (const char* env = std::getenv("DDO_HIP_ENGINE")) engine_kind_ = std::atoi(env) == 1 ? 1 : 2;

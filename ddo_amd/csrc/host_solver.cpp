@@ -489,6 +489,9 @@ struct ddo_solver {
                          (double)st_clk[8] / tl, (double)st_clk[9] / tl, (double)st_clk[10] / tl, (double)st_clk[11] / tl, (double)st_clk[16] / tl,
                          (double)st_clk[12] / tl, (double)st_clk[15] / tl, (double)st_clk[13] / tl, (double)st_clk[14] / tl, (double)st_clk[17] / tl);
             for (int q = 18; q < 24; ++q) std::fprintf(stderr, " aux%d %.2f", q - 8, st_clk[q] / 1e3 / std::max<uint64_t>(1, tl));
+            if (!st_clk[31] && (st_clk[24] | st_clk[25]))   // (without PROBES the slots carry finer ticks of the tie-break)
+                std::fprintf(stderr, " | classify sweep %.2f tie-break: gather %.2f pivot %.2f partition %.2f kcycles/layer", st_clk[24] / 1e3 / std::max<uint64_t>(1, tl),
+                             st_clk[25] / 1e3 / std::max<uint64_t>(1, tl), st_clk[26] / 1e3 / std::max<uint64_t>(1, tl), st_clk[27] / 1e3 / std::max<uint64_t>(1, tl));
             if (st_clk[31]) {   // thread 0's own node in expand (make PROBES=1): the dependent chain, cycles per probed node
                 const double np = (double)st_clk[31];
                 std::fprintf(stderr, " | expand chain per node (thread 0, %.0f probes): loads %.0f, children + stores + fence %.0f, table insert NO %.0f + its bookkeeping %.0f, table insert YES %.0f + its bookkeeping %.0f, record %.0f",

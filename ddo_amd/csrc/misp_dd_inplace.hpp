@@ -713,6 +713,7 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
         const uint64_t land = sh->land;
         const uint64_t ldiff = land ^ sh->lor;
         DD_SYNC();   // every thread has its copy before thread 0 resets land/lor for the next word
+        DD2_TICK2(PH_SELLEX, 17)
         if (ldiff == 0) continue;   // every tied node has the same word: nothing to decide here
         uint64_t pivw = 0;
         bool all_ge_kept = false;   // radix path only: the whole digit bucket stays, pivw's low bytes are unresolved (zero)
@@ -804,6 +805,7 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
             pivw = prefix;
             all_ge_kept = rdone;
         }
+        DD2_TICK2(PH_SELLEX, 18)
         // ---- partition: larger words stay, smaller ones are victims, equal ones remain tied
         PAR_BEGIN
         if (tid == 0) {
@@ -829,6 +831,7 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
         need -= sh->nrec;
         m = sh->nnew;
         DD_SYNC();
+        DD2_TICK2(PH_SELLEX, 19)
         uint16_t* t = cur;
         cur = nxt;
         nxt = t;
@@ -1035,6 +1038,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
             PAR_END
+            DD2_TICK2(PH_SELLEX, 16)
             if (K > 0 && tie_need >= 0) {
                 const int m = DD_UNIFORM(sh->nfl);
                 DD2_STAT(0, m)
@@ -2145,6 +2149,12 @@ DD_HD inline int dd2_tcount_len(int nthreads, int lex_cap) {
     return m < 64 ? 64 : m;
 }
 
+/// LDS bytes of the area the select histogram and the tie-break keys (8 bytes each) share
+DD_HD inline size_t dd2_hist_bytes(int hist_bins, int lex_cap) {
+    const size_t h = (size_t)(hist_bins > 0 ? hist_bins : 2048) * 4, l = (size_t)(lex_cap > 0 ? lex_cap : 0) * 8;
+    return ((h > l ? h : l) + 15) & ~(size_t)15;
+}
+
 inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool keys_in_lds = true, int hist_bins = 2048, int lex_cap = 1024, int ws = MAX_WS) {
     const size_t nbw = ((size_t)capS + 31) / 32;
     size_t b = keys_in_lds ? (size_t)capS * 4 : 0;   // key32 / value_bot
@@ -2153,7 +2163,7 @@ inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool 
     b += 4 * nbw * 4;                      // live, inex, okb, fresh
     b = (b + 15) & ~(size_t)15;
     b += (size_t)npad * 4;                 // cnt
-    b += (size_t)(hist_bins > 0 ? hist_bins : 2048) * 4;   // hist (squash phases only)
+    b += dd2_hist_bytes(hist_bins, lex_cap);               // hist / tie-break keys (squash phases only)
     b += (size_t)dd2_tcount_len(nthreads, lex_cap) * 4 * 2;   // rank-counting scratch
     b += dd2_shared_bytes(ws);
     return (b + 15) & ~(size_t)15;
@@ -2214,10 +2224,10 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.cnt = (LDS_PTR(int32_t))p;
     p += (size_t)P.npad * 4;
     c.hist = (LDS_PTR(uint32_t))p;
-    p += (size_t)(P.hist_bins > 0 ? P.hist_bins : 2048) * 4;
+    c.lex_cap = P.lex_cap > 0 && P.lex_cap <= 1024 ? P.lex_cap : 1024;
+    p += dd2_hist_bytes(P.hist_bins, c.lex_cap);
     c.wl = P.s_wl + s * 2 * capW;          // work lists live in HBM (written and read once per layer, coalesced)
     c.fl = c.wl + capW;
-    c.lex_cap = P.lex_cap > 0 && P.lex_cap <= 1024 ? P.lex_cap : 1024;
     c.tcount = (LDS_PTR(int32_t))p;
     p += (size_t)dd2_tcount_len(nthreads, c.lex_cap) * 4;
     c.tcount2 = (LDS_PTR(int32_t))p;
