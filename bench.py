@@ -64,6 +64,19 @@ def physical_cores():
     return (len(cores) or (os.cpu_count() or 1)), (os.cpu_count() or 1)
 
 
+def kernel_source_fingerprint():
+    """sha256 (16 hex digits) over the device / host sources the product library is built from: ties a rocprof summary to the
+    build it was collected on (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ddo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hpp", ".h", ".hip", ".cpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(instance, width, total_seconds, threads_arg):
     """The CPU oracle (C++ restatement of ddo, kind = "port") on the same instance / width, built -O3 -march=native for
     the host this runs on, swept over thread counts inside a bounded time budget; the best configuration is reported."""
@@ -294,16 +307,27 @@ def main():
         # HBM traffic: PMC counters cannot be read from inside this process; the committed rocprofv3 passes of this very
         # command and workload (tools/profile_round.sh -> profiles/<round>/pmc_summary.json; the workload is frozen, so
         # the profiled launches ARE these launches) give bytes per expanded node, scaled by the nodes of one launch.
-        traffic, traffic_src = None, None
+        # The summary is stamped with a fingerprint of the kernel sources and the dominant kernel's name: counters of another
+        # build, or of another kernel, say nothing about this run -- traffic is then null, with the reason.
+        traffic, traffic_src = None, "no profiles/<round>/pmc_summary.json"
         pdir = os.path.join(ROOT, "profiles")
         for rnd in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
             pj = os.path.join(pdir, rnd, "pmc_summary.json")
             if os.path.exists(pj):
                 try:
-                    tj = json.load(open(pj)).get("traffic")
+                    sj = json.load(open(pj))
+                    tj = sj.get("traffic")
                     if tj and tj.get("hbm_bytes_per_node"):
-                        traffic = tj["hbm_bytes_per_node"] * dom_nodes / launches
-                        traffic_src = f"profiles/{rnd}/pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per node, same frozen workload) x nodes per launch"
+                        stamp = sj.get("stamp") or {}
+                        if stamp.get("kernel_sources") != kernel_source_fingerprint():
+                            traffic_src = (f"null: profiles/{rnd}/pmc_summary.json was collected on kernel sources {stamp.get('kernel_sources')}, "
+                                           f"this build is {kernel_source_fingerprint()} (re-run tools/profile_round.sh)")
+                        elif stamp.get("kernel") != dom_name:
+                            traffic_src = f"null: profiles/{rnd}/pmc_summary.json describes {stamp.get('kernel')}, the dominant kernel here is {dom_name}"
+                        else:
+                            traffic = tj["hbm_bytes_per_node"] * dom_nodes / launches
+                            traffic_src = (f"profiles/{rnd}/pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per node, same frozen workload, kernel sources "
+                                           f"{stamp.get('kernel_sources')}, git {stamp.get('git')}) x nodes per launch")
                         break
                 except (ValueError, OSError):
                     pass
@@ -333,7 +357,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "kernel": dom_name, "kernel_ms_avg": 1e3 * kernel_s / launches, "launches": launches,
+                "kernel": dom_name, "kernel_sources": kernel_source_fingerprint(), "kernel_ms_avg": 1e3 * kernel_s / launches, "launches": launches,
                 "bytes_per_node": bytes_per_node, "children_per_node": c_mean, "nodes_per_launch": dom_nodes / launches,
                 "kernel_nodes_per_s": dom_nodes / max(kernel_s, 1e-12),
                 "all_kernels": {"kernel_ms": k1 - k0, "nodes_expanded": my_nodes, "GBps": my_nodes * bytes_per_node / max((k1 - k0) / 1e3, 1e-12) / 1e9},
@@ -366,6 +390,9 @@ def main():
         tp, (p_nodes, p_arcs, p_subs, p_kms, p_sent) = reduce_stats(
             dist, tp, [pc["nodes_expanded"], pc["arcs"], prover.explored(), pk_ms, search.nodes_sent], comm_device)
         proof = (proved, best, tp, p_nodes, p_arcs, p_subs, p_kms, p_sent, pl, prover.best_upper_bound())
+        proof_tiers = [{"layer_capacity": t["layer_capacity"], "threads": t["threads"], "dense": bool(t["dense"]), "slots": t["slots"],
+                        "kernel_s": t["kernel_ms"] / 1e3, "launches": t["launches"], "subproblems": t["subproblems"], "handed_up": t["retried"],
+                        "nodes_expanded": t["nodes_expanded"]} for t in prover.tier_stats()]
     if rank == 0:
         if proof is not None:
             proved, best, tp, p_nodes, p_arcs, p_subs, p_kms, p_sent, pl, p_ub = proof
@@ -379,7 +406,8 @@ def main():
                             "nodes_per_s": p_nodes / max(tp, 1e-9), "subproblems_handed_over": int(p_sent),
                             "roofline": {"bound": "hbm", "achieved": p_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "frac": p_ach / HBM_PEAK_GBS,
                                          "kernel_s_sum_over_gpus": p_kms / 1e3, "launches_rank0": pl, "bytes_per_node": p_bpn,
-                                         "note": "every compile launch of the whole search, all capacity tiers (their kernel time, HIP events)"}}
+                                         "note": "every compile launch of the whole search, all capacity tiers (their kernel time, HIP events)"},
+                            "tiers_rank0": proof_tiers}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1478,10 +1478,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // unchanged node of the next layer now, so a thread writes its two children, makes the stores visible to the
         // workgroup and inserts them right away -- the records never have to be read back.
         PAR_BEGIN
-        uint64_t adjv[WS];
+        uint64_t adjv[WS];   // (workgroup-uniform: kept in scalar registers)
 #pragma unroll
-        for (int k = 0; k < WS; ++k) adjv[k] = c.adj[(size_t)var * WS + k];
-        const int32_t wv = c.weight[var];
+        for (int k = 0; k < WS; ++k) adjv[k] = DD_UNIFORM64(c.adj[(size_t)var * WS + k]);
+        const int32_t wv = DD_UNIFORM(c.weight[var]);
 #if defined(DDO_HIP_PROBES)
         const bool probing = c.clocks && tid == 0;
         uint64_t probe[7] = {0, 0, 0, 0, 0, 0, 0};

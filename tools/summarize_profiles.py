@@ -44,6 +44,16 @@ def counters(sub):
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 steps, warm = bench["steps"], bench["warmup"]
 summary = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "steps", "warmup")}, "roofline": bench["roofline"]}
+# what these counters describe: bench.py refuses to quote them for another build or another dominant kernel
+try:
+    import subprocess
+    git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    dirty = subprocess.run(["git", "status", "--porcelain", "ddo_amd/csrc"], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip()
+    git = git + ("+uncommitted" if dirty else "")
+except OSError:
+    git = None
+summary["stamp"] = {"kernel_sources": bench["roofline"].get("kernel_sources"), "kernel": bench["roofline"].get("kernel"), "git": git,
+                    "command": "python bench.py (tools/profile_round.sh: kernel trace + one rocprofv3 --pmc pass per counter group)"}
 
 for name in ("kernel_stats.csv", "kernel_trace.csv"):
     p = find("trace", name)
