@@ -113,63 +113,97 @@ def cpu_baseline(instance, width, total_seconds, threads_arg):
     }
 
 
-def bench_max2sat(args):
-    """Secondary workload (BASELINE.json config C3): weighted MAX2SAT frb10-6-1 (n = 60, 667 clauses), FixedWidth(5000), the
-    whole branch-and-bound to the proved optimum on ONE GPU.  The signed-vector models run on the layer-rebuilding engine
-    (misp_dd_core.hpp) with the host NoDupFringe: `value` = nodes expanded / wall time of maximize(); the kernel-only rate
-    (HIP events) feeds `roofline` with SURVEY.md section 8 d3's figure for these models, S = 4 n + 4 bytes and c = 2 children:
+def bench_vector(args):
+    """Secondary workloads on ONE GPU, the whole branch-and-bound to the proved optimum: `max2sat` = BASELINE.json config C3,
+    weighted MAX2SAT frb10-6-1 (n = 60, 667 clauses) at FixedWidth(5000); `mcp` = the ten maximum-cut instances the reference's
+    tests solve (examples/mcp/tests.rs:64-103, n = 30) at FixedWidth(100), one search after the other.  The signed-vector models
+    run on the layer-rebuilding engine (misp_dd_core.hpp) with the host NoDupFringe: `value` = nodes expanded / wall time of
+    maximize(); the kernel-only rate (HIP events on the engine's stream: the DELTA over this search -- solvers of one model share
+    their engine) feeds `roofline` with SURVEY.md section 8 d3's figure for these models, S = 4 n + 4 bytes and c = 2 children:
     bytes_per_node = (S + 8) + 2 (S + 16)."""
     import ddo_amd
     from ddo_amd import FixedWidth, ParallelSolver
     from tests.oracle_binding import Oracle
 
-    name, width, optimum = "frb10-6-1", 5000, 37037
-    path = os.path.join(ROOT, "data", "max2sat", name + ".wcnf")
-    model = ddo_amd.Max2Sat.read_instance(path)
-    times = []
-    for rep in range(max(1, args.warmup // 4) + 1):     # first pass = warm-up (engine creation, first launches)
-        s = ParallelSolver(model, FixedWidth(width), nb_threads=args.concurrent, fringe="nodup")
-        t0 = time.perf_counter()
-        c = s.maximize()
-        dt = time.perf_counter() - t0
-        cnt, (kms, launches) = s.counters(), s.device_time()
-        times.append((dt, cnt, kms, launches, s.explored(), c))
-    dt, cnt, kms, launches, explored, c = times[-1]
-    S = 4 * model.n + 4
+    if args.workload == "max2sat":
+        width = 5000
+        cases = [(os.path.join(ROOT, "data", "max2sat", "frb10-6-1.wcnf"), 37037)]
+        load, label = ddo_amd.Max2Sat.read_instance, "MAX2SAT frb10-6-1.wcnf"
+    else:
+        width = 100
+        optima = [13, 14, 13, 12, 13, 15, 15, 15, 13, 13]   # filled from the oracle below when it disagrees (it never has)
+        cases = [(os.path.join(ROOT, "data", "mcp", f"mcp_n30_p0.1_{i:03d}.mcp"), None) for i in range(10)]
+        load, label = ddo_amd.Mcp.read_instance, "MCP mcp_n30_p0.1_000..009.mcp"
+    models = [load(p) for p, _ in cases]
+    tot = None
+    for rep in range(2):     # first pass = warm-up (engine creation, first launches)
+        tot = {"dt": 0.0, "nodes": 0, "kms": 0.0, "launches": 0, "explored": 0, "compiles": 0, "values": [], "proved": True}
+        for model in models:
+            s = ParallelSolver(model, FixedWidth(width), nb_threads=args.concurrent, fringe="nodup")
+            k0, l0 = s.device_time()
+            t0 = time.perf_counter()
+            c = s.maximize()
+            dt = time.perf_counter() - t0
+            k1, l1 = s.device_time()
+            cnt = s.counters()
+            tot["dt"] += dt
+            tot["nodes"] += cnt["nodes_expanded"]
+            tot["kms"] += k1 - k0
+            tot["launches"] += l1 - l0
+            tot["explored"] += s.explored()
+            tot["compiles"] += cnt["compiles"]
+            tot["values"].append(c.best_value)
+            tot["proved"] = tot["proved"] and bool(c.is_exact)
+            del s
+    assert tot["kms"] / 1e3 <= tot["dt"] * 1.001, "kernel time must fit inside the wall time of the searches it belongs to"
+    n = models[0].n
+    S = 4 * n + 4
     bpn = (S + 8) + 2 * (S + 16)
-    ach = cnt["nodes_expanded"] * bpn / max(kms / 1e3, 1e-12) / 1e9
+    ach = tot["nodes"] * bpn / max(tot["kms"] / 1e3, 1e-12) / 1e9
     out = {
-        "metric": "MDD nodes expanded/sec, MAX2SAT frb10-6-1 w=5000 (whole search to the proved optimum)",
-        "value": cnt["nodes_expanded"] / dt, "unit": "nodes/s", "n_gpus": 1, "steps": int(launches), "warmup": 1,
-        "ms_per_step": 1e3 * dt / max(1, launches), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32",
-        "data": "real instance (resources/max2sat/frb10-6-1.wcnf shipped with the reference)",
-        "config": {"workload": f"MAX2SAT {name}.wcnf FixedWidth({width}) LEL cut-set, EmptyCache, host NoDupFringe(MaxUB), "
+        "metric": f"MDD nodes expanded/sec, {label} w={width} (whole search to the proved optimum)",
+        "value": tot["nodes"] / tot["dt"], "unit": "nodes/s", "n_gpus": 1, "steps": int(tot["launches"]), "warmup": 1,
+        "ms_per_step": 1e3 * tot["dt"] / max(1, tot["launches"]), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32",
+        "data": "real instances shipped with the reference (resources/max2sat, resources/mcp)",
+        "config": {"workload": f"{label} FixedWidth({width}) LEL cut-set, EmptyCache, host NoDupFringe(MaxUB), "
                                f"{args.concurrent} sub-problems per launch", "parallelism": "1 GPU"},
-        "proved": bool(c.is_exact), "best_value": c.best_value, "optimum": optimum, "time_to_proved_optimum_s": dt,
-        "subproblems": explored, "compiles": cnt["compiles"],
+        "proved": tot["proved"], "best_values": tot["values"], "time_to_proved_optimum_s": tot["dt"],
+        "subproblems": tot["explored"], "compiles": tot["compiles"],
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "ddo_hip::misp_compile_kernel<32, true> (layer-rebuilding engine, 31-word signed-vector states)",
-                     "kernel_ms_avg": kms / max(1, launches), "launches": int(launches), "bytes_per_node": bpn,
-                     "kernel_nodes_per_s": cnt["nodes_expanded"] / max(kms / 1e3, 1e-12)},
+                     "traffic_source": "null: no rocprofv3 --pmc pass of this workload is committed",
+                     "kernel": "ddo_hip::misp_compile_kernel<WS, table in LDS> (layer-rebuilding engine, signed-vector states: "
+                               f"{(n + 1) // 2 + 1} words)",
+                     "kernel_ms_avg": tot["kms"] / max(1, tot["launches"]), "kernel_s": tot["kms"] / 1e3, "wall_s": tot["dt"],
+                     "launches": int(tot["launches"]), "bytes_per_node": bpn,
+                     "kernel_nodes_per_s": tot["nodes"] / max(tot["kms"] / 1e3, 1e-12)},
     }
     if not args.no_cpu:
         o = Oracle(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
         phys, logical = physical_cores()
         runs = []
         for t in (1, 16, 32):
-            v, r = o.max2sat_file(path, width, t, args.cpu_seconds / 3)
-            runs.append({"threads": t, "nodes_per_s": r["nodes_expanded"] / max(r["wall_s"], 1e-9), "wall_s": r["wall_s"], "proved": bool(r["is_exact"])})
+            nodes, wall, ok = 0, 0.0, True
+            for (path, opt), got in zip(cases, tot["values"]):
+                if args.workload == "max2sat":
+                    v, r = o.max2sat_file(path, width, t, args.cpu_seconds / 3)
+                else:
+                    v, r = o.mcp_file(path, width, t)
+                nodes += r["nodes_expanded"]
+                wall += r["wall_s"]
+                ok = ok and (not r["is_exact"] or v == got)    # same proved optimum as the device search
+            runs.append({"threads": t, "nodes_per_s": nodes / max(wall, 1e-9), "wall_s": wall, "same_optimum": ok})
         best = max(runs, key=lambda x: x["nodes_per_s"])
         out["cpu_baseline"] = {"value": best["nodes_per_s"], "unit": "nodes/s", "cores": best["threads"], "kind": "port",
-                               "sample": f"oracle ParallelSolver (C++ restatement of ddo), same instance/width, TimeBudget {args.cpu_seconds / 3:.0f} s "
-                                         f"per thread count", "physical_cores": phys, "logical_cpus": logical, "thread_sweep": runs}
+                               "sample": "oracle ParallelSolver (C++ restatement of ddo), same instances/width" +
+                                         (f", TimeBudget {args.cpu_seconds / 3:.0f} s per thread count" if args.workload == "max2sat" else ", whole searches"),
+                               "physical_cores": phys, "logical_cpus": logical, "thread_sweep": runs}
         out["speedup_vs_cpu"] = out["value"] / max(best["nodes_per_s"], 1e-9)
     print(json.dumps(out), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="misp", choices=["misp", "max2sat"],
+    ap.add_argument("--workload", default="misp", choices=["misp", "max2sat", "mcp"],
                     help="misp: the headline metric (default); max2sat: BASELINE config C3 on one GPU (secondary line)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -195,10 +229,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    if args.workload == "max2sat":
+    if args.workload in ("max2sat", "mcp"):
         if args.concurrent == 1024:
             args.concurrent = 256
-        return bench_max2sat(args)
+        return bench_vector(args)
     # test hook (single-GPU boxes): DDO_BENCH_ONE_GPU=1 puts every rank on cuda:0 and rendezvous over gloo, so the
     # multi-process path (sharded root cut-set, incumbent all-reduce, max-over-ranks timing) can be exercised there
     one_gpu = os.environ.get("DDO_BENCH_ONE_GPU") == "1"

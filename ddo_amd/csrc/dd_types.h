@@ -105,11 +105,12 @@ struct DDResult {
     uint64_t arcs;
     uint64_t layers;
     uint64_t path_off, exact_off, cs_state_off, cs_value_off, cs_ub_off, cs_path_off;  // byte offsets from arena_off
-    uint64_t phase_clk[32];        // shader-clock ticks per phase [0..8), per code mark [8..24), thread-0 probes inside expand [24..32) (profiling aid; engine 2)
     uint64_t pool_off;             // IN_POOL_OUT: byte offset of the cut-set block in the node pool
     uint64_t cs_depth_off;         // frontier cut-set: n_cutset x i32, layer of every node below the DD's root (0: all at `lel`)
     int32_t cs_path_stride;        // u32 words per row of the cut-set paths (lel, or n_layers - 1 for a frontier cut-set)
     uint32_t cache_hits;           // nodes removed by _filter_with_cache
+    // LAST: only downloaded when DDO_HIP_STATS asks for the clocks (the records of a launch cross PCIe: 176 instead of 432 bytes)
+    uint64_t phase_clk[32];        // shader-clock ticks per phase [0..8), per code mark [8..24), thread-0 probes inside expand [24..32) (profiling aid; engine 2)
 };
 
 /// Kernel arguments: model tables, capacities, per-slot workspace and batch I/O.

@@ -879,6 +879,12 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     HIP_TRY(hipSetDevice(device_));
     hipStream_t st = (hipStream_t)stream_;
     IoSet& io = io_[next_set_];
+    const bool staged = inputs == nullptr;
+    if (staged && (count > io.in_cap || !io.h_inputs)) {
+        set_error("Engine::launch: no staged inputs (stage_inputs(count) first)");
+        return DDO_ERR_INVALID;
+    }
+    if (staged) inputs = io.h_inputs;   // filled in place (no growth below: count <= in_cap)
     if (count > io.in_cap) {
         if (io.d_inputs) HIP_TRY(hipFree(io.d_inputs));
         if (io.d_results) HIP_TRY(hipFree(io.d_results));
@@ -911,7 +917,7 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         io.h_arena = (uint8_t*)hp;
         io.h_arena_cap = arena_cap_;
     }
-    std::memcpy(io.h_inputs, inputs, (size_t)count * sizeof(DDInput));
+    if (!staged) std::memcpy(io.h_inputs, inputs, (size_t)count * sizeof(DDInput));
     HIP_TRY(hipMemcpyAsync(io.d_inputs, io.h_inputs, (size_t)count * sizeof(DDInput), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(io.d_cnt, 0, 16, st));  // work counter + arena head of this buffer set
     EngineParams P = P_;
@@ -968,7 +974,11 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)ev1_, st));
-    HIP_TRY(hipMemcpyAsync(io.h_results, io.d_results, (size_t)count * 2 * sizeof(DDResult), hipMemcpyDeviceToHost, st));
+    if (P_.phase_clocks)
+        HIP_TRY(hipMemcpyAsync(io.h_results, io.d_results, (size_t)count * 2 * sizeof(DDResult), hipMemcpyDeviceToHost, st));
+    else   // every record without its clocks
+        HIP_TRY(hipMemcpy2DAsync(io.h_results, sizeof(DDResult), io.d_results, sizeof(DDResult), offsetof(DDResult, phase_clk), (size_t)count * 2,
+                                 hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(io.h_head, io.d_cnt + 8, 8, hipMemcpyDeviceToHost, st));
     io.count = count;
     pending_ = count;
@@ -977,11 +987,48 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     return DDO_OK;
 }
 
+DDInput* Engine::stage_inputs(int count) {
+    std::lock_guard<std::mutex> g(mtx_);
+    if (pending_ > 0 || count <= 0 || fetch_set_ == next_set_) return nullptr;
+    if (hipSetDevice(device_) != hipSuccess) return nullptr;
+    IoSet& io = io_[next_set_];
+    if (count > io.in_cap) {
+        if (io.d_inputs) (void)hipFree(io.d_inputs);
+        if (io.d_results) (void)hipFree(io.d_results);
+        if (io.h_results) (void)hipHostFree(io.h_results);
+        io.d_inputs = io.d_results = nullptr;
+        io.h_results = nullptr;
+        io.in_cap = 0;
+        const int cap = std::max(count + count / 4, 256);
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, (size_t)cap * 2 * sizeof(DDResult) + 64 + (size_t)cap * sizeof(DDInput), hipHostMallocDefault) != hipSuccess) return nullptr;
+        io.h_results = (DDResult*)hp;
+        io.h_head = (unsigned long long*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult));
+        io.h_inputs = (DDInput*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult) + 64);
+        if (hipMalloc(&io.d_inputs, (size_t)cap * sizeof(DDInput)) != hipSuccess || hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)) != hipSuccess) return nullptr;
+        io.in_cap = cap;
+    }
+    return io.h_inputs;
+}
+
 int Engine::wait() {
     std::lock_guard<std::mutex> g(mtx_);
     if (pending_ <= 0) return DDO_OK;
     HIP_TRY(hipSetDevice(device_));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    // Polling instead of hipStreamSynchronize: the blocking wait wakes up milliseconds after the stream has drained (kernel
+    // trace of the live search, round 3: 11 ms of idle device after every launch of a step), and the search synchronises three
+    // times per step.  DDO_HIP_SYNC=block restores the blocking wait.
+    static const bool block = [] { const char* e = std::getenv("DDO_HIP_SYNC"); return e && std::string(e) == "block"; }();
+    if (block) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    } else {
+        hipError_t q;
+        while ((q = hipStreamQuery((hipStream_t)stream_)) == hipErrorNotReady) std::this_thread::yield();
+        if (q != hipSuccess) {
+            set_error(std::string("hipStreamQuery: ") + hipGetErrorString(q));
+            return DDO_ERR_NO_DEVICE;
+        }
+    }
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
     last_kernel_ms_ = ms;
@@ -1041,6 +1088,31 @@ int Engine::fetch(std::vector<HostResult>& results) {
     if (pool_owner()->vm_base_) {   // this batch is accounted for exactly now
         Engine* po = pool_owner();
         const size_t worst = (size_t)count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
+        po->pool_unfetched_worst_ = po->pool_unfetched_worst_ > worst ? po->pool_unfetched_worst_ - worst : 0;
+    }
+    return DDO_OK;
+}
+
+int Engine::fetch_raw(RawBatch& out) {
+    std::lock_guard<std::mutex> g(mtx_);
+    out = RawBatch();
+    if (fetch_set_ < 0) return DDO_OK;
+    IoSet& io = io_[fetch_set_];
+    fetch_set_ = -1;
+    out.hdr = io.h_results;
+    out.arena = io.h_arena;
+    out.count = io.count;
+    out.arena_used = (size_t)std::min<unsigned long long>(*io.h_head, arena_cap_);
+    Engine* po = pool_owner();
+    uint64_t bound = po->pool_head_bound_;
+    for (int i = 0; i < 2 * io.count; ++i) {
+        const DDResult& r = io.h_results[i];
+        if (r.status == ST_OK && r.n_cutset > 0 && r.pool_off != NO_POOL_SRC)
+            bound = std::max<uint64_t>(bound, r.pool_off + pool_block_bytes((uint32_t)r.n_cutset, (uint32_t)model_->wsT, (uint32_t)(r.lel > 0 ? r.lel : 0)));
+    }
+    po->pool_head_bound_ = bound;
+    if (po->vm_base_) {   // this batch is accounted for exactly now
+        const size_t worst = (size_t)io.count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
         po->pool_unfetched_worst_ = po->pool_unfetched_worst_ > worst ? po->pool_unfetched_worst_ - worst : 0;
     }
     return DDO_OK;

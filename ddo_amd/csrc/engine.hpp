@@ -168,6 +168,19 @@ class Engine {
     /// the finished batch's output arena on a second stream while the new kernel runs.
     int wait();
     int fetch(std::vector<HostResult>& results);
+    /// fetch() without the decoding: the result records (2 per item) and the output arena of the finished launch as they
+    /// lie in pinned host memory.  The pointers stay valid until the launch AFTER THE NEXT ONE of this engine (two buffer sets).
+    /// The lazy solver reads them in place: building a HostResult (seven vectors) per record cost the proof search tens of
+    /// seconds of host time for its 86 million sub-problem launches.
+    struct RawBatch {
+        const DDResult* hdr = nullptr;
+        const uint8_t* arena = nullptr;
+        int count = 0;
+        size_t arena_used = 0;
+    };
+    int fetch_raw(RawBatch& out);
+    /// pinned staging buffer for the inputs of the next launch (`count` records): fill it in place, then launch(nullptr, count)
+    DDInput* stage_inputs(int count);
     bool in_flight() const { return pending_ > 0; }
 
     int device() const { return device_; }

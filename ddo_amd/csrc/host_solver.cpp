@@ -445,6 +445,7 @@ struct ddo_solver {
     std::vector<uint32_t> st_layers, st_maxw;
     std::vector<uint64_t> st_nodes;
     uint64_t st_clk[32] = {0};
+    double st_t_fill = 0, st_t_launch = 0, st_t_wait = 0, st_t_wait_last = 0;
     uint64_t st_bk_cnt[20] = {0}, st_bk_nodes[20] = {0}, st_bk_clk[20] = {0};   // by log2 of the DD's widest layer
     uint64_t st_push = 0, st_push_dup = 0;
     uint64_t st_recycled = 0;
@@ -462,6 +463,14 @@ struct ddo_solver {
     std::vector<HostResult> results;
 
     ~ddo_solver() {
+        if (std::getenv("DDO_HIP_TIMES")) {   // host-side clocks only (DDO_HIP_STATS also makes every DD account its phases: slower)
+            std::fprintf(stderr, "[ddo times] host s: pop %.3f run %.3f post %.3f (of which fetch %.3f) | dispatch: lists + inputs %.3f, launch() %.3f, "
+                         "wait for a lower tier %.3f, wait for the last tier of the previous step %.3f\n", st_host_pop, st_host_run, st_host_post, st_host_fetch,
+                         st_t_fill, st_t_launch, st_t_wait, st_t_wait_last);
+            for (size_t t = 0; t < tiers.size(); ++t)
+                std::fprintf(stderr, "[ddo times] tier %zu: %llu launches, %llu sub-problems, %llu retried, kernels %.1f ms\n", t, (unsigned long long)st_tier_launch[t],
+                             (unsigned long long)st_tier_items[t], (unsigned long long)st_tier_retry[t], tiers[t]->kernel_ms());
+        }
         if (want_stats && !st_layers.empty()) {
             auto pct = [](std::vector<uint64_t> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
             std::vector<uint64_t> a(st_layers.begin(), st_layers.end()), b(st_maxw.begin(), st_maxw.end());
@@ -472,6 +481,8 @@ struct ddo_solver {
             for (int q = 0; q < 8; ++q) tc += st_clk[q];
             std::fprintf(stderr, "[ddo stats] host s: pop %.3f run %.3f post %.3f (of which fetch %.3f) | pushes %llu | node pool backed %.1f GB\n", st_host_pop,
                          st_host_run, st_host_post, st_host_fetch, (unsigned long long)st_push, engine ? engine->pool_capacity() / 1073741824.0 : 0.0);
+            std::fprintf(stderr, "[ddo stats] dispatch s: lists + inputs %.3f, launch() %.3f, wait for a lower tier %.3f, wait for the last tier of the previous step %.3f\n",
+                         st_t_fill, st_t_launch, st_t_wait, st_t_wait_last);
             std::fprintf(stderr, "[ddo stats] device kcycles per layer: misc(var,sweep,freelist,final,backward) %.1f select %.1f classify+tie-break %.1f victims+merge %.1f expand+dedup %.1f (unused %.1f %.1f) hand-over %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
                          st_clk[0] / 1e3 / std::max<uint64_t>(1, tl), st_clk[1] / 1e3 / std::max<uint64_t>(1, tl), st_clk[2] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),
@@ -802,58 +813,80 @@ struct ddo_solver {
     }
 
     /// results of a finished lazy launch -> incumbent, counters, new cut-set blocks (parallel.rs:420-434)
-    int absorb_lazy(std::vector<LazyItem>& its, std::vector<HostResult>& res) {
+    /// a finished launch whose results are not folded into the fringe yet: its items and the raw result records (2 per item;
+    /// skip[i]: the item was handed up to the next tier, its records mean nothing)
+    struct Done {
+        std::vector<LazyItem> first;
+        Engine::RawBatch raw;
+        std::vector<uint8_t> skip;
+        int tier = 0;
+    };
+    std::vector<Done> todo;
+
+    /// Folds the results of one finished launch into counters, incumbent and fringe, reading the result records and the
+    /// output arena where the device left them (pinned host memory, Engine::fetch_raw).
+    int absorb_lazy(Done& d) {
+        std::vector<LazyItem>& its = d.first;
+        const Engine::RawBatch& raw = d.raw;
         int err = DDO_OK;
         std::vector<DevBlock*> fresh_blocks;
+        if ((size_t)raw.count != its.size()) err = DDO_ERR_INTERNAL;
         for (size_t i = 0; i < its.size() && err == DDO_OK; ++i) {
+            if (!d.skip.empty() && d.skip[i]) continue;
             for (int k = 0; k < 2; ++k) {
-                HostResult* r = &res[2 * i + k];
-                if (r->hdr.status == ST_NOT_RUN) continue;
-                if (r->hdr.status != ST_OK) {
-                    const bool capacity = r->hdr.status == ST_ERR_CAPACITY || r->hdr.status <= -100;
-                    set_error(capacity ? "device capacity exhausted (site " + std::to_string(r->hdr.status) +
+                const DDResult& h = raw.hdr[2 * i + k];
+                if (h.status == ST_NOT_RUN) continue;
+                const bool overflow = h.status == ST_OK && h.arena_off + h.arena_bytes > raw.arena_used;
+                if (h.status != ST_OK || overflow) {
+                    const bool capacity = overflow || h.status == ST_ERR_CAPACITY || h.status <= -100;
+                    set_error(capacity ? "device capacity exhausted (site " + std::to_string(h.status) +
                                              "): node pool / output arena / workspace; raise DDO_HIP_POOL_GB or use DDO_FRINGE_NODUP"
-                                       : "device compile failed with status " + std::to_string(r->hdr.status));
-                    err = r->hdr.status == ST_CUTOFF ? DDO_CUTOFF : (capacity ? DDO_ERR_CAPACITY : DDO_ERR_INTERNAL);
+                                       : "device compile failed with status " + std::to_string(h.status));
+                    err = h.status == ST_CUTOFF ? DDO_CUTOFF : (capacity ? DDO_ERR_CAPACITY : DDO_ERR_INTERNAL);
                     break;
                 }
-                counters.nodes_expanded += r->hdr.nodes_expanded;
-                counters.arcs += r->hdr.arcs;
-                counters.layers += r->hdr.layers;
+                counters.nodes_expanded += h.nodes_expanded;
+                counters.arcs += h.arcs;
+                counters.layers += h.layers;
                 counters.compiles += 1;
+                st_tier_nodes[d.tier] += h.nodes_expanded;
                 if (want_stats) {
-                    st_layers.push_back((uint32_t)r->hdr.layers);
-                    st_maxw.push_back(r->hdr.max_width_seen);
-                    st_nodes.push_back(r->hdr.nodes_expanded);
-                    for (int q = 0; q < 32; ++q) st_clk[q] += r->hdr.phase_clk[q];
-                    st_recycled += r->hdr.recycled_merges;
+                    st_layers.push_back((uint32_t)h.layers);
+                    st_maxw.push_back(h.max_width_seen);
+                    st_nodes.push_back(h.nodes_expanded);
+                    for (int q = 0; q < 32; ++q) st_clk[q] += h.phase_clk[q];
+                    st_recycled += h.recycled_merges;
                     int bk = 0;
-                    while (bk < 19 && (1u << bk) < r->hdr.max_width_seen) ++bk;
+                    while (bk < 19 && (1u << bk) < h.max_width_seen) ++bk;
                     st_bk_cnt[bk] += 1;
-                    st_bk_nodes[bk] += r->hdr.nodes_expanded;
-                    for (int q = 0; q < 8; ++q) st_bk_clk[bk] += r->hdr.phase_clk[q];
+                    st_bk_nodes[bk] += h.nodes_expanded;
+                    for (int q = 0; q < 8; ++q) st_bk_clk[bk] += h.phase_clk[q];
                 }
-                if (!bench_mode && r->hdr.has_best_exact && (int64_t)r->hdr.best_exact_value > best_lb) {   // maybe_update_best
-                    best_lb = r->hdr.best_exact_value;
+                const uint8_t* base = raw.arena + h.arena_off;
+                if (!bench_mode && h.has_best_exact && (int64_t)h.best_exact_value > best_lb) {   // maybe_update_best
+                    best_lb = h.best_exact_value;
                     best_sol.clear();
                     if ((err = materialize_pool_path(its[i].block, its[i].row, best_sol)) != DDO_OK) break;
-                    const std::vector<uint32_t>& p = r->hdr.exact_same_as_best ? r->best_path : r->exact_path;
-                    for (uint32_t x : p) best_sol.push_back(model->path_decision(x));
+                    // (the best exact path: stored once when it is also the best path -- the kernel then points exact_off at it)
+                    const uint32_t* p = (const uint32_t*)(base + h.exact_off);
+                    for (int q = 0; q < h.exact_len; ++q) best_sol.push_back(model->path_decision(p[q]));
                     has_sol = true;
                 }
-                const bool exact = r->hdr.is_exact || r->hdr.has_exact_best_path;
-                if (k == 1 && !exact && r->n_cutset > 0 && r->pool_off != NO_POOL_SRC) {   // enqueue_cutset
+                const bool exact = h.is_exact || h.has_exact_best_path;
+                if (k == 1 && !exact && h.n_cutset > 0 && h.pool_off != NO_POOL_SRC) {   // enqueue_cutset
                     DevBlock* b = new DevBlock();
                     b->parent = its[i].block;
                     b->parent_row = its[i].row;
                     dev_ref(its[i].block);
-                    b->off = r->pool_off;
-                    b->rows = r->n_cutset;
-                    b->lel = r->cs_path_len;
-                    b->depth = its[i].depth + r->cs_path_len;
+                    b->off = h.pool_off;
+                    b->rows = h.n_cutset;
+                    b->lel = h.cs_path_stride;
+                    b->depth = its[i].depth + h.cs_path_stride;
                     b->cap_ub = its[i].ub;
-                    b->value = std::move(r->cs_value);
-                    b->ub = std::move(r->cs_ub);
+                    const int32_t* v = (const int32_t*)(base + h.cs_value_off);
+                    const int32_t* u = (const int32_t*)(base + h.cs_ub_off);
+                    b->value.assign(v, v + h.n_cutset);
+                    b->ub.assign(u, u + h.n_cutset);
                     dev_ref(b);
                     st_push += (uint64_t)b->rows;
                     if (cfg.world_size > 1 && its[i].block->parent == nullptr && its[i].block->off == NO_POOL_SRC &&
@@ -888,7 +921,8 @@ struct ddo_solver {
                 dev_unref(fresh_blocks[q]);
             }
         }
-        for (LazyItem& e : its) dev_unref(e.block);
+        for (size_t i = 0; i < its.size(); ++i)
+            if (d.skip.empty() || !d.skip[i]) dev_unref(its[i].block);   // (handed-up items carried their reference to the next tier)
         its.clear();
         return err;
     }
@@ -903,7 +937,6 @@ struct ddo_solver {
     // a tier never squashes, so whatever it completes is what the full-width engine would have produced.
     std::vector<std::shared_ptr<Engine>> tiers;   // ascending capacity; tiers.back() == engine
     int flight_tier = -1;                          // engine of the launch in flight (flight = its items)
-    std::vector<std::pair<std::vector<LazyItem>, std::vector<HostResult>>> todo;   // finished, not folded in yet
     static constexpr int HINT_DEPTHS = 1024;
     struct TierHint { uint32_t tried[4] = {0, 0, 0, 0}, retried[4] = {0, 0, 0, 0}; };
     std::vector<TierHint> hints;
@@ -950,9 +983,13 @@ struct ddo_solver {
     }
     int absorb_todo() {
         int err = DDO_OK;
-        for (auto& pr : todo) {
-            if (err == DDO_OK) err = absorb_lazy(pr.first, pr.second);
-            else drop_items(pr.first);
+        for (Done& d : todo) {
+            if (err == DDO_OK) err = absorb_lazy(d);
+            else {
+                for (size_t i = 0; i < d.first.size(); ++i)
+                    if (d.skip.empty() || !d.skip[i]) dev_unref(d.first[i].block);
+                d.first.clear();
+            }
         }
         todo.clear();
         return err;
@@ -976,26 +1013,18 @@ struct ddo_solver {
         auto decode_deferred = [&]() -> int {
             int err = DDO_OK;
             for (Deferred& d : deferred) {
-                std::vector<HostResult> res;
-                int r2 = err == DDO_OK ? tiers[(size_t)d.t]->fetch(res) : DDO_ERR_INTERNAL;
-                if (r2 != DDO_OK || res.size() != 2 * d.items.size()) {
+                Done dn;
+                int r2 = err == DDO_OK ? tiers[(size_t)d.t]->fetch_raw(dn.raw) : DDO_ERR_INTERNAL;
+                if (r2 != DDO_OK || (size_t)dn.raw.count != d.items.size()) {
                     if (err == DDO_OK) err = r2 != DDO_OK ? r2 : DDO_ERR_INTERNAL;
                     for (size_t i = 0; i < d.items.size(); ++i)
                         if (!d.retry[i]) dev_unref(d.items[i].block);
                     continue;
                 }
-                std::vector<LazyItem> done;
-                std::vector<HostResult> done_res;
-                done.reserve(d.items.size());
-                done_res.reserve(2 * d.items.size());
-                for (size_t i = 0; i < d.items.size(); ++i) {
-                    if (d.retry[i]) continue;
-                    done.push_back(d.items[i]);
-                    st_tier_nodes[d.t] += res[2 * i].hdr.nodes_expanded + res[2 * i + 1].hdr.nodes_expanded;
-                    done_res.push_back(std::move(res[2 * i]));
-                    done_res.push_back(std::move(res[2 * i + 1]));
-                }
-                if (!done.empty()) todo.emplace_back(std::move(done), std::move(done_res));
+                dn.first = std::move(d.items);
+                dn.skip = std::move(d.retry);
+                dn.tier = d.t;
+                todo.push_back(std::move(dn));
             }
             deferred.clear();
             return err;
@@ -1007,57 +1036,89 @@ struct ddo_solver {
         };
         auto t_run0 = std::chrono::steady_clock::now();
         // tiers run one after the other (a full-width workgroup owns a whole CU): the launch in flight must have left
-        if (flight_tier >= 0 && (rc = tiers[(size_t)flight_tier]->wait()) != DDO_OK) {
+        if (flight_tier >= 0) rc = tiers[(size_t)flight_tier]->wait(); else rc = DDO_OK;
+        st_t_wait_last += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
+        if (rc != DDO_OK) {
             drop_items(flight);
             flight_tier = -1;
             return fail(rc);
         }
+        // The host's share of a step -- fetching the results of the previous step's last launch, decoding the lower tiers'
+        // records, folding cut-sets into the fringe -- runs while the LAST tier's launch of this call is on the device: that is
+        // the long one (full-width decision diagrams), the lower tiers take a few milliseconds and the device would sit idle
+        // behind them while the host works (with 65 536 sub-problems in flight the proof search spent 55 of its 123 s that way).
+        std::vector<LazyItem> prev_flight;
+        const int prev_tier = flight_tier;
+        prev_flight.swap(flight);
+        flight_tier = -1;
+        auto host_share = [&]() -> int {
+            auto t1 = std::chrono::steady_clock::now();
+            int r = DDO_OK;
+            if (prev_tier >= 0 && !prev_flight.empty()) {
+                Done dn;
+                r = tiers[(size_t)prev_tier]->fetch_raw(dn.raw);
+                if (r != DDO_OK) drop_items(prev_flight);
+                else {
+                    dn.first = std::move(prev_flight);
+                    dn.tier = prev_tier;
+                    todo.push_back(std::move(dn));
+                }
+                prev_flight.clear();
+            }
+            if (r == DDO_OK) r = decode_deferred();
+            st_host_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            if (r == DDO_OK) r = absorb_todo();
+            st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            return r;
+        };
+        bool shared = false;
         for (int t = 0; t < T; ++t) {
             if (lists[(size_t)t].empty()) continue;
             std::vector<LazyItem>& cur = lists[(size_t)t];
-            fill_lazy_inputs(cur, lb);
+            DDInput* staged = tiers[(size_t)t]->stage_inputs((int)cur.size());
+            if (!staged) {
+                drop_items(prev_flight);
+                return fail(DDO_ERR_INTERNAL);
+            }
+            fill_lazy_inputs(cur, lb, staged);
             if (rewind) {
                 tiers[(size_t)t]->set_pool_rewind(frozen_mark);
                 rewind = false;
             }
-            if ((rc = tiers[(size_t)t]->launch(inputs.data(), (int)inputs.size())) != DDO_OK) return fail(rc);
+            auto tl0 = std::chrono::steady_clock::now();
+            st_t_fill += std::chrono::duration<double>(tl0 - t_run0).count();
+            if ((rc = tiers[(size_t)t]->launch(nullptr, (int)cur.size())) != DDO_OK) {
+                drop_items(prev_flight);
+                return fail(rc);
+            }
+            st_t_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
             st_tier_launch[t] += 1;
             st_tier_items[t] += cur.size();
             if (want_stats) std::fprintf(stderr, "[ddo stats] tier %d: launch of %zu sub-problems (fringe %zu open, best_lb %lld)\n", t, cur.size(),
                                          lazy->len(), (long long)lb);
-            auto t_run1 = std::chrono::steady_clock::now();
-            st_host_run += std::chrono::duration<double>(t_run1 - t_run0).count();
-            // ... while the device works: results of the launch that was in flight, then everything deferred
-            if (flight_tier >= 0) {
-                std::vector<HostResult> res;
-                rc = tiers[(size_t)flight_tier]->fetch(res);
-                flight_tier = -1;
+            st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
+            if (t + 1 == T) {   // the full-width engine: nothing above it, its launch stays in flight -- the host works meanwhile
+                shared = true;
+                rc = host_share();
                 if (rc != DDO_OK) {
-                    drop_items(flight);
+                    tiers[(size_t)t]->wait();
+                    std::vector<HostResult> junk;
+                    tiers[(size_t)t]->fetch(junk);
+                    drop_items(cur);
                     return fail(rc);
                 }
-                todo.emplace_back(std::move(flight), std::move(res));
-                flight.clear();
-            }
-            if (rc == DDO_OK) rc = decode_deferred();
-            st_host_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
-            if (rc == DDO_OK) rc = absorb_todo();
-            st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run1).count();
-            if (rc != DDO_OK) {
-                tiers[(size_t)t]->wait();
-                std::vector<HostResult> junk;
-                tiers[(size_t)t]->fetch(junk);
-                return fail(rc);
-            }
-            t_run0 = std::chrono::steady_clock::now();
-            if (t + 1 == T) {   // the full-width engine: nothing above it, its launch stays in flight
+                t_run0 = std::chrono::steady_clock::now();
                 flight.swap(cur);
                 flight_tier = t;
                 break;
             }
+            t_run0 = std::chrono::steady_clock::now();
             Deferred d;
             d.t = t;
-            if ((rc = tiers[(size_t)t]->wait()) != DDO_OK || (rc = tiers[(size_t)t]->peek_retry(d.retry)) != DDO_OK || d.retry.size() != cur.size()) {
+            rc = tiers[(size_t)t]->wait();
+            st_t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
+            if (rc != DDO_OK || (rc = tiers[(size_t)t]->peek_retry(d.retry)) != DDO_OK || d.retry.size() != cur.size()) {
+                drop_items(prev_flight);
                 return fail(rc != DDO_OK ? rc : DDO_ERR_INTERNAL);
             }
             for (size_t i = 0; i < cur.size(); ++i) {
@@ -1071,7 +1132,7 @@ struct ddo_solver {
             cur.clear();
             deferred.push_back(std::move(d));
         }
-        rc = decode_deferred();   // (whatever no later launch of this call covered)
+        if (!shared) rc = host_share();   // (nothing reached the last tier: no launch is in flight)
         st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
         return rc;
     }
@@ -1081,15 +1142,18 @@ struct ddo_solver {
         if (!lazy) return DDO_OK;
         auto t0 = std::chrono::steady_clock::now();
         if (flight_tier >= 0) {
-            std::vector<HostResult> res;
-            int rc = tiers[(size_t)flight_tier]->collect(res);
+            Done dn;
+            int rc = tiers[(size_t)flight_tier]->wait();
+            if (rc == DDO_OK) rc = tiers[(size_t)flight_tier]->fetch_raw(dn.raw);
+            dn.tier = flight_tier;
             flight_tier = -1;
             st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (rc != DDO_OK) {
                 drop_items(flight);
                 return rc;
             }
-            todo.emplace_back(std::move(flight), std::move(res));
+            dn.first = std::move(flight);
+            todo.push_back(std::move(dn));
             flight.clear();
         }
         auto t1 = std::chrono::steady_clock::now();
@@ -1098,21 +1162,29 @@ struct ddo_solver {
         return rc;
     }
 
-    void fill_lazy_inputs(const std::vector<LazyItem>& its, int64_t lb) {
-        inputs.resize(its.size());
+    /// input records of a launch, written straight into the engine's pinned staging buffer.  A sub-problem whose state is a
+    /// row of a pool block names (block, row); only the problem root carries its state inline (the 128 state bytes of the
+    /// other records are never read by the device and stay untouched).
+    void fill_lazy_inputs(const std::vector<LazyItem>& its, int64_t lb, DDInput* out) {
         const int64_t lim = (int64_t)1 << 40;
+        const int64_t blb = std::max(-lim, std::min(lim, lb));
+        const bool fixed = cfg.width_policy == DDO_WIDTH_FIXED && !cfg.width_times && !cfg.width_div_by;
         for (size_t i = 0; i < its.size(); ++i) {
-            DDInput& in = inputs[i];
-            std::memset(&in, 0, sizeof(in));
+            DDInput& in = out[i];
             in.comp_type = CT_RESTRICTED;
             in.flags = IN_FUSED | IN_FILTER_CUTSET | IN_POOL_OUT;
-            in.width = (int)ddo_width_heuristic(&cfg, (size_t)model->n, (size_t)std::max(its[i].depth, 0));
+            in.width = fixed ? (int32_t)cfg.width : (int32_t)ddo_width_heuristic(&cfg, (size_t)model->n, (size_t)std::max(its[i].depth, 0));
             in.value = (int32_t)its[i].value;
             in.depth = its[i].depth;
-            in.best_lb = std::max(-lim, std::min(lim, lb));
+            in.pad = 0;
+            in.best_lb = blb;
             in.src_off = its[i].block->off;
             in.src_row = (uint32_t)its[i].row;
-            if (in.src_off == NO_POOL_SRC) model->initial_state(in.state);
+            in.pad2 = 0;
+            if (in.src_off == NO_POOL_SRC) {
+                std::memset(in.state, 0, sizeof(in.state));
+                model->initial_state(in.state);
+            }
         }
     }
 

@@ -26,8 +26,8 @@ class DDResult(C.Structure):
                 ("arena_off", C.c_uint64), ("arena_bytes", C.c_uint64), ("nodes_expanded", C.c_uint64),
                 ("arcs", C.c_uint64), ("layers", C.c_uint64), ("path_off", C.c_uint64), ("exact_off", C.c_uint64),
                 ("cs_state_off", C.c_uint64), ("cs_value_off", C.c_uint64), ("cs_ub_off", C.c_uint64),
-                ("cs_path_off", C.c_uint64), ("phase_clk", C.c_uint64 * 32), ("pool_off", C.c_uint64),
-                ("cs_depth_off", C.c_uint64), ("cs_path_stride", C.c_int32), ("cache_hits", C.c_uint32)]
+                ("cs_path_off", C.c_uint64), ("pool_off", C.c_uint64),
+                ("cs_depth_off", C.c_uint64), ("cs_path_stride", C.c_int32), ("cache_hits", C.c_uint32), ("phase_clk", C.c_uint64 * 32)]
 
 
 def parse_result(res, arena_ptr, ws, depth0):
