@@ -445,7 +445,7 @@ struct ddo_solver {
     std::vector<uint32_t> st_layers, st_maxw;
     std::vector<uint64_t> st_nodes;
     uint64_t st_clk[32] = {0};
-    double st_t_fill = 0, st_t_launch = 0, st_t_wait = 0, st_t_wait_last = 0;
+    double st_t_fill = 0, st_t_launch = 0, st_t_wait = 0, st_t_wait_last = 0, st_t_wait_flush = 0;
     uint64_t st_bk_cnt[20] = {0}, st_bk_nodes[20] = {0}, st_bk_clk[20] = {0};   // by log2 of the DD's widest layer
     uint64_t st_push = 0, st_push_dup = 0;
     uint64_t st_recycled = 0;
@@ -465,8 +465,8 @@ struct ddo_solver {
     ~ddo_solver() {
         if (std::getenv("DDO_HIP_TIMES")) {   // host-side clocks only (DDO_HIP_STATS also makes every DD account its phases: slower)
             std::fprintf(stderr, "[ddo times] host s: pop %.3f run %.3f post %.3f (of which fetch %.3f) | dispatch: lists + inputs %.3f, launch() %.3f, "
-                         "wait for a lower tier %.3f, wait for the last tier of the previous step %.3f\n", st_host_pop, st_host_run, st_host_post, st_host_fetch,
-                         st_t_fill, st_t_launch, st_t_wait, st_t_wait_last);
+                         "wait for a lower tier %.3f, wait for the last tier of the previous step %.3f (+ %.3f in flush)\n", st_host_pop, st_host_run, st_host_post, st_host_fetch,
+                         st_t_fill, st_t_launch, st_t_wait, st_t_wait_last, st_t_wait_flush);
             for (size_t t = 0; t < tiers.size(); ++t)
                 std::fprintf(stderr, "[ddo times] tier %zu: %llu launches, %llu sub-problems, %llu retried, kernels %.1f ms\n", t, (unsigned long long)st_tier_launch[t],
                              (unsigned long long)st_tier_items[t], (unsigned long long)st_tier_retry[t], tiers[t]->kernel_ms());
@@ -995,79 +995,94 @@ struct ddo_solver {
         return err;
     }
 
-    /// Compiles `batch` (restricted + relaxed DD per sub-problem, parallel.rs:391-437) through the tiers.  Software
-    /// pipeline: the first launch of this call goes out BEFORE the results of the previous call are folded into the
-    /// fringe, and every hand-over between tiers overlaps the host work on what the lower tier finished.  The launch
-    /// of the last tier stays in flight when the call returns.  Takes over the references held by `batch`.
+    /// one synchronous launch of `cur` on tier t: the finished items go to `todo` (not folded in yet), the handed-up ones to `up`
+    int run_tier_sync(int t, std::vector<LazyItem>& cur, int64_t lb, std::vector<LazyItem>& up) {
+        DDInput* staged = tiers[(size_t)t]->stage_inputs((int)cur.size());
+        if (!staged) {
+            drop_items(cur);
+            return DDO_ERR_INTERNAL;
+        }
+        fill_lazy_inputs(cur, lb, staged);
+        int rc = tiers[(size_t)t]->launch(nullptr, (int)cur.size());
+        if (rc != DDO_OK) {
+            drop_items(cur);
+            return rc;
+        }
+        st_tier_launch[t] += 1;
+        st_tier_items[t] += cur.size();
+        return settle(t, cur, up);
+    }
+    /// waits for tier t's launch of `cur`, splits it by status: handed-up items (ST_RETRY) move to `up`, the records of the
+    /// others are queued in `todo`.  Takes over `cur`.
+    int settle(int t, std::vector<LazyItem>& cur, std::vector<LazyItem>& up) {
+        Done dn;
+        auto t0 = std::chrono::steady_clock::now();
+        int rc = tiers[(size_t)t]->wait();
+        st_t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc == DDO_OK) rc = tiers[(size_t)t]->peek_retry(dn.skip);
+        if (rc == DDO_OK && dn.skip.size() != cur.size()) rc = DDO_ERR_INTERNAL;
+        if (rc == DDO_OK) rc = tiers[(size_t)t]->fetch_raw(dn.raw);
+        if (rc != DDO_OK) {
+            drop_items(cur);
+            return rc;
+        }
+        for (size_t i = 0; i < cur.size(); ++i) {
+            note_tier(cur[i], t, dn.skip[i] != 0);
+            if (dn.skip[i]) {
+                st_tier_retry[t] += 1;
+                up.push_back(cur[i]);
+            }
+        }
+        dn.first = std::move(cur);
+        dn.tier = t;
+        cur.clear();
+        todo.push_back(std::move(dn));
+        return DDO_OK;
+    }
+    /// The launch a step left in flight has to leave the device: its finished items are queued in `todo`; items it handed up
+    /// (only when the launch left in flight was not the last tier's) are appended to lists[tier + 1].
+    int settle_flight(std::vector<std::vector<LazyItem>>& lists) {
+        if (flight_tier < 0) return DDO_OK;
+        const int t = flight_tier;
+        flight_tier = -1;
+        std::vector<LazyItem> up;
+        int rc = settle(t, flight, up);
+        flight.clear();
+        if (rc != DDO_OK) return rc;
+        if (!up.empty()) {
+            if (t + 1 >= (int)tiers.size()) {
+                drop_items(up);
+                return DDO_ERR_INTERNAL;   // the last tier has nowhere to hand a DD
+            }
+            for (LazyItem& e : up) lists[(size_t)t + 1].push_back(e);
+        }
+        return DDO_OK;
+    }
+
+    /// Compiles `batch` (restricted + relaxed DD per sub-problem, parallel.rs:391-437) through the tiers.  A lower tier's
+    /// launch is waited for (who is handed up?) before the next tier's goes out; the LAST launch of a call -- the first tier
+    /// above which nothing is queued: nearly always the dense tier, the long one -- stays in flight when the call returns, and
+    /// the host's share of the step (folding the finished records of this and the previous step into counters, incumbent and
+    /// fringe) runs while it is on the device.  Whatever that launch hands up joins the next call's batch.
+    /// Takes over the references held by `batch`.
     int dispatch(std::vector<LazyItem>& batch, int64_t lb, bool rewind) {
         const int T = (int)tiers.size();
         std::vector<std::vector<LazyItem>> lists((size_t)T);
         hint_lb = lb > -((int64_t)1 << 40) ? lb : 0;
         for (LazyItem& e : batch) lists[(size_t)start_tier(e)].push_back(e);
         batch.clear();
-        int rc;
-        // a finished lower tier is split by status first (who is handed up?), the next tier is launched, and only then are
-        // its results decoded: the decode of 8192 result records is host work the device does not have to wait for
-        struct Deferred { int t; std::vector<LazyItem> items; std::vector<uint8_t> retry; };
-        std::vector<Deferred> deferred;
-        auto decode_deferred = [&]() -> int {
-            int err = DDO_OK;
-            for (Deferred& d : deferred) {
-                Done dn;
-                int r2 = err == DDO_OK ? tiers[(size_t)d.t]->fetch_raw(dn.raw) : DDO_ERR_INTERNAL;
-                if (r2 != DDO_OK || (size_t)dn.raw.count != d.items.size()) {
-                    if (err == DDO_OK) err = r2 != DDO_OK ? r2 : DDO_ERR_INTERNAL;
-                    for (size_t i = 0; i < d.items.size(); ++i)
-                        if (!d.retry[i]) dev_unref(d.items[i].block);
-                    continue;
-                }
-                dn.first = std::move(d.items);
-                dn.skip = std::move(d.retry);
-                dn.tier = d.t;
-                todo.push_back(std::move(dn));
-            }
-            deferred.clear();
-            return err;
-        };
         auto fail = [&](int rc) {
-            (void)decode_deferred();   // finished results are kept (or their references released)
             for (auto& l : lists) drop_items(l);
             return rc;
         };
         auto t_run0 = std::chrono::steady_clock::now();
         // tiers run one after the other (a full-width workgroup owns a whole CU): the launch in flight must have left
-        if (flight_tier >= 0) rc = tiers[(size_t)flight_tier]->wait(); else rc = DDO_OK;
+        int rc = settle_flight(lists);
         st_t_wait_last += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
-        if (rc != DDO_OK) {
-            drop_items(flight);
-            flight_tier = -1;
-            return fail(rc);
-        }
-        // The host's share of a step -- fetching the results of the previous step's last launch, decoding the lower tiers'
-        // records, folding cut-sets into the fringe -- runs while the LAST tier's launch of this call is on the device: that is
-        // the long one (full-width decision diagrams), the lower tiers take a few milliseconds and the device would sit idle
-        // behind them while the host works (with 65 536 sub-problems in flight the proof search spent 55 of its 123 s that way).
-        std::vector<LazyItem> prev_flight;
-        const int prev_tier = flight_tier;
-        prev_flight.swap(flight);
-        flight_tier = -1;
+        if (rc != DDO_OK) return fail(rc);
         auto host_share = [&]() -> int {
             auto t1 = std::chrono::steady_clock::now();
-            int r = DDO_OK;
-            if (prev_tier >= 0 && !prev_flight.empty()) {
-                Done dn;
-                r = tiers[(size_t)prev_tier]->fetch_raw(dn.raw);
-                if (r != DDO_OK) drop_items(prev_flight);
-                else {
-                    dn.first = std::move(prev_flight);
-                    dn.tier = prev_tier;
-                    todo.push_back(std::move(dn));
-                }
-                prev_flight.clear();
-            }
-            if (r == DDO_OK) r = decode_deferred();
-            st_host_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-            if (r == DDO_OK) r = absorb_todo();
+            int r = absorb_todo();
             st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
             return r;
         };
@@ -1075,11 +1090,11 @@ struct ddo_solver {
         for (int t = 0; t < T; ++t) {
             if (lists[(size_t)t].empty()) continue;
             std::vector<LazyItem>& cur = lists[(size_t)t];
+            bool last = true;   // nothing queued above: this launch ends the call (what it hands up joins the next one)
+            for (int u = t + 1; u < T; ++u) last = last && lists[(size_t)u].empty();
+            t_run0 = std::chrono::steady_clock::now();
             DDInput* staged = tiers[(size_t)t]->stage_inputs((int)cur.size());
-            if (!staged) {
-                drop_items(prev_flight);
-                return fail(DDO_ERR_INTERNAL);
-            }
+            if (!staged) return fail(DDO_ERR_INTERNAL);
             fill_lazy_inputs(cur, lb, staged);
             if (rewind) {
                 tiers[(size_t)t]->set_pool_rewind(frozen_mark);
@@ -1087,79 +1102,61 @@ struct ddo_solver {
             }
             auto tl0 = std::chrono::steady_clock::now();
             st_t_fill += std::chrono::duration<double>(tl0 - t_run0).count();
-            if ((rc = tiers[(size_t)t]->launch(nullptr, (int)cur.size())) != DDO_OK) {
-                drop_items(prev_flight);
-                return fail(rc);
-            }
+            if ((rc = tiers[(size_t)t]->launch(nullptr, (int)cur.size())) != DDO_OK) return fail(rc);
             st_t_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
             st_tier_launch[t] += 1;
             st_tier_items[t] += cur.size();
             if (want_stats) std::fprintf(stderr, "[ddo stats] tier %d: launch of %zu sub-problems (fringe %zu open, best_lb %lld)\n", t, cur.size(),
                                          lazy->len(), (long long)lb);
-            st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
-            if (t + 1 == T) {   // the full-width engine: nothing above it, its launch stays in flight -- the host works meanwhile
-                shared = true;
-                rc = host_share();
-                if (rc != DDO_OK) {
-                    tiers[(size_t)t]->wait();
-                    std::vector<HostResult> junk;
-                    tiers[(size_t)t]->fetch(junk);
-                    drop_items(cur);
-                    return fail(rc);
-                }
-                t_run0 = std::chrono::steady_clock::now();
+            if (last) {
                 flight.swap(cur);
                 flight_tier = t;
+                shared = true;
+                rc = host_share();   // ... while the launch runs
+                if (rc != DDO_OK) {
+                    std::vector<std::vector<LazyItem>> none((size_t)T);
+                    (void)settle_flight(none);
+                    for (auto& l : none) drop_items(l);
+                    (void)absorb_todo();
+                    return fail(rc);
+                }
                 break;
             }
-            t_run0 = std::chrono::steady_clock::now();
-            Deferred d;
-            d.t = t;
-            rc = tiers[(size_t)t]->wait();
-            st_t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
-            if (rc != DDO_OK || (rc = tiers[(size_t)t]->peek_retry(d.retry)) != DDO_OK || d.retry.size() != cur.size()) {
-                drop_items(prev_flight);
-                return fail(rc != DDO_OK ? rc : DDO_ERR_INTERNAL);
-            }
-            for (size_t i = 0; i < cur.size(); ++i) {
-                note_tier(cur[i], t, d.retry[i] != 0);
-                if (d.retry[i]) {
-                    st_tier_retry[t] += 1;
-                    lists[(size_t)t + 1].push_back(cur[i]);
-                }
-            }
-            d.items.swap(cur);
-            cur.clear();
-            deferred.push_back(std::move(d));
+            if ((rc = settle(t, cur, lists[(size_t)t + 1])) != DDO_OK) return fail(rc);
         }
-        if (!shared) rc = host_share();   // (nothing reached the last tier: no launch is in flight)
+        if (!shared) rc = host_share();   // (an empty batch: nothing was launched)
         st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
         return rc;
     }
 
-    /// waits for the launch in flight (if any) and folds every finished result into the fringe
+    /// waits for the launch in flight (if any), runs what it handed up through the tiers above, and folds every finished
+    /// result into the fringe
     int flush_lazy() {
         if (!lazy) return DDO_OK;
         auto t0 = std::chrono::steady_clock::now();
-        if (flight_tier >= 0) {
-            Done dn;
-            int rc = tiers[(size_t)flight_tier]->wait();
-            if (rc == DDO_OK) rc = tiers[(size_t)flight_tier]->fetch_raw(dn.raw);
-            dn.tier = flight_tier;
-            flight_tier = -1;
-            st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (rc != DDO_OK) {
-                drop_items(flight);
-                return rc;
+        const int T = (int)tiers.size();
+        std::vector<std::vector<LazyItem>> lists((size_t)T);
+        int rc = settle_flight(lists);
+        st_t_wait_flush += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int t = 0; t < T && rc == DDO_OK; ++t) {
+            if (lists[(size_t)t].empty()) continue;
+            std::vector<LazyItem> up;
+            rc = run_tier_sync(t, lists[(size_t)t], frozen.empty() ? best_lb : (bench_mode ? frozen_lb : best_lb), up);
+            if (rc == DDO_OK && !up.empty()) {
+                if (t + 1 >= T) {
+                    drop_items(up);
+                    rc = DDO_ERR_INTERNAL;
+                } else {
+                    for (LazyItem& e : up) lists[(size_t)t + 1].push_back(e);
+                }
             }
-            dn.first = std::move(flight);
-            todo.push_back(std::move(dn));
-            flight.clear();
         }
+        for (auto& l : lists) drop_items(l);
+        st_host_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         auto t1 = std::chrono::steady_clock::now();
-        int rc = absorb_todo();
+        int rc2 = absorb_todo();
         st_host_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-        return rc;
+        return rc != DDO_OK ? rc : rc2;
     }
 
     /// input records of a launch, written straight into the engine's pinned staging buffer.  A sub-problem whose state is a

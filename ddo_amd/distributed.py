@@ -86,11 +86,16 @@ DDO_CUTOFF = 2
 
 
 class DistributedSearch:
-    def __init__(self, solver, dist, device, rebalance_every=4, donate_min=64, donate_max=32768):
+    """`ub_gap`: a hand-over is also started when the best open bound of some rank lies at least that far below the best
+    open bound of another one (0 = only when a rank runs dry): hash-sharded best-first searches each follow their LOCAL
+    order, and a rank left with unpromising nodes expands sub-problems a global best-first search would have reached much
+    later, or never (search overhead).  The donor's best nodes then go round."""
+
+    def __init__(self, solver, dist, device, rebalance_every=4, donate_min=64, donate_max=32768, ub_gap=2):
         self.s, self.dist, self.device = solver, dist, device
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
-        self.rebalance_every, self.donate_min, self.donate_max = rebalance_every, donate_min, donate_max
+        self.rebalance_every, self.donate_min, self.donate_max, self.ub_gap = rebalance_every, donate_min, donate_max, ub_gap
         self.buf = self.work = None
         self.epochs = self.handovers = self.nodes_sent = self.nodes_received = 0
 
@@ -111,58 +116,67 @@ class DistributedSearch:
         self.work = None
         return [int(x) for x in self.buf.tolist()]
 
-    def _bcast(self, arr, src, dtype):
-        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64) if arr.dtype == np.uint64 else np.ascontiguousarray(arr)).to(self.device)
-        self.dist.broadcast(t, src=src)
-        out = t.cpu().numpy()
-        return out.view(dtype) if dtype == np.uint64 else out
+    def _to_dev(self, arr):
+        a = np.ascontiguousarray(arr)
+        return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(self.device)
+
+    def _send_nodes(self, nodes, idx, dst, ws):
+        """point-to-point: the records `idx` of an export, as one header and six arrays (xGMI is point-to-point: a receiver
+        gets its own share and nothing else)"""
+        offs = nodes["path_off"].astype(np.int64)
+        lens = offs[idx + 1] - offs[idx]
+        new_off = np.zeros(len(idx) + 1, dtype=np.int64)
+        new_off[1:] = np.cumsum(lens)
+        tot = int(new_off[-1])
+        paths = (np.concatenate([nodes["paths"][offs[i]:offs[i + 1]] for i in idx]) if tot else np.zeros((1, 2), dtype=np.int64)).reshape(-1, 2)
+        self.dist.send(self._to_dev(np.array([len(idx), tot], dtype=np.int64)), dst=dst)
+        for a in (nodes["states"][idx].reshape(len(idx), ws), nodes["value"][idx], nodes["ub"][idx], nodes["depth"][idx], new_off, paths):
+            self.dist.send(self._to_dev(a), dst=dst)
+
+    def _recv_nodes(self, src, ws):
+        hdr = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.dist.recv(hdr, src=src)
+        k, tot = int(hdr[0].item()), int(hdr[1].item())
+        shapes = [((k, ws), np.uint64), ((k,), np.int64), ((k,), np.int64), ((k,), np.int64), ((k + 1,), np.uint64), ((max(tot, 1), 2), np.int64)]
+        got = []
+        for shape, dt in shapes:
+            t = torch.zeros(shape, dtype=torch.int64, device=self.device)
+            self.dist.recv(t, src=src)
+            a = t.cpu().numpy()
+            got.append(a.view(np.uint64) if dt == np.uint64 else a)
+        return {"states": got[0], "value": got[1], "ub": got[2], "depth": got[3], "path_off": got[4], "paths": got[5][:tot]}
 
     def _handover(self, ws):
-        """All ranks call this together.  Donor = the rank with the most open nodes; receivers = the ranks with none."""
+        """All ranks call this together.  Donor = the rank with the best open bound (most open nodes among equals); receivers =
+        the ranks with no open node, and -- with ub_gap -- the ranks whose best open bound lies ub_gap below the donor's and
+        that hold far fewer nodes.  Each receiver gets its interleaved share of the donor's best nodes, point to point."""
         dist = self.dist
-        mine = torch.tensor([int(self.s.fringe_len())], dtype=torch.int64, device=self.device)
+        n_open = int(self.s.fringe_len())
+        top = int(self.s.fringe_best_ub()) if n_open > 0 else I64_LOW
+        mine = torch.tensor([n_open, max(top, I64_LOW)], dtype=torch.int64, device=self.device)
         allc = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(allc, mine)
-        counts = [int(c.item()) for c in allc]
-        donor = max(range(self.world), key=lambda r: (counts[r], -r))
-        receivers = [r for r in range(self.world) if counts[r] == 0 and r != donor]
+        counts = [int(c[0].item()) for c in allc]
+        tops = [int(c[1].item()) for c in allc]
+        donor = max(range(self.world), key=lambda r: (tops[r] if counts[r] >= self.donate_min else I64_LOW, counts[r], -r))
+        receivers = [r for r in range(self.world) if r != donor and
+                     (counts[r] == 0 or (self.ub_gap > 0 and tops[donor] - tops[r] >= self.ub_gap and 4 * counts[r] < counts[donor]))]
         if not receivers or counts[donor] < self.donate_min * (len(receivers) + 1):
             return False
         share = min(self.donate_max, counts[donor] // (len(receivers) + 1))
-        want = share * len(receivers)
         if self.rank == donor:
-            nodes = self.s.export_subproblems(want)
-            hdr = np.array([len(nodes["value"]), len(nodes["paths"])], dtype=np.int64)
-        else:
-            nodes, hdr = None, np.zeros(2, dtype=np.int64)
-        hdr = self._bcast(hdr, donor, np.int64)
-        k, tot = int(hdr[0]), int(hdr[1])
-        if k == 0:
-            return False
-        shapes = {"states": ((k, ws), np.uint64), "value": ((k,), np.int64), "ub": ((k,), np.int64), "depth": ((k,), np.int64),
-                  "path_off": ((k + 1,), np.uint64), "paths": ((max(tot, 1), 2), np.int64)}
-        got = {}
-        for key, (shape, dt) in shapes.items():
-            if self.rank == donor:
-                a = nodes[key] if key != "paths" or tot else np.zeros((1, 2), dtype=np.int64)
-            else:
-                a = np.zeros(shape, dtype=dt)
-            got[key] = self._bcast(a.reshape(shape), donor, dt).reshape(shape)
-        if self.rank == donor:
+            nodes = self.s.export_subproblems(share * len(receivers))
+            k = len(nodes["value"])
+            for j, r in enumerate(receivers):
+                self._send_nodes(nodes, np.arange(j, k, len(receivers)), r, ws)   # interleaved: everyone gets nodes from the top of the donor's order
             self.handovers += 1
             self.nodes_sent += k
         elif self.rank in receivers:
-            j = receivers.index(self.rank)
-            idx = np.arange(j, k, len(receivers))          # interleaved: every receiver gets nodes from the top of the donor's order
-            offs = got["path_off"].astype(np.int64)
-            lens = offs[idx + 1] - offs[idx]
-            new_off = np.zeros(len(idx) + 1, dtype=np.uint64)
-            new_off[1:] = np.cumsum(lens)
-            paths = np.concatenate([got["paths"][offs[i]:offs[i + 1]] for i in idx]) if len(idx) and lens.sum() else np.zeros((0, 2), dtype=np.int64)
-            self.s.import_subproblems({"states": got["states"][idx], "value": got["value"][idx], "ub": got["ub"][idx],
-                                       "depth": got["depth"][idx], "path_off": new_off, "paths": paths})
+            got = self._recv_nodes(donor, ws)
+            if len(got["value"]):
+                self.s.import_subproblems(got)
             self.handovers += 1
-            self.nodes_received += len(idx)
+            self.nodes_received += len(got["value"])
         return True
 
     def maximize(self):
@@ -181,10 +195,13 @@ class DistributedSearch:
             local_work = rc == 1
             self.epochs += 1
             open_n = int(s.fringe_len())
-            prev = self._post([max(int(s.best_lower_bound()), I64_LOW), 1 if local_work else 0, 1 if aborted else 0, open_n, -open_n])
+            top = int(s.fringe_best_ub()) if open_n > 0 else I64_LOW
+            # (a rank without open nodes does not take part in the smallest best bound: it is a receiver anyway)
+            prev = self._post([max(int(s.best_lower_bound()), I64_LOW), 1 if local_work else 0, 1 if aborted else 0, open_n, -open_n,
+                               max(top, I64_LOW), -top if open_n > 0 else I64_LOW])
             if prev is None:
                 continue
-            lb, any_work, any_abort, max_open, neg_min_open = prev
+            lb, any_work, any_abort, max_open, neg_min_open, max_top, neg_min_top = prev
             if lb > I64_LOW:
                 s.import_lower_bound(lb)
             if any_abort:        # a time budget ran out somewhere: everybody stops (parallel.rs:479-489 abort_search)
@@ -192,7 +209,9 @@ class DistributedSearch:
                 break
             if not any_work:
                 break
-            if self.epochs % self.rebalance_every == 0 and -neg_min_open == 0 and max_open >= 2 * self.donate_min:
+            dry = -neg_min_open == 0 and max_open >= 2 * self.donate_min
+            skew = self.ub_gap > 0 and neg_min_top > I64_LOW and max_top + neg_min_top >= self.ub_gap and max_open >= 4 * self.donate_min
+            if self.epochs % self.rebalance_every == 0 and (dry or skew):
                 # every rank saw the same reduced values: all of them take this branch together
                 last = self._drain()
                 if last is not None and last[0] > I64_LOW:

@@ -110,6 +110,9 @@ class _FakeSolver:
     def fringe_len(self):
         return len(self.open)
 
+    def fringe_best_ub(self):
+        return max(self.open) if self.open else -(1 << 62)
+
     def best_lower_bound(self):
         return self.lb
 
@@ -163,3 +166,37 @@ def test_distributed_search_terminates_and_hands_work_over_world3_gloo():
     assert all(o[6] == 0 for o in out)                                     # nothing left open anywhere
     assert out[1][3] > 0 and out[2][3] > 0                                 # the ranks that started empty did get work
     assert sum(o[4] for o in out) == sum(o[5] for o in out) > 0           # every node sent was received exactly once
+
+
+def _skew_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ddo_amd.distributed import DistributedSearch
+
+    # every rank has work, but rank 0 holds all the promising units (large bounds) and many of them: leaves only, nothing spawns
+    s = _FakeSolver(rank, limit=0, batch=4)
+    s.open = list(range(100000, 100400)) if rank == 0 else list(range(10 * rank, 10 * rank + 12))
+    search = DistributedSearch(s, dist, "cpu", rebalance_every=1, donate_min=4, donate_max=64, ub_gap=2)
+    proved, best = search.maximize()
+    q.put((rank, proved, best, s.done, search.nodes_sent, search.nodes_received, len(s.open)))
+    dist.destroy_process_group()
+
+
+def test_rebalancing_by_best_open_bound_world2_gloo():
+    """No rank runs dry, but one of them sits on all the promising sub-problems: with ub_gap the hand-over starts although
+    every rank has open nodes, point to point (send / recv), and every unit is processed exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_skew_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(o[3] for o in out) == 400 + 12
+    assert all(o[1] is True and o[2] == 100399 for o in out) and all(o[6] == 0 for o in out)
+    assert out[0][4] > 0 and out[1][5] == out[0][4]        # rank 0 gave, rank 1 received the same number
+    assert out[1][3] > 12                                   # ... and worked on them

@@ -86,3 +86,42 @@ def test_two_processes_on_one_gpu_prove_the_optimum(name, expected, width, world
     assert out["handed_over"] == out["received"]
     if "--no-handover" in extra:
         assert out["handed_over"] == 0
+
+
+def _run_dist_main(nproc, args, env_extra=None, timeout=600):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "ddo_amd.dist_main"] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_the_rccl_path_runs_with_one_rank():
+    """backend="nccl" (= RCCL on ROCm) with a world of ONE rank on the single GPU of this box: the process group, the
+    asynchronous MAX all-reduce per epoch, the all-gather of the rebalancing test and the final reductions all go through RCCL
+    once before an 8-GPU node runs them."""
+    r = _run_dist_main(1, [data_path("misp", "brock200_2.clq"), "-w", "100", "-t", "64", "--backend", "nccl", "--force-dist"])
+    assert r["proved"] and r["best_value"] == 12 and r["n_gpus"] == 1 and r["epochs"] > 1
+
+
+@pytest.mark.parametrize("args,expected", [
+    (["data/max2sat/frb10-6-1.wcnf", "-w", "500", "-t", "64"], 37037),
+    (["data/knapsack/f8_l-d_kp_23_10000", "-w", "20", "-t", "16", "--frontier", "--cache", "65536", "--dominance", "4096"], 9767),
+    (["data/mcp/mcp_n30_p0.1_003.mcp", "-w", "50", "-t", "32"], None),
+])
+def test_two_ranks_on_one_gpu_for_the_other_model_families(oracle, args, expected):
+    """dist_main takes any of the five model families (BASELINE config C5 is worded 8 x MI355X for TSPTW): two processes share
+    cuda:0 (gloo rendezvous), each with its shard of the root cut-set, host NoDupFringe, per-GPU cache / dominance tables."""
+    if expected is None:
+        expected = oracle.mcp_file(os.path.join(ROOT, args[0]), 0, 1)[0]
+    r = _run_dist_main(2, args, {"DDO_BENCH_ONE_GPU": "1"})
+    assert r["proved"] and r["best_value"] == expected and r["n_gpus"] == 2
+    assert all(x > 0 for x in r["subproblems_per_rank"])
