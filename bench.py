@@ -216,7 +216,8 @@ def main():
     ap.add_argument("--prove", type=float, default=400.0, metavar="SECONDS",
                     help="after the timed steps (N = 1 only), run the whole search to the PROVED optimum under this time budget and report "
                          "time_to_proved_optimum_s, the second half of BASELINE.json's metric (0 = skip)")
-    ap.add_argument("--prove-concurrent", type=int, default=8192, help="sub-problems in flight during the proof search")
+    ap.add_argument("--prove-concurrent", type=int, default=32768,
+                    help="sub-problems in flight during the proof search (8192: 93 s, 16384: 83 s, 32768: 78 s, 65536+: 79 s on one box, round 3)")
     ap.add_argument("--freeze-stride", type=int, default=0, help="experiments only: take every k-th root cut-set node (default 8 // world)")
     ap.add_argument("--instance", default=INSTANCE)
     ap.add_argument("--width", type=int, default=WIDTH)

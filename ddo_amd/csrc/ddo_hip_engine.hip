@@ -251,6 +251,14 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         const char* env = std::getenv("DDO_HIP_DENSE_TABLE");
         P.tab2_cap = std::min(t2, env ? std::max(64, std::atoi(env)) : 16384);
     }
+    // A WIDE capacity tier (layers of up to some thousand nodes, 256 threads): decision diagrams that are too wide for the
+    // narrow tiers but far from the full width spend their layers waiting on memory round trips with most of a 512-thread
+    // workgroup idle -- four of them per CU instead of two.  Like the dense tier it gets a table smaller than 3 x its layer
+    // capacity (a layer whose nodes and YES-children would fill more than 7/8 of it hands the DD up) and runs the 4-waves-per-SIMD
+    // build of the kernel; like every capacity tier it never squashes.
+    mid_ = owner && !dense_ && tier_threads == 256 && cap_width >= 2048;
+    if (mid_) P.tab2_cap = std::min(t2, 8192);
+    if (mid_ || dense_) P.capS = std::min(P.capS, (int)((long)P.tab2_cap * 7 / 8) + 16);
     long long neg = 0;
     for (int i = 0; i < model->n; ++i)
         if (model->weight[i] < 0) neg += model->weight[i];
@@ -264,7 +272,6 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         // node slots than that: fewer slots = smaller LDS bitmaps, and the room goes to the tie-break keys -- ties of a few
         // hundred nodes are the rule at width 10 000, and ranking them out of LDS costs a fraction of the radix rounds through
         // HBM scratch (round 3: 95 of the 320 kcycles a squashed layer spends on its squash).
-        P.capS = std::min(P.capS, (int)((long)P.tab2_cap * 7 / 8) + 16);
         const char* lenv = std::getenv("DDO_HIP_LEX_CAP");
         int lc = lenv ? P.lex_cap : 1024;
         while (lc > 128 && dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, false, P.hist_bins, lc, model->wsT) > lds_max / 2) lc -= 32;
@@ -276,7 +283,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     size_t lds2 = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, true, P.hist_bins, P.lex_cap, model->wsT);
     const size_t lds2g = dd2_lds_bytes(P.capS, P.tab2_cap, P.npad, threads_, false, P.hist_bins, P.lex_cap, model->wsT);
     // the dedup table always lives in LDS; the ranking keys join it when both fit, else they stay in HBM (L2-hot)
-    keys_global_ = lds2 > (dense_ ? lds_max / 2 : lds_max);
+    keys_global_ = lds2 > (dense_ ? lds_max / 2 : mid_ ? lds_max / 4 : lds_max);   // (room for 2 resp. 4 workgroups per CU)
     if (const char* env = std::getenv("DDO_HIP_KEYS_GLOBAL")) keys_global_ = std::atoi(env) != 0;
     if (keys_global_) lds2 = lds2g;
     if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
@@ -300,8 +307,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     int blocks_per_cu = (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(2048 / threads_));
     blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
     if (dense_) blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, 2));   // 2 x 8 waves at 128 VGPRs
+    else if (mid_) blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, 4));   // 4 x 4 waves at 128 VGPRs
     else if (owner)   // tier kernel: 3 waves per SIMD = 12 waves per CU (kernels_inplace_tier.hip)
-        blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(12 / (threads_ / 64))));
+        blocks_per_cu = std::max(1, (int)std::min<size_t>(lds_max / lds_bytes_, (size_t)(4 * tier_waves_per_simd() / (threads_ / 64))));
     int nslots = prop.multiProcessorCount * blocks_per_cu;
     if (P.tmode) nslots = std::min(nslots, 64);   // every layer of every DD in flight is kept: hundreds of MB per slot at large widths
     if (const char* env = std::getenv(owner ? "DDO_HIP_TIER_SLOTS" : "DDO_HIP_SLOTS")) {
@@ -526,7 +534,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     ev0_ = e0;
     ev1_ = e1;
 
-    kernel_fn fn = dense_ ? pick_kernel2_dense(model->wsT)
+    kernel_fn fn = (dense_ || mid_) ? pick_kernel2_dense(model->wsT)
                    : owner ? pick_kernel2_tier(model->wsT)
                    : engine_kind_ == 2 ? pick_kernel2(model->wsT, threads_)
                                        : pick_kernel(model->wsT, table_lds_);

@@ -221,6 +221,7 @@ class Engine {
     int cap_width_ = 0;              // capacity tier: layer capacity (0 = full-width engine)
     void* kernel_ = nullptr;         // the __global__ entry picked in init(): launch() must use the very same one
     bool dense_ = false;             // two 512-thread workgroups per CU (kernels_inplace_tier.hip: misp_compile_kernel2_dense)
+    bool mid_ = false;               // wide capacity tier: four 256-thread workgroups per CU on the same kernel build
     void decode(const DDResult& r, const uint8_t* arena, HostResult& out) const;
   public:
     /// After wait(), before fetch(): which sub-problems of the finished launch ended with ST_RETRY (a capacity tier hands them

@@ -1497,6 +1497,9 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
         if (s->cfg.width_policy == DDO_WIDTH_FIXED && s->cfg.width >= 4096) {
             spec.push_back({256, 64});
             if (s->cfg.width >= 4096) spec.push_back({1024, 128});
+            // (a wide capacity tier, "4096:256" in DDO_HIP_TIERS -- four 256-thread workgroups per CU, Engine::init: mid_ -- takes
+            // 6 M of the brock400_1 search's DDs off the dense tier and needs as long for them: 12.4 + 36.6 s against 49.4 s.  What
+            // limits those DDs is the memory system all CUs share, not the latency one CU can hide: not in the default list.)
         }
         if (const char* env = std::getenv("DDO_HIP_TIERS")) {   // "0" = none, "256:64,2048:256" = explicit list
             spec.clear();
@@ -1509,7 +1512,7 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
                 const size_t colon = tok.find(':');
                 const int w = std::atoi(tok.c_str());
                 const int th = colon == std::string::npos ? (w <= 512 ? 64 : (w <= 1024 ? 128 : 256)) : std::atoi(tok.c_str() + colon + 1);
-                if (w >= 8 && s->cfg.width_policy == DDO_WIDTH_FIXED && 2 * (size_t)w <= s->cfg.width && spec.size() < 2) spec.push_back({w, th});
+                if (w >= 8 && s->cfg.width_policy == DDO_WIDTH_FIXED && 2 * (size_t)w <= s->cfg.width && spec.size() < 3) spec.push_back({w, th});
                 pos = end + 1;
             }
         }

@@ -19,6 +19,8 @@ kernel_fn pick_kernel2_1024(int wsT);
 kernel_fn pick_kernel2_512(int wsT);
 /// capacity tiers: workgroups of 64..256 threads, 3 waves per SIMD (168 VGPRs: no spills, 12 waves per CU)
 kernel_fn pick_kernel2_tier(int wsT);
+/// waves per SIMD the capacity-tier kernel is compiled for (its register budget): 4 x that many waves share a CU
+int tier_waves_per_simd();
 /// two full-width DDs per CU: 512 threads, 4 waves per SIMD
 kernel_fn pick_kernel2_dense(int wsT);
 kernel_fn pick_kernel_lds(int wsT);

@@ -10,7 +10,10 @@
 namespace ddo_hip {
 
 template <int WS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) misp_compile_kernel2_tier(EngineParams P) {
+#if !defined(DDO_TIER_WAVES)
+#define DDO_TIER_WAVES 3
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDO_TIER_WAVES, DDO_TIER_WAVES))) misp_compile_kernel2_tier(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     DD2Ctx<WS> c;
     dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
@@ -54,6 +57,8 @@ kernel_fn pick_kernel2_dense(int wsT) {
         default: return nullptr;
     }
 }
+
+int tier_waves_per_simd() { return DDO_TIER_WAVES; }
 
 kernel_fn pick_kernel2_tier(int wsT) {
     switch (wsT) {
