@@ -109,7 +109,8 @@ struct DD2Shared {
     int32_t ncut, ncut2;
     uint32_t recycled_merges;
     int32_t maxn;
-    uint32_t kand, kor, pivKey;
+    uint32_t kbits_and[2], kbits_or[2];   // AND / OR of the keys of layer L in slot L & 1: gathered while layer L is built (sweep + expand of L - 1)
+    uint32_t pivKey;
     uint64_t land, lor;
     uint32_t gs[64];
     uint64_t pivLex[1];
@@ -549,43 +550,18 @@ DDO_DEV int32_t rub2_of(const DD2Ctx<WS>& c, const uint64_t* s) {
 /// sweep costs hi / (NT * KB) dependent round trips instead of hi / NT.
 /// DEEP (workgroups of up to 512 threads: 256 VGPRs per lane) doubles the loads in flight per thread in every sweep.
 template <int WS, int DEEP = 0>
-DDO_DEV void select_key2(DD2Ctx<WS>& c, int K) {
+DDO_DEV void select_key2(DD2Ctx<WS>& c, int K, int L) {
     constexpr int KB = DEEP ? 16 : 8;
     DD_TID_SETUP(c)
     LDS_PTR(DD2Shared) sh = c.sh;
     const int hi = DD_UNIFORM(sh->hiw);
-    PAR_BEGIN
-    if (tid == 0) {
-        sh->kand = 0xFFFFFFFFu;
-        sh->kor = 0;
-    }
-    PAR_END
-    PAR_BEGIN
-    uint32_t a = 0xFFFFFFFFu, o = 0;
-    for (int base = 0; base < hi; base += NT * KB) {
-        uint32_t kk[KB];
-#pragma unroll
-        for (int b = 0; b < KB; ++b) {
-            const int s = base + b * NT + tid;
-            kk[b] = s < hi ? K32(c, s) : 0u;
-        }
-#pragma unroll
-        for (int b = 0; b < KB; ++b) {
-            const int s = base + b * NT + tid;
-            if (s < hi && bm_test(c.live, s)) {
-                a &= kk[b];
-                o |= kk[b];
-            }
-        }
-    }
-    if (a != 0xFFFFFFFFu || o != 0) {
-        LDS_AND_U32(&sh->kand, a);
-        LDS_OR_U32(&sh->kor, o);
-    }
-    PAR_END
+    // Which key bits vary at all?  The AND / OR of the keys was gathered while the layer was built -- by the work-list sweep of the
+    // previous transition (every node it saw) and by expand (both children of every branching node): a superset of the layer's
+    // keys, which is all the skipping of constant digits needs, and one sweep over the keys less per squash.
     int need = K;
     bool done = false;
-    const uint32_t diff = sh->kand ^ sh->kor;
+    const uint32_t kand = sh->kbits_and[L & 1], kor = sh->kbits_or[L & 1];
+    const uint32_t diff = kand ^ kor;
     uint32_t piv = 0;
     // digits of key32, most significant first: bits 22..31, 11..21, 0..10
     // (a dense tier has 256 bins: four 8-bit digits)
@@ -597,7 +573,7 @@ DDO_DEV void select_key2(DD2Ctx<WS>& c, int K) {
         const int shift = dshift[d];
         const uint32_t dmask = (1u << dbits[d]) - 1;
         if (((diff >> shift) & dmask) == 0) {
-            piv |= sh->kand & (dmask << shift);
+            piv |= kand & (dmask << shift);
             continue;
         }
         const int nb = 1 << dbits[d];
@@ -894,6 +870,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         sh->nlive = 1;
         sh->hiw = 1;
         sh->varkey = 0xFFFFFFFFu;
+        sh->kbits_and[0] = sh->kbits_and[1] = 0xFFFFFFFFu;
+        sh->kbits_or[0] = sh->kbits_or[1] = 0;
         sh->nwl = 0;
         sh->nwl2 = 0;
         sh->nrec = 0;
@@ -997,7 +975,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
             const int K = restricted ? W : W - 1;
-            if (K > 0) select_key2<WS, DEEP>(c, K);
+            if (K > 0) select_key2<WS, DEEP>(c, K, L);
             DD2_TICK(PH_SELECT)
             PAR_BEGIN
             if (tid == 0) {
@@ -1304,6 +1282,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         }
         const int vw = var >> 6;
         const uint64_t vbit = 1ULL << (var & 63);
+
         // One sweep over the live slots does two jobs: (1) the work list -- nodes that contain the variable go to the
         // front of `wl`, fresh nodes that do not (their rough upper bound was never checked) to its back; (2) every
         // other node stays unchanged in the next layer and enters the dedup table right away with its cached hash
@@ -1316,6 +1295,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #endif
         PAR_BEGIN
         {
+            uint32_t kb_and = 0xFFFFFFFFu, kb_or = 0;   // key bits of the nodes seen (for the select of the next layer)
 #if defined(DDO_WORD_MAJOR)
             const uint64_t* row = c.st + (size_t)vw * capS;
 #else
@@ -1348,6 +1328,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     pslot[b] = (uint32_t)hh[b] & ((uint32_t)c.tab_cap - 1);
                     pmine[b] = (((uint32_t)hh[b] >> 20) << 20) | (uint32_t)s;
                     if (s >= hi || !bm_test(c.live, s)) continue;
+                    kb_and &= (uint32_t)(hh[b] >> 32);
+                    kb_or |= (uint32_t)(hh[b] >> 32);
                     if ((ww[b] & vbit) != 0) {
                         const int i = LDS_ADD_I32(&sh->nwl, 1);
                         if (i < c.capW) c.wl[i] = (uint16_t)s;
@@ -1385,6 +1367,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     if (!any) break;
                     if (round == c.tab_cap) sh->status = ST_ERR_INTERNAL;
                 }
+            }
+            if (kb_or != 0 || kb_and != 0xFFFFFFFFu) {
+                LDS_AND_U32(&sh->kbits_and[(L + 1) & 1], kb_and);
+                LDS_OR_U32(&sh->kbits_or[(L + 1) & 1], kb_or);
             }
         }
         PAR_END
@@ -1487,6 +1473,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         uint64_t probe[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t probe_t = probing ? dd_clock() : 0;
 #endif
+        uint32_t kb_and = 0xFFFFFFFFu, kb_or = 0;   // key bits of the children (for the select of the next layer)
         for (int i = tid; i < nwl; i += NT) {
             const int s = c.wl[i];
             const uint64_t kh = KH(c, s);
@@ -1527,6 +1514,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             const uint32_t newh = oldh ^ fold32(mixw(oldw, vw) ^ mixw(neww, vw));   // (the hash is XOR-linear in the per-word mixes)
             st_node<WS>(c, s, st, ppid);   // (one word changed: the whole line goes out, see st_node)
             const uint32_t kno = key - 1;  // popcount - 1, same value (cost 0)
+            kb_and &= kno;
+            kb_or |= kno;
             KH_ST(c, s, kno, newh);   // (cnt[var]: no state of the next layer contains the variable, it is zeroed with the layer)
             // ---- decision YES into a free slot (main.rs:95-102)
             const int r = LDS_ADD_I32(&sh->nrec, 1);                       // this node's event record ...
@@ -1551,6 +1540,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 yh = hash32_state<WS>(y);
                 st_node<WS>(c, ny, y, eid);
                 kyes = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | (uint32_t)ypop;
+                kb_and &= kyes;
+                kb_or |= kyes;
                 KH_ST(c, ny, kyes, yh);
                 bm_put(c.inex, ny, bm_test(c.inex, s));
                 bm_put(c.okb, ny, bm_test(c.okb, s));
@@ -1602,6 +1593,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 sh->mk[23] += 1;
             }
 #endif
+        }
+        if (kb_or != 0 || kb_and != 0xFFFFFFFFu) {
+            LDS_AND_U32(&sh->kbits_and[(L + 1) & 1], kb_and);
+            LDS_OR_U32(&sh->kbits_or[(L + 1) & 1], kb_or);
         }
         PAR_END
         const int nrec = DD_UNIFORM(sh->nrec);
@@ -1664,6 +1659,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     #if defined(DDO_HOST_EMULATION)
                 if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
     #endif
+                sh->kbits_and[L & 1] = 0xFFFFFFFFu;   // (this layer's select is over: the slot is filled again while layer L + 1 is built)
+                sh->kbits_or[L & 1] = 0;
                 sh->varkey = 0xFFFFFFFFu;   // next layer's next_variable / high-water mark / work lists start from scratch
                 sh->hiw = 1;
                 sh->nwl = 0;
@@ -1718,6 +1715,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     #if defined(DDO_HOST_EMULATION)
                 if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
     #endif
+                sh->kbits_and[L & 1] = 0xFFFFFFFFu;   // (this layer's select is over: the slot is filled again while layer L + 1 is built)
+                sh->kbits_or[L & 1] = 0;
                 sh->varkey = 0xFFFFFFFFu;   // next layer's next_variable / high-water mark / work lists start from scratch
                 sh->hiw = 1;
                 sh->nwl = 0;
