@@ -9,7 +9,7 @@ run() {  # nproc, extra args...
   local n=$1; shift
   local port=$((20000 + RANDOM % 20000))
   DDO_BENCH_ONE_GPU=1 DDO_HIP_POOL_GB=8 timeout -s KILL 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=$n --master-addr 127.0.0.1 --master-port $port \
-      -m ddo_amd.dist_main "$@" 2>/dev/null | grep '^{' | tail -1 | sed "s/^{/{\"args\": \"$*\", /" >> $OUT
+      -m ddo_amd.dist_main "$@" 2>/dev/null | grep '^{' | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); d['args'] = sys.argv[1]; print(json.dumps(d))" "$*" >> $OUT
 }
 for inst in "data/misp/brock200_4.clq -w 200 -t 256" "data/misp/p_hat300-1.clq -w 500 -t 256" "data/misp/brock200_1.clq -w 500 -t 512"; do
   for n in 1 2 4 8; do
