@@ -211,7 +211,9 @@ class DistributedSearch:
                 break
             dry = -neg_min_open == 0 and max_open >= 2 * self.donate_min
             skew = self.ub_gap > 0 and neg_min_top > I64_LOW and max_top + neg_min_top >= self.ub_gap and max_open >= 4 * self.donate_min
-            if self.epochs % self.rebalance_every == 0 and (dry or skew):
+            # (a dry rank is served at the next rebalancing epoch, a mere skew of the bounds four times less often: a hand-over
+            # costs an export, a transfer and an import -- profiles/r03/dist_overhead.jsonl)
+            if (dry and self.epochs % self.rebalance_every == 0) or (skew and self.epochs % (4 * self.rebalance_every) == 0):
                 # every rank saw the same reduced values: all of them take this branch together
                 last = self._drain()
                 if last is not None and last[0] > I64_LOW:
