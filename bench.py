@@ -391,6 +391,9 @@ def main():
             "config": {"workload": f"MISP {args.instance}.clq FixedWidth({args.width}) LEL cut-set, EmptyCache, SimpleFringe(MaxUB) kept in "
                                    f"the device node pool; frozen workload per GPU: {solver.bench_frozen()} sub-problems of the root cut-set "
                                    f"(every {stride}-th node of the rank's shard in fringe order), {nfrozen} batch(es), cycled",
+                       "dense_tier": ("on" if os.environ.get("DDO_HIP_DENSE", "1") != "0" else "off") +
+                                     " (default on: two 512-thread decision diagrams per CU; round 3, one box: on 1.703e10 nodes/s / 30.6 % of the"
+                                     " roofline, off -- DDO_HIP_DENSE=0, the 1024-thread kernel, one per CU -- 1.552e10 / 27.9 %)",
                        "subproblems_per_step": conc, "frozen_batches": nfrozen, "prefix_steps": PREFIX_STEPS,
                        "parallelism": f"fringe-shard x{world}"},
             "subproblems_per_s": subs / elapsed,
