@@ -164,6 +164,7 @@ struct EngineParams {
     int32_t tab2_cap;          // dedup table slots (power of two, LDS)
     int32_t vbase_off;         // lowest reachable value relative to the residual value (sum of negative weights)
     int32_t model_kind;        // MODEL_MISP | MODEL_KNAPSACK
+    int32_t lists_in_lds;      // in-place engine, narrow capacity tiers: work / free lists live in LDS behind the shared block
     int32_t keys_global;       // in-place engine: 1 = ranking keys live in HBM packed with the hashes (s_hash holds key32 << 32 | h32), 0 = keys in LDS
     const int32_t* kp_weight;  // knapsack: item weights [n]   (`weight` holds the profits)
     const int32_t* kp_order;   // knapsack: items by decreasing profit / weight [n]

@@ -298,6 +298,10 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         return DDO_ERR_UNSUPPORTED;
     }
     if (engine_kind_ == 2) lds_bytes_ = lds2;
+    if (engine_kind_ == 2 && owner && !dense_ && !mid_ && P.capW <= 512 && !std::getenv("DDO_HIP_LISTS_GLOBAL")) {
+        P.lists_in_lds = 1;
+        lds_bytes_ += ((size_t)4 * P.capW + 15) & ~(size_t)15;
+    }
     if (dense_ && (lds_bytes_ > lds_max / 2 || (long)P.tab2_cap * 7 / 8 < P.capW + 8)) {   // (the sweep alone inserts up to capW nodes)
         set_error("Engine::create_tier: the dense tier does not fit two workgroups per CU at this width");
         return DDO_ERR_UNSUPPORTED;

@@ -127,7 +127,7 @@ struct DD2Shared {
 };
 
 /// LDS bytes of the shared block of a WS-word engine
-inline size_t dd2_shared_bytes(int ws) { return (offsetof(DD2Shared, merged) + (size_t)ws * 8 + 15) & ~(size_t)15; }
+DD_HD inline size_t dd2_shared_bytes(int ws) { return (offsetof(DD2Shared, merged) + (size_t)ws * 8 + 15) & ~(size_t)15; }
 
 // DD2_STAT(k, v): profiling statistics (DDO_HIP_STATS) accumulated next to the code marks; workgroup-uniform context
 #define DD2_STAT(k, v)                                      \
@@ -2232,6 +2232,10 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.tcount2 = (LDS_PTR(int32_t))p;
     p += (size_t)dd2_tcount_len(nthreads, c.lex_cap) * 4;
     c.sh = (LDS_PTR(DD2Shared))p;
+    if (P.lists_in_lds) {   // narrow capacity tiers: the work / free lists (2 x capW x u16) behind the shared block -- one global round trip
+        c.wl = (uint16_t*)(p + dd2_shared_bytes(WS));   // less between the sweep that writes them and the expand that reads them
+        c.fl = c.wl + capW;
+    }
     c.arena = P.arena;
     c.arena_cap = P.arena_cap;
     c.arena_head = P.arena_head;
