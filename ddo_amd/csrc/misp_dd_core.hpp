@@ -654,6 +654,54 @@ DDO_DEV uint32_t dedup_insert(const DDCtx<WS>& c, int nxt, uint32_t cd, const ui
     return cd;
 }
 
+/// hash_state as a stream: h = hash_begin(); h = hash_step(h, word) for every state word in order; hash_end(h)
+DDO_DEV uint64_t hash_begin() { return 0x243F6A8885A308D3ULL; }
+DDO_DEV uint64_t hash_step(uint64_t h, uint64_t w) {
+    h ^= w;
+    h *= 0x9E3779B97F4A7C15ULL;
+    h ^= h >> 29;
+    return h;
+}
+DDO_DEV uint64_t hash_end(uint64_t h) {
+    h *= 0xBF58476D1CE4E5B9ULL;
+    h ^= h >> 32;
+    return h;
+}
+/// dedup_insert for a candidate whose state words ALREADY lie in cstate[nxt] (written by the caller, fenced) and whose hash the
+/// caller computed while it wrote them: the wide signed-vector states (31 to 72 words) are never held in a per-thread array --
+/// three such arrays per thread were 400+ registers, i.e. scratch memory, and the expansion of a MAX2SAT layer spent its time
+/// there (round 3: 2 600 cycles per node).  A tag match is verified word against word out of cstate[nxt], eight words per batch.
+template <int WS>
+DDO_DEV uint32_t dedup_insert_stored(const DDCtx<WS>& c, int nxt, uint32_t cd, uint64_t h, int mask) {
+    const uint32_t tag = (uint32_t)(h >> 52);  // 12 bits
+    const uint32_t mine = (tag << 20) | cd;
+    uint32_t slot = (uint32_t)h & (uint32_t)mask;
+    const uint64_t* st = c.cstate[nxt];
+    for (int probes = 0; probes <= mask; ++probes) {   // bounded: a full table is an internal error, not a hang
+        const uint32_t e = TAB_CAS(&c.table[slot], TAB_EMPTY, mine);
+        if (e == TAB_EMPTY) return cd;
+        if ((e >> 20) == tag) {
+            const uint32_t w = e & 0xFFFFFu;
+            bool eq = true;
+            for (int k0 = 0; k0 < WS && eq; k0 += 8) {
+                uint64_t a[8], b[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool in = k0 + q < WS;
+                    a[q] = in ? LD_U64(&st[(size_t)(k0 + q) * c.capC1 + w]) : 0;
+                    b[q] = in ? LD_U64(&st[(size_t)(k0 + q) * c.capC1 + cd]) : 0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) eq &= a[q] == b[q];
+            }
+            if (eq) return w;
+        }
+        slot = (slot + 1) & (uint32_t)mask;
+    }
+    c.sh->status = ST_ERR_INTERNAL;
+    return cd;
+}
+
 /// read-only probe (recycled-merge detection, clean.rs:830): candidate holding state s, or NONE32
 template <int WS>
 DDO_DEV uint32_t dedup_find(const DDCtx<WS>& c, int buf, const uint64_t* s, int mask) {
@@ -1357,6 +1405,152 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         int myarcs = 0, myuniq = 0;
         for (int pos = tid; pos < n; pos += NT) {
             const uint32_t p = c.keep[pos];
+            if (dd_is_vec(c.kind)) {
+                // ---- signed-vector models, STREAMED: the parent's words are read, turned into the two children's words and written
+                // out one at a time (hashes and sums accumulate alongside); no per-thread state arrays (see dedup_insert_stored)
+                const uint64_t pkey = LD_U64(&c.ckey[cur][p]);
+                const int32_t val = unbias32((uint32_t)(pkey >> 32));
+                const int pop = (int)c.cpop[cur][p];
+                const uint32_t pfl = LD_U32(&c.cflags[cur][p]);
+                const uint32_t inexact = (pfl & (NF_INEXACT | NF_RELAXED)) ? NF_INEXACT : 0u;
+                const uint32_t pok = (!inexact || (!(pfl & NF_RELAXED) && (uint32_t)pkey != NONE32 && ((uint32_t)pkey & KEY_OK))) ? KEY_OK : 0u;
+                const int depth = c.depth0 + L;
+                const uint64_t* src = c.cstate[cur] + p;
+                uint64_t* dst = c.cstate[nxt];
+                const int dw = (c.n + 1) / 2;   // index of the depth word
+                int32_t rub;
+                if (c.kind == MODEL_MAX2SAT) {   // max2sat/model.rs:231-240
+                    rub = depth >= c.n ? 0 : pop + c.vest[depth] - c.vr + c.vnk[depth];
+                } else {                          // mcp/relax.rs:123-130: sum of |benefit| over the vertices >= depth
+                    int32_t r = 0;
+#pragma unroll 4
+                    for (int k = 0; k < WS; ++k) {
+                        const uint64_t sw = src[(size_t)k * capC1];
+                        if (2 * k >= depth && 2 * k < c.n) r += iabs32((int32_t)(uint32_t)sw);
+                        if (2 * k + 1 >= depth && 2 * k + 1 < c.n) r += iabs32((int32_t)(uint32_t)(sw >> 32));
+                    }
+                    rub = r + c.vest[depth] - c.vr + c.vnk[depth];
+                }
+                if (c.tmode) c.lrub[(size_t)L * LS + pos] = rub;
+                if (rub == RUB_NEG_INF || (int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365
+                    for (int d = 0; d < c.fan; ++d) c.ctarget[(size_t)d * capN + pos] = NONE32;
+                    continue;
+                }
+                const uint32_t cd0 = (uint32_t)pos, cd1 = (uint32_t)(capN + pos);
+                int32_t sum0 = 0, sum1 = 0, rank0 = 0, rank1 = 0, sx = 0;
+                uint64_t h0 = hash_begin(), h1 = hash_begin();
+                const bool two = !(c.kind == MODEL_MCP && depth == 0);   // MCP: the first vertex is fixed on side S (model.rs:60-63)
+                if (c.kind == MODEL_MAX2SAT) {
+                    // max2sat/model.rs:270-329 (side 0 = T, side 1 = F)
+                    const int kx = var, nfree = c.n - depth - 1;
+                    const size_t row = (size_t)kx * c.n;
+                    sum0 = c.m2_wtt[row + kx];
+                    sum1 = c.m2_wff[row + kx];   // unit clauses (k) / (-k)
+#pragma unroll 2
+                    for (int k = 0; k < WS; ++k) {
+                        const uint64_t sw = src[(size_t)k * capC1];
+                        uint64_t w0 = 0, w1 = 0;
+#pragma unroll
+                        for (int hsel = 0; hsel < 2; ++hsel) {
+                            const int v = 2 * k + hsel;
+                            if (v >= c.n) continue;
+                            const int32_t sl = (int32_t)(uint32_t)(sw >> (32 * hsel));
+                            int32_t a = sl, b = sl;                       // child benefit under T / under F
+                            if (v == kx) {
+                                sx = sl;
+                                a = b = 0;
+                            } else if (c.m2_rankpos[v] < nfree) {
+                                const int32_t wtt = c.m2_wtt[row + v], wtf = c.m2_wtf[row + v];
+                                const int32_t wft = c.m2_wft[row + v], wff = c.m2_wff[row + v];
+                                const int32_t ps = sl > 0 ? sl : 0, ns = sl < 0 ? -sl : 0;
+                                const int32_t mt = ps + wft < ns + wff ? ps + wft : ns + wff;
+                                const int32_t mf = ps + wtt < ns + wtf ? ps + wtt : ns + wtf;
+                                sum0 += (wtf + wtt) + mt;
+                                sum1 += (wff + wft) + mf;
+                                a = sl + wft - wff;
+                                b = sl + wtt - wtf;
+                            }
+                            rank0 += iabs32(a);
+                            rank1 += iabs32(b);
+                            w0 |= (uint64_t)(uint32_t)a << (32 * hsel);
+                            w1 |= (uint64_t)(uint32_t)b << (32 * hsel);
+                        }
+                        if (k == dw) w0 = w1 = (uint64_t)(depth + 1);   // depth word
+                        dst[(size_t)k * capC1 + cd0] = w0;
+                        dst[(size_t)k * capC1 + cd1] = w1;
+                        h0 = hash_step(h0, w0);
+                        h1 = hash_step(h1, w1);
+                    }
+                } else {
+                    // mcp/model.rs:60-130 (side 0 = S, side 1 = T)
+                    const int x = var;
+                    const int32_t* wrow = c.vgraph + (size_t)x * c.n;
+#pragma unroll 2
+                    for (int k = 0; k < WS; ++k) {
+                        const uint64_t sw = src[(size_t)k * capC1];
+                        uint64_t w0 = 0, w1 = 0;
+#pragma unroll
+                        for (int hsel = 0; hsel < 2; ++hsel) {
+                            const int v = 2 * k + hsel;
+                            if (v >= c.n) continue;
+                            const int32_t skl = (int32_t)(uint32_t)(sw >> (32 * hsel));
+                            if (v == x) sx = skl;
+                            if (v < x) continue;
+                            const int32_t wkl = wrow[v];
+                            const int32_t mn = iabs32(skl) < iabs32(wkl) ? iabs32(skl) : iabs32(wkl);
+                            const int64_t prod = (int64_t)skl * (int64_t)wkl;
+                            if (prod <= 0) sum0 += mn;
+                            if (prod >= 0) sum1 += mn;
+                            const int32_t a = skl + wkl, b = skl - wkl;
+                            rank0 += iabs32(a);
+                            rank1 += iabs32(b);
+                            w0 |= (uint64_t)(uint32_t)a << (32 * hsel);
+                            w1 |= (uint64_t)(uint32_t)b << (32 * hsel);
+                        }
+                        if (k == dw) w0 = w1 = (uint64_t)(depth + 1);   // depth word
+                        dst[(size_t)k * capC1 + cd0] = w0;
+                        if (two) dst[(size_t)k * capC1 + cd1] = w1;
+                        h0 = hash_step(h0, w0);
+                        h1 = hash_step(h1, w1);
+                    }
+                }
+                int32_t cost0, cost1;
+                if (c.kind == MODEL_MAX2SAT) {
+                    cost0 = (sx > 0 ? sx : 0) + sum0;
+                    cost1 = (sx < 0 ? -sx : 0) + sum1;
+                } else {
+                    cost0 = depth == 0 ? 0 : (sx < 0 ? -sx : 0) + sum0;
+                    cost1 = depth == 0 ? 0 : (sx > 0 ? sx : 0) + sum1;
+                }
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t cd = side == 0 ? cd0 : cd1;
+                    if (side == 1 && !two) {
+                        c.ctarget[cd] = NONE32;
+                        break;
+                    }
+                    const int32_t cost = side == 0 ? cost0 : cost1;
+                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
+                    c.ckey[nxt][cd] = mykey;
+                    ac_next[cd] = cost;
+                    c.cpop[nxt][cd] = (uint32_t)(side == 0 ? rank0 : rank1);
+                    c.cflags[nxt][cd] = inexact;
+                }
+                FENCE_BLOCK();   // both children are visible to the workgroup before the table publishes them
+                for (int side = 0; side < (two ? 2 : 1); ++side) {
+                    const uint32_t cd = side == 0 ? cd0 : cd1;
+                    const int32_t cost = side == 0 ? cost0 : cost1;
+                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
+                    const uint32_t w = dedup_insert_stored<WS>(c, nxt, cd, hash_end(side == 0 ? h0 : h1), hmask);
+                    c.ctarget[cd] = w;
+                    ++myarcs;
+                    if (w == cd) ++myuniq;
+                    else {
+                        GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
+                        if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
+                    }
+                }
+                continue;
+            }
             uint64_t s[WS];
 #pragma unroll
             for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + p];
