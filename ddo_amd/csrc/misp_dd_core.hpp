@@ -1101,13 +1101,15 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 #pragma unroll
                             for (int k = 0; k < WS; ++k) {
                                 const int32_t a0 = (int32_t)(uint32_t)s[k], a1 = (int32_t)(uint32_t)(s[k] >> 32);
+                                // (the minimum settles after a few victims: a plain read -- same address for the whole wave, a
+                                // broadcast -- spares the atomic, which the hardware runs lane after lane)
                                 if (2 * k < c.n) {
-                                    LDS_MIN_U32(&sh->vmin[2 * k], (uint32_t)iabs32(a0));
+                                    if ((uint32_t)iabs32(a0) < sh->vmin[2 * k]) LDS_MIN_U32(&sh->vmin[2 * k], (uint32_t)iabs32(a0));
                                     if (a0 > 0) pm[(2 * k) >> 6] |= 1ULL << ((2 * k) & 63);
                                     if (a0 < 0) nm[(2 * k) >> 6] |= 1ULL << ((2 * k) & 63);
                                 }
                                 if (2 * k + 1 < c.n) {
-                                    LDS_MIN_U32(&sh->vmin[2 * k + 1], (uint32_t)iabs32(a1));
+                                    if ((uint32_t)iabs32(a1) < sh->vmin[2 * k + 1]) LDS_MIN_U32(&sh->vmin[2 * k + 1], (uint32_t)iabs32(a1));
                                     if (a1 > 0) pm[(2 * k + 1) >> 6] |= 1ULL << ((2 * k + 1) & 63);
                                     if (a1 < 0) nm[(2 * k + 1) >> 6] |= 1ULL << ((2 * k + 1) & 63);
                                 }
