@@ -1087,37 +1087,36 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     if (!keepit) {
                         cl = 2;
                         uint64_t s[WS];
+                        if (!dd_is_vec(c.kind)) {   // (the wide signed-vector states are streamed below, word by word: no array)
 #pragma unroll
-                        for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + cd];
+                            for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + cd];
+                        }
                         if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);  // it leaves the layer
                         if (relaxed && dd_is_vec(c.kind)) {
                             // McpRelax::merge (relax.rs:141-176): per variable the signs seen and the smallest |benefit|;
                             // relax (relax.rs:115-121) adds rank(victim) - rank(merged) to every redirected arc, so the
                             // merged node's value is max(value + rank) over the victims minus its own rank
-                            constexpr int NMW = (2 * WS + 63) / 64;
-                            uint64_t pm[NMW], nm[NMW];
-#pragma unroll
-                            for (int q = 0; q < NMW; ++q) pm[q] = nm[q] = 0;
-#pragma unroll
+                            uint64_t pmw = 0, nmw = 0;   // sign masks of the 64 variables of the current mask word (32 state words)
+#pragma unroll 4
                             for (int k = 0; k < WS; ++k) {
-                                const int32_t a0 = (int32_t)(uint32_t)s[k], a1 = (int32_t)(uint32_t)(s[k] >> 32);
+                                if (2 * k >= c.n) break;
+                                const uint64_t sw = c.cstate[cur][(size_t)k * capC1 + cd];
+                                const int32_t a0 = (int32_t)(uint32_t)sw, a1 = (int32_t)(uint32_t)(sw >> 32);
                                 // (the minimum settles after a few victims: a plain read -- same address for the whole wave, a
                                 // broadcast -- spares the atomic, which the hardware runs lane after lane)
-                                if (2 * k < c.n) {
-                                    if ((uint32_t)iabs32(a0) < sh->vmin[2 * k]) LDS_MIN_U32(&sh->vmin[2 * k], (uint32_t)iabs32(a0));
-                                    if (a0 > 0) pm[(2 * k) >> 6] |= 1ULL << ((2 * k) & 63);
-                                    if (a0 < 0) nm[(2 * k) >> 6] |= 1ULL << ((2 * k) & 63);
-                                }
+                                if ((uint32_t)iabs32(a0) < sh->vmin[2 * k]) LDS_MIN_U32(&sh->vmin[2 * k], (uint32_t)iabs32(a0));
+                                if (a0 > 0) pmw |= 1ULL << ((2 * k) & 63);
+                                if (a0 < 0) nmw |= 1ULL << ((2 * k) & 63);
                                 if (2 * k + 1 < c.n) {
                                     if ((uint32_t)iabs32(a1) < sh->vmin[2 * k + 1]) LDS_MIN_U32(&sh->vmin[2 * k + 1], (uint32_t)iabs32(a1));
-                                    if (a1 > 0) pm[(2 * k + 1) >> 6] |= 1ULL << ((2 * k + 1) & 63);
-                                    if (a1 < 0) nm[(2 * k + 1) >> 6] |= 1ULL << ((2 * k + 1) & 63);
+                                    if (a1 > 0) pmw |= 1ULL << ((2 * k + 1) & 63);
+                                    if (a1 < 0) nmw |= 1ULL << ((2 * k + 1) & 63);
                                 }
-                            }
-#pragma unroll
-                            for (int q = 0; q < (2 * WS + 63) / 64; ++q) {
-                                if (pm[q]) LDS_OR_U64(&sh->vposmask[q], pm[q]);
-                                if (nm[q]) LDS_OR_U64(&sh->vnegmask[q], nm[q]);
+                                if ((k & 31) == 31 || 2 * (k + 1) >= c.n) {   // the mask word is complete
+                                    if (pmw) LDS_OR_U64(&sh->vposmask[k >> 5], pmw);
+                                    if (nmw) LDS_OR_U64(&sh->vnegmask[k >> 5], nmw);
+                                    pmw = nmw = 0;
+                                }
                             }
                             const int32_t adj = unbias32((uint32_t)(key >> 32)) + (int32_t)c.cpop[cur][cd];
                             const uint64_t akey = ((uint64_t)bias32(adj) << 32) | (uint32_t)key;
