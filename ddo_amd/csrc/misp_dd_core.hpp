@@ -512,6 +512,19 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
     // ---- tie-break: lexicographic member order; digit = byte of brev(~word), MSB first
     // The pivot words live in LDS (sh->pivLex, zeroed above); only the word in progress is a register: a local array
     // indexed by the running word number would sit in scratch memory (31- and 69-word states).
+    // Which candidates are still tied with the pivot is kept as a byte per candidate (c.cls: the classification that follows
+    // overwrites every entry): a sweep of a later word then costs one byte per candidate and one state word per TIED candidate.
+    // (Until round 3 every sweep re-compared all the words before wj: with 31- to 72-word states and a sweep or two per word,
+    // the selection of a MAX2SAT layer was a quarter of its time.)
+    if (!done) {
+        PAR_BEGIN
+        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+        for (int j = lo; j < hi; ++j) {
+            int cd = lin2cand(j, nprev, c.capN);
+            c.cls[cd] = (cand_live(c, cur, cd) && k1_of(LD_U64(&key[cd]), pop[cd]) == pivK1) ? 1 : 0;
+        }
+        PAR_END
+    }
     uint64_t pw = 0;
     uint64_t ldiff = 0, land = 0;   // bits of word wj in which the nodes still tied differ / agree on 1
     for (int qd = 0; qd < 8 * WS && !done; ++qd) {
@@ -532,12 +545,7 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
             int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
             for (int j = lo; j < hi; ++j) {
                 int cd = lin2cand(j, nprev, c.capN);
-                if (!cand_live(c, cur, cd)) continue;
-                if (k1_of(LD_U64(&key[cd]), pop[cd]) != pivK1) continue;
-                bool active = true;
-                for (int k = 0; k < wj && active; ++k)
-                    active = lexkey(c, st[(size_t)k * capC1 + cd]) == sh->pivLex[k];
-                if (!active) continue;
+                if (!c.cls[cd]) continue;
                 const uint64_t lw = lexkey(c, st[(size_t)wj * capC1 + cd]);
                 a &= lw;
                 o |= lw;
@@ -561,12 +569,7 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
         for (int j = lo; j < hi; ++j) {
             int cd = lin2cand(j, nprev, c.capN);
-            if (!cand_live(c, cur, cd)) continue;
-            if (k1_of(LD_U64(&key[cd]), pop[cd]) != pivK1) continue;
-            bool active = true;
-            for (int k = 0; k < wj && active; ++k)
-                active = lexkey(c, st[(size_t)k * capC1 + cd]) == sh->pivLex[k];
-            if (!active) continue;
+            if (!c.cls[cd]) continue;
             uint64_t lw = lexkey(c, st[(size_t)wj * capC1 + cd]);
             if (shift + 8 < 64 && (lw >> (shift + 8)) != (pw >> (shift + 8))) continue;
             LDS_ADD_U32(&c.hist[(lw >> shift) & 0xFF], 1u);
@@ -591,6 +594,13 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         if (done || (qd & 7) == 7) {   // the word is finished (or the selection is): publish it
             PAR_BEGIN
             if (tid == 0) sh->pivLex[wj] = pw;
+            if (!done && ldiff != 0) {   // candidates whose word differs from the pivot's are decided: no longer tied
+                int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
+                for (int j = lo; j < hi; ++j) {
+                    int cd = lin2cand(j, nprev, c.capN);
+                    if (c.cls[cd] && lexkey(c, st[(size_t)wj * capC1 + cd]) != pw) c.cls[cd] = 0;
+                }
+            }
             PAR_END
         }
     }
