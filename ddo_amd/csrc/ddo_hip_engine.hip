@@ -674,6 +674,18 @@ int Engine::read_pool(uint64_t off, void* dst, size_t bytes) {
     return DDO_OK;
 }
 
+int Engine::read_pool_strided(uint64_t off, uint64_t* dst, size_t count, size_t stride_bytes) {
+    std::lock_guard<std::mutex> g(mtx_);
+    if (count == 0) return DDO_OK;
+    if (!P_.pool || off + (count - 1) * stride_bytes + 8 > P_.pool_cap) {
+        set_error("read_pool_strided: out of range");
+        return DDO_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipMemcpy2D(dst, 8, P_.pool + off, stride_bytes, 8, count, hipMemcpyDeviceToHost));
+    return DDO_OK;
+}
+
 DominanceTable* DominanceTable::create(const Model* model, int device, size_t capacity_per_depth) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {

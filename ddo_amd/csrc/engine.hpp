@@ -209,6 +209,8 @@ class Engine {
     /// appends a host-built block to the node pool (imported sub-problems); call with no launch in flight
     int pool_append(const void* data, size_t bytes, uint64_t* off);
     int read_pool(uint64_t off, void* dst, size_t bytes);
+    /// `count` 8-byte words that lie `stride_bytes` apart (one row of a word-major matrix in a pool block) with ONE copy
+    int read_pool_strided(uint64_t off, uint64_t* dst, size_t count, size_t stride_bytes);
     int words_per_state_device() const { return P_.ws; }
 
   private:

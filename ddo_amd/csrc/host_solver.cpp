@@ -25,6 +25,7 @@
 #include <limits>
 #include <map>
 #include <thread>
+#include <unordered_map>
 
 #include "../../include/ddo_hip.h"
 #include "engine.hpp"
@@ -626,6 +627,15 @@ struct ddo_solver {
     }
 
     /// problem-root path of a pool node: decisions stored as bit strings + per-block variable lists in HBM
+    /// per export call: what materialize_pool_path has read from the device so far -- a block's header and branching vertices,
+    /// the decisions of a (block, row) segment.  The nodes a rank hands over are the best of its fringe: siblings and cousins
+    /// that share nearly all of their ancestor chains (round 3: 1.5 M nodes handed over in a two-rank search cost minutes of
+    /// 8-byte device reads, one per header, vertex list and path word of every ancestor of every node).
+    struct BlockHdr { PoolBlockHeader h; std::vector<uint32_t> lvar; };
+    std::unordered_map<const DevBlock*, BlockHdr> x_hdr;
+    std::map<std::pair<const DevBlock*, int>, std::vector<ddo_decision>> x_seg;
+    bool x_cache = false;
+
     int materialize_pool_path(const DevBlock* b, int row, std::vector<ddo_decision>& out) {
         std::vector<std::pair<const DevBlock*, int>> chain;
         while (b) {
@@ -641,16 +651,37 @@ struct ddo_solver {
                 continue;
             }
             if (blk->off == NO_POOL_SRC || blk->lel == 0) continue;
-            PoolBlockHeader h;
-            int rc = engine->read_pool(blk->off, &h, sizeof(h));
-            if (rc != DDO_OK) return rc;
-            std::vector<uint32_t> lvar(h.lel);
-            if ((rc = engine->read_pool(blk->off + h.off_lvar, lvar.data(), (size_t)h.lel * 4)) != DDO_OK) return rc;
+            if (x_cache) {
+                auto f = x_seg.find({blk, it->second});
+                if (f != x_seg.end()) {
+                    out.insert(out.end(), f->second.begin(), f->second.end());
+                    continue;
+                }
+            }
+            BlockHdr local;
+            BlockHdr* bh = &local;
+            bool have = false;
+            if (x_cache) {
+                auto f = x_hdr.find(blk);
+                if (f != x_hdr.end()) {
+                    bh = &f->second;
+                    have = true;
+                }
+            }
+            int rc;
+            if (!have) {
+                if ((rc = engine->read_pool(blk->off, &local.h, sizeof(local.h))) != DDO_OK) return rc;
+                local.lvar.resize(local.h.lel);
+                if ((rc = engine->read_pool(blk->off + local.h.off_lvar, local.lvar.data(), (size_t)local.h.lel * 4)) != DDO_OK) return rc;
+                if (x_cache) bh = &(x_hdr[blk] = std::move(local));
+            }
+            const PoolBlockHeader& h = bh->h;
             std::vector<uint64_t> bits(h.pw);
-            for (uint32_t k = 0; k < h.pw; ++k)
-                if ((rc = engine->read_pool(blk->off + h.off_paths + ((uint64_t)k * h.rows + (uint64_t)it->second) * 8, &bits[k], 8)) != DDO_OK) return rc;
+            if ((rc = engine->read_pool_strided(blk->off + h.off_paths + (uint64_t)it->second * 8, bits.data(), h.pw, (size_t)h.rows * 8)) != DDO_OK) return rc;
+            const size_t before = out.size();
             for (uint32_t tr = 0; tr < h.lel; ++tr)   // root side first
-                out.push_back(ddo_decision{(int64_t)lvar[tr], (int64_t)((bits[tr >> 6] >> (tr & 63)) & 1ULL)});
+                out.push_back(ddo_decision{(int64_t)bh->lvar[tr], (int64_t)((bits[tr >> 6] >> (tr & 63)) & 1ULL)});
+            if (x_cache) x_seg[{blk, it->second}].assign(out.begin() + (long)before, out.end());
         }
         return DDO_OK;
     }
@@ -668,6 +699,15 @@ struct ddo_solver {
         size_t np = 0;
         path_off[0] = 0;
         std::vector<ddo_decision> path;
+        struct CacheScope {   // the caches live for this call only (a DevBlock may be freed and its address reused afterwards)
+            ddo_solver* s;
+            explicit CacheScope(ddo_solver* s_) : s(s_) { s->x_cache = true; }
+            ~CacheScope() {
+                s->x_cache = false;
+                s->x_hdr.clear();
+                s->x_seg.clear();
+            }
+        } scope(this);
         while (*n_out < max_count) {
             path.clear();
             const size_t i = *n_out;
@@ -678,10 +718,14 @@ struct ddo_solver {
                 std::vector<uint64_t> row((size_t)std::max(ws, engine->words_per_state_device()), 0);
                 if (it.block->off == NO_POOL_SRC) model->initial_state(row.data());
                 else {
+                    // (the block's header comes out of the call's cache once its path segment below has been built; here: the one
+                    // strided copy of the state's words)
                     PoolBlockHeader h;
-                    if ((rc = engine->read_pool(it.block->off, &h, sizeof(h))) != DDO_OK) return rc;
-                    for (uint32_t k = 0; k < h.ws && k < row.size(); ++k)
-                        if ((rc = engine->read_pool(it.block->off + h.off_states + ((uint64_t)k * h.rows + (uint64_t)it.row) * 8, &row[k], 8)) != DDO_OK) return rc;
+                    auto fh = x_hdr.find(it.block);
+                    if (fh != x_hdr.end()) h = fh->second.h;
+                    else if ((rc = engine->read_pool(it.block->off, &h, sizeof(h))) != DDO_OK) return rc;
+                    const size_t nwords = std::min<size_t>(h.ws, row.size());
+                    if ((rc = engine->read_pool_strided(it.block->off + h.off_states + (uint64_t)it.row * 8, row.data(), nwords, (size_t)h.rows * 8)) != DDO_OK) return rc;
                 }
                 std::memcpy(states + i * (size_t)ws, row.data(), (size_t)ws * 8);
                 value[i] = it.value;
