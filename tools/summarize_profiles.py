@@ -95,5 +95,8 @@ if "FETCH_SIZE" in pa and "WRITE_SIZE" in pa:
                           "hbm_bytes_per_launch": 2 * fetch + write,
                           "hbm_bytes_per_node": (2 * fetch + write) / bench["roofline"]["nodes_per_launch"],
                           "algorithmic_bytes_per_launch": bench["roofline"]["nodes_per_launch"] * bench["roofline"]["bytes_per_node"]}
+    # the bench run of a collection precedes its own counter passes: its line cannot carry them yet; this copy does
+    summary["roofline"]["traffic"] = 2 * fetch + write
+    summary["roofline"]["traffic_source"] = "this collection's rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, timed launches)"
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
