@@ -479,7 +479,7 @@ class SimpleCache:
 
 
 class Tsptw(Misp):
-    """TSPTW model == `Tsptw` + `TsptwRelax` + `TsptwRanking` (examples/tsptw); 5-word states (include/ddo_hip.h); variable k is the
+    """TSPTW model == `Tsptw` + `TsptwRelax` + `TsptwRanking` (examples/tsptw), up to 256 nodes; 5 / 8 / 14-word states (include/ddo_hip.h); variable k is the
     k-th move of the tour, its value the node visited; values are MINUS the elapsed time in 1/10000 units."""
 
     def __init__(self, handle):

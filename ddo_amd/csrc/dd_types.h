@@ -203,7 +203,7 @@ struct EngineParams {
     // squashes (its layer capacity is below every width it is asked for): a DD that outgrows it reports ST_RETRY and is
     // compiled again by the next tier.  hist_bins < 2048 shrinks the LDS area only the squash phases use.
     // TSPTW (examples/tsptw): distances [n][n], time windows, cheapest entering edge (dd_tsptw.hpp)
-    const int32_t *tw_dist, *tw_early, *tw_late, *tw_cheap;
+    const int32_t *tw_dist, *tw_early, *tw_late, *tw_cheap, *tw_order;   // tw_order: the nodes by increasing tw_cheap
     // TSPTW dominance (examples/tsptw/dominance.rs:26-60): best value per (depth, position, must_visit), same table layout as the cache
     uint64_t* dkey_tab;
     uint64_t dkey_cap;

@@ -62,7 +62,8 @@ void Model::initial_state(uint64_t* out) const {
     for (int k = 0; k < ws; ++k) out[k] = 0;
     if (kind == MODEL_MCP || kind == MODEL_MAX2SAT) return;                     // mcp/model.rs:51-53, max2sat/model.rs:259-264
     if (kind == MODEL_TSPTW) {   // tsptw/model.rs:36-47: at the depot (node 0) at time 0, every other node still to visit
-        out[1] = n >= 64 ? ~1ULL : (((1ULL << n) - 1) & ~1ULL);
+        const int K = tw_set_words(n);
+        for (int i = 1; i < n; ++i) out[K + i / 64] |= 1ULL << (i % 64);
         return;
     }
     if (kind == MODEL_KNAPSACK) out[0] = (uint64_t)kp_capacity;                 // knapsack/main.rs:100-102
@@ -71,7 +72,7 @@ void Model::initial_state(uint64_t* out) const {
 int Model::compare_states(const uint64_t* a, const uint64_t* b) const {
     if (kind == MODEL_KNAPSACK) return a[0] < b[0] ? -1 : (a[0] > b[0] ? 1 : 0);   // KPRanking (knapsack/main.rs:187-194)
     if (kind == MODEL_TSPTW) {   // TsptwRanking (tsptw/heuristics.rs:29-36): the depth; ties: packed words (shared tie-break)
-        const uint64_t da = (a[4] >> 32) & 0xFFFF, db = (b[4] >> 32) & 0xFFFF;
+        const uint64_t da = (a[ws - 1] >> 32) & 0xFFFF, db = (b[ws - 1] >> 32) & 0xFFFF;
         if (da != db) return da < db ? -1 : 1;
         for (int k = 0; k < ws; ++k)
             if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
@@ -400,7 +401,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
             return DDO_OK;
         };
         if ((rc = upi(model->tw_dist, P.tw_dist)) || (rc = upi(model->tw_early, P.tw_early)) || (rc = upi(model->tw_late, P.tw_late)) ||
-            (rc = upi(model->tw_cheap, P.tw_cheap)))
+            (rc = upi(model->tw_cheap, P.tw_cheap)) || (rc = upi(model->tw_order, P.tw_order)))
             return rc;
     }
     if (model->kind == MODEL_MAX2SAT) {
@@ -703,7 +704,8 @@ DominanceTable* DominanceTable::create(const Model* model, int device, size_t ca
         size_t cap = 1024;
         while (cap < capacity_per_depth) cap <<= 1;
         t->dkey_cap = cap;
-        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&t->dkey, cap * 6 * 8) != hipSuccess ||
+        t->dkey_stride = 3 + 2 * tw_set_words(model->n) + 1;
+        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&t->dkey, cap * (size_t)t->dkey_stride * 8) != hipSuccess ||
             hipMalloc((void**)&t->stats, 64) != hipSuccess || t->clear() != DDO_OK) {
             set_error("ddo_dominance_create: could not allocate device memory");
             delete t;
@@ -731,7 +733,7 @@ DominanceTable::~DominanceTable() {
 int DominanceTable::clear() {
     HIP_TRY(hipSetDevice(device));
     if (dkey) {
-        HIP_TRY(hipMemset(dkey, 0, dkey_cap * 6 * 8));
+        HIP_TRY(hipMemset(dkey, 0, dkey_cap * (size_t)dkey_stride * 8));
         HIP_TRY(hipMemset(stats, 0, 64));
         return DDO_OK;
     }
@@ -1461,8 +1463,8 @@ ddo_model* ddo_model_create_max2sat(int n, size_t nb_clauses, const int64_t* lit
 }
 
 ddo_model* ddo_model_create_tsptw(int n, const int64_t* distances, const int64_t* earliest, const int64_t* latest) {
-    if (n < 2 || n > 64 || !distances || !earliest || !latest) {
-        set_error("ddo_model_create_tsptw: 2 <= nb_nodes <= 64 (each of the reference's Set256 fields is one state word)");
+    if (n < 2 || n > 256 || !distances || !earliest || !latest) {
+        set_error("ddo_model_create_tsptw: 2 <= nb_nodes <= 256 (the reference's Set256, examples/tsptw/state.rs:34-69)");
         return nullptr;
     }
     int64_t worst = 0;
@@ -1491,9 +1493,9 @@ ddo_model* ddo_model_create_tsptw(int n, const int64_t* distances, const int64_t
     Model& M = m->m;
     M.kind = MODEL_TSPTW;
     M.n = n;
-    M.ws = 5;
-    M.wsT = pick_ws(5);
-    M.dbits = 6;
+    M.ws = tw_state_words(n);                   // 3K + 2 words, K words per node set (dd_tsptw.hpp): 5 / 8 / 14
+    M.wsT = M.ws == 5 ? 7 : (M.ws == 8 ? 8 : 16);   // the widths tw_k_of_ws maps back to K = 1 / 2 / 4
+    M.dbits = n <= 64 ? 6 : 8;
     M.unit_weights = false;
     M.weight.assign(n, 0);
     M.weight_abs_sum = worst;
@@ -1511,6 +1513,9 @@ ddo_model* ddo_model_create_tsptw(int n, const int64_t* distances, const int64_t
             if (j != i) c = std::min<int64_t>(c, distances[(size_t)j * n + i]);
         M.tw_cheap[i] = (int32_t)c;
     }
+    M.tw_order.resize(n);
+    for (int i = 0; i < n; ++i) M.tw_order[i] = i;
+    std::stable_sort(M.tw_order.begin(), M.tw_order.end(), [&](int32_t a, int32_t b) { return M.tw_cheap[a] < M.tw_cheap[b]; });
     return m;
 }
 

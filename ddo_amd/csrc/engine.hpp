@@ -45,7 +45,7 @@ struct Model {
     void initial_state(uint64_t* out) const;   // Problem::initial_state
     /// decision value of the device's decision bit: MISP / knapsack 0 | 1, MCP +1 (side S) | -1 (side T)
     int64_t decision_value(uint32_t bit) const { return (kind == MODEL_MCP || kind == MODEL_MAX2SAT) ? (bit ? -1 : 1) : (int64_t)bit; }   // TSPTW: the node index itself
-    /// decisions on the device wire: (variable << dbits) | decision index (binary models: 1 bit; TSPTW: the node, 6 bits)
+    /// decisions on the device wire: (variable << dbits) | decision index (binary models: 1 bit; TSPTW: the node, 6 bits up to 64 nodes, 8 bits above)
     int dbits = 1;
     ddo_decision path_decision(uint32_t x) const { return ddo_decision{(int64_t)(x >> dbits), decision_value(x & ((1u << dbits) - 1u))}; }
     uint32_t path_word(const ddo_decision& d) const {
@@ -53,7 +53,7 @@ struct Model {
         return ((uint32_t)d.variable << dbits) | idx;
     }
     // TSPTW (examples/tsptw): distance matrix and time windows in 1/10000 units (instance.rs:87-98), cheapest entering edges
-    std::vector<int32_t> tw_dist, tw_early, tw_late, tw_cheap;
+    std::vector<int32_t> tw_dist, tw_early, tw_late, tw_cheap, tw_order;
 
     std::mutex mtx;
     std::map<std::pair<int, long>, std::weak_ptr<class Engine>> engines;  // (device, max_width)
@@ -91,6 +91,7 @@ struct DominanceTable {
     // the cache's entry layout, 3 key words
     uint64_t* dkey = nullptr;
     uint64_t dkey_cap = 0;
+    int dkey_stride = 6;   // words per entry: 3 + the key (2K + 1 words, K = words of a node set, dd_tsptw.hpp)
     ~DominanceTable();
     static DominanceTable* create(const Model* model, int device, size_t capacity_per_depth);
     int clear();

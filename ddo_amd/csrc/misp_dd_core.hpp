@@ -342,8 +342,8 @@ DDO_DEV int32_t vec_rank(const uint64_t* s, int n, int from) {
 /// items in ratio order; the only floating point on the path: cap/weight * profit, floored)
 template <int WS>
 DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth) {
-    if constexpr (WS >= 5)
-        if (c.kind == MODEL_TSPTW) return tw_rub(c.tw, s);
+    if constexpr (tw_k_of_ws(WS) != 0)
+        if (c.kind == MODEL_TSPTW) return tw_rub<tw_k_of_ws(WS)>(c.tw, s);
     if (c.kind == MODEL_MCP)   // mcp/relax.rs:123-130
         return vec_rank<WS>(s, c.n, depth) + c.vest[depth] - c.vr + c.vnk[depth];
     if (c.kind == MODEL_MAX2SAT) {   // max2sat/model.rs:231-240; a complete assignment (depth n) has nothing left to gain
@@ -859,7 +859,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     const bool frontier = c.tmode && (in.flags & IN_FRONTIER) != 0;   // CUTSET_TYPE == FRONTIER
     const bool use_cache = c.tmode && (in.flags & IN_CACHE) != 0 && c.cache_cap != 0;
     const bool use_dom = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dom_cap != 0 && c.kind == MODEL_KNAPSACK;
-    const bool use_dkey = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dkey_cap != 0 && c.kind == MODEL_TSPTW;
+    constexpr int TWK = tw_k_of_ws(WS) != 0 ? tw_k_of_ws(WS) : 1;       // words of a TSPTW node set at this state width (dd_tsptw.hpp)
+    constexpr int DKW = 2 * TWK + 1;                                    // words of a TsptwDominance key
+    const bool use_dkey = tw_k_of_ws(WS) != 0 && c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dkey_cap != 0 && c.kind == MODEL_TSPTW;
 
     // ---------------------------------------------------------------- _clear + _initialize
     int cur = 0;
@@ -988,27 +990,25 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 if (tid == 0) sh->ncache = 0;
                 PAR_END
             }
-            struct { uint64_t* cache_tab; uint64_t cache_cap; int cache_stride; unsigned long long* cache_stats; } dk{c.dkey_tab, c.dkey_cap, 6, c.dkey_stats};
+            struct { uint64_t* cache_tab; uint64_t cache_cap; int cache_stride; unsigned long long* cache_stats; } dk{c.dkey_tab, c.dkey_cap, DKW + 3, c.dkey_stats};
             const int nclx = c.fan * nprev;
             PAR_BEGIN
             for (int j = tid; j < nclx; j += NT) {
                 const int cd = lin2cand(j, nprev, capN);
                 if (!cand_live(c, cur, cd) || (LD_U32(&c.cflags[cur][cd]) & (NF_INEXACT | NF_RELAXED))) continue;
-                const uint64_t w4 = c.cstate[cur][(size_t)4 * capC1 + cd];
-                const uint64_t key3[3] = {(w4 & TW_VIRTUAL) ? c.cstate[cur][cd] : (w4 & 0xFFFF), (w4 & TW_VIRTUAL) ? 1ULL : 0ULL,
-                                          c.cstate[cur][(size_t)1 * capC1 + cd]};
-                cache_update<3>(dk, key3, c.depth0 + L, th_pack(unbias32((uint32_t)(LD_U64(&c.ckey[cur][cd]) >> 32)), false));
+                uint64_t keyw[DKW];
+                tw_dominance_key<TWK>(c.cstate[cur], capC1, cd, keyw);
+                cache_update<DKW>(dk, keyw, c.depth0 + L, th_pack(unbias32((uint32_t)(LD_U64(&c.ckey[cur][cd]) >> 32)), false));
             }
             PAR_END
             PAR_BEGIN
             for (int j = tid; j < nclx; j += NT) {
                 const int cd = lin2cand(j, nprev, capN);
                 if (!cand_live(c, cur, cd) || (LD_U32(&c.cflags[cur][cd]) & (NF_INEXACT | NF_RELAXED))) continue;
-                const uint64_t w4 = c.cstate[cur][(size_t)4 * capC1 + cd];
-                const uint64_t key3[3] = {(w4 & TW_VIRTUAL) ? c.cstate[cur][cd] : (w4 & 0xFFFF), (w4 & TW_VIRTUAL) ? 1ULL : 0ULL,
-                                          c.cstate[cur][(size_t)1 * capC1 + cd]};
+                uint64_t keyw[DKW];
+                tw_dominance_key<TWK>(c.cstate[cur], capC1, cd, keyw);
                 int64_t packed = 0;
-                if (!cache_get<3>(dk, key3, c.depth0 + L, &packed)) continue;
+                if (!cache_get<DKW>(dk, keyw, c.depth0 + L, &packed)) continue;
                 const int32_t best = th_value(packed), val = unbias32((uint32_t)(LD_U64(&c.ckey[cur][cd]) >> 32));
                 if (best > val) {                                   // dominated: only the value differs -> threshold value - 1
                     c.cflags[cur][cd] = LD_U32(&c.cflags[cur][cd]) | NF_DOM;
@@ -1060,9 +1060,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (tid == 0) {
             sh->mergedKey = 0;
             for (int k = 0; k < WS; ++k) sh->merged[k] = 0;
-            if (c.kind == MODEL_TSPTW) {
-                sh->merged[1] = ~0ULL;      // intersection of the must-visit sets
-                sh->vmin[0] = 0xFFFFFFFFu;  // earliest elapsed time
+            if (tw_k_of_ws(WS) != 0 && c.kind == MODEL_TSPTW) {
+                for (int k = 0; k < TWK; ++k) sh->merged[TWK + k] = ~0ULL;   // intersection of the must-visit sets
+                sh->vmin[0] = 0xFFFFFFFFu;                                   // earliest elapsed time
             }
             if (dd_is_vec(c.kind)) {
                 for (int v = 0; v < MAX_VEC_VARS; ++v) sh->vmin[v] = 0xFFFFFFFFu;
@@ -1135,13 +1135,19 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                         } else if (relaxed && c.kind == MODEL_TSPTW) {
                             // TsptwRelax::merge (relax.rs:65-191): union of the positions, intersection / union of the must-visit
                             // sets, union of the maybe-visit sets, earliest and latest elapsed time
-                            if constexpr (WS >= 5) {
-                                LDS_OR_U64(&sh->merged[0], (s[4] & TW_VIRTUAL) ? s[0] : (1ULL << (s[4] & 0xFFFF)));
-                                LDS_AND_U64(&sh->merged[1], s[1]);
-                                LDS_OR_U64(&sh->merged[2], s[1]);
-                                if (s[4] & TW_MAYBE) LDS_OR_U64(&sh->merged[3], s[2]);
-                                LDS_MIN_U32(&sh->vmin[0], tw_earliest(s));
-                                LDS_MAX_I32(&sh->mrank, (int32_t)tw_latest(s));
+                            // (sh->merged: K words each of positions | agreed must | all must | all maybe -- 4K <= WS)
+                            if constexpr (tw_k_of_ws(WS) != 0) {
+                                const uint64_t meta = tw_meta<TWK>(s);
+#pragma unroll
+                                for (int q = 0; q < TWK; ++q) {
+                                    const uint64_t here = (meta & TW_VIRTUAL) ? s[q] : ((int)((meta & 0xFFFF) >> 6) == q ? 1ULL << (meta & 63) : 0ULL);
+                                    if (here) LDS_OR_U64(&sh->merged[q], here);
+                                    LDS_AND_U64(&sh->merged[TWK + q], s[TWK + q]);
+                                    if (s[TWK + q]) LDS_OR_U64(&sh->merged[2 * TWK + q], s[TWK + q]);
+                                    if ((meta & TW_MAYBE) && s[2 * TWK + q]) LDS_OR_U64(&sh->merged[3 * TWK + q], s[2 * TWK + q]);
+                                }
+                                LDS_MIN_U32(&sh->vmin[0], tw_earliest<TWK>(s));
+                                LDS_MAX_I32(&sh->mrank, (int32_t)tw_latest<TWK>(s));
                             }
                             if (key > mkey) mkey = key;
                             anydel = true;
@@ -1207,16 +1213,20 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 uint64_t ms[WS];
                 for (int k = 0; k < WS; ++k) ms[k] = sh->merged[k];
                 if (c.kind == MODEL_TSPTW) {   // RelaxHelper::get_* (relax.rs:120-166)
-                    const uint64_t pos = sh->merged[0], agree = sh->merged[1], all_must = sh->merged[2], all_maybe = sh->merged[3];
                     const uint32_t e = sh->vmin[0], l = (uint32_t)sh->mrank;
-                    const uint64_t maybe = (all_maybe | all_must) & ~agree;
                     for (int k = 0; k < WS; ++k) ms[k] = 0;
-                    if constexpr (WS >= 5) {
-                        ms[0] = pos;
-                        ms[1] = agree;
-                        ms[2] = maybe;
-                        ms[3] = (uint64_t)e | ((uint64_t)(e != l ? l : e) << 32);
-                        ms[4] = TW_VIRTUAL | (e != l ? TW_FUZZY : 0) | (maybe ? TW_MAYBE : 0) | ((uint64_t)(c.depth0 + L) << 32);
+                    if constexpr (tw_k_of_ws(WS) != 0) {
+                        uint64_t any_maybe = 0;
+                        for (int q = 0; q < TWK; ++q) {
+                            const uint64_t agree = sh->merged[TWK + q], all_must = sh->merged[2 * TWK + q], all_maybe = sh->merged[3 * TWK + q];
+                            const uint64_t maybe = (all_maybe | all_must) & ~agree;
+                            ms[q] = sh->merged[q];
+                            ms[TWK + q] = agree;
+                            ms[2 * TWK + q] = maybe;
+                            any_maybe |= maybe;
+                        }
+                        ms[3 * TWK] = (uint64_t)e | ((uint64_t)(e != l ? l : e) << 32);
+                        ms[3 * TWK + 1] = TW_VIRTUAL | (e != l ? TW_FUZZY : 0) | (any_maybe ? TW_MAYBE : 0) | ((uint64_t)(c.depth0 + L) << 32);
                     }
                     sh->mrank = 0;
                 }
@@ -1579,13 +1589,16 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int d = 0; d < c.fan; ++d) c.ctarget[(size_t)d * capN + pos] = NONE32;
                 continue;
             }
-            if (WS >= 5 && c.kind == MODEL_TSPTW) {
+            if (tw_k_of_ws(WS) != 0 && c.kind == MODEL_TSPTW) {
                 // examples/tsptw/model.rs:65-139: one child per node the salesman may visit next; decision index = node
-                uint64_t dom = 0;
-                if constexpr (WS >= 5) dom = tw_domain(c.tw, s);
+                uint64_t dom[TWK];
+                if constexpr (tw_k_of_ws(WS) != 0) tw_domain<TWK>(c.tw, s, dom);
                 for (int j = 0; j < c.fan; ++j) {
                     const uint32_t cd = (uint32_t)((size_t)j * capN + pos);
-                    if (!((dom >> j) & 1ULL)) {
+                    uint64_t dw = dom[0];
+#pragma unroll
+                    for (int q = 1; q < TWK; ++q) dw = (j >> 6) == q ? dom[q] : dw;
+                    if (!((dw >> (j & 63)) & 1ULL)) {
                         c.ctarget[cd] = NONE32;
                         continue;
                     }
@@ -1593,7 +1606,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 #pragma unroll
                     for (int k = 0; k < WS; ++k) y[k] = 0;
                     int32_t cost = 0;
-                    if constexpr (WS >= 5) tw_transition(c.tw, s, j, y, &cost);
+                    if constexpr (tw_k_of_ws(WS) != 0) tw_transition<TWK>(c.tw, s, j, y, &cost);
 #pragma unroll
                     for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
                     const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
@@ -2530,7 +2543,7 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.dom_lock = P.dom_lock;
     c.dom_cap = P.tmode ? P.dom_cap : 0;
     c.dom_stats = P.dom_stats;
-    c.tw = TwModel{P.n, P.tw_dist, P.tw_early, P.tw_late, P.tw_cheap};
+    c.tw = TwModel{P.n, P.tw_dist, P.tw_early, P.tw_late, P.tw_cheap, P.tw_order};
     c.dkey_tab = P.dkey_tab;
     c.dkey_cap = P.tmode ? P.dkey_cap : 0;
     c.dkey_stats = P.dkey_stats;

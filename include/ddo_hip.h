@@ -157,13 +157,15 @@ ddo_model* ddo_model_create_max2sat(int n, size_t nb_clauses, const int64_t* lit
 ddo_model* ddo_model_read_max2sat(const char* path);
 /** TSPTW (examples/tsptw/{instance,state,model,relax,heuristics,dominance}.rs: `Tsptw`, `TsptwRelax`, `TsptwRanking`).
  *  `distances`: nb_nodes x nb_nodes travel times, `earliest` / `latest`: one time window per node, all in the reference's
- *  fixed-point unit (1/10000, instance.rs:87-98); node 0 is the depot; 2 <= nb_nodes <= 64.  Variable k is the k-th move of
- *  the tour, its decision value the node visited (up to nb_nodes children per DD node; the last move returns to 0); the
- *  objective is MINUS the arrival time back at the depot (travel + waiting).  The state is `TsptwState { position,
- *  elapsed, must_visit, maybe_visit, depth }` (state.rs:34-69) in 5 words:
- *    [0] Position::Virtual(set) as a node bit mask (0 for Position::Node)   [1] must_visit   [2] maybe_visit (0 when None)
- *    [3] elapsed: earliest | latest << 32 (ElapsedTime::FixedAt(d): both d)
- *    [4] node of Position::Node | bit 16 position is virtual | bit 17 elapsed is fuzzy | bit 18 maybe_visit is Some | depth << 32 */
+ *  fixed-point unit (1/10000, instance.rs:87-98); node 0 is the depot; 2 <= nb_nodes <= 256 (the reference's Set256).
+ *  Variable k is the k-th move of the tour, its decision value the node visited (up to nb_nodes children per DD node; the last
+ *  move returns to 0); the objective is MINUS the arrival time back at the depot (travel + waiting).  The state is
+ *  `TsptwState { position, elapsed, must_visit, maybe_visit, depth }` (state.rs:34-69) in 3K + 2 words, K = words of one
+ *  node set = 1 up to 64 nodes, 2 up to 128 nodes, 4 up to 256 nodes (ddo_model_state_words: 5 / 8 / 14):
+ *    [0 .. K)   Position::Virtual(set) as a node bit mask (0 for Position::Node)
+ *    [K .. 2K)  must_visit                    [2K .. 3K)  maybe_visit (0 when None)
+ *    [3K]       elapsed: earliest | latest << 32 (ElapsedTime::FixedAt(d): both d)
+ *    [3K + 1]   node of Position::Node | bit 16 position is virtual | bit 17 elapsed is fuzzy | bit 18 maybe_visit is Some | depth << 32 */
 ddo_model* ddo_model_create_tsptw(int nb_nodes, const int64_t* distances, const int64_t* earliest, const int64_t* latest);
 /** Reads an instance exactly as examples/tsptw/instance.rs:52-109 does (`(f32 * 10000.0) as usize` per number). */
 ddo_model* ddo_model_read_tsptw(const char* path);

@@ -1182,23 +1182,30 @@ struct TsptwRelax : Relaxation<TsptwState> {
 };
 
 /// TsptwState on the device wire (include/ddo_hip.h, ddo_model_create_tsptw): 5 words; instances of at most 64 nodes
-inline void pack_tsptw_state(const TsptwState& s, uint64_t* out) {
-    out[0] = s.pos_virtual ? s.pos_set.w[0] : 0;
-    out[1] = s.must_visit.w[0];
-    out[2] = s.has_maybe ? s.maybe_visit.w[0] : 0;
-    out[3] = (uint64_t)(uint32_t)s.t_earliest | ((uint64_t)(uint32_t)(s.fuzzy ? s.t_latest : s.t_earliest) << 32);
-    out[4] = (s.pos_virtual ? 0ULL : (uint64_t)s.pos_node) | (s.pos_virtual ? 1ULL << 16 : 0) | (s.fuzzy ? 1ULL << 17 : 0) |
-             (s.has_maybe ? 1ULL << 18 : 0) | ((uint64_t)s.depth << 32);
+/// words of one node set on the wire for nb_nodes nodes (include/ddo_hip.h): 1 up to 64 nodes, 2 up to 128, 4 up to 256
+inline int tsptw_set_words(size_t nb_nodes) { return nb_nodes <= 64 ? 1 : (nb_nodes <= 128 ? 2 : 4); }
+/// the state in 3K + 2 words: position set | must_visit | maybe_visit (K words each) | elapsed | node, flags, depth
+inline void pack_tsptw_state(const TsptwState& s, int K, uint64_t* out) {
+    for (int q = 0; q < K; ++q) {
+        out[q] = s.pos_virtual ? s.pos_set.w[q] : 0;
+        out[K + q] = s.must_visit.w[q];
+        out[2 * K + q] = s.has_maybe ? s.maybe_visit.w[q] : 0;
+    }
+    out[3 * K] = (uint64_t)(uint32_t)s.t_earliest | ((uint64_t)(uint32_t)(s.fuzzy ? s.t_latest : s.t_earliest) << 32);
+    out[3 * K + 1] = (s.pos_virtual ? 0ULL : (uint64_t)s.pos_node) | (s.pos_virtual ? 1ULL << 16 : 0) | (s.fuzzy ? 1ULL << 17 : 0) |
+                     (s.has_maybe ? 1ULL << 18 : 0) | ((uint64_t)s.depth << 32);
 }
 /// heuristics.rs:26-51: the depth; ties (every pair of one layer) fall to the packed state words like for the other models
 /// whose ranking is not a total order (compare_signed_vectors): the reference leaves them to its hash map's order
 struct TsptwRanking : StateRanking<TsptwState> {
     int compare(const TsptwState& a, const TsptwState& b) const override {
         if (a.depth != b.depth) return a.depth < b.depth ? -1 : 1;
-        uint64_t x[5], y[5];
-        pack_tsptw_state(a, x);
-        pack_tsptw_state(b, y);
-        for (int k = 0; k < 5; ++k)
+        // (packed with four words per set: the words beyond the instance's K are zero on both sides, so the order is the one
+        // of the K-word packing the device compares)
+        uint64_t x[14], y[14];
+        pack_tsptw_state(a, 4, x);
+        pack_tsptw_state(b, 4, y);
+        for (int k = 0; k < 14; ++k)
             if (x[k] != y[k]) return x[k] < y[k] ? -1 : 1;
         return 0;
     }

@@ -57,7 +57,7 @@ void state_to_words(const KnapsackState& s, size_t, uint64_t* out) {   // device
     out[1] = (uint64_t)s.depth;
 }
 void state_to_words(const Max2SatState& s, size_t, uint64_t* out) { pack_signed_vector(s.substates, s.depth, out); }
-void state_to_words(const TsptwState& s, size_t, uint64_t* out) { pack_tsptw_state(s, out); }
+void state_to_words(const TsptwState& s, size_t ws, uint64_t* out) { pack_tsptw_state(s, (int)(ws - 2) / 3, out); }
 void state_to_words(const McpState& s, size_t, uint64_t* out) { pack_signed_vector(s.benef, s.depth, out); }
 
 template <class T, class D>
@@ -384,12 +384,12 @@ void* oracle_trace_solve_ex(const char* kind, const char* path, uint64_t width, 
         }
         if (k == "tsptw" || k == "tsptw+dominance") {   // width 0: TsptwWidth(nb_vars, 1) as in examples/tsptw/tests.rs:42; else FixedWidth
             Tsptw pb(read_tsptw_instance(path));
-            if (pb.nb_variables() > 64) throw std::runtime_error("tsptw traces pack states for at most 64 nodes");
+            const size_t tws = 3 * (size_t)tsptw_set_words(pb.nb_variables()) + 2;   // words of a packed state (include/ddo_hip.h)
             TsptwRelax relax(pb);
             TsptwRanking rank;
             TsptwWidth tw(pb.nb_variables(), 1);
             SimpleDominanceChecker<TsptwState, TsptwDominance> dom(TsptwDominance(), pb.nb_variables());
-            return traced_solve_any<TsptwState>(pb, relax, rank, pb.nb_variables(), 5, width, max_compiles, frontier, cache, out,
+            return traced_solve_any<TsptwState>(pb, relax, rank, pb.nb_variables(), tws, width, max_compiles, frontier, cache, out,
                                                 k == "tsptw" ? nullptr : &dom, width ? nullptr : &tw);
         }
         std::fprintf(stderr, "oracle_trace_solve_ex: unknown kind %s\n", kind);

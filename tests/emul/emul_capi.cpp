@@ -258,6 +258,7 @@ void* emul_create_model(const void* model_handle, int max_width, int nthreads, u
         P.tw_early = M.tw_early.data();
         P.tw_late = M.tw_late.data();
         P.tw_cheap = M.tw_cheap.data();
+        P.tw_order = M.tw_order.data();
     }
     if (M.kind == MODEL_MAX2SAT) {
         P.m2_wtt = M.m2_w[0].data();
@@ -300,7 +301,7 @@ void emul_set_dominance(void* h, uint32_t cap) {
     if (e->P.model_kind == MODEL_TSPTW) {   // TsptwDominance: one hash table of (depth, position, must_visit) keys
         uint64_t c2 = 1024;
         while (c2 < cap) c2 <<= 1;
-        e->dom_coord.assign(c2 * 6, 0);
+        e->dom_coord.assign(c2 * (size_t)(3 + 2 * tw_set_words(e->P.n) + 1), 0);   // entry = 3 words + the (2K + 1)-word key
         e->P.dkey_tab = e->dom_coord.data();
         e->P.dkey_cap = c2;
         e->dom_stats[0] = e->dom_stats[1] = 0;

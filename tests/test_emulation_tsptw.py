@@ -42,6 +42,37 @@ def test_tsptw_replay_of_oracle_search(oracle, fname, width, max_compiles, kind,
         assert inexact > 0
 
 
+BIG = [("AFG", "rbg067a.tw", 3, 30, 8), ("Dumas", "n80w20.001.txt", 3, 30, 8), ("AFG", "rbg125a.tw", 2, 20, 8), ("AFG", "rbg132.tw", 2, 20, 14),
+       ("Dumas", "n200w20.001.txt", 2, 12, 14), ("AFG", "rbg233.tw", 2, 10, 14)]
+
+
+@pytest.mark.parametrize("kind,frontier,cache", [("tsptw", False, False), ("tsptw+dominance", True, True)], ids=["lel", "frontier+cache+dominance"])
+@pytest.mark.parametrize("family,fname,width,max_compiles,words", BIG, ids=[b[1] for b in BIG])
+def test_tsptw_replay_beyond_64_nodes(oracle, family, fname, width, max_compiles, words, kind, frontier, cache):
+    """instances of the reference's resources/tsptw with 68 .. 232 nodes: the node sets take K = 2 / 4 words (the reference's Set256,
+    state.rs:34-69), states 3K + 2 words, decisions 8 bits; same replay as above"""
+    path = data_path("tsptw", family, fname)
+    model = ddo_amd.Tsptw.read_instance(path)
+    assert model.ws == words
+    summary, recs = oracle.trace_ex(kind, path, width, max_compiles, frontier, cache)
+    assert recs and len(recs[0]["state"]) == words
+    e = ModelEmul(model, max(int(r["width"]) for r in recs))
+    e.keep_layers(True, 1 << 15 if cache else 0)
+    if "dominance" in kind:
+        e.dominance(1 << 15)
+    merges = 0
+    for i, r in enumerate(recs):
+        fl = IN_WANT_PATHS | (IN_DOMINANCE if "dominance" in kind else 0) | (IN_FRONTIER if frontier else 0) | (IN_CACHE if cache else 0)
+        if cache and r["comp_type"] == 2:
+            fl |= IN_MUST_EXPLORE
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=fl)[0]
+        assert g is not None and g["status"] == 0, f"{fname} compile #{i}: status {None if g is None else g['status']}"
+        d = diff(r, g)
+        assert d is None, f"{fname} W={width} {kind} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+        merges += (r["comp_type"] == 1 and not r["is_exact"])
+    assert merges > 0
+
+
 def test_tsptw_model_host_side(tmp_path):
     """instance.rs:52-109 (`(f32 * 10000.0) as usize`), model.rs:36-47 (initial state: at the depot, everything else to visit)"""
     p = tmp_path / "t.dat"
@@ -51,7 +82,13 @@ def test_tsptw_model_host_side(tmp_path):
     s = m.initial_state()
     assert [int(x) for x in s] == [0, 0b110, 0, 0, 0]
     with pytest.raises(ddo_amd.DdoError):
-        ddo_amd.Tsptw.from_arrays([[0] * 70] * 70, [0] * 70, [1] * 70)      # more than 64 nodes
+        ddo_amd.Tsptw.from_arrays([[0] * 257] * 257, [0] * 257, [1] * 257)   # more than the 256 nodes of the reference's Set256
+    for nodes, words in ((64, 5), (65, 8), (128, 8), (129, 14), (256, 14)):   # K = 1 / 2 / 4 words per node set, 3K + 2 per state
+        big = ddo_amd.Tsptw.from_arrays([[0] * nodes] * nodes, [0] * nodes, [1] * nodes)
+        assert big.ws == words
+        s0 = [int(x) for x in big.initial_state()]
+        k = (words - 2) // 3
+        assert sum(bin(x).count("1") for x in s0[k:2 * k]) == nodes - 1 and not (s0[k] & 1) and not any(s0[:k]) and not any(s0[2 * k:])
     a, b = s.copy(), s.copy()
     b[4] = 1 << 32                                                           # deeper state ranks higher (TsptwRanking)
     assert m.compare(a, b) < 0 and m.compare(b, a) > 0 and m.compare(a, a) == 0
