@@ -5,7 +5,9 @@
       tests.rs:81-499; every tour is re-evaluated independently (time windows, each node once, length);
   (2) config C5 as worded -- FixedWidth(20000) -- on N40 instances;
   (3) traced oracle searches at small widths replayed compile by compile, in order, against one device cache and one device
-      dominance checker; sequential searches reproduce the oracle's explored count and counters."""
+      dominance checker; sequential searches reproduce the oracle's explored count and counters;
+  (4) instances of the reference's resources/tsptw beyond 64 nodes (AFG rbg*, Dumas n80 / n200: 68 .. 232 nodes -- node sets of
+      2 / 4 words like the reference's Set256, state.rs:34-69): the same replays, sequential parity and proved optima."""
 import numpy as np
 import pytest
 
@@ -31,8 +33,8 @@ def have_gpu():
     return True
 
 
-def _solve(oracle, name, expected, width, threads):
-    path = data_path("tsptw", "Langevin", name + ".dat")
+def _solve(oracle, name, expected, width, threads, family="Langevin"):
+    path = data_path("tsptw", family, name + (".dat" if family == "Langevin" else ""))
     model = ddo_amd.Tsptw.read_instance(path)
     s = ParallelSolver(model, width, nb_threads=threads, fringe="nodup", cutset_type=FRONTIER, cache_entries=1 << 20, dominance_entries=1 << 20)
     c = s.maximize()
@@ -100,3 +102,51 @@ def test_sequential_solver_matches_the_oracle(have_gpu, oracle, name, width):
     cnt = s.counters()
     assert (s.explored(), cnt["nodes_expanded"], cnt["arcs"], cnt["layers"], cnt["compiles"]) == \
            (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
+
+
+BIG = [("AFG", "rbg067a.tw", 3, 30, 8), ("Dumas", "n80w20.001.txt", 3, 30, 8), ("AFG", "rbg125a.tw", 2, 20, 8), ("AFG", "rbg132.tw", 2, 20, 14),
+       ("Dumas", "n200w20.001.txt", 2, 12, 14), ("AFG", "rbg233.tw", 2, 10, 14)]
+
+
+@pytest.mark.parametrize("kind,frontier,cache", [("tsptw", False, False), ("tsptw+dominance", True, True)], ids=["lel", "frontier+cache+dominance"])
+@pytest.mark.parametrize("family,fname,width,max_compiles,words", BIG, ids=[b[1] for b in BIG])
+def test_replay_beyond_64_nodes(have_gpu, oracle, family, fname, width, max_compiles, words, kind, frontier, cache):
+    path = data_path("tsptw", family, fname)
+    model = ddo_amd.Tsptw.read_instance(path)
+    assert model.ws == words
+    _, recs = oracle.trace_ex(kind, path, width, max_compiles, frontier, cache)
+    mdd = ddo_amd.Mdd(model, max(int(r["width"]) for r in recs), cutset_type=FRONTIER if frontier else LAST_EXACT_LAYER, caching=True)
+    ch = ddo_amd.SimpleCache(model, 1 << 16) if cache else None
+    dom = ddo_amd.SimpleDominanceChecker(model, 1 << 16) if "dominance" in kind else None
+    merges = 0
+    for i, r in enumerate(recs):
+        comp = mdd.compile(r["comp_type"], r["width"], _sub(r), r["best_lb"], cache=ch, dominance=dom)
+        got = canon_from_mdd(mdd, comp, model.ws)
+        d = diff(r, got)
+        assert d is None, f"{fname} W={width} {kind} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+        for n in got["cutset_nodes"]:
+            assert len(n.path) == n.depth - r["depth"] and all(0 <= dd.value < model.n for dd in n.path)
+        merges += (r["comp_type"] == 1 and not r["is_exact"])
+    assert merges > 0
+
+
+@pytest.mark.parametrize("family,fname", [("AFG", "rbg067a.tw"), ("Dumas", "n80w20.001.txt"), ("AFG", "rbg132.tw")])
+def test_sequential_solver_matches_the_oracle_beyond_64_nodes(have_gpu, oracle, family, fname):
+    """frontier + cache + dominance with TsptwWidth(nb_vars, 1), one sub-problem at a time: explored count and counters equal the oracle's"""
+    path = data_path("tsptw", family, fname)
+    model = ddo_amd.Tsptw.read_instance(path)
+    ref, _ = oracle.trace_ex("tsptw+dominance", path, 0, 0, True, True)
+    s = SequentialSolver(model, TsptwWidth(1), cutset_type=FRONTIER, cache_entries=1 << 18, dominance_entries=1 << 18)
+    c = s.maximize()
+    assert c.is_exact and c.best_value == ref["best_value"]
+    cnt = s.counters()
+    assert (s.explored(), cnt["nodes_expanded"], cnt["arcs"], cnt["layers"], cnt["compiles"]) == \
+           (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
+
+
+# optima proved by the oracle (examples/tsptw/tests.rs:33-63's configuration) in seconds; the device search must prove the same
+@pytest.mark.parametrize("family,fname,expected", [("AFG", "rbg067a.tw", 10331.0), ("Dumas", "n80w20.001.txt", 729.0), ("AFG", "rbg125a.tw", 14214.0),
+                                                   ("AFG", "rbg132.tw", 18524.0), ("Dumas", "n200w20.001.txt", 1139.0)])
+def test_proved_optima_beyond_64_nodes(have_gpu, oracle, family, fname, expected):
+    model, s = _solve(oracle, fname, expected, TsptwWidth(1), 32, family=family)
+    assert s.explored() >= 1
