@@ -73,6 +73,24 @@ def test_tsptw_replay_beyond_64_nodes(oracle, family, fname, width, max_compiles
     assert merges > 0
 
 
+def test_tsptw_whole_search_of_rbg132(oracle):
+    """the oracle's whole sequential search of AFG/rbg132 (131 nodes: 4-word node sets, 14-word states) in the reference's example
+    configuration -- TsptwWidth(nb_vars, 1), frontier cut-set, SimpleCache, TsptwDominance: 487 compiles up to 1 834 nodes wide"""
+    path = data_path("tsptw", "AFG", "rbg132.tw")
+    model = ddo_amd.Tsptw.read_instance(path)
+    summary, recs = oracle.trace_ex("tsptw+dominance", path, 0, 0, True, True)
+    assert summary["is_exact"] and summary["best_value"] == -185240000 and len(recs) == summary["compiles"]
+    e = ModelEmul(model, max(int(r["width"]) for r in recs))
+    e.keep_layers(True, 1 << 22)
+    e.dominance(1 << 22)
+    for i, r in enumerate(recs):
+        fl = IN_WANT_PATHS | IN_DOMINANCE | IN_FRONTIER | IN_CACHE | (IN_MUST_EXPLORE if r["comp_type"] == 2 else 0)
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=fl)[0]
+        assert g is not None and g["status"] == 0
+        d = diff(r, g)
+        assert d is None, f"compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+
+
 def test_tsptw_model_host_side(tmp_path):
     """instance.rs:52-109 (`(f32 * 10000.0) as usize`), model.rs:36-47 (initial state: at the depot, everything else to visit)"""
     p = tmp_path / "t.dat"
