@@ -245,6 +245,7 @@ struct DDCtx {
     DDShared* sh;
     // frontier cut-set / thresholds / cache (dd_thresholds.hpp): every layer is kept
     int tmode, lstride;
+    int cdbits;          // bits of a candidate index in a dedup table entry (tag | candidate): 20, more when fan * capN needs them
     int clocks;          // DDO_HIP_STATS: phase clocks on
     uint64_t* lstate;
     int32_t *lval, *lrub, *lvb, *lth;
@@ -642,8 +643,8 @@ DDO_DEV bool ranks_above(const DDCtx<WS>& c, int cur, int a, int b) {
 template <int WS>
 DDO_DEV uint32_t dedup_insert(const DDCtx<WS>& c, int nxt, uint32_t cd, const uint64_t* s, int mask) {
     const uint64_t h = hash_state<WS>(s);
-    const uint32_t tag = (uint32_t)(h >> 52);  // 12 bits
-    const uint32_t mine = (tag << 20) | cd;
+    const uint32_t tag = (uint32_t)(h >> (32 + c.cdbits));  // 12 bits (fewer when the candidate index needs more than 20)
+    const uint32_t mine = (tag << c.cdbits) | cd;
     uint32_t slot = (uint32_t)h & (uint32_t)mask;
     const uint64_t* st = c.cstate[nxt];
     for (int probes = 0; probes <= mask; ++probes) {   // bounded: a full table is an internal error, not a hang
@@ -652,8 +653,8 @@ DDO_DEV uint32_t dedup_insert(const DDCtx<WS>& c, int nxt, uint32_t cd, const ui
             e = TAB_CAS(&c.table[slot], TAB_EMPTY, mine);
             if (e == TAB_EMPTY) return cd;
         }
-        if ((e >> 20) == tag) {
-            const uint32_t w = e & 0xFFFFFu;
+        if ((e >> c.cdbits) == tag) {
+            const uint32_t w = e & ((1u << c.cdbits) - 1u);
             bool eq = true;
             for (int k = 0; k < WS && eq; ++k) eq = LD_U64(&st[(size_t)k * c.capC1 + w]) == s[k];
             if (eq) return w;
@@ -683,15 +684,15 @@ DDO_DEV uint64_t hash_end(uint64_t h) {
 /// there (round 3: 2 600 cycles per node).  A tag match is verified word against word out of cstate[nxt], eight words per batch.
 template <int WS>
 DDO_DEV uint32_t dedup_insert_stored(const DDCtx<WS>& c, int nxt, uint32_t cd, uint64_t h, int mask) {
-    const uint32_t tag = (uint32_t)(h >> 52);  // 12 bits
-    const uint32_t mine = (tag << 20) | cd;
+    const uint32_t tag = (uint32_t)(h >> (32 + c.cdbits));  // 12 bits (fewer when the candidate index needs more than 20)
+    const uint32_t mine = (tag << c.cdbits) | cd;
     uint32_t slot = (uint32_t)h & (uint32_t)mask;
     const uint64_t* st = c.cstate[nxt];
     for (int probes = 0; probes <= mask; ++probes) {   // bounded: a full table is an internal error, not a hang
         const uint32_t e = TAB_CAS(&c.table[slot], TAB_EMPTY, mine);
         if (e == TAB_EMPTY) return cd;
-        if ((e >> 20) == tag) {
-            const uint32_t w = e & 0xFFFFFu;
+        if ((e >> c.cdbits) == tag) {
+            const uint32_t w = e & ((1u << c.cdbits) - 1u);
             bool eq = true;
             for (int k0 = 0; k0 < WS && eq; k0 += 8) {
                 uint64_t a[8], b[8];
@@ -716,14 +717,14 @@ DDO_DEV uint32_t dedup_insert_stored(const DDCtx<WS>& c, int nxt, uint32_t cd, u
 template <int WS>
 DDO_DEV uint32_t dedup_find(const DDCtx<WS>& c, int buf, const uint64_t* s, int mask) {
     const uint64_t h = hash_state<WS>(s);
-    const uint32_t tag = (uint32_t)(h >> 52);
+    const uint32_t tag = (uint32_t)(h >> (32 + c.cdbits));
     uint32_t slot = (uint32_t)h & (uint32_t)mask;
     const uint64_t* st = c.cstate[buf];
     for (int probes = 0; probes <= mask; ++probes) {
         uint32_t e = c.table[slot];
         if (e == TAB_EMPTY) return NONE32;
-        if ((e >> 20) == tag) {
-            const uint32_t w = e & 0xFFFFFu;
+        if ((e >> c.cdbits) == tag) {
+            const uint32_t w = e & ((1u << c.cdbits) - 1u);
             bool eq = true;
             for (int k = 0; k < WS && eq; ++k) eq = st[(size_t)k * c.capC1 + w] == s[k];
             if (eq) return w;
@@ -2519,6 +2520,8 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.tmode = P.tmode;
     c.clocks = P.phase_clocks;
     c.lstride = P.tmode ? P.lstride : P.capN;
+    c.cdbits = 20;   // an entry is never TAB_EMPTY: candidate indices stay below 2^cdbits - 1
+    while ((1u << c.cdbits) <= (uint32_t)P.capC1) ++c.cdbits;
     c.lstate = nullptr;
     c.lval = c.lrub = c.lvb = c.lth = c.cth = nullptr;
     if (P.tmode) {

@@ -91,6 +91,24 @@ def test_tsptw_whole_search_of_rbg132(oracle):
         assert d is None, f"compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
 
 
+def test_tsptw_candidate_indices_beyond_20_bits(oracle):
+    """a DD slot sized for 60 000 nodes per layer: 21 children per node make 1.26 M candidate slots, so the dedup table's entries
+    (tag | candidate) carry 21-bit candidate indices instead of 20 (DDCtx::cdbits) -- the solvers size their slots like this under
+    TsptwWidth (nb_vars^2 nodes); the replay is the one of the small-width test above"""
+    path = data_path("tsptw", "Langevin", "N20ft405.dat")
+    model = ddo_amd.Tsptw.read_instance(path)
+    summary, recs = oracle.trace_ex("tsptw+dominance", path, 3, 0, True, True)
+    e = ModelEmul(model, 60000)
+    e.keep_layers(True, 1 << 15)
+    e.dominance(1 << 15)
+    for i, r in enumerate(recs):
+        fl = IN_WANT_PATHS | IN_DOMINANCE | IN_FRONTIER | IN_CACHE | (IN_MUST_EXPLORE if r["comp_type"] == 2 else 0)
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=fl)[0]
+        assert g is not None and g["status"] == 0
+        d = diff(r, g)
+        assert d is None, f"compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+
+
 def test_tsptw_model_host_side(tmp_path):
     """instance.rs:52-109 (`(f32 * 10000.0) as usize`), model.rs:36-47 (initial state: at the depot, everything else to visit)"""
     p = tmp_path / "t.dat"

@@ -130,6 +130,21 @@ def test_replay_beyond_64_nodes(have_gpu, oracle, family, fname, width, max_comp
     assert merges > 0
 
 
+@pytest.mark.parametrize("family,fname,width,max_compiles", [("AFG", "rbg125a.tw", 2, 20), ("AFG", "rbg132.tw", 0, 40)], ids=["rbg125a", "rbg132"])
+def test_replay_in_slots_sized_like_the_solvers(have_gpu, oracle, family, fname, width, max_compiles):
+    """the DD slots sized for nb_vars^2 nodes per layer, as the solvers size them under TsptwWidth: 2.0 / 2.25 M candidate slots, i.e.
+    21- and 22-bit candidate indices in the dedup table (DDCtx::cdbits), the 1024-thread kernel with its table in HBM"""
+    path = data_path("tsptw", family, fname)
+    model = ddo_amd.Tsptw.read_instance(path)
+    _, recs = oracle.trace_ex("tsptw+dominance", path, width, max_compiles, True, True)
+    mdd = ddo_amd.Mdd(model, model.n * model.n, cutset_type=FRONTIER, caching=True)
+    ch, dom = ddo_amd.SimpleCache(model, 1 << 20), ddo_amd.SimpleDominanceChecker(model, 1 << 20)
+    for i, r in enumerate(recs):
+        comp = mdd.compile(r["comp_type"], r["width"], _sub(r), r["best_lb"], cache=ch, dominance=dom)
+        d = diff(r, canon_from_mdd(mdd, comp, model.ws))
+        assert d is None, f"{fname} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+
+
 @pytest.mark.parametrize("family,fname", [("AFG", "rbg067a.tw"), ("Dumas", "n80w20.001.txt"), ("AFG", "rbg132.tw")])
 def test_sequential_solver_matches_the_oracle_beyond_64_nodes(have_gpu, oracle, family, fname):
     """frontier + cache + dominance with TsptwWidth(nb_vars, 1), one sub-problem at a time: explored count and counters equal the oracle's"""
