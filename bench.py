@@ -208,10 +208,98 @@ def bench_vector(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_tsptw(args):
+    """Secondary workload on ONE GPU: BASELINE.json config C5 -- TSPTW, resources/tsptw n ~ 40, width 20000 -- as whole searches
+    to the proved optimum in the reference's example configuration (examples/tsptw/main.rs:70-128: frontier cut-set, SimpleCache,
+    SimpleDominanceChecker(TsptwDominance)) with FixedWidth(20000) in place of TsptwWidth; `--instance FAMILY/FILE` runs one
+    instance of data/tsptw under TsptwWidth(nb_vars, 1) instead (e.g. AFG/rbg125a.tw: 126 nodes, 2-word node sets).
+    D-ary layer-rebuilding engine (misp_dd_core.hpp + dd_tsptw.hpp), host NoDupFringe.  `roofline` uses SURVEY.md section 8 d3's
+    formula with the TSPTW state (S = 8 * state words) and the MEASURED mean fan-out c = arcs / nodes expanded:
+    bytes_per_node = (S + 8) + c (S + 16)."""
+    import ddo_amd
+    from ddo_amd import FRONTIER, FixedWidth, ParallelSolver, TsptwWidth
+    from tests.oracle_binding import Oracle
+
+    if args.instance != INSTANCE:
+        cases = [os.path.join(ROOT, "data", "tsptw", args.instance)]
+        width, wlabel, label = TsptwWidth(1), "TsptwWidth(nb_vars, 1)", f"TSPTW {args.instance}"
+    else:
+        cases = [os.path.join(ROOT, "data", "tsptw", "Langevin", f + ".dat") for f in ("N40ft201", "N40ft207", "N40ft403", "N40ft410")]
+        width, wlabel, label = FixedWidth(20000), "FixedWidth(20000)", "TSPTW Langevin N40ft201/207/403/410 (config C5)"
+    models = [ddo_amd.Tsptw.read_instance(p) for p in cases]
+    tot = None
+    for rep in range(2):     # first pass = warm-up (engine creation, first launches)
+        tot = {"dt": 0.0, "nodes": 0, "arcs": 0, "kms": 0.0, "launches": 0, "explored": 0, "compiles": 0, "values": [], "proved": True}
+        for model in models:
+            s = ParallelSolver(model, width, ddo_amd.TimeBudget(120.0), nb_threads=args.concurrent, fringe="nodup", cutset_type=FRONTIER,
+                               cache_entries=1 << 22, dominance_entries=1 << 22)
+            k0, l0 = s.device_time()
+            t0 = time.perf_counter()
+            c = s.maximize()
+            dt = time.perf_counter() - t0
+            k1, l1 = s.device_time()
+            cnt = s.counters()
+            tot["dt"] += dt
+            tot["nodes"] += cnt["nodes_expanded"]
+            tot["arcs"] += cnt["arcs"]
+            tot["kms"] += k1 - k0
+            tot["launches"] += l1 - l0
+            tot["explored"] += s.explored()
+            tot["compiles"] += cnt["compiles"]
+            tot["values"].append(c.best_value)
+            tot["proved"] = tot["proved"] and bool(c.is_exact)
+            del s
+    assert tot["kms"] / 1e3 <= tot["dt"] * 1.001, "kernel time must fit inside the wall time of the searches it belongs to"
+    S = 8 * models[0].ws
+    fan = tot["arcs"] / max(1, tot["nodes"])
+    bpn = (S + 8) + fan * (S + 16)
+    ach = tot["nodes"] * bpn / max(tot["kms"] / 1e3, 1e-12) / 1e9
+    out = {
+        "metric": f"MDD nodes expanded/sec, {label} {wlabel} (whole searches to the proved optimum)",
+        "value": tot["nodes"] / tot["dt"], "unit": "nodes/s", "n_gpus": 1, "steps": int(tot["launches"]), "warmup": 1,
+        "ms_per_step": 1e3 * tot["dt"] / max(1, tot["launches"]), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 sets / i32 times",
+        "data": "real instances shipped with the reference (resources/tsptw)",
+        "config": {"workload": f"{label} {wlabel} frontier cut-set, SimpleCache, TsptwDominance, host NoDupFringe(MaxUB), "
+                               f"{args.concurrent} sub-problems in flight", "parallelism": "1 GPU"},
+        "proved": tot["proved"], "best_values": tot["values"], "time_to_proved_optimum_s": tot["dt"] if tot["proved"] else None,
+        "subproblems": tot["explored"], "compiles": tot["compiles"], "arcs_per_node": fan,
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "traffic_source": "null: no rocprofv3 --pmc pass of this workload is committed",
+                     "kernel": f"ddo_hip::misp_compile_kernel<WS, table in LDS / HBM> (layer-rebuilding engine, {models[0].ws}-word TSPTW states, "
+                               f"{models[0].n} children per node)",
+                     "kernel_ms_avg": tot["kms"] / max(1, tot["launches"]), "kernel_s": tot["kms"] / 1e3, "wall_s": tot["dt"],
+                     "launches": int(tot["launches"]), "bytes_per_node": bpn,
+                     "kernel_nodes_per_s": tot["nodes"] / max(tot["kms"] / 1e3, 1e-12)},
+    }
+    if not args.no_cpu:
+        o = Oracle(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+        phys, logical = physical_cores()
+        runs = []
+        if args.instance != INSTANCE:      # the oracle's ParallelSolver in the same configuration, swept over thread counts
+            for t in (1, 16, 32):
+                v, r = o.tsptw_file(cases[0], 1, t)
+                runs.append({"threads": t, "nodes_per_s": r["nodes_expanded"] / max(r["wall_s"], 1e-9), "wall_s": r["wall_s"],
+                             "same_optimum": (not r["is_exact"]) or v == tot["values"][0]})
+        else:                               # fixed width: the oracle's traced sequential search (one thread)
+            nodes, wall, ok = 0, 0.0, True
+            for path, got in zip(cases, tot["values"]):
+                r, _ = o.trace_ex("tsptw+dominance", path, 20000, 0, True, True)
+                nodes += r["nodes_expanded"]
+                wall += r["wall_s"]
+                ok = ok and r["best_value"] == got
+            runs.append({"threads": 1, "nodes_per_s": nodes / max(wall, 1e-9), "wall_s": wall, "same_optimum": ok})
+        best = max(runs, key=lambda x: x["nodes_per_s"])
+        out["cpu_baseline"] = {"value": best["nodes_per_s"], "unit": "nodes/s", "cores": best["threads"], "kind": "port",
+                               "sample": "oracle (C++ restatement of ddo), same instances / width / cut-set / cache / dominance, whole searches",
+                               "physical_cores": phys, "logical_cpus": logical, "thread_sweep": runs}
+        out["speedup_vs_cpu"] = out["value"] / max(best["nodes_per_s"], 1e-9)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="misp", choices=["misp", "max2sat", "mcp"],
-                    help="misp: the headline metric (default); max2sat: BASELINE config C3 on one GPU (secondary line)")
+    ap.add_argument("--workload", default="misp", choices=["misp", "max2sat", "mcp", "tsptw"],
+                    help="misp: the headline metric (default); max2sat: BASELINE config C3 on one GPU (secondary line); tsptw: config C5 on one GPU")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
@@ -241,6 +329,10 @@ def main():
         if args.concurrent == 1024:
             args.concurrent = 256
         return bench_vector(args)
+    if args.workload == "tsptw":
+        if args.concurrent == 1024:
+            args.concurrent = 64
+        return bench_tsptw(args)
     # test hook (single-GPU boxes): DDO_BENCH_ONE_GPU=1 puts every rank on cuda:0 and rendezvous over gloo, so the
     # multi-process path (sharded root cut-set, incumbent all-reduce, max-over-ranks timing) can be exercised there
     one_gpu = os.environ.get("DDO_BENCH_ONE_GPU") == "1"
