@@ -2110,34 +2110,36 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     PAR_END
 }
 
-/// restricted, then (when inexact) relaxed: the device half of process_one_node (parallel.rs:391-437)
+/// restricted, then (when inexact) relaxed: the device half of process_one_node (parallel.rs:391-437).
+/// ONE call site of run_dd2 (a loop over the two compilations): the function is inlined once, not three times -- the kernel's
+/// code is a third of what it was (round 3: 48 000 lines of ISA, several times the instruction cache two CUs share).
 template <int WS, int DEEP = 0>
 DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
     DD_TID_SETUP(c)
     (void)NT;
-    if (in.flags & IN_FUSED) {
-        run_dd2<WS, DEEP>(c, in, CT_RESTRICTED, in.best_lb, &res2[0]);
-        PAR_BEGIN
-        if (tid == 0) {
-            c.sh->sel_above = (res2[0].status == ST_OK && !res2[0].is_exact) ? 1 : 0;
-            c.sh->sel_bucket = res2[0].has_best_exact ? 1 : 0;
-            c.sh->sel_digit = res2[0].best_exact_value;
-        }
-        PAR_END
-        const bool go = c.sh->sel_above != 0;
-        int64_t lb = in.best_lb;
-        if (c.sh->sel_bucket && (int64_t)c.sh->sel_digit > lb) lb = c.sh->sel_digit;  // maybe_update_best
-        if (go) run_dd2<WS, DEEP>(c, in, CT_RELAXED, lb, &res2[1]);
-        else {
+    const bool fused = (in.flags & IN_FUSED) != 0;
+    int64_t lb = in.best_lb;
+    bool go = true;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !(fused && go)) {
             PAR_BEGIN
             if (tid == 0) res2[1].status = ST_NOT_RUN;
             PAR_END
+            break;
         }
-    } else {
-        run_dd2<WS, DEEP>(c, in, in.comp_type, in.best_lb, &res2[0]);
-        PAR_BEGIN
-        if (tid == 0) res2[1].status = ST_NOT_RUN;
-        PAR_END
+        run_dd2<WS, DEEP>(c, in, fused ? (pass == 0 ? CT_RESTRICTED : CT_RELAXED) : in.comp_type, lb, &res2[pass]);
+        if (pass == 0 && fused) {
+            PAR_BEGIN
+            if (tid == 0) {
+                c.sh->sel_above = (res2[0].status == ST_OK && !res2[0].is_exact) ? 1 : 0;
+                c.sh->sel_bucket = res2[0].has_best_exact ? 1 : 0;
+                c.sh->sel_digit = res2[0].best_exact_value;
+            }
+            PAR_END
+            go = c.sh->sel_above != 0;
+            if (c.sh->sel_bucket && (int64_t)c.sh->sel_digit > lb) lb = c.sh->sel_digit;  // maybe_update_best
+            DD_SYNC();
+        }
     }
 }
 
