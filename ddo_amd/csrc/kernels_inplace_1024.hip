@@ -4,6 +4,10 @@
 #include "kernels.hpp"
 #include "misp_dd_inplace.hpp"
 
+#if !defined(DDO_G8_FULL)
+#define DDO_G8_FULL 0
+#endif
+
 namespace ddo_hip {
 
 // MAXT = 512 lets the register allocator use 256 VGPRs (the 1024-thread variant is capped at 128 and spills)
@@ -19,18 +23,30 @@ __global__ void __launch_bounds__(MAXT) misp_compile_kernel2(EngineParams P) {
         const int w = c.sh->work;
         __syncthreads();
         if (w >= P.nbatch) break;
-        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+        run_work_item2<WS, 0, DDO_G8_FULL>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }
 
 kernel_fn pick_kernel2_1024(int wsT) {
     switch (wsT) {
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 1
         case 1: return misp_compile_kernel2<1, 1024>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 2
         case 2: return misp_compile_kernel2<2, 1024>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 4
         case 4: return misp_compile_kernel2<4, 1024>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 7
         case 7: return misp_compile_kernel2<7, 1024>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 8
         case 8: return misp_compile_kernel2<8, 1024>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 16
         case 16: return misp_compile_kernel2<16, 1024>;
+#endif
         default: return nullptr;
     }
 }

@@ -7,6 +7,14 @@
 #include "kernels.hpp"
 #include "misp_dd_inplace.hpp"
 
+// DDO_G8_*: nodes in flight per 8-lane group of expand_g8 (misp_dd_inplace.hpp); 0 = the thread-per-node expand loop
+#if !defined(DDO_G8_TIER)
+#define DDO_G8_TIER 0
+#endif
+#if !defined(DDO_G8_DENSE)
+#define DDO_G8_DENSE 2
+#endif
+
 namespace ddo_hip {
 
 template <int WS>
@@ -24,7 +32,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDO_TI
         const int w = c.sh->work;
         __syncthreads();
         if (w >= P.nbatch) break;
-        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+        run_work_item2<WS, 0, DDO_G8_TIER>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }
 
@@ -42,18 +50,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int w = c.sh->work;
         __syncthreads();
         if (w >= P.nbatch) break;
-        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
+        run_work_item2<WS, 0, DDO_G8_DENSE>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }
 
 kernel_fn pick_kernel2_dense(int wsT) {
     switch (wsT) {
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 1
         case 1: return misp_compile_kernel2_dense<1>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 2
         case 2: return misp_compile_kernel2_dense<2>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 4
         case 4: return misp_compile_kernel2_dense<4>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 7
         case 7: return misp_compile_kernel2_dense<7>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 8
         case 8: return misp_compile_kernel2_dense<8>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 16
         case 16: return misp_compile_kernel2_dense<16>;
+#endif
         default: return nullptr;
     }
 }
@@ -62,12 +82,24 @@ int tier_waves_per_simd() { return DDO_TIER_WAVES; }
 
 kernel_fn pick_kernel2_tier(int wsT) {
     switch (wsT) {
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 1
         case 1: return misp_compile_kernel2_tier<1>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 2
         case 2: return misp_compile_kernel2_tier<2>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 4
         case 4: return misp_compile_kernel2_tier<4>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 7
         case 7: return misp_compile_kernel2_tier<7>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 8
         case 8: return misp_compile_kernel2_tier<8>;
+#endif
+#if !defined(DDO_WS_ONLY) || DDO_WS_ONLY == 16
         case 16: return misp_compile_kernel2_tier<16>;
+#endif
         default: return nullptr;
     }
 }

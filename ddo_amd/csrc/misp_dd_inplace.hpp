@@ -36,6 +36,8 @@ namespace ddo_hip {
 constexpr uint32_t T2_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t T2_TOMB = 0xFFFFFFFEu;
 constexpr uint32_t EV_CREATED = 0x80000000u;  // flag on a YES target: the slot was created by this arc
+constexpr uint32_t EV_RAISED = 0x40000000u;   // flag on a target: the arc raised its target's key (see the event records of run_dd2)
+constexpr uint32_t EV_SLOT_MASK = 0x000FFFFFu;
 constexpr int KEY_POP_BITS = 11;              // key32 = (value - vbase) << 11 | popcount
 constexpr uint32_t KEY_POP_MASK = (1u << KEY_POP_BITS) - 1;
 
@@ -829,17 +831,331 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
     return true;
 }
 
+#if !defined(DDO_HOST_EMULATION)
+// =============================================================================
+// 8 lanes per node (round 4).  A node record is one 64-byte line (RW = 8 words; 16 / 24 for the wide states): lane k of an
+// 8-lane group holds word k (+ 8, + 16) of the record -- state words, then the path id.  The record of a branching node is
+// read and both children are written with ONE coalesced 64-byte request each (thread-per-node: four 16-byte requests per
+// record and lane, 12 write requests per branching node; tools/micro/counter_calibration: the memory system completes about
+// 60 G random lines per second whatever their shape, but 4 requests per line cost 1.7 x the line's time on the write side).
+// `& adj[v]` is lane-local, popcount / hash are 3-step DPP reductions inside the group, a twin's record is compared by the
+// 8 lanes at once and judged by one ballot -- and a lane keeps 3 words per node in flight instead of 3 x WS.
+// =============================================================================
+template <int CTRL>
+DDO_DEV uint32_t g8_dpp(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false); }
+/// sum over the 8 lanes of a group (every lane of the wave must call)
+DDO_DEV uint32_t g8_add(uint32_t x) {
+    x += g8_dpp<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += g8_dpp<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += g8_dpp<0x141>(x);   // row_half_mirror: lane i <-> 7 - i of its 8-lane half row
+    return x;
+}
+DDO_DEV uint64_t g8_xor64(uint64_t x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo ^= g8_dpp<0xB1>(lo); hi ^= g8_dpp<0xB1>(hi);
+    lo ^= g8_dpp<0x4E>(lo); hi ^= g8_dpp<0x4E>(hi);
+    lo ^= g8_dpp<0x141>(lo); hi ^= g8_dpp<0x141>(hi);
+    return ((uint64_t)hi << 32) | lo;
+}
+/// the value lane `src` (0..7) of the group holds
+DDO_DEV uint64_t g8_bcast64(uint64_t x, int gl, int src) { return (uint64_t)__shfl((unsigned long long)x, gl | src, 64); }
+DDO_DEV int g8_bcast32(int x, int gl, int src) { return __shfl(x, gl | src, 64); }
+
+/// expand + dedup of the nwl nodes that contain the branching variable (clean.rs:360-370, 738-775, 199-220; MISP transition
+/// main.rs:77-102), U nodes in flight per group.  Same contract as the thread-per-node loop in run_dd2: event record
+/// nrec0 + i belongs to work item i.
+template <int WS, int U>
+DDO_DEV void expand_g8(DD2Ctx<WS>& c, const int L, const int var, const int nwl, const int nrec0, const uint64_t aff_off, const int nfl_lim,
+                       const bool fl_implicit, const int hiw_now, const int32_t vbase, const int64_t best_lb) {
+    constexpr int RW = ((WS + 1 + 7) / 8) * 8, NW = RW / 8;
+    constexpr int KP = WS & 7, JP = WS >> 3;   // lane / word-of-lane of the path id
+    const int tid = c.tid_, NT = c.NT;
+    LDS_PTR(DD2Shared) sh = c.sh;
+    const int lane = tid & 63, k = tid & 7, gl = lane & 56, g = tid >> 3, NG = NT >> 3;
+    const int vw = var >> 6, kv = vw & 7, jv = vw >> 3;
+    const uint64_t vbit = 1ULL << (var & 63);
+    const uint32_t mask = (uint32_t)c.tab_cap - 1;
+    uint64_t adjv[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) adjv[j] = (k + 8 * j) < WS ? c.adj[(size_t)var * WS + k + 8 * j] : 0ULL;
+    const int32_t wv = DD_UNIFORM(c.weight[var]);
+    uint32_t kb_and = 0xFFFFFFFFu, kb_or = 0;
+    int dlive = 0, dpruned = 0;
+    for (int base = 0; base < nwl; base += NG * U) {
+        int s[U];
+        bool act[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * NG + g;
+            act[u] = i < nwl;
+            s[u] = act[u] ? (int)c.wl[i] : 0;
+        }
+        uint64_t kh[U], x[U][NW];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kh[u] = act[u] ? KH(c, s[u]) : 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) x[u][j] = act[u] ? c.rec[(size_t)s[u] * RW + k + 8 * j] : 0ULL;
+        }
+        // ---- rough upper bound (main.rs:191-193), children's states, keys and hashes
+        bool br[U];
+        int ny[U];
+        uint64_t y[U][NW];
+        uint32_t kno[U], kyes[U], newh[U], yh[U], eid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t key = (uint32_t)(kh[u] >> 32), oldh = (uint32_t)kh[u];
+            const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
+            int32_t rub = (int32_t)(key & KEY_POP_MASK);
+            if (!c.unit_weights) {
+                int32_t sum = 0;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    uint64_t b = (k + 8 * j) < WS ? x[u][j] : 0ULL;
+                    while (b) {
+                        sum += c.weight[(k + 8 * j) * 64 + dd_ctz(b)];
+                        b &= b - 1;
+                    }
+                }
+                rub = (int32_t)g8_add((uint32_t)sum);
+            }
+            const bool pruned = act[u] && (int64_t)rub + (int64_t)val <= best_lb;   // clean.rs:364-365: no children
+            br[u] = act[u] && !pruned;
+            // decision NO, in place (main.rs:77-85): the word holding the variable changes
+            uint64_t oldw = 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+                if (j == jv) oldw = g8_bcast64(x[u][j], gl, kv);
+            const uint64_t neww = oldw & ~vbit;
+            newh[u] = oldh ^ fold32(mixw(oldw, vw) ^ mixw(neww, vw));   // (the hash is XOR-linear in the per-word mixes)
+            kno[u] = key - 1;                                            // popcount - 1, same value (cost 0)
+            if (br[u] && k == kv) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j)
+                    if (j == jv) x[u][j] = neww;
+            }
+            // decision YES (main.rs:95-102)
+            uint32_t ypop = 0;
+            uint64_t hx = 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const bool isw = (k + 8 * j) < WS;
+                y[u][j] = isw ? (x[u][j] & adjv[j]) : 0ULL;
+                ypop += (uint32_t)dd_popc(y[u][j]);
+                if (isw) hx ^= mixw(y[u][j], k + 8 * j);
+            }
+            ypop = g8_add(ypop);
+            yh[u] = fold32(g8_xor64(hx));
+            kyes[u] = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | ypop;
+            // a free slot for the YES-child: one LDS atomic per wave
+            const uint64_t m = __ballot(br[u] && k == 0);
+            int fbase = 0;
+            if (lane == 0 && m) fbase = LDS_ADD_I32(&sh->nnew, dd_popc(m));
+            fbase = __builtin_amdgcn_readfirstlane(fbase);
+            const int fi = fbase + dd_popc(m & ((1ULL << gl) - 1ULL));
+            ny[u] = -1;
+            if (br[u]) {
+                if (fi < nfl_lim) ny[u] = fl_implicit ? hiw_now + fi : (int)c.fl[fi];
+                else if (k == 0) sh->status = ST_ERR_CAPACITY - 100 * 6;
+            }
+            eid[u] = (uint32_t)(aff_off >> 2) + (uint32_t)(nrec0 + base + u * NG + g);   // event record = path-tree node of the YES arc
+            if (br[u]) {
+                kb_and &= kno[u];
+                kb_or |= kno[u];
+                if (ny[u] >= 0) {
+                    kb_and &= kyes[u];
+                    kb_or |= kyes[u];
+                }
+            }
+            if (act[u] && k == 4) bm_clr(c.fresh, s[u]);
+        }
+        // ---- both records go out as whole lines; key|hash words, path-tree node and flags by single lanes
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!br[u]) continue;
+            const uint32_t ppid = (uint32_t)g8_bcast64(x[u][JP], gl, KP);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) c.rec[(size_t)s[u] * RW + k + 8 * j] = x[u][j];
+            if (ny[u] >= 0) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    const int w = k + 8 * j;
+                    c.rec[(size_t)ny[u] * RW + w] = w < WS ? y[u][j] : (w == WS ? (uint64_t)eid[u] : 0ULL);
+                }
+            }
+            if (k == 0) KH_ST(c, s[u], kno[u], newh[u]);   // (cnt[var]: no state of the next layer contains the variable, it is zeroed with the layer)
+            if (ny[u] >= 0) {
+                if (k == 1) KH_ST(c, ny[u], kyes[u], yh[u]);
+                if (k == 2) c.pt[eid[u]] = (uint64_t)ppid | ((uint64_t)(uint32_t)L << 32);   // the child's best path: the parent's plus decision 1 at layer L
+                if (k == 3) {
+                    bm_put(c.inex, ny[u], bm_test(c.inex, s[u]));
+                    bm_put(c.okb, ny[u], bm_test(c.okb, s[u]));
+                }
+            }
+        }
+        FENCE_BLOCK();   // the records are visible to the workgroup before the table publishes their slots
+        // ---- dedup of both children (append_edge_to!, clean.rs:199-220): lane 0 of a group probes for the NO-child, lane 1 for
+        // the YES-child.  LDS phase: up to a claimed entry or a matching tag; global phase: the 8 lanes compare the holder's
+        // record with the child's and one ballot decides.
+        int res[U];
+        uint32_t pp[U], mine[U];
+        bool pend[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t h = k == 0 ? newh[u] : yh[u];
+            const int own = k == 0 ? s[u] : ny[u];
+            pend[u] = br[u] && k < 2 && own >= 0;
+            mine[u] = ((h >> 20) << 20) | (uint32_t)own;
+            pp[u] = h & mask;
+            res[u] = own;
+        }
+        for (uint32_t round = 0;; ++round) {
+            int cand[U];
+            bool anyc = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                cand[u] = -1;
+                if (pend[u]) {
+                    for (uint32_t probes = 0;; ++probes) {
+                        const uint32_t e = TAB_CAS(&c.tab[pp[u]], T2_EMPTY, mine[u]);
+                        if (e == T2_EMPTY) {
+                            pend[u] = false;
+                            break;
+                        }
+                        if ((e >> 20) == (mine[u] >> 20)) {
+                            cand[u] = (int)(e & 0xFFFFFu);
+                            break;
+                        }
+                        pp[u] = (pp[u] + 1) & mask;
+                        if (probes > mask) {   // the table is full (cannot happen: tab_limit)
+                            sh->status = ST_ERR_INTERNAL;
+                            pend[u] = false;
+                            break;
+                        }
+                    }
+                    anyc |= cand[u] >= 0;
+                }
+            }
+            if (!__ballot(anyc)) break;
+            if (round > mask) {
+                if (tid == 0) sh->status = ST_ERR_INTERNAL;
+                break;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c1 = g8_bcast32(cand[u], gl, 0), c2 = g8_bcast32(cand[u], gl, 1);
+                // the holders may have been written by other waves a moment ago: agent-scope loads bypass this CU's vector L1
+                bool ne1 = false, ne2 = false;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    const int w = k + 8 * j;
+                    if (w < WS) {
+                        const uint64_t a = c1 >= 0 ? LD_U64(&c.rec[(size_t)c1 * RW + w]) : x[u][j];
+                        const uint64_t b = c2 >= 0 ? LD_U64(&c.rec[(size_t)c2 * RW + w]) : y[u][j];
+                        ne1 |= a != x[u][j];
+                        ne2 |= b != y[u][j];
+                    }
+                }
+                const uint32_t g1 = (uint32_t)(__ballot(ne1) >> gl) & 0xFFu, g2 = (uint32_t)(__ballot(ne2) >> gl) & 0xFFu;
+                if (cand[u] >= 0) {
+                    const bool eq = (k == 0 ? g1 : g2) == 0;
+                    if (eq) {
+                        res[u] = cand[u];
+                        pend[u] = false;
+                    } else {
+                        pp[u] = (pp[u] + 1) & mask;
+                    }
+                }
+            }
+        }
+        // ---- twins: the holder's key keeps the maximum (both children's atomics in one instruction)
+        uint32_t old[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            old[u] = 0;
+            const int own = k == 0 ? s[u] : ny[u];
+            if (br[u] && k < 2 && own >= 0 && res[u] != own) old[u] = K32_MAX(c, res[u], k == 0 ? kno[u] : kyes[u], k == 0 ? newh[u] : yh[u]);
+        }
+        // ---- bookkeeping: vertex counters by all lanes (each its own words), bitmaps and the event record by lane 0
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t0 = g8_bcast32(res[u], gl, 0), t1 = g8_bcast32(res[u], gl, 1);
+            const uint32_t old1 = (uint32_t)g8_bcast32((int)old[u], gl, 1);
+            if (!act[u]) continue;
+            const bool dis0 = br[u] && t0 != s[u];                     // the in-place NO-child dissolves into its twin t0
+            const bool new1 = br[u] && ny[u] >= 0 && t1 == ny[u];      // a new node enters the layer
+            if (!br[u] || dis0) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    uint64_t b = (k + 8 * j) < WS ? x[u][j] : 0ULL;
+                    while (b) {
+                        LDS_ADD_I32(&c.cnt[(k + 8 * j) * 64 + dd_ctz(b)], -1);
+                        b &= b - 1;
+                    }
+                }
+            }
+            if (new1) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    uint64_t b = y[u][j];
+                    while (b) {
+                        LDS_ADD_I32(&c.cnt[(k + 8 * j) * 64 + dd_ctz(b)], 1);
+                        b &= b - 1;
+                    }
+                }
+            }
+            if (k != 0) continue;
+            U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)(nrec0 + base + u * NG + g));
+            if (!br[u]) {
+                bm_clr(c.live, s[u]);
+                dlive -= 1;
+                dpruned += 1;
+                *rec4 = U32x4{(uint32_t)s[u], NONE32, NONE32, NONE32};
+                continue;
+            }
+            uint32_t e_no = (uint32_t)s[u], e_yes = NONE32;
+            if (!dis0) {
+                bm_set(c.fresh, s[u]);   // it stays in the layer; its rub shrank: check it again before it is expanded
+            } else {
+                if (bm_test(c.inex, s[u])) bm_set(c.inex, t0);
+                bm_clr(c.live, s[u]);
+                dlive -= 1;
+                e_no = (uint32_t)t0 | (kno[u] > old[u] ? EV_RAISED : 0u);
+            }
+            if (ny[u] >= 0) {
+                if (new1) {
+                    bm_set(c.live, ny[u]);
+                    bm_set(c.fresh, ny[u]);
+                    dlive += 1;
+                    LDS_MAX_I32(&sh->hiw, ny[u] + 1);
+                    e_yes = (uint32_t)ny[u] | EV_CREATED;
+                } else {
+                    if (bm_test(c.inex, ny[u])) bm_set(c.inex, t1);
+                    e_yes = (uint32_t)t1 | (kyes[u] > old1 ? EV_RAISED : 0u);
+                }
+            }
+            // parent | NO target | YES target | slot allocated for the YES-child
+            *rec4 = U32x4{(uint32_t)s[u], e_no, e_yes, ny[u] >= 0 ? (uint32_t)ny[u] : NONE32};
+        }
+    }
+    if (dlive) LDS_ADD_I32(&sh->nlive, dlive);
+    if (dpruned) LDS_ADD_I32(&sh->npruned, dpruned);
+    if (kb_or != 0 || kb_and != 0xFFFFFFFFu) {
+        LDS_AND_U32(&sh->kbits_and[(L + 1) & 1], kb_and);
+        LDS_OR_U32(&sh->kbits_or[(L + 1) & 1], kb_or);
+    }
+}
+#endif
+
 /// One compile() (clean.rs:345-381) with in-place layers.
 ///
 /// Event records (u32 stream `ev`, per transition L -> L+1, 4 words per affected or pruned parent):
 ///   [0] parent slot   [1] NO target | flags   [2] YES target | flags   [3] slot allocated for the YES-child
 /// flags: EV_CREATED (bit 31, YES target is the new node), EV_RAISED (bit 30, the arc raised its target's key).
 /// The squash of layer L (deleted slots, merged slot, re-added duplicate) is stored with iteration L.
-constexpr uint32_t EV_RAISED = 0x40000000u;
-constexpr uint32_t EV_SLOT_MASK = 0x000FFFFFu;
 
 
-template <int WS, int DEEP = 0>
+template <int WS, int DEEP = 0, int G8 = 0>
 DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
     constexpr int KB = DEEP ? 16 : 8;
     DD_TID_SETUP(c)
@@ -1463,6 +1779,17 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // ---- nodes containing the variable: expansion AND dedup (clean.rs:738-775) in one pass.  The table holds every
         // unchanged node of the next layer now, so a thread writes its two children, makes the stores visible to the
         // workgroup and inserts them right away -- the records never have to be read back.
+        int nrec_g8 = -1;
+#if !defined(DDO_HOST_EMULATION)
+        if constexpr (G8 > 0) {   // 8 lanes per node (expand_g8)
+            const int nrec0 = DD_UNIFORM(sh->nrec);   // records of the pruned fresh nodes above
+            PAR_BEGIN
+            expand_g8<WS, (WS <= 7 ? G8 : (G8 > 2 ? 2 : G8))>(c, L, var, nwl, nrec0, aff_off, nfl_lim, fl_implicit, hiw_now, vbase, best_lb);
+            PAR_END
+            nrec_g8 = nrec0 + nwl;   // every work item has its event record
+        } else
+#endif
+        {
         PAR_BEGIN
         uint64_t adjv[WS];   // (workgroup-uniform: kept in scalar registers)
 #pragma unroll
@@ -1599,7 +1926,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             LDS_OR_U32(&sh->kbits_or[(L + 1) & 1], kb_or);
         }
         PAR_END
-        const int nrec = DD_UNIFORM(sh->nrec);
+        }
+        const int nrec = nrec_g8 >= 0 ? nrec_g8 : DD_UNIFORM(sh->nrec);
         if (sh->status != ST_OK) { failed = true; break; }
         DD2_STAT(5, nrec)
         DD2_TICK(PH_EXP1)
@@ -2113,7 +2441,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 /// restricted, then (when inexact) relaxed: the device half of process_one_node (parallel.rs:391-437).
 /// ONE call site of run_dd2 (a loop over the two compilations): the function is inlined once, not three times -- the kernel's
 /// code is a third of what it was (round 3: 48 000 lines of ISA, several times the instruction cache two CUs share).
-template <int WS, int DEEP = 0>
+template <int WS, int DEEP = 0, int G8 = 0>
 DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
     DD_TID_SETUP(c)
     (void)NT;
@@ -2127,7 +2455,7 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
             PAR_END
             break;
         }
-        run_dd2<WS, DEEP>(c, in, fused ? (pass == 0 ? CT_RESTRICTED : CT_RELAXED) : in.comp_type, lb, &res2[pass]);
+        run_dd2<WS, DEEP, G8>(c, in, fused ? (pass == 0 ? CT_RESTRICTED : CT_RELAXED) : in.comp_type, lb, &res2[pass]);
         if (pass == 0 && fused) {
             PAR_BEGIN
             if (tid == 0) {
