@@ -460,7 +460,7 @@ def main():
                             traffic_src = f"null: profiles/{rnd}/pmc_summary.json describes {stamp.get('kernel')}, the dominant kernel here is {dom_name}"
                         else:
                             traffic = tj["hbm_bytes_per_node"] * dom_nodes / launches
-                            traffic_src = (f"profiles/{rnd}/pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE per node, same frozen workload, kernel sources "
+                            traffic_src = (f"profiles/{rnd}/pmc_summary.json (FETCH_SIZE x calibrated factor + WRITE_SIZE per node -- counter_calibration.json --, same frozen workload, kernel sources "
                                            f"{stamp.get('kernel_sources')}, git {stamp.get('git')}) x nodes per launch")
                         break
                 except (ValueError, OSError):

@@ -4,26 +4,23 @@
 #include "kernels.hpp"
 #include "misp_dd_inplace.hpp"
 
-#if !defined(DDO_G8_FULL)
-#define DDO_G8_FULL 0
-#endif
-
 namespace ddo_hip {
 
 // MAXT = 512 lets the register allocator use 256 VGPRs (the 1024-thread variant is capped at 128 and spills)
 template <int WS, int MAXT>
 __global__ void __launch_bounds__(MAXT) misp_compile_kernel2(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    DD2Ctx<WS> c;
-    dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
-    c.tid_ = (int)threadIdx.x;
+    static_assert(sizeof(DD2Ctx<WS>) <= DD2_CTX_BYTES, "DD2_CTX_BYTES");
+    DD2Ctx<WS>& c = *(DD2Ctx<WS>*)lds;   // the context lives in LDS (misp_dd_inplace.hpp: DD2_CTX_BYTES)
+    if (threadIdx.x == 0) dd2_bind<WS>(c, P, (int)blockIdx.x, lds + DD2_CTX_BYTES, (int)blockDim.x);
+    __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
         __syncthreads();
         const int w = c.sh->work;
         __syncthreads();
         if (w >= P.nbatch) break;
-        run_work_item2<WS, 0, DDO_G8_FULL>(c, P.inputs[w], P.results + 2 * (size_t)w);
+        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }
 

@@ -7,14 +7,6 @@
 #include "kernels.hpp"
 #include "misp_dd_inplace.hpp"
 
-// DDO_G8_*: nodes in flight per 8-lane group of expand_g8 (misp_dd_inplace.hpp); 0 = the thread-per-node expand loop
-#if !defined(DDO_G8_TIER)
-#define DDO_G8_TIER 0
-#endif
-#if !defined(DDO_G8_DENSE)
-#define DDO_G8_DENSE 2
-#endif
-
 namespace ddo_hip {
 
 template <int WS>
@@ -23,16 +15,17 @@ template <int WS>
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDO_TIER_WAVES, DDO_TIER_WAVES))) misp_compile_kernel2_tier(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    DD2Ctx<WS> c;
-    dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
-    c.tid_ = (int)threadIdx.x;
+    static_assert(sizeof(DD2Ctx<WS>) <= DD2_CTX_BYTES, "DD2_CTX_BYTES");
+    DD2Ctx<WS>& c = *(DD2Ctx<WS>*)lds;   // the context lives in LDS (misp_dd_inplace.hpp: DD2_CTX_BYTES)
+    if (threadIdx.x == 0) dd2_bind<WS>(c, P, (int)blockIdx.x, lds + DD2_CTX_BYTES, (int)blockDim.x);
+    __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
         __syncthreads();
         const int w = c.sh->work;
         __syncthreads();
         if (w >= P.nbatch) break;
-        run_work_item2<WS, 0, DDO_G8_TIER>(c, P.inputs[w], P.results + 2 * (size_t)w);
+        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }
 
@@ -41,16 +34,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDO_TI
 template <int WS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) misp_compile_kernel2_dense(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    DD2Ctx<WS> c;
-    dd2_bind<WS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
-    c.tid_ = (int)threadIdx.x;
+    static_assert(sizeof(DD2Ctx<WS>) <= DD2_CTX_BYTES, "DD2_CTX_BYTES");
+    DD2Ctx<WS>& c = *(DD2Ctx<WS>*)lds;   // the context lives in LDS (misp_dd_inplace.hpp: DD2_CTX_BYTES)
+    if (threadIdx.x == 0) dd2_bind<WS>(c, P, (int)blockIdx.x, lds + DD2_CTX_BYTES, (int)blockDim.x);
+    __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
         __syncthreads();
         const int w = c.sh->work;
         __syncthreads();
         if (w >= P.nbatch) break;
-        run_work_item2<WS, 0, DDO_G8_DENSE>(c, P.inputs[w], P.results + 2 * (size_t)w);
+        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }
 

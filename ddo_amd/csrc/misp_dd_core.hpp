@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #define DDO_DEV inline
 #define PAR_BEGIN for (int tid = 0; tid < NT; ++tid) {
 #define PAR_END }
@@ -105,7 +106,7 @@ __device__ __forceinline__ uint32_t dd_tab_cas(P p, uint32_t cmp, uint32_t v) {
 #define TAB_CAS(p, c, v) dd_tab_cas((p), (c), (v))
 #define GLB_MAX_U64(p, v) atomicMax((unsigned long long*)(p), (unsigned long long)(v))
 #define GLB_OR_U32(p, v) atomicOr((p), (v))
-#define GLB_ADD_U64(p, v) atomicAdd((p), (v))
+#define GLB_ADD_U64(p, v) __hip_atomic_fetch_add((p), (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   // (any address space)
 #define GLB_ADD_I32(p, v) atomicAdd((p), (v))
 // Words that other waves update with L2 atomics (ckey, cflags) or have just stored
 // (dedup compare) are read with agent-scope relaxed atomic loads: they bypass the CU's
@@ -274,7 +275,7 @@ struct DDCtx {
 #if defined(DDO_HOST_EMULATION)
 #define DD_TID_SETUP(c) const int NT = (c).NT;
 #else
-#define DD_TID_SETUP(c) const int NT = (c).NT; const int tid = (c).tid_;
+#define DD_TID_SETUP(c) const int NT = (c).NT; const int tid = (int)threadIdx.x;
 #endif
 
 DDO_DEV uint32_t bias32(int32_t v) { return (uint32_t)v ^ 0x80000000u; }

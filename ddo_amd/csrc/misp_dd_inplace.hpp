@@ -87,10 +87,10 @@ constexpr int PH_SELLEX = 2, PH_EXP1 = 4, PH_TABLE = 5, PH_EXP2 = 6;
 #else
 #define KH_LD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define KH_ST64(p, v) __hip_atomic_store((p), (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define KH_MAX64(p, v) (uint64_t)atomicMax((unsigned long long*)(p), (unsigned long long)(v))
+#define KH_MAX64(p, v) __hip_atomic_fetch_max((p), (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define KL_LD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define KL_ST32(p, v) __hip_atomic_store((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define KL_MAX32(p, v) atomicMax((p), (uint32_t)(v))
+#define KL_MAX32(p, v) __hip_atomic_fetch_max((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 #define K32(c, i) k32_ld((c), (i))
 #define KH(c, i) kh_ld((c), (i))
@@ -179,37 +179,45 @@ DD_HD inline size_t dd2_shared_bytes(int ws) { return (offsetof(DD2Shared, merge
         PAR_END                                             \
     }
 
+// Pointers into HBM carry their address space like the LDS ones: the context lives in LDS (round 4), and a pointer loaded
+// from memory whose address space is unknown turns every access through it into a FLAT instruction.
+#if defined(DDO_HOST_EMULATION)
+#define GLB_PTR(T) T*
+#else
+#define GLB_PTR(T) __attribute__((address_space(1))) T*
+#endif
+
 template <int WS>
 struct DD2Ctx {
     int n, npad, unit_weights;
-    const uint64_t* adj;
-    const int32_t* weight;
+    GLB_PTR(const uint64_t) adj;
+    GLB_PTR(const int32_t) weight;
     int capS, capW, max_layers, nbw;
     // HBM, per engine slot
 #if defined(DDO_WORD_MAJOR)
-    uint64_t* st;      // [ws][capS]   word-major copy of the states: only the streaming "who contains v" scan reads it
+    GLB_PTR(uint64_t) st;      // [ws][capS]   word-major copy of the states: only the streaming "who contains v" scan reads it
 #endif
-    uint64_t* rec;     // [capS][RW]   node records, one (or two) 64-byte lines each: state words, then the cached hash
-    uint64_t* pt;      // [ev_cap / 4]  path tree: one entry per event record, parent path id | layer << 32 (see PID_NONE)
-    uint64_t* keyh;    // [capS]       key32 << 32 | h32 of every node when the keys live in HBM (else nullptr): streamed by the
+    GLB_PTR(uint64_t) rec;     // [capS][RW]   node records, one (or two) 64-byte lines each: state words, then the cached hash
+    GLB_PTR(uint64_t) pt;      // [ev_cap / 4]  path tree: one entry per event record, parent path id | layer << 32 (see PID_NONE)
+    GLB_PTR(uint64_t) keyh;    // [capS]       key32 << 32 | h32 of every node when the keys live in HBM (else nullptr): streamed by the
                        //              select sweeps and by the per-layer table rebuild
-    uint32_t* h32;     // [capS]       h32 of every node when the keys live in LDS (else nullptr)
+    GLB_PTR(uint32_t) h32;     // [capS]       h32 of every node when the keys live in LDS (else nullptr)
     int RW;
     LDS_PTR(uint32_t) tab;
     int tab_cap;
-    uint32_t* ev;
+    GLB_PTR(uint32_t) ev;
     uint64_t ev_cap;
-    uint32_t* evoff;   // [max_layers][8]: aff_off_lo, aff_off_hi, n_aff, del_off_lo, del_off_hi, n_del, merged|dup.., var
-    int32_t* lvar;
-    int32_t* ldup;     // [max_layers][2] (dup from, dup to)
-    int32_t* lmerge;   // [max_layers]   merged slot (-1 none)
-    uint32_t* cs_slot;
-    uint64_t* cs_state;
-    uint32_t* cs_pid;  // [capW]        path ids of the snapshot's nodes
-    int32_t* cs_value;
-    uint32_t* cs_pop;
+    GLB_PTR(uint32_t) evoff;   // [max_layers][8]: aff_off_lo, aff_off_hi, n_aff, del_off_lo, del_off_hi, n_del, merged|dup.., var
+    GLB_PTR(int32_t) lvar;
+    GLB_PTR(int32_t) ldup;     // [max_layers][2] (dup from, dup to)
+    GLB_PTR(int32_t) lmerge;   // [max_layers]   merged slot (-1 none)
+    GLB_PTR(uint32_t) cs_slot;
+    GLB_PTR(uint64_t) cs_state;
+    GLB_PTR(uint32_t) cs_pid;  // [capW]        path ids of the snapshot's nodes
+    GLB_PTR(int32_t) cs_value;
+    GLB_PTR(uint32_t) cs_pop;
     // LDS
-    uint32_t* key32;   // capS   keys in LDS (nullptr when they are packed into keyh); the backward pass reuses the key storage for value_bot
+    LDS_PTR(uint32_t) key32;   // capS   keys in LDS (nullptr when they are packed into keyh); the backward pass reuses the key storage for value_bot
     LDS_PTR(uint32_t) live;    // nbw
     LDS_PTR(uint32_t) inex;    // nbw
     LDS_PTR(uint32_t) okb;     // nbw
@@ -221,13 +229,13 @@ struct DD2Ctx {
     LDS_PTR(int32_t) tcount;   // NT
     LDS_PTR(int32_t) tcount2;  // NT
     LDS_PTR(DD2Shared) sh;
-    uint8_t* arena;
+    GLB_PTR(uint8_t) arena;
     uint64_t arena_cap;
-    unsigned long long* arena_head;
-    const int32_t* cutoff_flag;
-    uint8_t* pool;
+    GLB_PTR(unsigned long long) arena_head;
+    GLB_PTR(const int32_t) cutoff_flag;
+    GLB_PTR(uint8_t) pool;
     uint64_t pool_cap;
-    unsigned long long* pool_head;
+    GLB_PTR(unsigned long long) pool_head;
     int vbase_off;
     int NT;
     int lex_cap;
@@ -235,9 +243,6 @@ struct DD2Ctx {
     int tab_limit;   // entries the dedup table may hold (a dense tier's table is smaller than 3 x the layer capacity)
     int clocks;        // per-phase shader-clock accounting (DDO_HIP_STATS): costs one barrier per phase
     int tier;          // capacity tier: no squash phases (their LDS is not there), capacity errors mean ST_RETRY
-#if !defined(DDO_HOST_EMULATION)
-    int tid_;
-#endif
 };
 
 template <int WS> DDO_DEV uint32_t k32_ld(const DD2Ctx<WS>& c, int i) {
@@ -391,7 +396,7 @@ DDO_DEV int tab2_insert(const DD2Ctx<WS>& c, int x, uint32_t h, const uint64_t* 
             const int w = (int)(e & 0xFFFFFu);
             // the holder may have been written by another wave a moment ago (expand publishes a node right after
             // storing it): agent-scope loads bypass this CU's vector L1, which other waves' stores do not refresh
-            const uint64_t* o = c.rec + (size_t)w * c.RW;
+            GLB_PTR(const uint64_t) o = c.rec + (size_t)w * c.RW;
             bool eq = true;
 #pragma unroll
             for (int k = 0; k < WS; ++k) eq &= LD_U64(&o[k]) == s[k];
@@ -479,8 +484,8 @@ DDO_DEV void tab2_insert2(const DD2Ctx<WS>& c, int x1, uint32_t h1, const uint64
         if (c1 < 0 && c2 < 0) break;
         // the holders may have been written by other waves a moment ago (a node is published right after it is stored):
         // agent-scope loads bypass this CU's vector L1, which other waves' stores do not refresh
-        const uint64_t* o1 = c.rec + (size_t)(c1 >= 0 ? c1 : 0) * c.RW;
-        const uint64_t* o2 = c.rec + (size_t)(c2 >= 0 ? c2 : 0) * c.RW;
+        GLB_PTR(const uint64_t) o1 = c.rec + (size_t)(c1 >= 0 ? c1 : 0) * c.RW;
+        GLB_PTR(const uint64_t) o2 = c.rec + (size_t)(c2 >= 0 ? c2 : 0) * c.RW;
         uint64_t a[WS], b[WS];
 #pragma unroll
         for (int k = 0; k < WS; ++k) a[k] = c1 >= 0 ? LD_U64(&o1[k]) : 0;
@@ -712,7 +717,8 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
                     const int j0 = (int)((long long)part * m / P), j1 = (int)((long long)(part + 1) * m / P);
                     const uint64_t v = lwl[i];
                     int gt = 0, ge = 0;
-                    for (int j = j0; j < j1; ++j) {
+#pragma unroll 8
+                    for (int j = j0; j < j1; ++j) {   // (unrolled: eight LDS reads in flight instead of one dependent read per step)
                         const uint64_t u = lwl[j];
                         gt += u > v ? 1 : 0;
                         ge += u >= v ? 1 : 0;
@@ -732,6 +738,7 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
                 for (int i = tid; i < m; i += NT) {
                     const uint64_t v = lwl[i];
                     int gt = 0, ge = 0;
+#pragma unroll 8
                     for (int j = 0; j < m; ++j) {
                         const uint64_t u = lwl[j];
                         gt += u > v ? 1 : 0;
@@ -831,322 +838,6 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
     return true;
 }
 
-#if !defined(DDO_HOST_EMULATION)
-// =============================================================================
-// 8 lanes per node (round 4).  A node record is one 64-byte line (RW = 8 words; 16 / 24 for the wide states): lane k of an
-// 8-lane group holds word k (+ 8, + 16) of the record -- state words, then the path id.  The record of a branching node is
-// read and both children are written with ONE coalesced 64-byte request each (thread-per-node: four 16-byte requests per
-// record and lane, 12 write requests per branching node; tools/micro/counter_calibration: the memory system completes about
-// 60 G random lines per second whatever their shape, but 4 requests per line cost 1.7 x the line's time on the write side).
-// `& adj[v]` is lane-local, popcount / hash are 3-step DPP reductions inside the group, a twin's record is compared by the
-// 8 lanes at once and judged by one ballot -- and a lane keeps 3 words per node in flight instead of 3 x WS.
-// =============================================================================
-template <int CTRL>
-DDO_DEV uint32_t g8_dpp(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false); }
-/// sum over the 8 lanes of a group (every lane of the wave must call)
-DDO_DEV uint32_t g8_add(uint32_t x) {
-    x += g8_dpp<0xB1>(x);    // quad_perm [1,0,3,2]
-    x += g8_dpp<0x4E>(x);    // quad_perm [2,3,0,1]
-    x += g8_dpp<0x141>(x);   // row_half_mirror: lane i <-> 7 - i of its 8-lane half row
-    return x;
-}
-DDO_DEV uint64_t g8_xor64(uint64_t x) {
-    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    lo ^= g8_dpp<0xB1>(lo); hi ^= g8_dpp<0xB1>(hi);
-    lo ^= g8_dpp<0x4E>(lo); hi ^= g8_dpp<0x4E>(hi);
-    lo ^= g8_dpp<0x141>(lo); hi ^= g8_dpp<0x141>(hi);
-    return ((uint64_t)hi << 32) | lo;
-}
-/// the value lane `src` (0..7) of the group holds
-DDO_DEV uint64_t g8_bcast64(uint64_t x, int gl, int src) { return (uint64_t)__shfl((unsigned long long)x, gl | src, 64); }
-DDO_DEV int g8_bcast32(int x, int gl, int src) { return __shfl(x, gl | src, 64); }
-
-/// expand + dedup of the nwl nodes that contain the branching variable (clean.rs:360-370, 738-775, 199-220; MISP transition
-/// main.rs:77-102), U nodes in flight per group.  Same contract as the thread-per-node loop in run_dd2: event record
-/// nrec0 + i belongs to work item i.
-template <int WS, int U>
-DDO_DEV void expand_g8(DD2Ctx<WS>& c, const int L, const int var, const int nwl, const int nrec0, const uint64_t aff_off, const int nfl_lim,
-                       const bool fl_implicit, const int hiw_now, const int32_t vbase, const int64_t best_lb) {
-    constexpr int RW = ((WS + 1 + 7) / 8) * 8, NW = RW / 8;
-    constexpr int KP = WS & 7, JP = WS >> 3;   // lane / word-of-lane of the path id
-    const int tid = c.tid_, NT = c.NT;
-    LDS_PTR(DD2Shared) sh = c.sh;
-    const int lane = tid & 63, k = tid & 7, gl = lane & 56, g = tid >> 3, NG = NT >> 3;
-    const int vw = var >> 6, kv = vw & 7, jv = vw >> 3;
-    const uint64_t vbit = 1ULL << (var & 63);
-    const uint32_t mask = (uint32_t)c.tab_cap - 1;
-    uint64_t adjv[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) adjv[j] = (k + 8 * j) < WS ? c.adj[(size_t)var * WS + k + 8 * j] : 0ULL;
-    const int32_t wv = DD_UNIFORM(c.weight[var]);
-    uint32_t kb_and = 0xFFFFFFFFu, kb_or = 0;
-    int dlive = 0, dpruned = 0;
-    for (int base = 0; base < nwl; base += NG * U) {
-        int s[U];
-        bool act[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = base + u * NG + g;
-            act[u] = i < nwl;
-            s[u] = act[u] ? (int)c.wl[i] : 0;
-        }
-        uint64_t kh[U], x[U][NW];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            kh[u] = act[u] ? KH(c, s[u]) : 0;
-#pragma unroll
-            for (int j = 0; j < NW; ++j) x[u][j] = act[u] ? c.rec[(size_t)s[u] * RW + k + 8 * j] : 0ULL;
-        }
-        // ---- rough upper bound (main.rs:191-193), children's states, keys and hashes
-        bool br[U];
-        int ny[U];
-        uint64_t y[U][NW];
-        uint32_t kno[U], kyes[U], newh[U], yh[U], eid[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t key = (uint32_t)(kh[u] >> 32), oldh = (uint32_t)kh[u];
-            const int32_t val = vbase + (int32_t)(key >> KEY_POP_BITS);
-            int32_t rub = (int32_t)(key & KEY_POP_MASK);
-            if (!c.unit_weights) {
-                int32_t sum = 0;
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    uint64_t b = (k + 8 * j) < WS ? x[u][j] : 0ULL;
-                    while (b) {
-                        sum += c.weight[(k + 8 * j) * 64 + dd_ctz(b)];
-                        b &= b - 1;
-                    }
-                }
-                rub = (int32_t)g8_add((uint32_t)sum);
-            }
-            const bool pruned = act[u] && (int64_t)rub + (int64_t)val <= best_lb;   // clean.rs:364-365: no children
-            br[u] = act[u] && !pruned;
-            // decision NO, in place (main.rs:77-85): the word holding the variable changes
-            uint64_t oldw = 0;
-#pragma unroll
-            for (int j = 0; j < NW; ++j)
-                if (j == jv) oldw = g8_bcast64(x[u][j], gl, kv);
-            const uint64_t neww = oldw & ~vbit;
-            newh[u] = oldh ^ fold32(mixw(oldw, vw) ^ mixw(neww, vw));   // (the hash is XOR-linear in the per-word mixes)
-            kno[u] = key - 1;                                            // popcount - 1, same value (cost 0)
-            if (br[u] && k == kv) {
-#pragma unroll
-                for (int j = 0; j < NW; ++j)
-                    if (j == jv) x[u][j] = neww;
-            }
-            // decision YES (main.rs:95-102)
-            uint32_t ypop = 0;
-            uint64_t hx = 0;
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const bool isw = (k + 8 * j) < WS;
-                y[u][j] = isw ? (x[u][j] & adjv[j]) : 0ULL;
-                ypop += (uint32_t)dd_popc(y[u][j]);
-                if (isw) hx ^= mixw(y[u][j], k + 8 * j);
-            }
-            ypop = g8_add(ypop);
-            yh[u] = fold32(g8_xor64(hx));
-            kyes[u] = ((uint32_t)(val + wv - vbase) << KEY_POP_BITS) | ypop;
-            // a free slot for the YES-child: one LDS atomic per wave
-            const uint64_t m = __ballot(br[u] && k == 0);
-            int fbase = 0;
-            if (lane == 0 && m) fbase = LDS_ADD_I32(&sh->nnew, dd_popc(m));
-            fbase = __builtin_amdgcn_readfirstlane(fbase);
-            const int fi = fbase + dd_popc(m & ((1ULL << gl) - 1ULL));
-            ny[u] = -1;
-            if (br[u]) {
-                if (fi < nfl_lim) ny[u] = fl_implicit ? hiw_now + fi : (int)c.fl[fi];
-                else if (k == 0) sh->status = ST_ERR_CAPACITY - 100 * 6;
-            }
-            eid[u] = (uint32_t)(aff_off >> 2) + (uint32_t)(nrec0 + base + u * NG + g);   // event record = path-tree node of the YES arc
-            if (br[u]) {
-                kb_and &= kno[u];
-                kb_or |= kno[u];
-                if (ny[u] >= 0) {
-                    kb_and &= kyes[u];
-                    kb_or |= kyes[u];
-                }
-            }
-            if (act[u] && k == 4) bm_clr(c.fresh, s[u]);
-        }
-        // ---- both records go out as whole lines; key|hash words, path-tree node and flags by single lanes
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!br[u]) continue;
-            const uint32_t ppid = (uint32_t)g8_bcast64(x[u][JP], gl, KP);
-#pragma unroll
-            for (int j = 0; j < NW; ++j) c.rec[(size_t)s[u] * RW + k + 8 * j] = x[u][j];
-            if (ny[u] >= 0) {
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    const int w = k + 8 * j;
-                    c.rec[(size_t)ny[u] * RW + w] = w < WS ? y[u][j] : (w == WS ? (uint64_t)eid[u] : 0ULL);
-                }
-            }
-            if (k == 0) KH_ST(c, s[u], kno[u], newh[u]);   // (cnt[var]: no state of the next layer contains the variable, it is zeroed with the layer)
-            if (ny[u] >= 0) {
-                if (k == 1) KH_ST(c, ny[u], kyes[u], yh[u]);
-                if (k == 2) c.pt[eid[u]] = (uint64_t)ppid | ((uint64_t)(uint32_t)L << 32);   // the child's best path: the parent's plus decision 1 at layer L
-                if (k == 3) {
-                    bm_put(c.inex, ny[u], bm_test(c.inex, s[u]));
-                    bm_put(c.okb, ny[u], bm_test(c.okb, s[u]));
-                }
-            }
-        }
-        FENCE_BLOCK();   // the records are visible to the workgroup before the table publishes their slots
-        // ---- dedup of both children (append_edge_to!, clean.rs:199-220): lane 0 of a group probes for the NO-child, lane 1 for
-        // the YES-child.  LDS phase: up to a claimed entry or a matching tag; global phase: the 8 lanes compare the holder's
-        // record with the child's and one ballot decides.
-        int res[U];
-        uint32_t pp[U], mine[U];
-        bool pend[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t h = k == 0 ? newh[u] : yh[u];
-            const int own = k == 0 ? s[u] : ny[u];
-            pend[u] = br[u] && k < 2 && own >= 0;
-            mine[u] = ((h >> 20) << 20) | (uint32_t)own;
-            pp[u] = h & mask;
-            res[u] = own;
-        }
-        for (uint32_t round = 0;; ++round) {
-            int cand[U];
-            bool anyc = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                cand[u] = -1;
-                if (pend[u]) {
-                    for (uint32_t probes = 0;; ++probes) {
-                        const uint32_t e = TAB_CAS(&c.tab[pp[u]], T2_EMPTY, mine[u]);
-                        if (e == T2_EMPTY) {
-                            pend[u] = false;
-                            break;
-                        }
-                        if ((e >> 20) == (mine[u] >> 20)) {
-                            cand[u] = (int)(e & 0xFFFFFu);
-                            break;
-                        }
-                        pp[u] = (pp[u] + 1) & mask;
-                        if (probes > mask) {   // the table is full (cannot happen: tab_limit)
-                            sh->status = ST_ERR_INTERNAL;
-                            pend[u] = false;
-                            break;
-                        }
-                    }
-                    anyc |= cand[u] >= 0;
-                }
-            }
-            if (!__ballot(anyc)) break;
-            if (round > mask) {
-                if (tid == 0) sh->status = ST_ERR_INTERNAL;
-                break;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c1 = g8_bcast32(cand[u], gl, 0), c2 = g8_bcast32(cand[u], gl, 1);
-                // the holders may have been written by other waves a moment ago: agent-scope loads bypass this CU's vector L1
-                bool ne1 = false, ne2 = false;
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    const int w = k + 8 * j;
-                    if (w < WS) {
-                        const uint64_t a = c1 >= 0 ? LD_U64(&c.rec[(size_t)c1 * RW + w]) : x[u][j];
-                        const uint64_t b = c2 >= 0 ? LD_U64(&c.rec[(size_t)c2 * RW + w]) : y[u][j];
-                        ne1 |= a != x[u][j];
-                        ne2 |= b != y[u][j];
-                    }
-                }
-                const uint32_t g1 = (uint32_t)(__ballot(ne1) >> gl) & 0xFFu, g2 = (uint32_t)(__ballot(ne2) >> gl) & 0xFFu;
-                if (cand[u] >= 0) {
-                    const bool eq = (k == 0 ? g1 : g2) == 0;
-                    if (eq) {
-                        res[u] = cand[u];
-                        pend[u] = false;
-                    } else {
-                        pp[u] = (pp[u] + 1) & mask;
-                    }
-                }
-            }
-        }
-        // ---- twins: the holder's key keeps the maximum (both children's atomics in one instruction)
-        uint32_t old[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            old[u] = 0;
-            const int own = k == 0 ? s[u] : ny[u];
-            if (br[u] && k < 2 && own >= 0 && res[u] != own) old[u] = K32_MAX(c, res[u], k == 0 ? kno[u] : kyes[u], k == 0 ? newh[u] : yh[u]);
-        }
-        // ---- bookkeeping: vertex counters by all lanes (each its own words), bitmaps and the event record by lane 0
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t0 = g8_bcast32(res[u], gl, 0), t1 = g8_bcast32(res[u], gl, 1);
-            const uint32_t old1 = (uint32_t)g8_bcast32((int)old[u], gl, 1);
-            if (!act[u]) continue;
-            const bool dis0 = br[u] && t0 != s[u];                     // the in-place NO-child dissolves into its twin t0
-            const bool new1 = br[u] && ny[u] >= 0 && t1 == ny[u];      // a new node enters the layer
-            if (!br[u] || dis0) {
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    uint64_t b = (k + 8 * j) < WS ? x[u][j] : 0ULL;
-                    while (b) {
-                        LDS_ADD_I32(&c.cnt[(k + 8 * j) * 64 + dd_ctz(b)], -1);
-                        b &= b - 1;
-                    }
-                }
-            }
-            if (new1) {
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    uint64_t b = y[u][j];
-                    while (b) {
-                        LDS_ADD_I32(&c.cnt[(k + 8 * j) * 64 + dd_ctz(b)], 1);
-                        b &= b - 1;
-                    }
-                }
-            }
-            if (k != 0) continue;
-            U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)(nrec0 + base + u * NG + g));
-            if (!br[u]) {
-                bm_clr(c.live, s[u]);
-                dlive -= 1;
-                dpruned += 1;
-                *rec4 = U32x4{(uint32_t)s[u], NONE32, NONE32, NONE32};
-                continue;
-            }
-            uint32_t e_no = (uint32_t)s[u], e_yes = NONE32;
-            if (!dis0) {
-                bm_set(c.fresh, s[u]);   // it stays in the layer; its rub shrank: check it again before it is expanded
-            } else {
-                if (bm_test(c.inex, s[u])) bm_set(c.inex, t0);
-                bm_clr(c.live, s[u]);
-                dlive -= 1;
-                e_no = (uint32_t)t0 | (kno[u] > old[u] ? EV_RAISED : 0u);
-            }
-            if (ny[u] >= 0) {
-                if (new1) {
-                    bm_set(c.live, ny[u]);
-                    bm_set(c.fresh, ny[u]);
-                    dlive += 1;
-                    LDS_MAX_I32(&sh->hiw, ny[u] + 1);
-                    e_yes = (uint32_t)ny[u] | EV_CREATED;
-                } else {
-                    if (bm_test(c.inex, ny[u])) bm_set(c.inex, t1);
-                    e_yes = (uint32_t)t1 | (kyes[u] > old1 ? EV_RAISED : 0u);
-                }
-            }
-            // parent | NO target | YES target | slot allocated for the YES-child
-            *rec4 = U32x4{(uint32_t)s[u], e_no, e_yes, ny[u] >= 0 ? (uint32_t)ny[u] : NONE32};
-        }
-    }
-    if (dlive) LDS_ADD_I32(&sh->nlive, dlive);
-    if (dpruned) LDS_ADD_I32(&sh->npruned, dpruned);
-    if (kb_or != 0 || kb_and != 0xFFFFFFFFu) {
-        LDS_AND_U32(&sh->kbits_and[(L + 1) & 1], kb_and);
-        LDS_OR_U32(&sh->kbits_or[(L + 1) & 1], kb_or);
-    }
-}
-#endif
-
 /// One compile() (clean.rs:345-381) with in-place layers.
 ///
 /// Event records (u32 stream `ev`, per transition L -> L+1, 4 words per affected or pruned parent):
@@ -1155,7 +846,7 @@ DDO_DEV void expand_g8(DD2Ctx<WS>& c, const int L, const int var, const int nwl,
 /// The squash of layer L (deleted slots, merged slot, re-added duplicate) is stored with iteration L.
 
 
-template <int WS, int DEEP = 0, int G8 = 0>
+template <int WS, int DEEP = 0>
 DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
     constexpr int KB = DEEP ? 16 : 8;
     DD_TID_SETUP(c)
@@ -1620,7 +1311,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             // sweep, a contiguous 8-byte stream, but every YES-child then cost 7 scattered 8-byte stores to keep it up to date,
             // and partial-line write requests are what the memory system handles worst (tools/micro/expand_patterns.hip: 100 of
             // the 155 kcycles a workgroup spends per 512 new nodes; the strided sweep adds 6 cycles per node).
-            const uint64_t* row = c.rec + vw;
+            GLB_PTR(const uint64_t) row = c.rec + vw;
 #endif
             const int hi = DD_UNIFORM(sh->hiw);
             for (int base = 0; base < hi; base += NT * KS) {
@@ -1779,17 +1470,6 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // ---- nodes containing the variable: expansion AND dedup (clean.rs:738-775) in one pass.  The table holds every
         // unchanged node of the next layer now, so a thread writes its two children, makes the stores visible to the
         // workgroup and inserts them right away -- the records never have to be read back.
-        int nrec_g8 = -1;
-#if !defined(DDO_HOST_EMULATION)
-        if constexpr (G8 > 0) {   // 8 lanes per node (expand_g8)
-            const int nrec0 = DD_UNIFORM(sh->nrec);   // records of the pruned fresh nodes above
-            PAR_BEGIN
-            expand_g8<WS, (WS <= 7 ? G8 : (G8 > 2 ? 2 : G8))>(c, L, var, nwl, nrec0, aff_off, nfl_lim, fl_implicit, hiw_now, vbase, best_lb);
-            PAR_END
-            nrec_g8 = nrec0 + nwl;   // every work item has its event record
-        } else
-#endif
-        {
         PAR_BEGIN
         uint64_t adjv[WS];   // (workgroup-uniform: kept in scalar registers)
 #pragma unroll
@@ -1926,8 +1606,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             LDS_OR_U32(&sh->kbits_or[(L + 1) & 1], kb_or);
         }
         PAR_END
-        }
-        const int nrec = nrec_g8 >= 0 ? nrec_g8 : DD_UNIFORM(sh->nrec);
+        const int nrec = DD_UNIFORM(sh->nrec);
         if (sh->status != ST_OK) { failed = true; break; }
         DD2_STAT(5, nrec)
         DD2_TICK(PH_EXP1)
@@ -1943,7 +1622,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         const bool tie_pass = relaxed && lel >= 0;   // see the region after this one
         PAR_BEGIN
         for (int r = tid; r < nrec; r += NT) {
-            uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
+            GLB_PTR(uint32_t) rec = c.ev + aff_off + 4ull * (uint64_t)r;
             if (rec[1] == NONE32) continue;
             for (int which = 0; which < 2; ++which) {
                 const uint32_t w = rec[1 + which];
@@ -1971,7 +1650,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 c.lmerge[L] = merged_slot;
                 c.ldup[2 * L] = dup_from;
                 c.ldup[2 * L + 1] = dup_to;
-                uint32_t* eo = c.evoff + (size_t)L * 8;
+                GLB_PTR(uint32_t) eo = c.evoff + (size_t)L * 8;
                 eo[0] = (uint32_t)aff_off;
                 eo[1] = (uint32_t)(aff_off >> 32);
                 eo[2] = (uint32_t)nrec;
@@ -2003,7 +1682,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         if (tie_pass) {
             PAR_BEGIN
             for (int r = tid; r < nrec; r += NT) {
-                const uint32_t* rec = c.ev + aff_off + 4ull * (uint64_t)r;
+                GLB_PTR(const uint32_t) rec = c.ev + aff_off + 4ull * (uint64_t)r;
                 if (rec[1] == NONE32) continue;
                 for (int which = 0; which < 2; ++which) {
                     const uint32_t w = rec[1 + which];
@@ -2027,7 +1706,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 c.lmerge[L] = merged_slot;
                 c.ldup[2 * L] = dup_from;
                 c.ldup[2 * L + 1] = dup_to;
-                uint32_t* eo = c.evoff + (size_t)L * 8;
+                GLB_PTR(uint32_t) eo = c.evoff + (size_t)L * 8;
                 eo[0] = (uint32_t)aff_off;
                 eo[1] = (uint32_t)(aff_off >> 32);
                 eo[2] = (uint32_t)nrec;
@@ -2122,7 +1801,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_END
         for (int tr = L - 1; tr >= lel; --tr) {
             // (1) undo the squash of layer tr+1: arcs into a deleted node were redirected to the merged node
-            const uint32_t* eo1 = c.evoff + (size_t)(tr + 1) * 8;
+            GLB_PTR(const uint32_t) eo1 = c.evoff + (size_t)(tr + 1) * 8;
             const int nd = (int)eo1[5];
             const int m = c.lmerge[tr + 1];
             if (nd > 0 && m >= 0) {
@@ -2145,7 +1824,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
             // (2) parents of the transition tr -> tr+1
-            const uint32_t* eo = c.evoff + (size_t)tr * 8;
+            GLB_PTR(const uint32_t) eo = c.evoff + (size_t)tr * 8;
             const int na = (int)eo[2];
             const uint64_t aoff = (uint64_t)eo[0] | ((uint64_t)eo[1] << 32);
             const int32_t wv = c.weight[c.lvar[tr]];
@@ -2153,7 +1832,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const int cnt_here = na - base < c.capW ? na - base : c.capW;
                 PAR_BEGIN
                 for (int i = tid; i < cnt_here; i += NT) {
-                    const uint32_t* rec = c.ev + aoff + 4ull * (uint64_t)(base + i);
+                    GLB_PTR(const uint32_t) rec = c.ev + aoff + 4ull * (uint64_t)(base + i);
                     int32_t best = VB_UNMARKED;
                     if (rec[1] != NONE32) {
                         int32_t v = vb[rec[1] & EV_SLOT_MASK];
@@ -2168,7 +1847,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 PAR_END
                 PAR_BEGIN
                 for (int i = tid; i < cnt_here; i += NT) {
-                    const uint32_t* rec = c.ev + aoff + 4ull * (uint64_t)(base + i);
+                    GLB_PTR(const uint32_t) rec = c.ev + aoff + 4ull * (uint64_t)(base + i);
                     vb[rec[0]] = tmp[i];
                 }
                 PAR_END
@@ -2252,7 +1931,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     }
     PAR_END
     const uint64_t pool_off = sh->ev_pos;
-    uint8_t* pblock = pool_bytes ? c.pool + pool_off : nullptr;
+    GLB_PTR(uint8_t) pblock = pool_bytes ? c.pool + pool_off : (GLB_PTR(uint8_t))nullptr;
     // block-relative offsets (PoolBlockHeader)
     const uint64_t b_lvar = 64;
     const uint64_t b_states = b_lvar + (((uint64_t)cs_path_len * 4 + 7) & ~7ULL);
@@ -2260,7 +1939,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     const uint64_t b_values = b_paths + (uint64_t)pw * (uint64_t)ncut * 8;
     const uint64_t b_ubs = b_values + (((uint64_t)ncut * 4 + 7) & ~7ULL);
     const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;
-    uint8_t* base = c.arena + sh->arena_off;
+    GLB_PTR(uint8_t) base = c.arena + sh->arena_off;
 
     if (arena_ok && !failed) {
         // the two best paths as bit strings (LDS scratch: the merged-state words and the candidate list are free now)
@@ -2441,7 +2120,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 /// restricted, then (when inexact) relaxed: the device half of process_one_node (parallel.rs:391-437).
 /// ONE call site of run_dd2 (a loop over the two compilations): the function is inlined once, not three times -- the kernel's
 /// code is a third of what it was (round 3: 48 000 lines of ISA, several times the instruction cache two CUs share).
-template <int WS, int DEEP = 0, int G8 = 0>
+template <int WS, int DEEP = 0>
 DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
     DD_TID_SETUP(c)
     (void)NT;
@@ -2455,7 +2134,7 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
             PAR_END
             break;
         }
-        run_dd2<WS, DEEP, G8>(c, in, fused ? (pass == 0 ? CT_RESTRICTED : CT_RELAXED) : in.comp_type, lb, &res2[pass]);
+        run_dd2<WS, DEEP>(c, in, fused ? (pass == 0 ? CT_RESTRICTED : CT_RELAXED) : in.comp_type, lb, &res2[pass]);
         if (pass == 0 && fused) {
             PAR_BEGIN
             if (tid == 0) {
@@ -2484,9 +2163,15 @@ DD_HD inline size_t dd2_hist_bytes(int hist_bins, int lex_cap) {
     return ((h > l ? h : l) + 15) & ~(size_t)15;
 }
 
+/// The context of a workgroup (DD2Ctx) lives at the start of its LDS block: every phase reads the few fields it needs right
+/// there instead of the whole kernel carrying sixty pointers and sizes in registers from the first layer to the result record
+/// (round 3: 397 SGPR and 183 VGPR spills at the 128-VGPR budget of the dense kernel).
+constexpr size_t DD2_CTX_BYTES = 512;
+
 inline size_t dd2_lds_bytes(int capS, int tab_cap, int npad, int nthreads, bool keys_in_lds = true, int hist_bins = 2048, int lex_cap = 1024, int ws = MAX_WS) {
     const size_t nbw = ((size_t)capS + 31) / 32;
-    size_t b = keys_in_lds ? (size_t)capS * 4 : 0;   // key32 / value_bot
+    size_t b = DD2_CTX_BYTES;
+    b += keys_in_lds ? (size_t)capS * 4 : 0;   // key32 / value_bot
     b = (b + 15) & ~(size_t)15;
     b += (size_t)tab_cap * 4;              // dedup table
     b += 4 * nbw * 4;                      // live, inex, okb, fresh
@@ -2503,8 +2188,8 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.n = P.n;
     c.npad = P.npad;
     c.unit_weights = P.unit_weights;
-    c.adj = P.adj;
-    c.weight = P.weight;
+    c.adj = (GLB_PTR(const uint64_t))(P.adj);
+    c.weight = (GLB_PTR(const int32_t))(P.weight);
     c.capS = P.capS;
     c.capW = P.capW;
     c.max_layers = P.max_layers;
@@ -2512,31 +2197,31 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     const size_t capS = (size_t)P.capS, capW = (size_t)P.capW, ml = (size_t)P.max_layers, s = (size_t)slot;
     c.RW = ((WS + 1 + 7) / 8) * 8;
 #if defined(DDO_WORD_MAJOR)
-    c.st = P.s_state + s * (size_t)WS * capS;
+    c.st = (GLB_PTR(uint64_t))(P.s_state + s * (size_t)WS * capS);
 #endif
-    c.rec = P.s_rec + s * capS * (size_t)c.RW;
-    c.pt = P.s_ptree + s * (P.ev_cap / 4);
+    c.rec = (GLB_PTR(uint64_t))(P.s_rec + s * capS * (size_t)c.RW);
+    c.pt = (GLB_PTR(uint64_t))(P.s_ptree + s * (P.ev_cap / 4));
     c.tab_cap = P.tab2_cap;
-    c.ev = P.s_ev + s * P.ev_cap;
+    c.ev = (GLB_PTR(uint32_t))(P.s_ev + s * P.ev_cap);
     c.ev_cap = P.ev_cap;
-    c.evoff = P.s_evoff + s * ml * 8;
-    c.lvar = P.lvar + s * ml;
-    c.ldup = P.ldup + s * ml * 2;
-    c.lmerge = P.nlayer + s * ml;          // the per-layer node counts of engine 1 are not needed here
-    c.cs_slot = P.s_cs_slot + s * capW;
-    c.cs_state = P.cs_state + s * (size_t)WS * (size_t)P.capN;   // capN >= capW words per row are reserved
-    c.cs_pid = (uint32_t*)(P.s_cs_path + s * (size_t)WS * capW);
-    c.cs_value = P.cs_value + s * (size_t)P.capN;
-    c.cs_pop = P.cs_pop + s * (size_t)P.capN;
+    c.evoff = (GLB_PTR(uint32_t))(P.s_evoff + s * ml * 8);
+    c.lvar = (GLB_PTR(int32_t))(P.lvar + s * ml);
+    c.ldup = (GLB_PTR(int32_t))(P.ldup + s * ml * 2);
+    c.lmerge = (GLB_PTR(int32_t))(P.nlayer + s * ml);          // the per-layer node counts of engine 1 are not needed here
+    c.cs_slot = (GLB_PTR(uint32_t))(P.s_cs_slot + s * capW);
+    c.cs_state = (GLB_PTR(uint64_t))(P.cs_state + s * (size_t)WS * (size_t)P.capN);   // capN >= capW words per row are reserved
+    c.cs_pid = (GLB_PTR(uint32_t))((uint32_t*)(P.s_cs_path + s * (size_t)WS * capW));
+    c.cs_value = (GLB_PTR(int32_t))(P.cs_value + s * (size_t)P.capN);
+    c.cs_pop = (GLB_PTR(uint32_t))(P.cs_pop + s * (size_t)P.capN);
     unsigned char* p = lds;
     if (P.keys_global) {
-        c.keyh = P.s_hash + s * capS;      // keys in HBM, packed with the hashes: the LDS footprint halves, two workgroups share a CU
+    c.keyh = (GLB_PTR(uint64_t))(P.s_hash + s * capS);      // keys in HBM, packed with the hashes: the LDS footprint halves, two workgroups share a CU
         c.key32 = nullptr;
         c.h32 = nullptr;
     } else {
         c.keyh = nullptr;
-        c.h32 = (uint32_t*)(P.s_hash + s * capS);
-        c.key32 = (uint32_t*)p;
+    c.h32 = (GLB_PTR(uint32_t))((uint32_t*)(P.s_hash + s * capS));
+        c.key32 = (LDS_PTR(uint32_t))p;
         p += ((size_t)P.capS * 4 + 15) & ~(size_t)15;
     }
     c.tab = (LDS_PTR(uint32_t))p;
@@ -2566,13 +2251,13 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
         c.wl = (uint16_t*)(p + dd2_shared_bytes(WS));   // less between the sweep that writes them and the expand that reads them
         c.fl = c.wl + capW;
     }
-    c.arena = P.arena;
+    c.arena = (GLB_PTR(uint8_t))(P.arena);
     c.arena_cap = P.arena_cap;
-    c.arena_head = P.arena_head;
-    c.cutoff_flag = P.cutoff_flag;
-    c.pool = P.pool;
+    c.arena_head = (GLB_PTR(unsigned long long))(P.arena_head);
+    c.cutoff_flag = (GLB_PTR(const int32_t))(P.cutoff_flag);
+    c.pool = (GLB_PTR(uint8_t))(P.pool);
     c.pool_cap = P.pool_cap;
-    c.pool_head = P.pool_head;
+    c.pool_head = (GLB_PTR(unsigned long long))(P.pool_head);
     c.vbase_off = P.vbase_off;
     c.clocks = P.phase_clocks;
     c.hist_bins = P.hist_bins > 0 ? P.hist_bins : 2048;

@@ -1,5 +1,5 @@
-"""INTEGRATION.md documents the Rust shim a maintainer would add (no Rust toolchain in this image, so it is never
-compiled).  This keeps it mechanically consistent with include/ddo_hip.h: every `#[repr(C)]` struct has the header's
+"""hip_mdd/ is the Rust shim a maintainer would add, laid out as a crate (no Rust toolchain in this image, so it is never
+compiled here; INTEGRATION.md documents it).  This keeps hip_mdd/src/lib.rs mechanically consistent with include/ddo_hip.h: every `#[repr(C)]` struct has the header's
 fields in the header's order with compatible types, every `extern "C"` prototype names a function the header declares
 with the same number of parameters, and every `pub const DDO_*` equals the header's `#define`."""
 import os
@@ -20,10 +20,9 @@ def _header():
 
 
 def _rust():
-    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    blocks = re.findall(r"```rust\n(.*?)```", md, flags=re.S)
-    assert blocks, "INTEGRATION.md lost its Rust shim"
-    return re.sub(r"//[^\n]*", "", "\n".join(blocks))
+    src = open(os.path.join(ROOT, "hip_mdd", "src", "lib.rs")).read()
+    assert "impl DecisionDiagram for HipMdd" in src and "impl Cache for HipCache" in src, "hip_mdd/src/lib.rs lost the shim"
+    return re.sub(r"//[^\n]*", "", src)
 
 
 def _c_struct_fields(hdr, name):
@@ -119,3 +118,21 @@ def test_constants_equal_the_header_defines():
         assert int(val.strip(), 0) == int(m.group(1).strip("()"), 0), f"{name}: shim {val} != header {m.group(1)}"
     # return codes the shim matches on
     assert re.search(r"#define\s+DDO_CUTOFF\s+2\b", hdr) and "2 => Err(Reason::CutoffOccurred)" in rs
+
+
+def test_the_crate_is_laid_out_and_its_optima_are_the_oracle_suite_s():
+    """hip_mdd/ has what `cargo test` needs, and the optima its tests assert are the ones tests/test_oracle.py pins the oracle on
+    (ddo/examples/misp/tests.rs:71-161) -- for instance files that exist under data/misp."""
+    for f in ("Cargo.toml", "build.rs", os.path.join("src", "lib.rs"), os.path.join("tests", "misp.rs")):
+        assert os.path.exists(os.path.join(ROOT, "hip_mdd", f)), f
+    cargo = open(os.path.join(ROOT, "hip_mdd", "Cargo.toml")).read()
+    assert re.search(r'^ddo\s*=', cargo, flags=re.M) and re.search(r'^bit-set\s*=', cargo, flags=re.M)
+    assert "rustc-link-lib=dylib=ddo_hip" in open(os.path.join(ROOT, "hip_mdd", "build.rs")).read()
+    from tests.test_oracle import MISP_KATS
+    known = dict(MISP_KATS)
+    known.update({"keller4": 11, "brock200_3": 15, "brock200_4": 17, "hamming8-4": 16})   # test_oracle.py's slow cases, test_gpu_parity.py
+    pairs = re.findall(r'"([\w\-]+)\.clq"\s*=>\s*(\d+)', open(os.path.join(ROOT, "hip_mdd", "tests", "misp.rs")).read())
+    assert len(pairs) >= 15
+    for name, value in pairs:
+        assert os.path.exists(os.path.join(ROOT, "data", "misp", name + ".clq")), name
+        assert known[name] == int(value), (name, value, known[name])

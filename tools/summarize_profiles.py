@@ -86,17 +86,29 @@ with open(os.path.join(dst, "pmc_counters.csv"), "w", newline="") as f:
 
 pa = summary.get("pmc_timed_avg", {})
 if "FETCH_SIZE" in pa and "WRITE_SIZE" in pa:
-    # FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB; gfx950 reports half of a wide read stream
-    # (MI355X_MICROARCH.md, HBM section): FETCH is doubled.  This kernel's reads are mostly 8-64 B gathers, for
-    # which the guide calls the counter uncalibrated, so both the raw and the doubled figure are kept.
+    # FETCH_SIZE / WRITE_SIZE are in units of 1 KB.  What a counter byte is worth depends on the access pattern; it was
+    # calibrated on this kernel's patterns with known byte counts (tools/micro/counter_calibration.hip ->
+    # profiles/<round>/counter_calibration.json): a 64-byte record line read by one lane (4 x 16 B) or 8 bytes of it (the
+    # work-list sweep) within a DD's slot count 1 / 1.10 and 1 / 1.14 of their lines -- NOT the 1/2 the guide measured for wide
+    # coalesced streams, which this kernel has next to none of -- and WRITE_SIZE counts a whole line as 64 B (x 1.07) and an
+    # 8-byte store as the 32-byte sector it moves.  One figure: FETCH_SIZE x fetch_factor + WRITE_SIZE.
+    cal = None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for cand in (os.path.join(dst, "counter_calibration.json"), os.path.join(here, "..", "profiles", "r04", "counter_calibration.json")):
+        if os.path.exists(cand):
+            cal = json.load(open(cand))["patterns"]
+            break
+    ff = 0.5 * (cal["read_line64_slot"]["fetch_factor_lines"] + cal["read_word8_slot"]["fetch_factor_lines"]) if cal else 2.0
     fetch = pa["FETCH_SIZE"] * 1024.0
     write = pa["WRITE_SIZE"] * 1024.0
-    summary["traffic"] = {"fetch_bytes_raw": fetch, "fetch_bytes_x2": 2 * fetch, "write_bytes": write,
-                          "hbm_bytes_per_launch": 2 * fetch + write,
-                          "hbm_bytes_per_node": (2 * fetch + write) / bench["roofline"]["nodes_per_launch"],
+    summary["traffic"] = {"fetch_bytes_raw": fetch, "fetch_factor": ff, "write_bytes": write,
+                          "fetch_factor_source": "counter_calibration.json: mean of read_line64_slot and read_word8_slot" if cal else "guide's x2 (no calibration file)",
+                          "hbm_bytes_per_launch": ff * fetch + write,
+                          "hbm_bytes_per_node": (ff * fetch + write) / bench["roofline"]["nodes_per_launch"],
                           "algorithmic_bytes_per_launch": bench["roofline"]["nodes_per_launch"] * bench["roofline"]["bytes_per_node"]}
+    summary["traffic"]["ratio_to_algorithmic"] = summary["traffic"]["hbm_bytes_per_launch"] / summary["traffic"]["algorithmic_bytes_per_launch"]
     # the bench run of a collection precedes its own counter passes: its line cannot carry them yet; this copy does
-    summary["roofline"]["traffic"] = 2 * fetch + write
-    summary["roofline"]["traffic_source"] = "this collection's rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, timed launches)"
+    summary["roofline"]["traffic"] = ff * fetch + write
+    summary["roofline"]["traffic_source"] = "this collection's rocprofv3 --pmc passes (FETCH_SIZE x %.2f [calibrated] + WRITE_SIZE, timed launches)" % ff
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
