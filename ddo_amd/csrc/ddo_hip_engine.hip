@@ -1038,6 +1038,24 @@ DDInput* Engine::stage_inputs(int count) {
 }
 
 int Engine::wait() {
+    {   // poll WITHOUT the engine lock: other host threads' calls are not locked out for the length of the kernel, and after a
+        // bounded spin the waiting thread sleeps in the driver instead of burning a core
+        void* st = nullptr;
+        {
+            std::lock_guard<std::mutex> g(mtx_);
+            if (pending_ <= 0) return DDO_OK;
+            st = stream_;
+        }
+        static const bool block0 = [] { const char* e = std::getenv("DDO_HIP_SYNC"); return e && std::string(e) == "block"; }();
+        if (!block0) {
+            (void)hipSetDevice(device_);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (hipStreamQuery((hipStream_t)st) == hipErrorNotReady) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // a launch this long: let the driver wait
+                std::this_thread::yield();
+            }
+        }
+    }
     std::lock_guard<std::mutex> g(mtx_);
     if (pending_ <= 0) return DDO_OK;
     HIP_TRY(hipSetDevice(device_));
@@ -1045,16 +1063,8 @@ int Engine::wait() {
     // trace of the live search, round 3: 11 ms of idle device after every launch of a step), and the search synchronises three
     // times per step.  DDO_HIP_SYNC=block restores the blocking wait.
     static const bool block = [] { const char* e = std::getenv("DDO_HIP_SYNC"); return e && std::string(e) == "block"; }();
-    if (block) {
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
-    } else {
-        hipError_t q;
-        while ((q = hipStreamQuery((hipStream_t)stream_)) == hipErrorNotReady) std::this_thread::yield();
-        if (q != hipSuccess) {
-            set_error(std::string("hipStreamQuery: ") + hipGetErrorString(q));
-            return DDO_ERR_NO_DEVICE;
-        }
-    }
+    (void)block;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));   // (drained already unless the spin above gave up)
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
     last_kernel_ms_ = ms;

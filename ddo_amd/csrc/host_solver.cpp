@@ -1484,12 +1484,14 @@ extern "C" {
 size_t ddo_width_heuristic(const ddo_solver_config* cfg, size_t nb_vars, size_t depth) {
     if (!cfg) return 0;
     size_t w;
+    // the inner policy's RAW value (it may be 0: NbUnassignedWidth at depth == nb_vars, TsptwWidth with factor 0); the decorators
+    // apply their own max(1, .) like the reference's, and the engine never gets less than 1
     if (cfg->width_policy == DDO_WIDTH_FIXED) w = cfg->width;                                             // width.rs:168-170
-    else if (cfg->width_policy == DDO_WIDTH_TSPTW) w = nb_vars * (depth + 1) * std::max<size_t>(1, cfg->width);   // tsptw/heuristics.rs:48-52
-    else w = std::max<size_t>(1, nb_vars > depth ? nb_vars - depth : 0);                                   // width.rs:399-401 (never 0 here: a DD has a root)
-    if (cfg->width_times > 0) w = std::max<size_t>(1, cfg->width_times * w);                               // Times, width.rs:638-641
-    if (cfg->width_div_by > 0) w = std::max<size_t>(1, w / cfg->width_div_by);                             // DivBy, width.rs:877-880
-    return w;
+    else if (cfg->width_policy == DDO_WIDTH_TSPTW) w = nb_vars * (depth + 1) * (size_t)cfg->width;        // tsptw/heuristics.rs:48-52
+    else w = nb_vars > depth ? nb_vars - depth : 0;                                                        // width.rs:399-401
+    if (cfg->width_times > 0) w = std::max<size_t>(1, cfg->width_times * w);                               // Times, width.rs:638-641: 1.max(k * inner)
+    if (cfg->width_div_by > 0) w = std::max<size_t>(1, w / cfg->width_div_by);                             // DivBy, width.rs:877-880: 1.max(inner / k)
+    return std::max<size_t>(1, w);
 }
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg) {

@@ -328,6 +328,12 @@ DDO_DEV int32_t vec_get(const uint64_t* s, int v) {
 DDO_DEV int32_t iabs32(int32_t x) { return x < 0 ? -x : x; }
 /// the signed-vector models (MCP, MAX2SAT) share merge, relax, ranking and state layout; transitions and bounds differ
 DDO_DEV bool dd_is_vec(int kind) { return kind == MODEL_MCP || kind == MODEL_MAX2SAT; }
+/// States wider than 16 words only exist for the signed-vector models (MAX2SAT / MCP beyond 30 variables): in the 32- and
+/// 72-word instantiations the model kind is a compile-time fact, and the code of the other models -- which keeps whole states in
+/// per-thread arrays -- is not generated at all (round 3: 7 000 spilled registers in the 72-word kernel, most of them for paths it
+/// can never take).
+template <int WS> DDO_DEV bool dd_is_vec_w(int kind) { return WS > 16 ? true : dd_is_vec(kind); }
+template <int WS> DDO_DEV bool dd_kind_is(int kind, int what) { return WS > 16 ? false : kind == what; }
 /// sum of |benefit| over the variables >= from (from = 0: McpRanking's key, model.rs:154-163)
 template <int WS>
 DDO_DEV int32_t vec_rank(const uint64_t* s, int n, int from) {
@@ -345,14 +351,14 @@ DDO_DEV int32_t vec_rank(const uint64_t* s, int n, int from) {
 template <int WS>
 DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth) {
     if constexpr (tw_k_of_ws(WS) != 0)
-        if (c.kind == MODEL_TSPTW) return tw_rub<tw_k_of_ws(WS)>(c.tw, s);
+        if (dd_kind_is<WS>(c.kind, MODEL_TSPTW)) return tw_rub<tw_k_of_ws(WS)>(c.tw, s);
     if (c.kind == MODEL_MCP)   // mcp/relax.rs:123-130
         return vec_rank<WS>(s, c.n, depth) + c.vest[depth] - c.vr + c.vnk[depth];
     if (c.kind == MODEL_MAX2SAT) {   // max2sat/model.rs:231-240; a complete assignment (depth n) has nothing left to gain
         if (depth >= c.n) return 0;
         return pop + c.vest[depth] - c.vr + c.vnk[depth];
     }
-    if (c.kind == MODEL_KNAPSACK) {
+    if (dd_kind_is<WS>(c.kind, MODEL_KNAPSACK)) {
         int64_t cap = (int64_t)s[0];
         int64_t max_profit = 0;
         for (int d = depth; cap > 0 && d < c.n; ++d) {
@@ -370,6 +376,7 @@ DDO_DEV int32_t rub_of(const DDCtx<WS>& c, const uint64_t* s, int pop, int depth
         }
         return (int32_t)max_profit;
     }
+    if constexpr (WS > 16) return 0;   // (only the signed-vector models have states this wide: dd_is_vec_w)
     if (c.unit_weights) return pop;
     int32_t sum = 0;
 #pragma unroll
@@ -860,15 +867,19 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     const int LS = c.tmode ? c.lstride : capN;                        // nodes per layer in the per-layer arrays
     const bool frontier = c.tmode && (in.flags & IN_FRONTIER) != 0;   // CUTSET_TYPE == FRONTIER
     const bool use_cache = c.tmode && (in.flags & IN_CACHE) != 0 && c.cache_cap != 0;
-    const bool use_dom = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dom_cap != 0 && c.kind == MODEL_KNAPSACK;
+    const bool use_dom = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dom_cap != 0 && dd_kind_is<WS>(c.kind, MODEL_KNAPSACK);
     constexpr int TWK = tw_k_of_ws(WS) != 0 ? tw_k_of_ws(WS) : 1;       // words of a TSPTW node set at this state width (dd_tsptw.hpp)
     constexpr int DKW = 2 * TWK + 1;                                    // words of a TsptwDominance key
-    const bool use_dkey = tw_k_of_ws(WS) != 0 && c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dkey_cap != 0 && c.kind == MODEL_TSPTW;
+    const bool use_dkey = tw_k_of_ws(WS) != 0 && c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dkey_cap != 0 && dd_kind_is<WS>(c.kind, MODEL_TSPTW);
 
     // ---------------------------------------------------------------- _clear + _initialize
     int cur = 0;
-    const int hsize = table_size_for(c.fan * (W + 2) + 1, c.table_cap);
-    const int hmask = hsize - 1;
+    // The dedup table is sized PER LAYER for the candidates the layer can have -- fan x its parents -- not for the widest layer
+    // the DD may ever see: a TSPTW DD asked for width 20 000 cleared a table of 2 M entries per layer for layers of a few dozen
+    // nodes (round 3: 195 us per layer, 0.045 x ONE thread of the oracle on config C5).  `hmask` is the mask of the table of the
+    // CURRENT unique layer: set when expand builds it, used again by the recycled-merge probe of the next layer's squash.
+    int hsize = table_size_for(c.fan + 2, c.table_cap);
+    int hmask = hsize - 1;
     PAR_BEGIN
     for (int i = tid; i < c.npad; i += NT) c.cnt[i] = 0;
     if (tid == 0) {
@@ -885,9 +896,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         sh->cache_hits = 0;
         for (int k = 0; k < WS; ++k) c.cstate[0][(size_t)k * capC1] = in.state[k];
         int pop = 0;
-        if (c.kind == MODEL_MISP)
+        if (dd_kind_is<WS>(c.kind, MODEL_MISP))
             for (int k = 0; k < WS; ++k) pop += dd_popc(in.state[k]);
-        if (dd_is_vec(c.kind)) pop = vec_rank<WS>(in.state, c.n, 0);
+        if (dd_is_vec_w<WS>(c.kind)) pop = vec_rank<WS>(in.state, c.n, 0);
         c.ckey[0][0] = ((uint64_t)bias32(in.value) << 32) | NONE32;
         c.cpop[0][0] = (uint32_t)pop;
         c.cflags[0][0] = 0;
@@ -896,7 +907,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     }
     PAR_END
     PAR_BEGIN
-    if (tid == 0) if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, in.state, +1);
+    if (tid == 0) if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, in.state, +1);
     // the table must describe the current unique layer (needed by recycled-merge probes)
     for (int i = tid; i < hsize; i += NT) c.table[i] = TAB_EMPTY;
     PAR_END
@@ -916,9 +927,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         PAR_END
         PAR_BEGIN
-        if (c.kind != MODEL_MISP) {   // static order (knapsack/main.rs:118-125, mcp/model.rs:88-96); an empty layer ends the DD
+        if (!dd_kind_is<WS>(c.kind, MODEL_MISP)) {   // static order (knapsack/main.rs:118-125, mcp/model.rs:88-96); an empty layer ends the DD
             if (tid == 0 && c.depth0 + L < c.n && sh->nU > 0)
-                sh->varkey = (c.kind == MODEL_MCP || c.kind == MODEL_TSPTW) ? (uint32_t)(c.depth0 + L)   // tsptw/model.rs:140-147
+                sh->varkey = (c.kind == MODEL_MCP || dd_kind_is<WS>(c.kind, MODEL_TSPTW)) ? (uint32_t)(c.depth0 + L)   // tsptw/model.rs:140-147
                              : c.kind == MODEL_MAX2SAT ? (uint32_t)c.m2_order[c.n - (c.depth0 + L) - 1]   // model.rs:330-346
                                                        : (uint32_t)c.kp_order[c.depth0 + L];
         } else {
@@ -961,7 +972,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 if (tv != TH_INF && val > tv) continue;            // node.value_top > threshold.value: keep
                 c.cflags[cur][cd] = LD_U32(&c.cflags[cur][cd]) | NF_CACHE;
                 c.cth[cd] = tv;
-                if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);   // it leaves the layer next_variable will look at
+                if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, s, -1);   // it leaves the layer next_variable will look at
                 LDS_ADD_I32(&sh->ncache, 1);
             }
             PAR_END
@@ -1062,11 +1073,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (tid == 0) {
             sh->mergedKey = 0;
             for (int k = 0; k < WS; ++k) sh->merged[k] = 0;
-            if (tw_k_of_ws(WS) != 0 && c.kind == MODEL_TSPTW) {
+            if (tw_k_of_ws(WS) != 0 && dd_kind_is<WS>(c.kind, MODEL_TSPTW)) {
                 for (int k = 0; k < TWK; ++k) sh->merged[TWK + k] = ~0ULL;   // intersection of the must-visit sets
                 sh->vmin[0] = 0xFFFFFFFFu;                                   // earliest elapsed time
             }
-            if (dd_is_vec(c.kind)) {
+            if (dd_is_vec_w<WS>(c.kind)) {
                 for (int v = 0; v < MAX_VEC_VARS; ++v) sh->vmin[v] = 0xFFFFFFFFu;
                 for (int q = 0; q < (MAX_VEC_VARS + 63) / 64; ++q) sh->vposmask[q] = sh->vnegmask[q] = 0;
             }
@@ -1099,12 +1110,12 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     if (!keepit) {
                         cl = 2;
                         uint64_t s[WS];
-                        if (!dd_is_vec(c.kind)) {   // (the wide signed-vector states are streamed below, word by word: no array)
+                        if (!dd_is_vec_w<WS>(c.kind)) {   // (the wide signed-vector states are streamed below, word by word: no array)
 #pragma unroll
                             for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + cd];
                         }
-                        if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);  // it leaves the layer
-                        if (relaxed && dd_is_vec(c.kind)) {
+                        if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, s, -1);  // it leaves the layer
+                        if (relaxed && dd_is_vec_w<WS>(c.kind)) {
                             // McpRelax::merge (relax.rs:141-176): per variable the signs seen and the smallest |benefit|;
                             // relax (relax.rs:115-121) adds rank(victim) - rank(merged) to every redirected arc, so the
                             // merged node's value is max(value + rank) over the victims minus its own rank
@@ -1134,7 +1145,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                             const uint64_t akey = ((uint64_t)bias32(adj) << 32) | (uint32_t)key;
                             if (akey > mkey) mkey = akey;
                             anydel = true;
-                        } else if (relaxed && c.kind == MODEL_TSPTW) {
+                        } else if (relaxed && dd_kind_is<WS>(c.kind, MODEL_TSPTW)) {
                             // TsptwRelax::merge (relax.rs:65-191): union of the positions, intersection / union of the must-visit
                             // sets, union of the maybe-visit sets, earliest and latest elapsed time
                             // (sh->merged: K words each of positions | agreed must | all must | all maybe -- 4K <= WS)
@@ -1154,7 +1165,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                             if (key > mkey) mkey = key;
                             anydel = true;
                         } else if (relaxed) {
-                            if (c.kind == MODEL_KNAPSACK) {   // KPRelax::merge: the largest capacity (main.rs:150-152)
+                            if (dd_kind_is<WS>(c.kind, MODEL_KNAPSACK)) {   // KPRelax::merge: the largest capacity (main.rs:150-152)
 #pragma unroll
                                 for (int k = 0; k < WS; ++k)
                                     if (s[k] > mor[k]) mor[k] = s[k];   // word 1 is the depth, equal over the layer
@@ -1173,9 +1184,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         c.tcount[tid] = kept;
         if (anydel) {
-            if (dd_is_vec(c.kind) || c.kind == MODEL_TSPTW) {
+            if (dd_is_vec_w<WS>(c.kind) || dd_kind_is<WS>(c.kind, MODEL_TSPTW)) {
                 // reductions already done per victim
-            } else if (c.kind == MODEL_KNAPSACK) {
+            } else if (dd_kind_is<WS>(c.kind, MODEL_KNAPSACK)) {
 #pragma unroll
                 for (int k = 0; k < WS; ++k) LDS_MAX_U64(&sh->merged[k], mor[k]);
             } else {
@@ -1214,7 +1225,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (tid == 0) {
                 uint64_t ms[WS];
                 for (int k = 0; k < WS; ++k) ms[k] = sh->merged[k];
-                if (c.kind == MODEL_TSPTW) {   // RelaxHelper::get_* (relax.rs:120-166)
+                if (dd_kind_is<WS>(c.kind, MODEL_TSPTW)) {   // RelaxHelper::get_* (relax.rs:120-166)
                     const uint32_t e = sh->vmin[0], l = (uint32_t)sh->mrank;
                     for (int k = 0; k < WS; ++k) ms[k] = 0;
                     if constexpr (tw_k_of_ws(WS) != 0) {
@@ -1232,7 +1243,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     }
                     sh->mrank = 0;
                 }
-                if (dd_is_vec(c.kind)) {
+                if (dd_is_vec_w<WS>(c.kind)) {
                     // merged benefit: all signs agree -> the value closest to zero, else 0 (relax.rs:141-176)
                     int32_t mrank = 0;
                     for (int k = 0; k < WS; ++k) {
@@ -1266,9 +1277,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     int pop = 0;
                     for (int k = 0; k < WS; ++k) {
                         c.cstate[cur][(size_t)k * capC1 + MERGED] = ms[k];
-                        if (c.kind == MODEL_MISP) pop += dd_popc(ms[k]);
+                        if (dd_kind_is<WS>(c.kind, MODEL_MISP)) pop += dd_popc(ms[k]);
                     }
-                    if (dd_is_vec(c.kind)) pop = sh->mrank;
+                    if (dd_is_vec_w<WS>(c.kind)) pop = sh->mrank;
                     c.ckey[cur][MERGED] = sh->mergedKey;
                     c.cpop[cur][MERGED] = (uint32_t)pop;
                     c.cflags[cur][MERGED] = NF_RELAXED | NF_INEXACT;
@@ -1276,7 +1287,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     c.posmap[MERGED] = (uint32_t)nkept;
                     c.cls[MERGED] = 1;
                     sh->merged_pos = nkept;
-                    if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, ms, +1);
+                    if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, ms, +1);
                 }
             }
             PAR_END
@@ -1306,14 +1317,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     sh->xbest = best;
                     uint64_t s[WS];
                     for (int k = 0; k < WS; ++k) s[k] = c.cstate[cur][(size_t)k * capC1 + best];
-                    if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, +1);
+                    if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, s, +1);
                     c.cls[best] = 1;
                     c.keep[nkept] = (uint32_t)best;
                     c.posmap[best] = (uint32_t)nkept;
                     sh->dup_from = nkept;
                     sh->dup_to = sh->merged_pos;
                     // its arcs were ALSO redirected to the recycled node, with relaxed costs (relax.rs:115-121)
-                    if (dd_is_vec(c.kind)) sh->xdelta = (int32_t)c.cpop[cur][best] - sh->mrank;
+                    if (dd_is_vec_w<WS>(c.kind)) sh->xdelta = (int32_t)c.cpop[cur][best] - sh->mrank;
                 }
                 PAR_END
                 n = nkept + 1;
@@ -1400,7 +1411,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     else {
                         out = (uint32_t)merged_pos;
                         // Relaxation::relax of a redirected arc (mcp/relax.rs:115-121): + rank(old target) - rank(merged)
-                        if (dd_is_vec(c.kind)) ac[cd] += (int32_t)c.cpop[cur][t] - sh->mrank;
+                        if (dd_is_vec_w<WS>(c.kind)) ac[cd] += (int32_t)c.cpop[cur][t] - sh->mrank;
                     }
                 }
                 at[cd] = out;
@@ -1411,12 +1422,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         DD1_TICK(5)   // layer bookkeeping (kept layers, arcs)
         // ------------------------------------------------------------ expand (clean.rs:360-370, 728-776)
         const int nxt = cur ^ 1;
+        hsize = table_size_for(c.fan * (n + 1) + 2, c.table_cap);   // at most fan children per node of this layer
+        hmask = hsize - 1;
         PAR_BEGIN
         for (int i = tid; i < hsize; i += NT) c.table[i] = TAB_EMPTY;
         if (tid == 0) sh->nU = 0;
         PAR_END
         PAR_BEGIN
-        const bool kp = c.kind == MODEL_KNAPSACK;
+        const bool kp = dd_kind_is<WS>(c.kind, MODEL_KNAPSACK);
         uint64_t adjv[WS];
 #pragma unroll
         for (int k = 0; k < WS; ++k) adjv[k] = kp ? 0 : c.adj[(size_t)var * WS + k];
@@ -1428,7 +1441,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         int myarcs = 0, myuniq = 0;
         for (int pos = tid; pos < n; pos += NT) {
             const uint32_t p = c.keep[pos];
-            if (dd_is_vec(c.kind)) {
+            if (dd_is_vec_w<WS>(c.kind)) {
                 // ---- signed-vector models, STREAMED: the parent's words are read, turned into the two children's words and written
                 // out one at a time (hashes and sums accumulate alongside); no per-thread state arrays (see dedup_insert_stored)
                 const uint64_t pkey = LD_U64(&c.ckey[cur][p]);
@@ -1587,11 +1600,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             const int32_t rub = rub_of<WS>(c, s, pop, c.depth0 + L);
             if (c.tmode) c.lrub[(size_t)L * LS + pos] = rub;   // node.rub (clean.rs:363), read again by _compute_thresholds
             if (rub == RUB_NEG_INF || (int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded (isize::MIN + value saturates)
-                if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);
+                if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, s, -1);
                 for (int d = 0; d < c.fan; ++d) c.ctarget[(size_t)d * capN + pos] = NONE32;
                 continue;
             }
-            if (tw_k_of_ws(WS) != 0 && c.kind == MODEL_TSPTW) {
+            if (tw_k_of_ws(WS) != 0 && dd_kind_is<WS>(c.kind, MODEL_TSPTW)) {
                 // examples/tsptw/model.rs:65-139: one child per node the salesman may visit next; decision index = node
                 uint64_t dom[TWK];
                 if constexpr (tw_k_of_ws(WS) != 0) tw_domain<TWK>(c.tw, s, dom);
@@ -1615,137 +1628,6 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     c.ckey[nxt][cd] = mykey;
                     ac_next[cd] = cost;
                     c.cpop[nxt][cd] = 0;                       // TsptwRanking compares depths: equal within a layer
-                    c.cflags[nxt][cd] = inexact;
-                    FENCE_BLOCK();
-                    const uint32_t w = dedup_insert<WS>(c, nxt, cd, y, hmask);
-                    c.ctarget[cd] = w;
-                    ++myarcs;
-                    if (w == cd) ++myuniq;
-                    else {
-                        GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
-                        if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
-                    }
-                }
-                continue;
-            }
-            if (c.kind == MODEL_MAX2SAT) {
-                // max2sat/model.rs:270-329: variable k is set to T (+1, slot `pos`) or F (-1, slot capN + pos); the benefits
-                // of the still-free variables (the first n - depth - 1 of the branching order) move by the clause weights,
-                // the arc cost is what k's assignment satisfies for sure plus the least the free variables still yield
-                const int kx = var, depth = c.depth0 + L;
-                const int nfree = c.n - depth - 1;
-                const size_t row = (size_t)kx * c.n;
-                const int32_t sk = vec_get<WS>(s, kx);
-                int32_t sum_t = c.m2_wtt[row + kx], sum_f = c.m2_wff[row + kx];   // unit clauses (k) / (-k)
-                int32_t rank_t = 0, rank_f = 0;
-                uint64_t cs[WS], ct[WS];
-#pragma unroll
-                for (int k = 0; k < WS; ++k) {
-                    uint64_t wt_ = 0, wf_ = 0;
-#pragma unroll
-                    for (int hsel = 0; hsel < 2; ++hsel) {
-                        const int v = 2 * k + hsel;
-                        if (v >= c.n) continue;
-                        const int32_t sl = (int32_t)(uint32_t)(s[k] >> (32 * hsel));
-                        int32_t a = sl, b = sl;                       // child benefit under T / under F
-                        if (v == kx) a = b = 0;
-                        else if (c.m2_rankpos[v] < nfree) {
-                            const int32_t wtt = c.m2_wtt[row + v], wtf = c.m2_wtf[row + v];
-                            const int32_t wft = c.m2_wft[row + v], wff = c.m2_wff[row + v];
-                            const int32_t ps = sl > 0 ? sl : 0, ns = sl < 0 ? -sl : 0;
-                            const int32_t mt = ps + wft < ns + wff ? ps + wft : ns + wff;
-                            const int32_t mf = ps + wtt < ns + wtf ? ps + wtt : ns + wtf;
-                            sum_t += (wtf + wtt) + mt;
-                            sum_f += (wff + wft) + mf;
-                            a = sl + wft - wff;
-                            b = sl + wtt - wtf;
-                        }
-                        rank_t += iabs32(a);
-                        rank_f += iabs32(b);
-                        wt_ |= (uint64_t)(uint32_t)a << (32 * hsel);
-                        wf_ |= (uint64_t)(uint32_t)b << (32 * hsel);
-                    }
-                    ct[k] = wt_;
-                    cs[k] = wf_;
-                }
-#pragma unroll
-                for (int k = 0; k < WS; ++k)
-                    if (k == (c.n + 1) / 2) cs[k] = ct[k] = (uint64_t)(depth + 1);   // depth word
-                const int32_t cost_t = (sk > 0 ? sk : 0) + sum_t;
-                const int32_t cost_f = (sk < 0 ? -sk : 0) + sum_f;
-                for (int side = 0; side < 2; ++side) {
-                    const uint32_t cd = side == 0 ? (uint32_t)pos : (uint32_t)(capN + pos);
-                    const uint64_t* y = side == 0 ? ct : cs;
-                    const int32_t cost = side == 0 ? cost_t : cost_f;
-#pragma unroll
-                    for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
-                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
-                    c.ckey[nxt][cd] = mykey;
-                    ac_next[cd] = cost;
-                    c.cpop[nxt][cd] = (uint32_t)(side == 0 ? rank_t : rank_f);
-                    c.cflags[nxt][cd] = inexact;
-                    FENCE_BLOCK();
-                    const uint32_t w = dedup_insert<WS>(c, nxt, cd, y, hmask);
-                    c.ctarget[cd] = w;
-                    ++myarcs;
-                    if (w == cd) ++myuniq;
-                    else {
-                        GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
-                        if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
-                    }
-                }
-                continue;
-            }
-            if (c.kind == MODEL_MCP) {
-                // mcp/model.rs:60-130: vertex x = depth goes to side S (+1, slot `pos`) or T (-1, slot capN + pos; not at
-                // depth 0).  Child benefit_v = benefit_v +- w[x][v] for v >= x, 0 before; the arc costs depend on the
-                // parent's benefits.
-                const int x = var, depth = c.depth0 + L;
-                const int32_t* wrow = c.vgraph + (size_t)x * c.n;
-                const int32_t bx = vec_get<WS>(s, x);
-                int32_t sum_s = 0, sum_t = 0, rank_s = 0, rank_t = 0;
-                uint64_t cs[WS], ct[WS];
-#pragma unroll
-                for (int k = 0; k < WS; ++k) {
-                    uint64_t ws_ = 0, wt_ = 0;
-#pragma unroll
-                    for (int hsel = 0; hsel < 2; ++hsel) {
-                        const int v = 2 * k + hsel;
-                        if (v < x || v >= c.n) continue;
-                        const int32_t skl = (int32_t)(uint32_t)(s[k] >> (32 * hsel));
-                        const int32_t wkl = wrow[v];
-                        const int32_t mn = iabs32(skl) < iabs32(wkl) ? iabs32(skl) : iabs32(wkl);
-                        const int64_t prod = (int64_t)skl * (int64_t)wkl;
-                        if (prod <= 0) sum_s += mn;
-                        if (prod >= 0) sum_t += mn;
-                        const int32_t a = skl + wkl, b = skl - wkl;
-                        rank_s += iabs32(a);
-                        rank_t += iabs32(b);
-                        ws_ |= (uint64_t)(uint32_t)a << (32 * hsel);
-                        wt_ |= (uint64_t)(uint32_t)b << (32 * hsel);
-                    }
-                    cs[k] = ws_;
-                    ct[k] = wt_;
-                }
-#pragma unroll
-                for (int k = 0; k < WS; ++k)
-                    if (k == (c.n + 1) / 2) cs[k] = ct[k] = (uint64_t)(depth + 1);   // depth word
-                const int32_t cost_s = depth == 0 ? 0 : (bx < 0 ? -bx : 0) + sum_s;
-                const int32_t cost_t = depth == 0 ? 0 : (bx > 0 ? bx : 0) + sum_t;
-                for (int side = 0; side < 2; ++side) {
-                    const uint32_t cd = side == 0 ? (uint32_t)pos : (uint32_t)(capN + pos);
-                    if (side == 1 && depth == 0) {   // the first vertex is fixed on side S (model.rs:60-63)
-                        c.ctarget[cd] = NONE32;
-                        break;
-                    }
-                    const uint64_t* y = side == 0 ? cs : ct;
-                    const int32_t cost = side == 0 ? cost_s : cost_t;
-#pragma unroll
-                    for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
-                    const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
-                    c.ckey[nxt][cd] = mykey;
-                    ac_next[cd] = cost;
-                    c.cpop[nxt][cd] = (uint32_t)(side == 0 ? rank_s : rank_t);
                     c.cflags[nxt][cd] = inexact;
                     FENCE_BLOCK();
                     const uint32_t w = dedup_insert<WS>(c, nxt, cd, y, hmask);
@@ -1795,7 +1677,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 else {
                     GLB_MAX_U64(&c.ckey[nxt][w], mykey);            // append_edge_to!: value >= value_top
                     if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);
-                    if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, s, -1);                      // duplicate: not a new member of next_l
+                    if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, s, -1);                      // duplicate: not a new member of next_l
                 }
             }
             // ---- decision YES (only when the variable is in the state, main.rs:95-102)
@@ -1826,7 +1708,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 ++myarcs;
                 if (w == cd) {
                     ++myuniq;
-                    if (c.kind == MODEL_MISP) add_bits<WS>(c.cnt, y, +1);
+                    if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, y, +1);
                 } else {
                     GLB_MAX_U64(&c.ckey[nxt][w], mykey);
                     if (inexact) GLB_OR_U32(&c.cflags[nxt][w], NF_INEXACT);

@@ -121,30 +121,41 @@ class DistributedSearch:
         return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(self.device)
 
     def _send_nodes(self, nodes, idx, dst, ws):
-        """point-to-point: the records `idx` of an export, as one header and six arrays (xGMI is point-to-point: a receiver
-        gets its own share and nothing else)"""
+        """point-to-point: the records `idx` of an export as a two-word header and -- unless the share is empty -- ONE packed
+        int64 message (states, value, ub, depth, path offsets, paths): xGMI is point-to-point, a receiver gets its own share and
+        nothing else, and a share costs two transfers instead of seven"""
+        k = len(idx)
         offs = nodes["path_off"].astype(np.int64)
-        lens = offs[idx + 1] - offs[idx]
-        new_off = np.zeros(len(idx) + 1, dtype=np.int64)
+        lens = offs[idx + 1] - offs[idx] if k else np.zeros(0, dtype=np.int64)
+        new_off = np.zeros(k + 1, dtype=np.int64)
         new_off[1:] = np.cumsum(lens)
         tot = int(new_off[-1])
-        paths = (np.concatenate([nodes["paths"][offs[i]:offs[i + 1]] for i in idx]) if tot else np.zeros((1, 2), dtype=np.int64)).reshape(-1, 2)
-        self.dist.send(self._to_dev(np.array([len(idx), tot], dtype=np.int64)), dst=dst)
-        for a in (nodes["states"][idx].reshape(len(idx), ws), nodes["value"][idx], nodes["ub"][idx], nodes["depth"][idx], new_off, paths):
-            self.dist.send(self._to_dev(a), dst=dst)
+        self.dist.send(self._to_dev(np.array([k, tot], dtype=np.int64)), dst=dst)
+        if k == 0:
+            return
+        paths = np.concatenate([nodes["paths"][offs[i]:offs[i + 1]] for i in idx]).reshape(-1, 2) if tot else np.zeros((0, 2), dtype=np.int64)
+        parts = [nodes["states"][idx].reshape(k, ws).view(np.int64).ravel(), nodes["value"][idx].astype(np.int64), nodes["ub"][idx].astype(np.int64),
+                 nodes["depth"][idx].astype(np.int64), new_off, paths.astype(np.int64).ravel()]
+        self.dist.send(self._to_dev(np.concatenate(parts)), dst=dst)
 
     def _recv_nodes(self, src, ws):
         hdr = torch.zeros(2, dtype=torch.int64, device=self.device)
         self.dist.recv(hdr, src=src)
         k, tot = int(hdr[0].item()), int(hdr[1].item())
-        shapes = [((k, ws), np.uint64), ((k,), np.int64), ((k,), np.int64), ((k,), np.int64), ((k + 1,), np.uint64), ((max(tot, 1), 2), np.int64)]
-        got = []
-        for shape, dt in shapes:
-            t = torch.zeros(shape, dtype=torch.int64, device=self.device)
-            self.dist.recv(t, src=src)
-            a = t.cpu().numpy()
-            got.append(a.view(np.uint64) if dt == np.uint64 else a)
-        return {"states": got[0], "value": got[1], "ub": got[2], "depth": got[3], "path_off": got[4], "paths": got[5][:tot]}
+        if k == 0:   # an empty share: nothing else was sent
+            return {"states": np.zeros((0, ws), dtype=np.uint64), "value": np.zeros(0, dtype=np.int64), "ub": np.zeros(0, dtype=np.int64),
+                    "depth": np.zeros(0, dtype=np.int64), "path_off": np.zeros(1, dtype=np.uint64), "paths": np.zeros((0, 2), dtype=np.int64)}
+        t = torch.zeros(k * ws + 3 * k + (k + 1) + 2 * tot, dtype=torch.int64, device=self.device)
+        self.dist.recv(t, src=src)
+        a = t.cpu().numpy()
+        o = 0
+        out = {}
+        for name, n, shape, dt in (("states", k * ws, (k, ws), np.uint64), ("value", k, (k,), np.int64), ("ub", k, (k,), np.int64),
+                                   ("depth", k, (k,), np.int64), ("path_off", k + 1, (k + 1,), np.uint64), ("paths", 2 * tot, (tot, 2), np.int64)):
+            piece = a[o:o + n].reshape(shape)
+            out[name] = piece.view(np.uint64) if dt == np.uint64 else piece
+            o += n
+        return out
 
     def _handover(self, ws):
         """All ranks call this together.  Donor = the rank with the best open bound (most open nodes among equals); receivers =
@@ -169,15 +180,18 @@ class DistributedSearch:
             k = len(nodes["value"])
             for j, r in enumerate(receivers):
                 self._send_nodes(nodes, np.arange(j, k, len(receivers)), r, ws)   # interleaved: everyone gets nodes from the top of the donor's order
-            self.handovers += 1
+            self.handovers += 1 if k else 0
             self.nodes_sent += k
-        elif self.rank in receivers:
+            return k > 0
+        if self.rank in receivers:
             got = self._recv_nodes(donor, ws)
-            if len(got["value"]):
+            n = len(got["value"])
+            if n:
                 self.s.import_subproblems(got)
-            self.handovers += 1
-            self.nodes_received += len(got["value"])
-        return True
+                self.handovers += 1
+            self.nodes_received += n
+            return n > 0          # (a receiver whose share was empty has no new work: it does not step on nothing)
+        return False
 
     def maximize(self):
         """Runs the sharded search to completion on every rank.  Returns (is_exact, global best value or None)."""

@@ -196,6 +196,10 @@ def test_width_heuristics_known_answers():
     assert w(DivBy(2, NbUnassignedWidth(5)), 5, 3) == 1                          # width.rs:732-745
     assert w(DivBy(4, Times(3, NbUnassignedWidth(10))), 10, 2) == 6
     assert w(TsptwWidth(2), 7, 3) == 7 * 4 * 2                                   # tsptw/heuristics.rs:48-52
+    # the decorators see the inner policy's RAW value: at depth == nb_vars NbUnassignedWidth is 0 and Times(k, .) is max(1, k * 0) = 1
+    # (the inner value used to be clamped to 1 first, which made this k); the engine itself never gets less than 1
+    assert w(Times(7, NbUnassignedWidth(5)), 5, 5) == 1 and w(NbUnassignedWidth(5), 5, 5) == 1
+    assert w(DivBy(2, Times(4, NbUnassignedWidth(6))), 6, 6) == 1
     import pytest
     with pytest.raises(ZeroDivisionError):                                       # width.rs:1073: DivBy(0, ..) panics
         DivBy(0, FixedWidth(3))

@@ -200,3 +200,43 @@ def test_rebalancing_by_best_open_bound_world2_gloo():
     assert all(o[1] is True and o[2] == 100399 for o in out) and all(o[6] == 0 for o in out)
     assert out[0][4] > 0 and out[1][5] == out[0][4]        # rank 0 gave, rank 1 received the same number
     assert out[1][3] > 12                                   # ... and worked on them
+
+
+class _StingySolver(_FakeSolver):
+    """exports at most ONE unit whatever it is asked for: with two receivers one share is empty"""
+
+    def export_subproblems(self, k):
+        return super().export_subproblems(min(k, 1))
+
+
+def _empty_share_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ddo_amd.distributed import DistributedSearch
+
+    s = _StingySolver(rank, limit=0, batch=2)          # leaves only: nothing spawns
+    s.open = list(range(50, 90)) if rank == 0 else []  # ranks 1 and 2 are dry receivers
+    search = DistributedSearch(s, dist, "cpu", rebalance_every=1, donate_min=2, donate_max=8)
+    proved, best = search.maximize()
+    q.put((rank, proved, best, s.done, search.nodes_sent, search.nodes_received, len(s.open), search.handovers))
+    dist.destroy_process_group()
+
+
+def test_a_receiver_whose_share_is_empty_world3_gloo():
+    """The donor exports fewer nodes than there are receivers: the receiver of the empty share gets a header and
+    nothing else, does not count a hand-over, and the search still processes every unit exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_share_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(o[3] for o in out) == 40 and all(o[1] is True and o[2] == 89 for o in out) and all(o[6] == 0 for o in out)
+    assert out[0][4] == out[1][5] + out[2][5] > 0          # sent == received, one unit per hand-over
+    assert out[2][5] == 0 and out[2][7] == 0               # the second receiver's share was always empty: no hand-over counted there
+    assert out[1][5] == out[1][7]                          # the first receiver: one unit per counted hand-over

@@ -1,6 +1,7 @@
 cd "$GRAFT_REPO_ROOT"
-timeout -s KILL 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden or shrunk or maximum or lazy or tiers or dense or full_size or (replay_of_oracle and (brock200_2 or keller4 or brock400))" 2>&1 | tail -4
-echo "no-stash: $(DDO_HIP_NO_WLKH=1 timeout -s KILL 300 python bench.py --no-cpu 2>&1 | grep -o '"value": [0-9.]*')"
-bash tools/ab_builds.sh _build_g0
-echo "no-stash: $(DDO_HIP_NO_WLKH=1 timeout -s KILL 300 python bench.py --no-cpu 2>&1 | grep -o '"value": [0-9.]*')"
-DDO_HIP_STATS=1 python bench.py --no-cpu 2>&1 >/dev/null | grep "ddo stats" | grep -E "kcycles per layer|per layer:" 
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r04a
+timeout -s KILL 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+for w in tsptw mcp max2sat; do timeout -s KILL 300 python bench.py --workload $w > gpurun_out/r04a/bench_$w.json 2> gpurun_out/r04a/bench_$w.err; tail -c 900 gpurun_out/r04a/bench_$w.json; echo; done
+timeout -s KILL 200 python bench.py --workload max2sat --instance frb15-9-1 --prove 30 --no-cpu > gpurun_out/r04a/bench_max2sat_frb15.json 2>/dev/null; tail -c 600 gpurun_out/r04a/bench_max2sat_frb15.json; echo
+timeout -s KILL 1000 python tools/fringe_dups.py > gpurun_out/r04a/fringe_dups.jsonl 2> gpurun_out/r04a/fringe_dups.err; cat gpurun_out/r04a/fringe_dups.jsonl
