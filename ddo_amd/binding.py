@@ -561,20 +561,23 @@ class Mdd:
         return Completion(bool(out.is_exact), out.best_value if out.has_best_value else None)
 
     @staticmethod
-    def compile_batch(mdds, comp_types, max_widths, residuals, best_lbs, cache=None):
+    def compile_batch(mdds, comp_types, max_widths, residuals, best_lbs, cache=None, cutoffs=None):
+        """`cutoffs`: one ctypes c_int (or None) per compile, polled like Cutoff::must_stop; a compile stopped by ITS flag comes
+        back as None, the others run to the end whatever their neighbours' flags do."""
         n = len(mdds)
         keep = []
         cis = (_CompileInput * n)()
         for i in range(n):
-            cis[i] = _fill_input(mdds[i].model, comp_types[i], max_widths[i], residuals[i], best_lbs[i], keep, None, cache)
+            cut = C.pointer(cutoffs[i]) if cutoffs is not None and cutoffs[i] is not None else None
+            cis[i] = _fill_input(mdds[i].model, comp_types[i], max_widths[i], residuals[i], best_lbs[i], keep, cut, cache)
         hs = (C.c_void_p * n)(*[m._h for m in mdds])
         outs = (_Completion * n)()
         sts = (C.c_int * n)()
         rc = lib().ddo_mdd_compile_batch(hs, cis, outs, sts, n)
         if rc < 0:
             raise DdoError(f"ddo_mdd_compile_batch rc={rc}: {_err()} statuses={list(sts)}")
-        return [HANDED_UP if sts[i] == DDO_HANDED_UP else Completion(bool(o.is_exact), o.best_value if o.has_best_value else None)
-                for i, o in enumerate(outs)]
+        return [HANDED_UP if sts[i] == DDO_HANDED_UP else None if sts[i] == DDO_CUTOFF else
+                Completion(bool(o.is_exact), o.best_value if o.has_best_value else None) for i, o in enumerate(outs)]
 
     def is_exact(self):
         return bool(lib().ddo_mdd_is_exact(self._h))

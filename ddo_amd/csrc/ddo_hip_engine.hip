@@ -578,6 +578,7 @@ Engine::~Engine() {
 }
 
 void Engine::set_cutoff(bool on) {
+    std::lock_guard<std::mutex> g(mtx_);
     int32_t v = on ? 1 : 0;
     (void)hipSetDevice(device_);
     (void)hipMemcpy((uint8_t*)d_counters_ + 16, &v, 4, hipMemcpyHostToDevice);
@@ -1683,6 +1684,30 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
     for (size_t a : active) stops.push_back(inputs[a].cutoff);
     int rc = eng->run_batch(din.data(), (int)din.size(), res, cache ? cache->t : nullptr, dom ? dom->t : nullptr, stops.data(), (int)stops.size());
     if (rc != DDO_OK) return rc;
+    // Cutoff::must_stop is per compile (clean.rs:352), the device flag is per launch: a raised flag of ONE caller ends every DD
+    // of the launch with ST_CUTOFF.  Compiles that were cut although their own flag is not raised (or absent) run again, among
+    // themselves, until each of them has either finished or been stopped by its own flag.
+    for (int round = 0; round < 64; ++round) {
+        std::vector<size_t> again;
+        for (size_t a = 0; a < active.size(); ++a) {
+            const volatile int* f = inputs[active[a]].cutoff;
+            if (res[2 * a].hdr.status == ST_CUTOFF && !(f && *f)) again.push_back(a);
+        }
+        if (again.empty()) break;
+        std::vector<DDInput> din2;
+        std::vector<const volatile int*> stops2;
+        for (size_t a : again) {
+            din2.push_back(din[a]);
+            stops2.push_back(inputs[active[a]].cutoff);
+        }
+        std::vector<HostResult> res2;
+        rc = eng->run_batch(din2.data(), (int)din2.size(), res2, cache ? cache->t : nullptr, dom ? dom->t : nullptr, stops2.data(), (int)stops2.size());
+        if (rc != DDO_OK) return rc;
+        for (size_t k = 0; k < again.size(); ++k) {
+            res[2 * again[k]] = std::move(res2[2 * k]);
+            res[2 * again[k] + 1] = std::move(res2[2 * k + 1]);
+        }
+    }
     // The output arena is shared by the compiles of a launch: one that found it full is compiled again on its own, and if
     // its cut-set alone does not fit, the arena grows -- as the solver host does (Engine::run_solo_growing; a compile that
     // failed on the arena wrote nothing to the cache).

@@ -55,6 +55,30 @@ def test_a_cutoff_raised_mid_compile_interrupts_it():
     assert again is not None and again.best_value == full.best_value
 
 
+def test_a_raised_flag_stops_only_its_own_compile_of_a_batch():
+    """Cutoff::must_stop is per compile (clean.rs:352).  Two wide compiles share one launch; the flag of the first goes up
+    a fraction into it.  The device flag is per launch, so both DDs are cut on the device -- the ABI runs the second one again
+    (its own flag is down) and hands back the same result as a compile on its own."""
+    import threading
+    import time
+    model = ddo_amd.Misp.read_instance(data_path("misp", "brock400_1.clq"))
+    W = 30000
+    mdds = [ddo_amd.Mdd(model, W) for _ in range(2)]
+    lb = -(1 << 62)
+    t0 = time.perf_counter()
+    alone = mdds[1].compile(CompilationType.Relaxed, W, model.root(), lb)
+    whole = time.perf_counter() - t0
+    assert alone is not None and whole > 0.02
+    flags = [C.c_int(0), C.c_int(0)]
+    t = threading.Timer(whole / 10, lambda: setattr(flags[0], "value", 1))
+    t.start()
+    out = ddo_amd.Mdd.compile_batch(mdds, [CompilationType.Relaxed] * 2, [W, W], [model.root(), model.root()], [lb, lb], cutoffs=flags)
+    t.join()
+    assert out[0] is None, "the first compile ran to the end although its flag went up a tenth into it"
+    assert out[1] is not None and out[1].best_value == alone.best_value and out[1].is_exact == alone.is_exact
+    assert len(mdds[1].drain_cutset()) > 0
+
+
 def test_best_exact_solution_of_a_relaxed_dd(brock):
     """best_exact_value / best_exact_solution (mdd.rs:96-110): the best terminal reached by an exact path"""
     mdd = ddo_amd.Mdd(brock, 50)

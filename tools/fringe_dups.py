@@ -13,7 +13,10 @@ sys.path.insert(0, os.getcwd())
 import ddo_amd
 from ddo_amd import FixedWidth, ParallelSolver
 
-CASES = (("brock200_1", 10000, 4096, 120), ("brock200_1", 10000, 32768, 120), ("brock400_1", 10000, 32768, 100))
+CASES = (("brock200_1", 10000, 4096, 120), ("brock200_1", 10000, 32768, 120), ("brock400_1", 10000, 32768, 100),
+         ("brock200_2", 1000, 256, 60), ("brock200_4", 1000, 256, 60), ("brock200_1", 2000, 1024, 90), ("keller4", 100, 256, 60), ("p_hat300-1", 100, 256, 60))
+if "--small" in sys.argv:
+    CASES = CASES[3:]
 for name, w, conc, budget in CASES:
     model = ddo_amd.Misp.read_instance(f"data/misp/{name}.clq")
     for fr in ("lazy", "nodup"):

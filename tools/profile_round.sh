@@ -17,3 +17,12 @@ timeout -s KILL 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WA
 timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_ATOMIC_RETURN SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS --kernel-trace -d $OUT/sq2 -o r --output-format csv -- $B > $OUT/sq2.log 2>&1
 find $OUT -name "*.csv" | head -30
 du -sh $OUT
+# ---- round 4 additions: L2 hit rate of the dense kernel, the whole search per kernel (capacity tiers), the layer-rebuilding engine
+timeout -s KILL 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace -d $OUT/tcc -o r --output-format csv -- $B > $OUT/tcc.log 2>&1
+timeout -s KILL 900 rocprofv3 --kernel-trace --stats -d $OUT/proof_trace -o r --output-format csv -- python bench.py --cpu-seconds 1 > $OUT/proof_trace.log 2>&1
+M="python bench.py --workload max2sat --instance frb15-9-1 --prove 10 --no-cpu"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/m2_trace -o r --output-format csv -- $M > $OUT/m2_trace.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/m2_fetch -o r --output-format csv -- $M > $OUT/m2_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/m2_write -o r --output-format csv -- $M > $OUT/m2_write.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d $OUT/m2_sq -o r --output-format csv -- $M > $OUT/m2_sq.log 2>&1
+find $OUT -name "*stats*.csv" | head; du -sh $OUT

@@ -1,7 +1,10 @@
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r04a
-timeout -s KILL 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
-for w in tsptw mcp max2sat; do timeout -s KILL 300 python bench.py --workload $w > gpurun_out/r04a/bench_$w.json 2> gpurun_out/r04a/bench_$w.err; tail -c 900 gpurun_out/r04a/bench_$w.json; echo; done
-timeout -s KILL 200 python bench.py --workload max2sat --instance frb15-9-1 --prove 30 --no-cpu > gpurun_out/r04a/bench_max2sat_frb15.json 2>/dev/null; tail -c 600 gpurun_out/r04a/bench_max2sat_frb15.json; echo
-timeout -s KILL 1000 python tools/fringe_dups.py > gpurun_out/r04a/fringe_dups.jsonl 2> gpurun_out/r04a/fringe_dups.err; cat gpurun_out/r04a/fringe_dups.jsonl
+timeout -s KILL 600 python -m pytest tests/test_gpu_api_surface.py -x -q -m gpu 2>&1 | tail -3
+timeout -s KILL 600 python bench.py --cpu-seconds 4 > gpurun_out/bench_kp.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/bench_kp.json").read().strip().splitlines()[-1])
+p=d.get("proof",{})
+print("value %.4g frac %.4f" % (d["value"], d["roofline"]["frac"]), "proof_s", p.get("time_to_proved_optimum_s"), "kernels", p.get("kernel_s"), [ (t.get("kernel_ms"), t.get("subproblems"), t.get("handed_up")) for t in p.get("tiers_rank0",[])])
+PY
