@@ -1,16 +1,10 @@
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r04c
-timeout -s KILL 900 python -m pytest tests/test_gpu_vector_parity.py tests/test_gpu_max2sat.py tests/test_gpu_mcp.py -x -q -m gpu 2>&1 | tail -2
-for w in mcp max2sat; do timeout -s KILL 300 python bench.py --workload $w > gpurun_out/r04c/bench_$w.json 2>/dev/null; python - <<PY
-import json
-d=json.loads(open("gpurun_out/r04c/bench_$w.json").read().strip().splitlines()[-1])
-print("$w", "value %.4g" % d["value"], "frac %.5f" % d["roofline"]["frac"], "kernel_s %.4f wall_s %.4f" % (d["roofline"]["kernel_s"], d["roofline"]["wall_s"]), "speedup", d.get("speedup_vs_cpu"))
-PY
-done
-timeout -s KILL 200 python bench.py --workload max2sat --instance frb15-9-1 --prove 30 --no-cpu > gpurun_out/r04c/bench_max2sat_frb15.json 2>/dev/null; python - <<PY
-import json
-d=json.loads(open("gpurun_out/r04c/bench_max2sat_frb15.json").read().strip().splitlines()[-1])
-print("frb15 value %.4g frac %.4f" % (d["value"], d["roofline"]["frac"]))
-PY
-DDO_HIP_STATS=1 timeout 200 python bench.py --workload max2sat --instance frb15-9-1 --prove 10 --no-cpu 2>&1 >/dev/null | grep "kcycles per layer" | tail -1 | cut -c1-330
+run() { env $2 timeout -s KILL 400 python bench.py --cpu-seconds 1 --steps 2 --warmup 1 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); p=d['proof']; print('$1 proof %.2f s kernels %s handed_up %s' % (p['wall_s'], [round(t['kernel_s'],2) for t in p['tiers_rank0']], [t['handed_up'] for t in p['tiers_rank0']]))"; }
+run "skip90(default)" "X=1"
+run "skip50" "DDO_HIP_TIER_SKIP=50"
+run "skip70" "DDO_HIP_TIER_SKIP=70"
+run "skip30" "DDO_HIP_TIER_SKIP=30"
+run "tiers 512:64,2048:128" "DDO_HIP_TIERS=512:64,2048:128"
