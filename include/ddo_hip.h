@@ -218,7 +218,9 @@ void ddo_mdd_destroy(ddo_mdd* mdd);
  *  Returns DDO_OK, DDO_CUTOFF, or DDO_ERR_*. */
 int ddo_mdd_compile(ddo_mdd* mdd, const ddo_compile_input* input, ddo_completion* out);
 /** Extension (not in the reference): B independent compiles in one device launch.
- *  statuses[i] receives the per-compile DDO_OK / DDO_CUTOFF / error. */
+ *  statuses[i] receives the per-compile DDO_OK / DDO_CUTOFF / error.  inputs[i].cutoff is polled per compile like
+ *  Cutoff::must_stop (clean.rs:352): a compile is stopped by ITS flag only -- the device-visible flag belongs to the launch, so
+ *  compiles that a neighbour's flag cut are run again before the call returns. */
 int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs, ddo_completion* outs,
                           int* statuses, size_t count);
 /** mdd.rs:86 */
