@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 timeout -s KILL 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 DDO_HIP_LEX_CAP=3 timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden or replay" 2>&1 | tail -2
-DDO_HIP_ENGINE=1 timeout -s KILL 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden or replay or sequential_parity" 2>&1 | tail -2
+DDO_HIP_ENGINE=1 timeout -s KILL 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "(golden or replay or sequential_parity) and not dense and not tier" 2>&1 | tail -2
 for cfg in DDO_HIP_THREADS=512 DDO_HIP_KEYS_GLOBAL=1 DDO_HIP_SLOTS=7; do   # alternate launch shapes: keys in L2, half-size workgroups, few slots
     env $cfg timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden or replay or lazy" 2>&1 | tail -1
 done
