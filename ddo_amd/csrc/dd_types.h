@@ -142,6 +142,11 @@ struct EngineParams {
     uint32_t* arct;            // [slot][max_layers][2*capN] arc -> child position (relaxed, below LEL)
     int32_t* arcc;             // [slot][max_layers][2*capN] arc cost (as relaxed when the arc was redirected to a merged node)
     int32_t* nlayer;           // [slot][max_layers]     nodes per layer
+    // kept layers and arc arrays as per-slot POOLS (layer-keeping mode of the D-ary models, round 4): 0 = fixed strides
+    uint64_t lpool_nodes;      // node records per slot shared by all kept layers of a DD (ninfo / lstate / lval / lrub / lvb / lth)
+    uint64_t apool_arcs;       // arc records per slot (arct / arcc)
+    uint64_t* lbase;           // [slot][max_layers + 1] first node record of every layer
+    uint64_t* abase;           // [slot][max_layers + 1] first arc record of the arcs entering every layer
     int32_t* lvar;             // [slot][max_layers]     variable branched below each layer
     int32_t* ldup;             // [slot][max_layers][2]  recycled-merge duplicate (from pos, to pos)
     uint64_t* cs_state;        // [slot][ws][capN]       copy of the last exact layer

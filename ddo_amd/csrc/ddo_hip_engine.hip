@@ -329,8 +329,25 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
                           : wsT * (size_t)P.capS * 8 + (size_t)P.capS * 8 * (((wsT + 8) / 8) * 8 + ((wsT + 7) / 8) * 8) +
                                 (size_t)P.capS * 12 + capN * 4 + P.ev_cap * 4 + P.ev_cap * 2 + ml * 8 * 4 + ml * 4 * 4 + capN * 4 + 2 * wsT * capN * 8 + capN * 8;
     if (P.tmode) {
-        per_slot += ml * (size_t)P.lstride * (wsT * 8 + 6 * 4) + capC1 * 8;
-        nslots = std::min(nslots, (int)std::max<size_t>(4, (8ull << 30) / per_slot));   // D-ary models: up to a GB per slot
+        // Kept layers at fixed strides cost ml * lstride node records per slot -- (nb_vars + 2) * nb_vars^3 of them under TsptwWidth,
+        // 25 GB per slot at 126 nodes (round 3: four DDs at a time).  Beyond 1 GB per slot the kept layers and the arc arrays become
+        // per-slot POOLS that a DD fills layer by layer with what it really holds (run_dd: lbase / abase); a DD that outgrows its
+        // pools ends with a capacity error.  DDO_HIP_LPOOL_M / DDO_HIP_APOOL_M: pool sizes in millions of records.
+        const size_t node_b = wsT * 8 + 6 * 4;
+        const size_t fixed_nodes = ml * (size_t)P.lstride, fixed_arcs = ml * (size_t)P.fan * capN;
+        if (model->kind == MODEL_TSPTW && fixed_nodes * node_b > (1ull << 30) && !std::getenv("DDO_HIP_FIXED_LAYERS")) {
+            size_t ln = std::min<size_t>(fixed_nodes, 8ull << 20), an = std::min<size_t>(fixed_arcs, 96ull << 20);
+            if (const char* env = std::getenv("DDO_HIP_LPOOL_M")) ln = std::min<size_t>(fixed_nodes, (size_t)std::max(1, std::atoi(env)) << 20);
+            if (const char* env = std::getenv("DDO_HIP_APOOL_M")) an = std::min<size_t>(fixed_arcs, (size_t)std::max(1, std::atoi(env)) << 20);
+            P.lpool_nodes = ln;
+            P.apool_arcs = an;
+            per_slot -= 2 * ml * (size_t)P.fan * capN * 4 + ml * capN * 4;   // (the fixed arc arrays and ninfo counted above)
+            per_slot += ln * node_b + an * 8 + capC1 * 8 + 2 * (ml + 1) * 8;
+            nslots = std::min(nslots, (int)std::max<size_t>(4, (160ull << 30) / per_slot));
+        } else {
+            per_slot += fixed_nodes * node_b + capC1 * 8;
+            nslots = std::min(nslots, (int)std::max<size_t>(4, (8ull << 30) / per_slot));   // D-ary models: up to a GB per slot
+        }
     }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -430,17 +447,21 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         if ((rc = dev_alloc(allocs_, P.keep, S * (P.tmode ? capC1 : capN)))) return rc;
         if ((rc = dev_alloc(allocs_, P.posmap, S * capC1))) return rc;
         if ((rc = dev_alloc(allocs_, P.cls, S * capC1))) return rc;
-        if ((rc = dev_alloc(allocs_, P.ninfo, S * ml * (size_t)P.lstride))) return rc;
+        if ((rc = dev_alloc(allocs_, P.ninfo, S * (P.lpool_nodes ? (size_t)P.lpool_nodes : ml * (size_t)P.lstride)))) return rc;
         if (P.tmode) {
-            const size_t lsz = S * ml * (size_t)P.lstride;
+            const size_t lsz = S * (P.lpool_nodes ? (size_t)P.lpool_nodes : ml * (size_t)P.lstride);
+            if (P.lpool_nodes) {
+                if ((rc = dev_alloc(allocs_, P.lbase, S * (ml + 1)))) return rc;
+                if ((rc = dev_alloc(allocs_, P.abase, S * (ml + 1)))) return rc;
+            }
             if ((rc = dev_alloc(allocs_, P.lstate, lsz * wsT))) return rc;
             if ((rc = dev_alloc(allocs_, P.lval, lsz))) return rc;
             if ((rc = dev_alloc(allocs_, P.lrub, lsz))) return rc;
             if ((rc = dev_alloc(allocs_, P.lvb, lsz))) return rc;
             if ((rc = dev_alloc(allocs_, P.lth, lsz + S * capC1))) return rc;
         }
-        if ((rc = dev_alloc(allocs_, P.arct, S * ml * (size_t)P.fan * capN))) return rc;
-        if ((rc = dev_alloc(allocs_, P.arcc, S * ml * (size_t)P.fan * capN))) return rc;
+        if ((rc = dev_alloc(allocs_, P.arct, S * (P.lpool_nodes ? (size_t)P.apool_arcs : ml * (size_t)P.fan * capN)))) return rc;
+        if ((rc = dev_alloc(allocs_, P.arcc, S * (P.lpool_nodes ? (size_t)P.apool_arcs : ml * (size_t)P.fan * capN)))) return rc;
         if ((rc = dev_alloc(allocs_, P.lddelta, S * ml))) return rc;
     } else {
         const size_t capS = P.capS, capW = P.capW;
@@ -888,6 +909,8 @@ int Engine::run_solo_growing(const DDInput& input, std::vector<HostResult>& resu
         if (rc == DDO_OK) rc = collect(results);
         if (rc != DDO_OK) return rc;
         if (!(capacity(results[0]) || capacity(results[1])) || arena_cap_ >= (8ull << 30)) return DDO_OK;
+        auto pools = [](const HostResult& r) { return r.hdr.status == ST_ERR_CAPACITY - 2100 || r.hdr.status == ST_ERR_CAPACITY - 2200; };
+        if (pools(results[0]) || pools(results[1])) return DDO_OK;   // the layer pools, not the arena: growing the arena does not help
         if ((rc = grow_arena(arena_cap_ * 4)) != DDO_OK) return rc;
     }
 }

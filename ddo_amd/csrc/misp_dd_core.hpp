@@ -252,6 +252,8 @@ struct DDCtx {
     int32_t *lval, *lrub, *lvb, *lth;
     int32_t* cth;        // [capC1] theta of the candidates the cache pruned in the layer being built
     int32_t* lntot;      // [max_layers] nodes per layer including the ones the cache pruned
+    uint64_t lpool, apool;       // per-slot pools of node / arc records (0: fixed strides), see run_dd
+    uint64_t *lbase, *abase;     // [max_layers + 1] where each kept layer / its entering arcs start in the pools
     uint64_t* cache_tab;
     uint64_t cache_cap;
     int cache_stride;
@@ -865,6 +867,23 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     const bool restricted = comp_type == CT_RESTRICTED;
     const uint32_t dmask = (1u << c.dbits) - 1u;
     const int LS = c.tmode ? c.lstride : capN;                        // nodes per layer in the per-layer arrays
+    // Kept layers and arc arrays either sit at fixed strides (layer X at X * LS, its arcs at X * fan * capN: a slot is sized for
+    // the widest layer any DD may have in EVERY layer) or -- c.lpool != 0, round 4: TSPTW beyond 64 nodes, where that is 25 GB per
+    // slot and four DDs in flight -- are carved out of two per-slot pools as the DD grows: layer X starts at lbase[X] and holds
+    // lntot[X] nodes, the arcs entering it start at abase[X] and are indexed by (decision, parent position) of the nlayer[X - 1]
+    // parents.  A DD whose layers outgrow the pools ends with a capacity error (loud), never with a wrong result.
+    const bool dynl = c.lpool != 0;
+    auto LB = [&](int X) -> size_t { return dynl ? (size_t)c.lbase[X] : (size_t)X * (size_t)LS; };
+    auto LSX = [&](int X, int k, size_t pos) -> size_t {   // index of word k of node pos of kept layer X in c.lstate
+        return dynl ? (size_t)c.lbase[X] * WS + (size_t)k * (size_t)c.lntot[X] + pos : ((size_t)X * WS + k) * (size_t)LS + pos;
+    };
+    auto AB = [&](int X) -> size_t { return dynl ? (size_t)c.abase[X] : (size_t)X * (size_t)c.fan * (size_t)capN; };
+    auto AI = [&](uint32_t cd, int np) -> size_t {   // index of candidate cd = decision * capN + parent position among np parents
+        return dynl ? (size_t)(cd / (uint32_t)capN) * (size_t)np + (size_t)(cd % (uint32_t)capN) : (size_t)cd;
+    };
+    uint64_t node_off = 0, arc_off = 0;   // pool heads of this DD (every thread counts along: workgroup-uniform)
+    size_t lb_cur = 0;                    // start of the layer being built
+    size_t ab_cur = 0;                    // start of the arcs ENTERING the layer being built
     const bool frontier = c.tmode && (in.flags & IN_FRONTIER) != 0;   // CUTSET_TYPE == FRONTIER
     const bool use_cache = c.tmode && (in.flags & IN_CACHE) != 0 && c.cache_cap != 0;
     const bool use_dom = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dom_cap != 0 && dd_kind_is<WS>(c.kind, MODEL_KNAPSACK);
@@ -1360,23 +1379,38 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 
         DD1_TICK(3)   // classify, positions, merged node
         // ------------------------------------------------------------ layers.push (clean.rs:678-684)
+        if (dynl) {   // room for this layer's nodes in the pool?
+            if (node_off + (uint64_t)ntot > c.lpool) {
+                PAR_BEGIN
+                if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 21;
+                PAR_END
+                failed = true;
+                break;
+            }
+            lb_cur = (size_t)node_off;
+            node_off += (uint64_t)ntot;
+        } else {
+            lb_cur = (size_t)L * (size_t)LS;
+        }
         PAR_BEGIN
         if (tid == 0) {
             if (c.tmode) c.lntot[L] = ntot;
+            if (dynl) c.lbase[L] = (uint64_t)lb_cur;
             c.nlayer[L] = n;
             c.lvar[L] = var;
             c.ldup[2 * L] = sh->dup_from;
             c.ldup[2 * L + 1] = sh->dup_to;
             if (c.lddelta) c.lddelta[L] = sh->xdelta;
         }
-        uint32_t* ni = c.ninfo + (size_t)L * LS;
+        uint32_t* ni = c.ninfo + lb_cur;
         for (int pos = tid; pos < ntot; pos += NT) {
             uint32_t cd = c.keep[pos];
             const uint64_t nkey = LD_U64(&c.ckey[cur][cd]);
             if (c.tmode) {   // the layer is kept: state, value, and the slots the backward passes fill
-                const size_t li = (size_t)L * LS + pos;
+                const size_t li = lb_cur + pos;
 #pragma unroll
-                for (int k = 0; k < WS; ++k) c.lstate[((size_t)L * WS + k) * LS + pos] = c.cstate[cur][(size_t)k * capC1 + cd];
+                for (int k = 0; k < WS; ++k)
+                    c.lstate[(dynl ? lb_cur * WS + (size_t)k * (size_t)ntot : ((size_t)L * WS + k) * (size_t)LS) + pos] = c.cstate[cur][(size_t)k * capC1 + cd];
                 c.lval[li] = unbias32((uint32_t)(nkey >> 32));
                 c.lrub[li] = INT32_MAX;
                 c.lvb[li] = VB_UNMARKED;
@@ -1400,10 +1434,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         // arcs entering this layer, translated to node positions (needed by the backward pass)
         if (((relaxed && lel >= 0) || c.tmode) && L >= 1) {
-            uint32_t* at = c.arct + (size_t)L * c.fan * capN;
-            int32_t* ac = c.arcc + (size_t)L * c.fan * capN;
+            uint32_t* at = c.arct + ab_cur;   // (the arcs entering this layer: allocated when the layer above was expanded)
+            int32_t* ac = c.arcc + ab_cur;
             for (int j = tid; j < ncl; j += NT) {
                 int cd = lin2cand(j, nprev, capN);
+                const size_t ai = dynl ? (size_t)j : (size_t)cd;
                 uint32_t t = c.ctarget[cd];
                 uint32_t out = NONE32;
                 if (t != NONE32) {
@@ -1411,10 +1446,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     else {
                         out = (uint32_t)merged_pos;
                         // Relaxation::relax of a redirected arc (mcp/relax.rs:115-121): + rank(old target) - rank(merged)
-                        if (dd_is_vec_w<WS>(c.kind)) ac[cd] += (int32_t)c.cpop[cur][t] - sh->mrank;
+                        if (dd_is_vec_w<WS>(c.kind)) ac[ai] += (int32_t)c.cpop[cur][t] - sh->mrank;
                     }
                 }
-                at[cd] = out;
+                at[ai] = out;
             }
         }
         PAR_END
@@ -1422,6 +1457,18 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         DD1_TICK(5)   // layer bookkeeping (kept layers, arcs)
         // ------------------------------------------------------------ expand (clean.rs:360-370, 728-776)
         const int nxt = cur ^ 1;
+        size_t ab_next = (size_t)(L + 1) * (size_t)c.fan * (size_t)capN;
+        if (dynl) {   // room for the arcs entering layer L + 1: fan per expanded node of this layer
+            if (arc_off + (uint64_t)c.fan * (uint64_t)n > c.apool) {
+                PAR_BEGIN
+                if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 22;
+                PAR_END
+                failed = true;
+                break;
+            }
+            ab_next = (size_t)arc_off;
+            arc_off += (uint64_t)c.fan * (uint64_t)n;
+        }
         hsize = table_size_for(c.fan * (n + 1) + 2, c.table_cap);   // at most fan children per node of this layer
         hmask = hsize - 1;
         PAR_BEGIN
@@ -1437,7 +1484,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         const uint64_t vbit = 1ULL << (var & 63);
         const int32_t wv = c.weight[var];
         const uint64_t kpw = kp ? (uint64_t)c.kp_weight[var] : 0;
-        int32_t* ac_next = c.arcc + (size_t)(L + 1) * c.fan * capN;   // costs of the arcs entering layer L + 1
+        int32_t* ac_next = c.arcc + ab_next;   // costs of the arcs entering layer L + 1
         int myarcs = 0, myuniq = 0;
         for (int pos = tid; pos < n; pos += NT) {
             const uint32_t p = c.keep[pos];
@@ -1467,7 +1514,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     }
                     rub = r + c.vest[depth] - c.vr + c.vnk[depth];
                 }
-                if (c.tmode) c.lrub[(size_t)L * LS + pos] = rub;
+                if (c.tmode) c.lrub[lb_cur + pos] = rub;
                 if (rub == RUB_NEG_INF || (int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365
                     for (int d = 0; d < c.fan; ++d) c.ctarget[(size_t)d * capN + pos] = NONE32;
                     continue;
@@ -1567,7 +1614,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     const int32_t cost = side == 0 ? cost0 : cost1;
                     const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
                     c.ckey[nxt][cd] = mykey;
-                    ac_next[cd] = cost;
+                    ac_next[AI(cd, n)] = cost;
                     c.cpop[nxt][cd] = (uint32_t)(side == 0 ? rank0 : rank1);
                     c.cflags[nxt][cd] = inexact;
                 }
@@ -1598,7 +1645,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             // does this parent have an exact best path (see KEY_OK) ?
             const uint32_t pok = (!inexact || (!(pfl & NF_RELAXED) && (uint32_t)pkey != NONE32 && ((uint32_t)pkey & KEY_OK))) ? KEY_OK : 0u;
             const int32_t rub = rub_of<WS>(c, s, pop, c.depth0 + L);
-            if (c.tmode) c.lrub[(size_t)L * LS + pos] = rub;   // node.rub (clean.rs:363), read again by _compute_thresholds
+            if (c.tmode) c.lrub[lb_cur + pos] = rub;   // node.rub (clean.rs:363), read again by _compute_thresholds
             if (rub == RUB_NEG_INF || (int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded (isize::MIN + value saturates)
                 if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, s, -1);
                 for (int d = 0; d < c.fan; ++d) c.ctarget[(size_t)d * capN + pos] = NONE32;
@@ -1626,7 +1673,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
                     const uint64_t mykey = ((uint64_t)bias32(val + cost) << 32) | pok | cd;
                     c.ckey[nxt][cd] = mykey;
-                    ac_next[cd] = cost;
+                    ac_next[AI(cd, n)] = cost;
                     c.cpop[nxt][cd] = 0;                       // TsptwRanking compares depths: equal within a layer
                     c.cflags[nxt][cd] = inexact;
                     FENCE_BLOCK();
@@ -1666,7 +1713,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = s[k];
                 const uint64_t mykey = ((uint64_t)bias32(val) << 32) | pok | cd;
                 c.ckey[nxt][cd] = mykey;
-                ac_next[cd] = 0;                                   // transition_cost of NO / LEAVE_IT_OUT
+                ac_next[AI(cd, n)] = 0;                                   // transition_cost of NO / LEAVE_IT_OUT
                 c.cpop[nxt][cd] = (uint32_t)(pop - ((hasv && !kp) ? 1 : 0));
                 c.cflags[nxt][cd] = inexact;
                 FENCE_BLOCK();
@@ -1699,7 +1746,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int k = 0; k < WS; ++k) c.cstate[nxt][(size_t)k * capC1 + cd] = y[k];
                 const uint64_t mykey = ((uint64_t)bias32(val + wv) << 32) | pok | cd;
                 c.ckey[nxt][cd] = mykey;
-                ac_next[cd] = wv;                                  // transition_cost of YES / TAKE_IT
+                ac_next[AI(cd, n)] = wv;                                  // transition_cost of YES / TAKE_IT
                 c.cpop[nxt][cd] = (uint32_t)ypop;
                 c.cflags[nxt][cd] = inexact;
                 FENCE_BLOCK();
@@ -1722,6 +1769,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (tid == 0) {
             sh->nodes += (uint64_t)n;
             if (n > sh->maxn) sh->maxn = n;
+            if (dynl) c.abase[L + 1] = (uint64_t)ab_next;
         }
         PAR_END
 #if defined(DDO_HOST_EMULATION)
@@ -1730,6 +1778,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 
         cur = nxt;
         nprev = n;
+        ab_cur = ab_next;
         L += 1;
     }
 
@@ -1777,22 +1826,38 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             }
         }
         PAR_END
+        bool pool_full = false;
+        if (dynl) {
+            pool_full = node_off + (uint64_t)nT > c.lpool;
+            lb_cur = (size_t)node_off;
+            node_off += (uint64_t)nT;
+        } else {
+            lb_cur = (size_t)L * (size_t)LS;
+        }
+        if (pool_full) {
+            PAR_BEGIN
+            if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 21;
+            PAR_END
+            nT = 0;
+        }
         PAR_BEGIN
         if (tid == 0) {
             c.nlayer[L] = nT;
             if (c.tmode) c.lntot[L] = nT;
+            if (dynl) c.lbase[L] = (uint64_t)lb_cur;
             c.lvar[L] = -1;
             c.ldup[2 * L] = -1;
             c.ldup[2 * L + 1] = -1;
         }
-        uint32_t* ni = c.ninfo + (size_t)L * LS;
+        uint32_t* ni = c.ninfo + lb_cur;
         for (int pos = tid; pos < nT; pos += NT) {
             uint32_t cd = c.keep[pos];
             uint64_t key = LD_U64(&c.ckey[cur][cd]);
             if (c.tmode) {
-                const size_t li = (size_t)L * LS + pos;
+                const size_t li = lb_cur + pos;
 #pragma unroll
-                for (int k = 0; k < WS; ++k) c.lstate[((size_t)L * WS + k) * LS + pos] = c.cstate[cur][(size_t)k * capC1 + cd];
+                for (int k = 0; k < WS; ++k)
+                    c.lstate[(dynl ? lb_cur * WS + (size_t)k * (size_t)nT : ((size_t)L * WS + k) * (size_t)LS) + pos] = c.cstate[cur][(size_t)k * capC1 + cd];
                 c.lval[li] = unbias32((uint32_t)(key >> 32));
                 c.lrub[li] = INT32_MAX;      // the terminal layer is never bounded (clean.rs:360 does not reach it)
                 c.lvb[li] = VB_UNMARKED;
@@ -1819,11 +1884,11 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (!(fl & (NF_INEXACT | NF_RELAXED))) LDS_MAX_U64(&sh->bestExactKey, bk + 1);
         }
         if (((relaxed && lel >= 0) || c.tmode) && L >= 1) {
-            uint32_t* at = c.arct + (size_t)L * c.fan * capN;
-            for (int j = tid; j < ncl; j += NT) {
+            uint32_t* at = c.arct + ab_cur;
+            for (int j = tid; j < (pool_full ? 0 : ncl); j += NT) {
                 int cd = lin2cand(j, nprev, capN);
                 uint32_t t = c.ctarget[cd];
-                at[cd] = t != NONE32 ? c.posmap[t] : NONE32;
+                at[dynl ? (size_t)j : (size_t)cd] = t != NONE32 ? c.posmap[t] : NONE32;
             }
         }
         PAR_END
@@ -1864,7 +1929,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 // _has_exact_best_path (clean.rs:643-655) walks the best arcs up to the first exact (-> true) or relaxed
                 // (-> false) node; the best arc of every node already prefers a parent for which that walk succeeds
                 // (KEY_OK), so the answer for the best terminal node is in its own word
-                const uint32_t w = c.ninfo[(size_t)(n_layers - 1) * LS + best_pos];
+                const uint32_t w = c.ninfo[LB((n_layers - 1)) + best_pos];
                 if (!(w & (NI_INEXACT | NI_RELAXED))) res_e = 1;
                 else if (w & NI_RELAXED) res_e = 0;
                 else res_e = (w & NI_OKPATH) ? 1 : 0;
@@ -1894,25 +1959,25 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         const bool th_on = relaxed || is_exact;                              // clean.rs:479, 551
         if (relaxed && lel >= 0 && lel < n_layers) {                          // _compute_local_bounds (clean.rs:448-475)
             PAR_BEGIN
-            for (int pos = tid; pos < c.lntot[T]; pos += NT) c.lvb[(size_t)T * LS + pos] = 0;
+            for (int pos = tid; pos < c.lntot[T]; pos += NT) c.lvb[LB(T) + pos] = 0;
             PAR_END
             for (int Lc = T; Lc >= 1; --Lc) {
                 const int nP = c.nlayer[Lc - 1];
                 PAR_BEGIN
-                const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
-                const int32_t* ac = c.arcc + (size_t)Lc * c.fan * capN;
+                const uint32_t* at = c.arct + AB(Lc);
+                const int32_t* ac = c.arcc + AB(Lc);
                 const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
                 for (int j = tid; j < c.fan * nP; j += NT) {
                     const int d = j / nP;
                     const int pp = j - d * nP;
-                    const uint32_t t = at[d * capN + pp];
+                    const uint32_t t = at[dynl ? (size_t)j : (size_t)d * capN + pp];
                     if (t == NONE32) continue;
-                    const int32_t cost = ac[d * capN + pp];
-                    const int32_t v = LD_I32(&c.lvb[(size_t)Lc * LS + t]);
-                    if (v != VB_UNMARKED) GLB_MAX_I32(&c.lvb[(size_t)(Lc - 1) * LS + pp], v + cost);
+                    const int32_t cost = ac[dynl ? (size_t)j : (size_t)d * capN + pp];
+                    const int32_t v = LD_I32(&c.lvb[LB(Lc) + t]);
+                    if (v != VB_UNMARKED) GLB_MAX_I32(&c.lvb[LB((Lc - 1)) + pp], v + cost);
                     if ((int)t == dfrom) {   // the arcs of the node a recycled merge re-added also go to the merged node
-                        const int32_t v2 = LD_I32(&c.lvb[(size_t)Lc * LS + dto]);
-                        if (v2 != VB_UNMARKED) GLB_MAX_I32(&c.lvb[(size_t)(Lc - 1) * LS + pp], v2 + cost + (c.lddelta ? c.lddelta[Lc] : 0));
+                        const int32_t v2 = LD_I32(&c.lvb[LB(Lc) + dto]);
+                        if (v2 != VB_UNMARKED) GLB_MAX_I32(&c.lvb[LB((Lc - 1)) + pp], v2 + cost + (c.lddelta ? c.lddelta[Lc] : 0));
                     }
                 }
                 PAR_END
@@ -1923,21 +1988,21 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             PAR_BEGIN
             if (!frontier) {
                 if (lel_eff < n_layers)
-                    for (int pos = tid; pos < c.lntot[lel_eff]; pos += NT) c.ninfo[(size_t)lel_eff * LS + pos] |= NI_CUTSET;
+                    for (int pos = tid; pos < c.lntot[lel_eff]; pos += NT) c.ninfo[LB(lel_eff) + pos] |= NI_CUTSET;
             } else {
                 for (int Lc = 1; Lc <= T; ++Lc) {
                     const int nP = c.nlayer[Lc - 1];
-                    const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
+                    const uint32_t* at = c.arct + AB(Lc);
                     const int dfrom = c.ldup[2 * Lc];
                     for (int j = tid; j < c.fan * nP; j += NT) {
                         const int d = j / nP;
                         const int pp = j - d * nP;
-                        const uint32_t t = at[d * capN + pp];
+                        const uint32_t t = at[dynl ? (size_t)j : (size_t)d * capN + pp];
                         if (t == NONE32) continue;
-                        const bool child_inexact = (c.ninfo[(size_t)Lc * LS + t] & (NI_INEXACT | NI_RELAXED)) != 0 || (int)t == dfrom;
+                        const bool child_inexact = (c.ninfo[LB(Lc) + t] & (NI_INEXACT | NI_RELAXED)) != 0 || (int)t == dfrom;
                         if (!child_inexact) continue;
-                        const uint32_t pw = LD_U32(&c.ninfo[(size_t)(Lc - 1) * LS + pp]);
-                        if (!(pw & (NI_INEXACT | NI_RELAXED | NI_CUTSET))) GLB_OR_U32(&c.ninfo[(size_t)(Lc - 1) * LS + pp], NI_CUTSET);
+                        const uint32_t pw = LD_U32(&c.ninfo[LB((Lc - 1)) + pp]);
+                        if (!(pw & (NI_INEXACT | NI_RELAXED | NI_CUTSET))) GLB_OR_U32(&c.ninfo[LB((Lc - 1)) + pp], NI_CUTSET);
                     }
                 }
             }
@@ -1956,15 +2021,15 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             for (int pos = tid; pos < nP; pos += NT) vbB[pos] = VB_UNMARKED;
             PAR_END
             PAR_BEGIN
-            const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
-            const int32_t* ac = c.arcc + (size_t)Lc * c.fan * capN;
+            const uint32_t* at = c.arct + AB(Lc);
+            const int32_t* ac = c.arcc + AB(Lc);
             const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
             for (int j = tid; j < c.fan * nP; j += NT) {
                 const int d = j / nP;
                 const int pp = j - d * nP;
-                const uint32_t t = at[d * capN + pp];
+                const uint32_t t = at[dynl ? (size_t)j : (size_t)d * capN + pp];
                 if (t == NONE32) continue;
-                const int32_t cost = ac[d * capN + pp];
+                const int32_t cost = ac[dynl ? (size_t)j : (size_t)d * capN + pp];
                 int32_t v = vbA[t];
                 if (v != VB_UNMARKED) LDS_MAX_I32(&vbB[pp], v + cost);
                 if ((int)t == dfrom) {  // arcs of the re-added node were also redirected (clean.rs:851-866)
@@ -1996,7 +2061,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         int mine = 0;
         for (int Lc = cs_first; Lc <= cs_last; ++Lc)
             for (int pos = tid; pos < c.lntot[Lc]; pos += NT) {
-                const size_t li = (size_t)Lc * LS + pos;
+                const size_t li = LB(Lc) + pos;
                 if (!(LD_U32(&c.ninfo[li]) & NI_CUTSET)) continue;
                 const int32_t vb = LD_I32(&c.lvb[li]);
                 if (vb == VB_UNMARKED) continue;
@@ -2086,15 +2151,15 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (has_best_exact && T >= 0 && nT > 0) {
                 PAR_BEGIN
                 for (int pos = tid; pos < nT; pos += NT) {
-                    const bool nex = !(c.ninfo[(size_t)T * LS + pos] & (NI_INEXACT | NI_RELAXED));
-                    if ((!frontier && is_exact) || (frontier && nex)) c.lth[(size_t)T * LS + pos] = bk;
+                    const bool nex = !(c.ninfo[LB(T) + pos] & (NI_INEXACT | NI_RELAXED));
+                    if ((!frontier && is_exact) || (frontier && nex)) c.lth[LB(T) + pos] = bk;
                 }
                 PAR_END
             }
             for (int Lc = T; Lc >= 0; --Lc) {
                 PAR_BEGIN
                 for (int pos = tid; pos < c.lntot[Lc]; pos += NT) {
-                    const size_t li = (size_t)Lc * LS + pos;
+                    const size_t li = LB(Lc) + pos;
                     const uint32_t w = LD_U32(&c.ninfo[li]);
                     if (w & NI_CACHE) continue;                       // its theta is the cached threshold: only propagated
                     const bool nex = !(w & (NI_INEXACT | NI_RELAXED));
@@ -2124,7 +2189,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     if (use_cache && th != TH_NONE && above) {
                         uint64_t st[WS];
 #pragma unroll
-                        for (int k = 0; k < WS; ++k) st[k] = c.lstate[((size_t)Lc * WS + k) * LS + pos];
+                        for (int k = 0; k < WS; ++k) st[k] = c.lstate[LSX(Lc, k, pos)];
                         cache_update<WS>(c, st, c.depth0 + Lc, th_pack(th, !(w & NI_CUTSET)));
                     }
                 }
@@ -2132,20 +2197,20 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 if (Lc == 0) break;
                 const int nP = c.nlayer[Lc - 1];
                 PAR_BEGIN
-                const uint32_t* at = c.arct + (size_t)Lc * c.fan * capN;
-                const int32_t* ac = c.arcc + (size_t)Lc * c.fan * capN;
+                const uint32_t* at = c.arct + AB(Lc);
+                const int32_t* ac = c.arcc + AB(Lc);
                 const int dfrom = c.ldup[2 * Lc], dto = c.ldup[2 * Lc + 1];
                 for (int j = tid; j < c.fan * nP; j += NT) {
                     const int d = j / nP;
                     const int pp = j - d * nP;
-                    const uint32_t t = at[d * capN + pp];
+                    const uint32_t t = at[dynl ? (size_t)j : (size_t)d * capN + pp];
                     if (t == NONE32) continue;
-                    const int32_t cost = ac[d * capN + pp];
-                    const int32_t th = LD_I32(&c.lth[(size_t)Lc * LS + t]);
-                    if (th != TH_NONE) GLB_MIN_I32(&c.lth[(size_t)(Lc - 1) * LS + pp], th_sub(th, cost));
+                    const int32_t cost = ac[dynl ? (size_t)j : (size_t)d * capN + pp];
+                    const int32_t th = LD_I32(&c.lth[LB(Lc) + t]);
+                    if (th != TH_NONE) GLB_MIN_I32(&c.lth[LB((Lc - 1)) + pp], th_sub(th, cost));
                     if ((int)t == dfrom) {
-                        const int32_t th2 = LD_I32(&c.lth[(size_t)Lc * LS + dto]);
-                        if (th2 != TH_NONE) GLB_MIN_I32(&c.lth[(size_t)(Lc - 1) * LS + pp], th_sub(th2, cost + (c.lddelta ? c.lddelta[Lc] : 0)));
+                        const int32_t th2 = LD_I32(&c.lth[LB(Lc) + dto]);
+                        if (th2 != TH_NONE) GLB_MIN_I32(&c.lth[LB((Lc - 1)) + pp], th_sub(th2, cost + (c.lddelta ? c.lddelta[Lc] : 0)));
                     }
                 }
                 PAR_END
@@ -2160,7 +2225,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             uint32_t* out = (uint32_t*)(base + path_off);
             int p = best_pos;
             for (int Lc = n_layers - 1, i = 0; Lc >= 1; --Lc, ++i) {
-                uint32_t w = c.ninfo[(size_t)Lc * LS + p];
+                uint32_t w = c.ninfo[LB(Lc) + p];
                 uint32_t arc = w & NI_ARC_MASK;
                 out[i] = ((uint32_t)c.lvar[Lc - 1] << c.dbits) | (arc & dmask);
                 p = (int)(arc >> c.dbits);
@@ -2170,7 +2235,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             uint32_t* out = (uint32_t*)(base + exact_off);
             int p = exact_pos;
             for (int Lc = n_layers - 1, i = 0; Lc >= 1; --Lc, ++i) {
-                uint32_t w = c.ninfo[(size_t)Lc * LS + p];
+                uint32_t w = c.ninfo[LB(Lc) + p];
                 uint32_t arc = w & NI_ARC_MASK;
                 out[i] = ((uint32_t)c.lvar[Lc - 1] << c.dbits) | (arc & dmask);
                 p = (int)(arc >> c.dbits);
@@ -2185,7 +2250,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             int32_t* o_depth = (int32_t*)(base + cs_depth_off);
             for (int Lc = cs_first; Lc <= cs_last; ++Lc)
                 for (int pos = tid; pos < c.lntot[Lc]; pos += NT) {
-                    const size_t li = (size_t)Lc * LS + pos;
+                    const size_t li = LB(Lc) + pos;
                     if (!(LD_U32(&c.ninfo[li]) & NI_CUTSET)) continue;
                     const int32_t vb = LD_I32(&c.lvb[li]);
                     if (vb == VB_UNMARKED) continue;
@@ -2196,13 +2261,13 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     if (filter && ub <= best_lb) continue;
                     const int idx = LDS_ADD_I32(&sh->ncut2, 1);
 #pragma unroll
-                    for (int k = 0; k < WS; ++k) o_state[(size_t)idx * WS + k] = c.lstate[((size_t)Lc * WS + k) * LS + pos];
+                    for (int k = 0; k < WS; ++k) o_state[(size_t)idx * WS + k] = c.lstate[LSX(Lc, k, pos)];
                     o_value[idx] = (int32_t)v;
                     o_ub[idx] = (int32_t)ub;
                     o_depth[idx] = Lc;
                     int p = pos;
                     for (int Lw = Lc, i = 0; Lw >= 1; --Lw, ++i) {
-                        const uint32_t arc = c.ninfo[(size_t)Lw * LS + p] & NI_ARC_MASK;
+                        const uint32_t arc = c.ninfo[LB(Lw) + p] & NI_ARC_MASK;
                         o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lw - 1] << c.dbits) | (arc & dmask);
                         p = (int)(arc >> c.dbits);
                     }
@@ -2230,7 +2295,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 o_ub[idx] = (int32_t)ub;
                 int p = pos;
                 for (int Lc = lel, i = 0; Lc >= 1; --Lc, ++i) {
-                    uint32_t w = c.ninfo[(size_t)Lc * LS + p];
+                    uint32_t w = c.ninfo[LB(Lc) + p];
                     uint32_t arc = w & NI_ARC_MASK;
                     o_path[(size_t)idx * cs_path_len + i] = ((uint32_t)c.lvar[Lc - 1] << c.dbits) | (arc & dmask);
                     p = (int)(arc >> c.dbits);
@@ -2391,8 +2456,13 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.posmap = P.posmap + s * capC1;
     c.cls = P.cls + s * capC1;
     c.ninfo = P.ninfo + s * ml * capN;
-    c.arct = P.arct + s * ml * (size_t)c.fan * capN;
-    c.arcc = P.arcc + s * ml * (size_t)c.fan * capN;
+    const bool dynpool = P.tmode && P.lpool_nodes != 0;
+    c.lpool = dynpool ? P.lpool_nodes : 0;
+    c.apool = dynpool ? P.apool_arcs : 0;
+    c.lbase = dynpool ? P.lbase + s * (ml + 1) : nullptr;
+    c.abase = dynpool ? P.abase + s * (ml + 1) : nullptr;
+    c.arct = P.arct + s * (dynpool ? (size_t)P.apool_arcs : ml * (size_t)c.fan * capN);
+    c.arcc = P.arcc + s * (dynpool ? (size_t)P.apool_arcs : ml * (size_t)c.fan * capN);
     c.nlayer = P.nlayer + s * ml;
     c.lvar = P.lvar + s * ml;
     c.ldup = P.ldup + s * ml * 2;
@@ -2408,7 +2478,7 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.lstate = nullptr;
     c.lval = c.lrub = c.lvb = c.lth = c.cth = nullptr;
     if (P.tmode) {
-        const size_t lsz = ml * (size_t)P.lstride;
+        const size_t lsz = dynpool ? (size_t)P.lpool_nodes : ml * (size_t)P.lstride;
         c.ninfo = P.ninfo + s * lsz;
         c.lstate = P.lstate + s * lsz * (size_t)WS;
         c.lval = P.lval + s * lsz;

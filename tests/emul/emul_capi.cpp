@@ -36,6 +36,7 @@ struct Emul {
     std::vector<unsigned char> lds2;
     std::vector<int32_t> aux[2], lddelta;   // knapsack tables, per-layer relax deltas
     std::vector<unsigned char> mem3;         // kept layers (frontier cut-set / thresholds / cache)
+    std::vector<uint64_t> lbase, abase;      // DDO_EMUL_LPOOL: kept layers and arcs as pools (run_dd: dynl)
     std::vector<uint64_t> cache_tab;
     std::vector<uint64_t> dom_coord;
     std::vector<int32_t> dom_value;
@@ -278,6 +279,16 @@ void* emul_create_model(const void* model_handle, int max_width, int nthreads, u
 void emul_set_keep_layers(void* h, int on, uint64_t cache_entries) {
     Emul* e = (Emul*)h;
     e->P.tmode = on ? 1 : 0;
+    e->P.lpool_nodes = e->P.apool_arcs = 0;
+    if (on && std::getenv("DDO_EMUL_LPOOL")) {   // the same arrays, used as pools: layer X starts where layer X - 1 ended
+        const size_t ml = (size_t)e->P.max_layers;
+        e->P.lpool_nodes = ml * (size_t)e->P.lstride;
+        e->P.apool_arcs = ml * (size_t)(e->P.fan > 2 ? e->P.fan : 2) * (size_t)e->P.capN;
+        e->lbase.assign(ml + 1, 0);
+        e->abase.assign(ml + 1, 0);
+        e->P.lbase = e->lbase.data();
+        e->P.abase = e->abase.data();
+    }
     e->P.cache_cap = 0;
     e->P.cache_tab = nullptr;
     if (on && cache_entries) {

@@ -46,11 +46,16 @@ BIG = [("AFG", "rbg067a.tw", 3, 30, 8), ("Dumas", "n80w20.001.txt", 3, 30, 8), (
        ("Dumas", "n200w20.001.txt", 2, 12, 14), ("AFG", "rbg233.tw", 2, 10, 14)]
 
 
+@pytest.mark.parametrize("pools", [False, True], ids=["fixed-strides", "layer-pools"])
 @pytest.mark.parametrize("kind,frontier,cache", [("tsptw", False, False), ("tsptw+dominance", True, True)], ids=["lel", "frontier+cache+dominance"])
 @pytest.mark.parametrize("family,fname,width,max_compiles,words", BIG, ids=[b[1] for b in BIG])
-def test_tsptw_replay_beyond_64_nodes(oracle, family, fname, width, max_compiles, words, kind, frontier, cache):
+def test_tsptw_replay_beyond_64_nodes(oracle, monkeypatch, family, fname, width, max_compiles, words, kind, frontier, cache, pools):
     """instances of the reference's resources/tsptw with 68 .. 232 nodes: the node sets take K = 2 / 4 words (the reference's Set256,
-    state.rs:34-69), states 3K + 2 words, decisions 8 bits; same replay as above"""
+    state.rs:34-69), states 3K + 2 words, decisions 8 bits; same replay as above.  `layer-pools`: the kept layers and the arc arrays
+    are carved out of per-slot pools layer by layer (run_dd: dynl; what the device does for these instances since round 4) instead of
+    sitting at fixed strides."""
+    if pools:
+        monkeypatch.setenv("DDO_EMUL_LPOOL", "1")
     path = data_path("tsptw", family, fname)
     model = ddo_amd.Tsptw.read_instance(path)
     assert model.ws == words

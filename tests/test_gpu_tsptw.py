@@ -160,11 +160,13 @@ def test_sequential_solver_matches_the_oracle_beyond_64_nodes(have_gpu, oracle, 
            (ref["explored"], ref["nodes_expanded"], ref["arcs"], ref["layers"], ref["compiles"])
 
 
-# optima proved by the oracle (examples/tsptw/tests.rs:33-63's configuration) in a second; the device search must prove the same.
-# (Under TsptwWidth the engine sizes every DD slot for the widest layer a sub-problem may ask for, nb_vars^2 nodes, and keeps every
-# layer at candidate capacity: beyond ~130 nodes few slots fit and beyond ~190 none does -- those instances run under FixedWidth;
-# the sequential test above proves rbg132 (131 nodes, 4-word sets).)
-@pytest.mark.parametrize("family,fname,expected", [("AFG", "rbg067a.tw", 10331.0), ("Dumas", "n80w20.001.txt", 729.0)])
+# optima proved by the oracle (examples/tsptw/tests.rs:33-63's configuration) in a second or two; the device search must prove the same.
+# (Under TsptwWidth a DD may ask for nb_vars^2 nodes per layer.  Until round 3 every kept layer of a slot had that capacity -- 25 GB per
+# slot at 126 nodes, nothing at 190 and above; since round 4 the kept layers and arcs of these instances live in per-slot pools
+# (run_dd: lbase / abase), and Dumas n200w20.001 -- 201 nodes -- is proved under TsptwWidth.  AFG rbg233 still outgrows the ARC pool:
+# its arcs are indexed by candidate, 233 x 54 289 per layer.)
+@pytest.mark.parametrize("family,fname,expected", [("AFG", "rbg067a.tw", 10331.0), ("Dumas", "n80w20.001.txt", 729.0), ("AFG", "rbg125a.tw", 14214.0),
+                                                    ("Dumas", "n200w20.001.txt", 1139.0)])
 def test_proved_optima_beyond_64_nodes(have_gpu, oracle, family, fname, expected):
     model, s = _solve(oracle, fname, expected, TsptwWidth(1), 32, family=family)
     assert s.explored() >= 1

@@ -1,6 +1,6 @@
 """TSPTW instances beyond 64 nodes (node sets of 2 / 4 words, dd_tsptw.hpp) in the reference's example configuration
 (examples/tsptw/main.rs:70-128: frontier cut-set + SimpleCache + TsptwDominance, TsptwWidth(nb_vars, 1)): the device search next
-to the oracle's ParallelSolver on the host cores.  One JSON line per instance (profiles/r03/tsptw_beyond_64.jsonl).
+to the oracle's ParallelSolver on the host cores.  One JSON line per instance (profiles/r0N/tsptw_beyond_64.jsonl).
 
     python tools/tsptw_big.py [threads-on-the-device] [oracle-threads]
 """
@@ -14,15 +14,22 @@ import ddo_amd
 from ddo_amd import FRONTIER, ParallelSolver, TimeBudget, TsptwWidth
 from tests.oracle_binding import Oracle
 
-INSTANCES = ["AFG/rbg067a.tw", "Dumas/n80w20.001.txt", "AFG/rbg125a.tw", "AFG/rbg132.tw"]   # n200 / rbg233: no DD slot fits under TsptwWidth
+INSTANCES = ["AFG/rbg067a.tw", "Dumas/n80w20.001.txt", "AFG/rbg125a.tw", "AFG/rbg132.tw", "Dumas/n200w20.001.txt", "AFG/rbg233.tw"]   # the last two: only with the layer pools of round 4
+if "--small" in sys.argv:
+    INSTANCES = INSTANCES[:4]
+    sys.argv.remove("--small")
 conc = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 othreads = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 oracle = Oracle(os.path.join("oracle", "_build", "liboracle.so"))
 for name in INSTANCES:
     path = os.path.join("data", "tsptw", name)
     model = ddo_amd.Tsptw.read_instance(path)
-    s = ParallelSolver(model, TsptwWidth(1), TimeBudget(60.0), nb_threads=conc, fringe="nodup", cutset_type=FRONTIER,
-                       cache_entries=1 << 22, dominance_entries=1 << 22)
+    try:
+        s = ParallelSolver(model, TsptwWidth(1), TimeBudget(60.0), nb_threads=conc, fringe="nodup", cutset_type=FRONTIER,
+                           cache_entries=1 << 22, dominance_entries=1 << 22)
+    except ddo_amd.DdoError as err:
+        print(json.dumps({"instance": name, "nb_nodes": model.n, "error": str(err)}), flush=True)
+        continue
     t0 = time.perf_counter()
     c = s.maximize()
     dt = time.perf_counter() - t0
