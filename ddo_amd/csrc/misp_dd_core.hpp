@@ -192,6 +192,18 @@ struct DDShared {
 
 
 /// Everything one workgroup needs: model, slot-local workspace and LDS carve-up.
+/// two buffers picked by a select (see DDCtx::cstate)
+template <class T>
+struct Buf2 {
+    T* a;
+    T* b;
+    DDO_DEV T* operator[](int i) const { return i ? b : a; }
+    DDO_DEV void set(int i, T* p) {
+        if (i) b = p;
+        else a = p;
+    }
+};
+
 template <int WS>
 struct DDCtx {
     // model
@@ -219,10 +231,12 @@ struct DDCtx {
     unsigned long long* dkey_stats;
     int fan, dbits;      // children per node (2; TSPTW: nb_nodes) and the bits a decision index takes in arc / path words
     // slot workspace
-    uint64_t* cstate[2];
-    uint64_t* ckey[2];
-    uint32_t* cpop[2];
-    uint32_t* cflags[2];
+    // the two candidate buffers (current / next layer), picked by SELECTS, not by indexing an array member: an array indexed at run
+    // time pins the whole context in scratch memory -- every `c.field` a scratch load -- where it could live in scalar registers
+    Buf2<uint64_t> cstate;
+    Buf2<uint64_t> ckey;
+    Buf2<uint32_t> cpop;
+    Buf2<uint32_t> cflags;
     uint32_t* ctarget;
     uint32_t* keep;
     uint32_t* posmap;
@@ -252,8 +266,6 @@ struct DDCtx {
     int32_t *lval, *lrub, *lvb, *lth;
     int32_t* cth;        // [capC1] theta of the candidates the cache pruned in the layer being built
     int32_t* lntot;      // [max_layers] nodes per layer including the ones the cache pruned
-    uint64_t lpool, apool;       // per-slot pools of node / arc records (0: fixed strides), see run_dd
-    uint64_t *lbase, *abase;     // [max_layers + 1] where each kept layer / its entering arcs start in the pools
     uint64_t* cache_tab;
     uint64_t cache_cap;
     int cache_stride;
@@ -272,6 +284,10 @@ struct DDCtx {
 #if !defined(DDO_HOST_EMULATION)
     int tid_;
 #endif
+    // (appended LAST: this struct lives in scratch memory in the wide instantiations -- its [2]-arrays are indexed at run time --
+    // and moving the offsets of the fields the hot loops read cost the 72-word kernel 30 % on frb15-9-1)
+    uint64_t lpool, apool;       // per-slot pools of node / arc records (0: fixed strides), see run_dd
+    uint64_t *lbase, *abase;     // [max_layers + 1] where each kept layer / its entering arcs start in the pools
 };
 
 #if defined(DDO_HOST_EMULATION)
@@ -872,18 +888,20 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     // slot and four DDs in flight -- are carved out of two per-slot pools as the DD grows: layer X starts at lbase[X] and holds
     // lntot[X] nodes, the arcs entering it start at abase[X] and are indexed by (decision, parent position) of the nlayer[X - 1]
     // parents.  A DD whose layers outgrow the pools ends with a capacity error (loud), never with a wrong result.
-    const bool dynl = c.lpool != 0;
-    auto LB = [&](int X) -> size_t { return dynl ? (size_t)c.lbase[X] : (size_t)X * (size_t)LS; };
-    auto LSX = [&](int X, int k, size_t pos) -> size_t {   // index of word k of node pos of kept layer X in c.lstate
-        return dynl ? (size_t)c.lbase[X] * WS + (size_t)k * (size_t)c.lntot[X] + pos : ((size_t)X * WS + k) * (size_t)LS + pos;
-    };
-    auto AB = [&](int X) -> size_t { return dynl ? (size_t)c.abase[X] : (size_t)X * (size_t)c.fan * (size_t)capN; };
-    auto AI = [&](uint32_t cd, int np) -> size_t {   // index of candidate cd = decision * capN + parent position among np parents
-        return dynl ? (size_t)(cd / (uint32_t)capN) * (size_t)np + (size_t)(cd % (uint32_t)capN) : (size_t)cd;
-    };
+    constexpr bool POOLS = tw_k_of_ws(WS) != 0;   // only the D-ary model uses the pools: the other instantiations do not even carry the offsets
+    const bool dynl = POOLS && c.lpool != 0;
+    // (macros, not lambdas: capturing lambdas changed the register allocation of the 72-word kernel enough to cost it 30 % on frb15-9-1)
+#define LB(X) (dynl ? (size_t)c.lbase[(X)] : (size_t)(X) * (size_t)LS)
+#define LSX(X, k, pos) (dynl ? (size_t)c.lbase[(X)] * WS + (size_t)(k) * (size_t)c.lntot[(X)] + (pos) : ((size_t)(X) * WS + (k)) * (size_t)LS + (pos))   /* word k of node pos of kept layer X in c.lstate */
+#define AB(X) (dynl ? (size_t)c.abase[(X)] : (size_t)(X) * (size_t)c.fan * (size_t)capN)
+#define AI(cd, np) (dynl ? (size_t)((cd) / (uint32_t)capN) * (size_t)(np) + (size_t)((cd) % (uint32_t)capN) : (size_t)(cd))   /* candidate cd = decision * capN + parent position, among np parents */
     uint64_t node_off = 0, arc_off = 0;   // pool heads of this DD (every thread counts along: workgroup-uniform)
-    size_t lb_cur = 0;                    // start of the layer being built
-    size_t ab_cur = 0;                    // start of the arcs ENTERING the layer being built
+    size_t lb_cur_ = 0, ab_cur_ = 0, ab_next_ = 0;   // POOLS: start of the layer being built, of the arcs entering it, of the arcs entering the next one
+    // (without POOLS these are plain expressions of the layer number, as they were: the 72-word kernel is sensitive to every
+    // loop-carried scalar -- carrying them cost it 27 % on frb15-9-1)
+#define lb_cur (POOLS ? lb_cur_ : (size_t)L * (size_t)LS)
+#define ab_cur (POOLS ? ab_cur_ : (size_t)L * (size_t)c.fan * (size_t)capN)
+#define ab_next (POOLS ? ab_next_ : (size_t)(L + 1) * (size_t)c.fan * (size_t)capN)
     const bool frontier = c.tmode && (in.flags & IN_FRONTIER) != 0;   // CUTSET_TYPE == FRONTIER
     const bool use_cache = c.tmode && (in.flags & IN_CACHE) != 0 && c.cache_cap != 0;
     const bool use_dom = c.tmode && (in.flags & IN_DOMINANCE) != 0 && c.dom_cap != 0 && dd_kind_is<WS>(c.kind, MODEL_KNAPSACK);
@@ -1387,10 +1405,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 failed = true;
                 break;
             }
-            lb_cur = (size_t)node_off;
+            lb_cur_ = (size_t)node_off;
             node_off += (uint64_t)ntot;
         } else {
-            lb_cur = (size_t)L * (size_t)LS;
+            lb_cur_ = (size_t)L * (size_t)LS;
         }
         PAR_BEGIN
         if (tid == 0) {
@@ -1457,7 +1475,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         DD1_TICK(5)   // layer bookkeeping (kept layers, arcs)
         // ------------------------------------------------------------ expand (clean.rs:360-370, 728-776)
         const int nxt = cur ^ 1;
-        size_t ab_next = (size_t)(L + 1) * (size_t)c.fan * (size_t)capN;
+        ab_next_ = (size_t)(L + 1) * (size_t)c.fan * (size_t)capN;
         if (dynl) {   // room for the arcs entering layer L + 1: fan per expanded node of this layer
             if (arc_off + (uint64_t)c.fan * (uint64_t)n > c.apool) {
                 PAR_BEGIN
@@ -1466,7 +1484,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 failed = true;
                 break;
             }
-            ab_next = (size_t)arc_off;
+            ab_next_ = (size_t)arc_off;
             arc_off += (uint64_t)c.fan * (uint64_t)n;
         }
         hsize = table_size_for(c.fan * (n + 1) + 2, c.table_cap);   // at most fan children per node of this layer
@@ -1778,7 +1796,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
 
         cur = nxt;
         nprev = n;
-        ab_cur = ab_next;
+        ab_cur_ = ab_next_;
         L += 1;
     }
 
@@ -1829,10 +1847,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         bool pool_full = false;
         if (dynl) {
             pool_full = node_off + (uint64_t)nT > c.lpool;
-            lb_cur = (size_t)node_off;
+            lb_cur_ = (size_t)node_off;
             node_off += (uint64_t)nT;
         } else {
-            lb_cur = (size_t)L * (size_t)LS;
+            lb_cur_ = (size_t)L * (size_t)LS;
         }
         if (pool_full) {
             PAR_BEGIN
@@ -1970,9 +1988,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int j = tid; j < c.fan * nP; j += NT) {
                     const int d = j / nP;
                     const int pp = j - d * nP;
-                    const uint32_t t = at[dynl ? (size_t)j : (size_t)d * capN + pp];
+                    const uint32_t t = at[dynl ? j : d * capN + pp];
                     if (t == NONE32) continue;
-                    const int32_t cost = ac[dynl ? (size_t)j : (size_t)d * capN + pp];
+                    const int32_t cost = ac[dynl ? j : d * capN + pp];
                     const int32_t v = LD_I32(&c.lvb[LB(Lc) + t]);
                     if (v != VB_UNMARKED) GLB_MAX_I32(&c.lvb[LB((Lc - 1)) + pp], v + cost);
                     if ((int)t == dfrom) {   // the arcs of the node a recycled merge re-added also go to the merged node
@@ -1997,7 +2015,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     for (int j = tid; j < c.fan * nP; j += NT) {
                         const int d = j / nP;
                         const int pp = j - d * nP;
-                        const uint32_t t = at[dynl ? (size_t)j : (size_t)d * capN + pp];
+                        const uint32_t t = at[dynl ? j : d * capN + pp];
                         if (t == NONE32) continue;
                         const bool child_inexact = (c.ninfo[LB(Lc) + t] & (NI_INEXACT | NI_RELAXED)) != 0 || (int)t == dfrom;
                         if (!child_inexact) continue;
@@ -2027,9 +2045,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             for (int j = tid; j < c.fan * nP; j += NT) {
                 const int d = j / nP;
                 const int pp = j - d * nP;
-                const uint32_t t = at[dynl ? (size_t)j : (size_t)d * capN + pp];
+                const uint32_t t = at[dynl ? j : d * capN + pp];
                 if (t == NONE32) continue;
-                const int32_t cost = ac[dynl ? (size_t)j : (size_t)d * capN + pp];
+                const int32_t cost = ac[dynl ? j : d * capN + pp];
                 int32_t v = vbA[t];
                 if (v != VB_UNMARKED) LDS_MAX_I32(&vbB[pp], v + cost);
                 if ((int)t == dfrom) {  // arcs of the re-added node were also redirected (clean.rs:851-866)
@@ -2203,9 +2221,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 for (int j = tid; j < c.fan * nP; j += NT) {
                     const int d = j / nP;
                     const int pp = j - d * nP;
-                    const uint32_t t = at[dynl ? (size_t)j : (size_t)d * capN + pp];
+                    const uint32_t t = at[dynl ? j : d * capN + pp];
                     if (t == NONE32) continue;
-                    const int32_t cost = ac[dynl ? (size_t)j : (size_t)d * capN + pp];
+                    const int32_t cost = ac[dynl ? j : d * capN + pp];
                     const int32_t th = LD_I32(&c.lth[LB(Lc) + t]);
                     if (th != TH_NONE) GLB_MIN_I32(&c.lth[LB((Lc - 1)) + pp], th_sub(th, cost));
                     if ((int)t == dfrom) {
@@ -2345,6 +2363,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     PAR_END
 }
 
+#undef lb_cur
+#undef ab_cur
+#undef ab_next
+#undef LB
+#undef LSX
+#undef AB
+#undef AI
+
 /// Restricted, then -- when that was not exact -- relaxed: the device half of
 /// ParallelSolver::process_one_node (parallel.rs:391-437).
 template <int WS>
@@ -2444,10 +2470,10 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.max_layers = P.max_layers;
     const size_t capC1 = (size_t)P.capC1, capN = (size_t)P.capN, ml = (size_t)P.max_layers, s = (size_t)slot;
     for (int b = 0; b < 2; ++b) {
-        c.cstate[b] = P.cstate + (s * 2 + b) * (size_t)WS * capC1;
-        c.ckey[b] = P.ckey + (s * 2 + b) * capC1;
-        c.cpop[b] = P.cpop + (s * 2 + b) * capC1;
-        c.cflags[b] = P.cflags + (s * 2 + b) * capC1;
+        c.cstate.set(b, P.cstate + (s * 2 + b) * (size_t)WS * capC1);
+        c.ckey.set(b, P.ckey + (s * 2 + b) * capC1);
+        c.cpop.set(b, P.cpop + (s * 2 + b) * capC1);
+        c.cflags.set(b, P.cflags + (s * 2 + b) * capC1);
     }
     c.fan = P.fan > 2 ? P.fan : 2;
     c.dbits = P.fan > 2 ? P.dbits : 1;
