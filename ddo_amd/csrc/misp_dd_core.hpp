@@ -192,8 +192,8 @@ struct DDShared {
 
 
 /// Everything one workgroup needs: model, slot-local workspace and LDS carve-up.
-/// two buffers picked by a select (see DDCtx::cstate)
-template <class T>
+/// two buffers: picked by a SELECT (SEL: the context can then live in registers, see DDCtx::cstate) or kept as an array member
+template <class T, bool SEL>
 struct Buf2 {
     T* a;
     T* b;
@@ -202,6 +202,12 @@ struct Buf2 {
         if (i) b = p;
         else a = p;
     }
+};
+template <class T>
+struct Buf2<T, false> {
+    T* v[2];
+    DDO_DEV T* operator[](int i) const { return v[i]; }
+    DDO_DEV void set(int i, T* p) { v[i] = p; }
 };
 
 template <int WS>
@@ -231,12 +237,15 @@ struct DDCtx {
     unsigned long long* dkey_stats;
     int fan, dbits;      // children per node (2; TSPTW: nb_nodes) and the bits a decision index takes in arc / path words
     // slot workspace
-    // the two candidate buffers (current / next layer), picked by SELECTS, not by indexing an array member: an array indexed at run
-    // time pins the whole context in scratch memory -- every `c.field` a scratch load -- where it could live in scalar registers
-    Buf2<uint64_t> cstate;
-    Buf2<uint64_t> ckey;
-    Buf2<uint32_t> cpop;
-    Buf2<uint32_t> cflags;
+    // the two candidate buffers (current / next layer).  In the wide instantiations (signed-vector models, WS > 16) they are picked
+    // by SELECTS, not by indexing an array member: an array indexed at run time pins the whole context in scratch memory -- every
+    // `c.field` a scratch load -- where it could live in scalar registers (72-word kernel: 2 224 -> 1 552 B/lane of scratch, C3 kernels
+    // -13 %).  The narrow instantiations keep the array: with the context in registers the 16-word kernel faults on the GPU for TSPTW
+    // states of four-word node sets (rbg132, n200w20.001; not reproduced by the host emulation, not understood yet).
+    Buf2<uint64_t, (WS > 16)> cstate;
+    Buf2<uint64_t, (WS > 16)> ckey;
+    Buf2<uint32_t, (WS > 16)> cpop;
+    Buf2<uint32_t, (WS > 16)> cflags;
     uint32_t* ctarget;
     uint32_t* keep;
     uint32_t* posmap;
