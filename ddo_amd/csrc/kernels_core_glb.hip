@@ -9,7 +9,7 @@ namespace ddo_hip {
 template <int WS, bool TLDS>
 __global__ void __launch_bounds__(1024) misp_compile_kernel(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    DDCtx<WS> c = {};   // (value-initialised: a field dd_bind does not set for this mode is 0, not undefined)
+    DDCtx<WS> c;
     dd_bind<WS, TLDS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
     c.tid_ = (int)threadIdx.x;
     for (;;) {

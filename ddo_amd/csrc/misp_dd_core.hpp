@@ -275,6 +275,10 @@ struct DDCtx {
     int32_t *lval, *lrub, *lvb, *lth;
     int32_t* cth;        // [capC1] theta of the candidates the cache pruned in the layer being built
     int32_t* lntot;      // [max_layers] nodes per layer including the ones the cache pruned
+    // (where these sit matters: in the narrow instantiations this struct lives in scratch memory, and the offsets of the fields behind
+    // them decide how the hot loops' context reads fall -- appended last they cost MCP n = 30 58 % and config C5 28 % of kernel time)
+    uint64_t lpool, apool;       // per-slot pools of node / arc records (0: fixed strides), see run_dd
+    uint64_t *lbase, *abase;     // [max_layers + 1] where each kept layer / its entering arcs start in the pools
     uint64_t* cache_tab;
     uint64_t cache_cap;
     int cache_stride;
@@ -293,10 +297,6 @@ struct DDCtx {
 #if !defined(DDO_HOST_EMULATION)
     int tid_;
 #endif
-    // (appended LAST: this struct lives in scratch memory in the wide instantiations -- its [2]-arrays are indexed at run time --
-    // and moving the offsets of the fields the hot loops read cost the 72-word kernel 30 % on frb15-9-1)
-    uint64_t lpool, apool;       // per-slot pools of node / arc records (0: fixed strides), see run_dd
-    uint64_t *lbase, *abase;     // [max_layers + 1] where each kept layer / its entering arcs start in the pools
 };
 
 #if defined(DDO_HOST_EMULATION)
