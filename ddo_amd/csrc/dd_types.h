@@ -159,6 +159,8 @@ struct EngineParams {
     int32_t nbatch;
     int32_t phase_clocks;      // 1: engine 2 accounts shader-clock ticks per phase (one extra barrier per phase)
     int32_t* work_counter;
+    const uint32_t* order;     // in-place engine: the k-th draw of the work counter compiles inputs[order[k]] (longest first, ddo_hip_engine.hip:
+                               // lpt_order_kernel); nullptr = input order
     unsigned long long* arena_head;
     uint8_t* arena;
     uint64_t arena_cap;

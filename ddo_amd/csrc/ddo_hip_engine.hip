@@ -27,6 +27,39 @@
 
 namespace ddo_hip {
 
+// Launch order of a batch on the in-place engine: sub-problems by decreasing number of vertices left in their residual state (one
+// workgroup; a counting sort over the popcounts, ties in no particular order).  order[k] = index of the k-th DD to be drawn.
+__global__ void __launch_bounds__(1024) lpt_order_kernel(const DDInput* __restrict__ in, int n, const uint8_t* __restrict__ pool, int ws, uint32_t* __restrict__ order) {
+    constexpr int BINS = 64 * MAX_WS + 1;
+    __shared__ uint32_t bin[BINS];
+    auto vertices_left = [&](int i) -> int {
+        const DDInput& d = in[i];
+        int pc = 0;
+        if (d.src_off != NO_POOL_SRC) {   // a row of a cut-set block in the device pool (word-major rows)
+            const PoolBlockHeader* h = (const PoolBlockHeader*)(pool + d.src_off);
+            const uint64_t* rows = (const uint64_t*)(pool + d.src_off + h->off_states);
+            for (int k = 0; k < (int)h->ws && k < ws; ++k) pc += __popcll(rows[(size_t)k * h->rows + d.src_row]);
+        } else {
+            for (int k = 0; k < ws; ++k) pc += __popcll(d.state[k]);
+        }
+        return pc < BINS ? pc : BINS - 1;
+    };
+    for (int b = threadIdx.x; b < BINS; b += blockDim.x) bin[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&bin[vertices_left(i)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {   // start of every bin, the fullest states first
+        uint32_t at = 0;
+        for (int b = BINS - 1; b >= 0; --b) {
+            const uint32_t cnt = bin[b];
+            bin[b] = at;
+            at += cnt;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&bin[vertices_left(i)], 1u)] = (uint32_t)i;
+}
+
 static int pick_ws(int ws) {
     const int opts[] = {1, 2, 4, 7, 8, 16, 32, 72};
     for (int o : opts)
@@ -947,7 +980,7 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         io.h_results = (DDResult*)hp;
         io.h_head = (unsigned long long*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult));
         io.h_inputs = (DDInput*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult) + 64);
-        HIP_TRY(hipMalloc(&io.d_inputs, (size_t)cap * sizeof(DDInput)));
+        HIP_TRY(hipMalloc(&io.d_inputs, (size_t)cap * (sizeof(DDInput) + sizeof(uint32_t))));   // + the launch order (lpt_order_kernel)
         HIP_TRY(hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)));
         io.in_cap = cap;
     }
@@ -975,6 +1008,18 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     P.results = (DDResult*)io.d_results;
     P.nbatch = count;
     P.work_counter = (int32_t*)io.d_cnt;
+    P.order = nullptr;
+    static const bool lpt = [] { const char* e = std::getenv("DDO_HIP_LPT"); return !(e && std::atoi(e) == 0); }();
+    if (lpt && engine_kind_ == 2 && count > nslots_) {
+        // More DDs than slots: the workgroups draw them from a counter, and the launch lasts until the LAST one is done.  In input
+        // order a slot that draws a large DD late sets the length of the launch (brock400_1, 1024 root sub-problems on 512 slots:
+        // 1.58 x the mean load of a slot); drawn largest first the launch ends within one DD of the mean (1.20 x).  The number of
+        // vertices left in the residual state predicts the nodes of its DDs (correlation 0.995, tools/tail_predict.py).
+        uint32_t* order = (uint32_t*)((uint8_t*)io.d_inputs + (size_t)io.in_cap * sizeof(DDInput));
+        hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, (const DDInput*)io.d_inputs, count, (const uint8_t*)P_.pool, model_->wsT, order);
+        HIP_TRY(hipGetLastError());
+        P.order = order;
+    }
     P.arena_head = (unsigned long long*)(io.d_cnt + 8);
     P.arena = io.h_arena;
     if (cache && P_.tmode && cache->device == device_) {
@@ -1055,7 +1100,7 @@ DDInput* Engine::stage_inputs(int count) {
         io.h_results = (DDResult*)hp;
         io.h_head = (unsigned long long*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult));
         io.h_inputs = (DDInput*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult) + 64);
-        if (hipMalloc(&io.d_inputs, (size_t)cap * sizeof(DDInput)) != hipSuccess || hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)) != hipSuccess) return nullptr;
+        if (hipMalloc(&io.d_inputs, (size_t)cap * (sizeof(DDInput) + sizeof(uint32_t))) != hipSuccess || hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)) != hipSuccess) return nullptr;
         io.in_cap = cap;
     }
     return io.h_inputs;

@@ -17,9 +17,10 @@ __global__ void __launch_bounds__(MAXT) misp_compile_kernel2(EngineParams P) {
     for (;;) {
         if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
         __syncthreads();
-        const int w = c.sh->work;
+        const int drawn = c.sh->work;
         __syncthreads();
-        if (w >= P.nbatch) break;
+        if (drawn >= P.nbatch) break;
+        const int w = P.order ? (int)P.order[drawn] : drawn;   // (longest first: Engine::launch)
         run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }

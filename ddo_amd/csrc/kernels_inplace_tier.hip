@@ -22,9 +22,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDO_TI
     for (;;) {
         if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
         __syncthreads();
-        const int w = c.sh->work;
+        const int drawn = c.sh->work;
         __syncthreads();
-        if (w >= P.nbatch) break;
+        if (drawn >= P.nbatch) break;
+        const int w = P.order ? (int)P.order[drawn] : drawn;   // (longest first: Engine::launch)
         run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }
@@ -41,9 +42,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     for (;;) {
         if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
         __syncthreads();
-        const int w = c.sh->work;
+        const int drawn = c.sh->work;
         __syncthreads();
-        if (w >= P.nbatch) break;
+        if (drawn >= P.nbatch) break;
+        const int w = P.order ? (int)P.order[drawn] : drawn;   // (longest first: Engine::launch)
         run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
     }
 }
