@@ -27,37 +27,63 @@
 
 namespace ddo_hip {
 
-// Launch order of a batch on the in-place engine: sub-problems by decreasing number of vertices left in their residual state (one
-// workgroup; a counting sort over the popcounts, ties in no particular order).  order[k] = index of the k-th DD to be drawn.
-__global__ void __launch_bounds__(1024) lpt_order_kernel(const DDInput* __restrict__ in, int n, const uint8_t* __restrict__ pool, int ws, uint32_t* __restrict__ order) {
-    constexpr int BINS = 64 * MAX_WS + 1;
-    __shared__ uint32_t bin[BINS];
-    auto vertices_left = [&](int i) -> int {
-        const DDInput& d = in[i];
-        int pc = 0;
-        if (d.src_off != NO_POOL_SRC) {   // a row of a cut-set block in the device pool (word-major rows)
-            const PoolBlockHeader* h = (const PoolBlockHeader*)(pool + d.src_off);
-            const uint64_t* rows = (const uint64_t*)(pool + d.src_off + h->off_states);
-            for (int k = 0; k < (int)h->ws && k < ws; ++k) pc += __popcll(rows[(size_t)k * h->rows + d.src_row]);
-        } else {
-            for (int k = 0; k < ws; ++k) pc += __popcll(d.state[k]);
-        }
-        return pc < BINS ? pc : BINS - 1;
-    };
-    for (int b = threadIdx.x; b < BINS; b += blockDim.x) bin[b] = 0;
+// host seconds inside launch(), by section (DDO_HIP_TIMES prints them when an engine goes away): checks + staging, inputs to the device,
+// launch order, pool growth, kernel launch, result copies
+static double g_launch_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static unsigned long long g_launch_n = 0;
+
+
+// Launch order of a batch on the in-place engine: sub-problems by decreasing number of vertices left in their residual state -- a
+// counting sort over the popcounts, ties in no particular order.  order[k] = index of the k-th DD to be drawn.
+//   lpt_count_kernel   (n threads)       key[i] = vertices left in sub-problem i, bins[key[i]] += 1   (bins zeroed by the caller)
+//   lpt_order_kernel   (one workgroup)   start of every bin (the fullest states first), then order[start[key[i]]++] = i
+constexpr int LPT_BINS = 64 * MAX_WS + 1;
+struct LptBuffers {   // behind the inputs of an I/O set (Engine::launch)
+    uint32_t* order;
+    uint32_t* key;
+    uint32_t* bins;
+    static size_t bytes(int cap) { return (size_t)cap * 8 + (size_t)LPT_BINS * 4; }
+    LptBuffers(void* d_inputs, int cap) {
+        order = (uint32_t*)((uint8_t*)d_inputs + (size_t)cap * sizeof(DDInput));
+        key = order + cap;
+        bins = key + cap;
+    }
+};
+
+__global__ void __launch_bounds__(256) lpt_count_kernel(const DDInput* __restrict__ in, int n, const uint8_t* __restrict__ pool, int ws, uint32_t* __restrict__ key,
+                                                        uint32_t* __restrict__ bins) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DDInput& d = in[i];
+    int pc = 0;
+    if (d.src_off != NO_POOL_SRC) {   // a row of a cut-set block in the device pool (word-major rows)
+        const PoolBlockHeader* h = (const PoolBlockHeader*)(pool + d.src_off);
+        const uint64_t* rows = (const uint64_t*)(pool + d.src_off + h->off_states);
+        const int hw = (int)h->ws < ws ? (int)h->ws : ws;
+        const size_t stride = h->rows;
+        for (int k = 0; k < hw; ++k) pc += __popcll(rows[(size_t)k * stride + d.src_row]);
+    } else {
+        for (int k = 0; k < ws; ++k) pc += __popcll(d.state[k]);
+    }
+    pc = pc < LPT_BINS ? pc : LPT_BINS - 1;
+    key[i] = (uint32_t)pc;
+    atomicAdd(&bins[pc], 1u);
+}
+
+__global__ void __launch_bounds__(1024) lpt_order_kernel(int n, const uint32_t* __restrict__ key, const uint32_t* __restrict__ bins, uint32_t* __restrict__ order) {
+    __shared__ uint32_t start[LPT_BINS];
+    for (int b = threadIdx.x; b < LPT_BINS; b += blockDim.x) start[b] = bins[b];
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&bin[vertices_left(i)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {   // start of every bin, the fullest states first
+    if (threadIdx.x == 0) {
         uint32_t at = 0;
-        for (int b = BINS - 1; b >= 0; --b) {
-            const uint32_t cnt = bin[b];
-            bin[b] = at;
+        for (int b = LPT_BINS - 1; b >= 0; --b) {
+            const uint32_t cnt = start[b];
+            start[b] = at;
             at += cnt;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&bin[vertices_left(i)], 1u)] = (uint32_t)i;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&start[key[i]], 1u)] = (uint32_t)i;
 }
 
 static int pick_ws(int ws) {
@@ -616,6 +642,11 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
 }
 
 Engine::~Engine() {
+    if (g_launch_n && std::getenv("DDO_HIP_TIMES")) {
+        std::fprintf(stderr, "[ddo times] launch() host s over %llu launches: checks %.3f, inputs %.3f, launch order %.3f, parameters + rewind %.3f, first event %.3f, pool growth %.3f, kernel %.3f, result copies %.3f\n",
+                     g_launch_n, g_launch_s[0], g_launch_s[1], g_launch_s[2], g_launch_s[6], g_launch_s[7], g_launch_s[3], g_launch_s[4], g_launch_s[5]);
+        g_launch_n = 0;
+    }
     if (device_ >= 0) (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize((hipStream_t)stream_);
     for (void* p : allocs_) (void)hipFree(p);
@@ -950,6 +981,12 @@ int Engine::run_solo_growing(const DDInput& input, std::vector<HostResult>& resu
 
 int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, const DominanceTable* dom) {
     std::lock_guard<std::mutex> g(mtx_);
+    auto lt0 = std::chrono::steady_clock::now();
+    auto tick = [&](int k) {
+        const auto now = std::chrono::steady_clock::now();
+        g_launch_s[k] += std::chrono::duration<double>(now - lt0).count();
+        lt0 = now;
+    };
     if (pending_ > 0) {
         set_error("Engine::launch: a batch is already in flight");
         return DDO_ERR_INVALID;
@@ -980,7 +1017,7 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         io.h_results = (DDResult*)hp;
         io.h_head = (unsigned long long*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult));
         io.h_inputs = (DDInput*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult) + 64);
-        HIP_TRY(hipMalloc(&io.d_inputs, (size_t)cap * (sizeof(DDInput) + sizeof(uint32_t))));   // + the launch order (lpt_order_kernel)
+        HIP_TRY(hipMalloc(&io.d_inputs, (size_t)cap * sizeof(DDInput) + LptBuffers::bytes(cap)));   // + the launch order (lpt_order_kernel)
         HIP_TRY(hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)));
         io.in_cap = cap;
     }
@@ -1000,9 +1037,11 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         io.h_arena = (uint8_t*)hp;
         io.h_arena_cap = arena_cap_;
     }
+    tick(0);
     if (!staged) std::memcpy(io.h_inputs, inputs, (size_t)count * sizeof(DDInput));
     HIP_TRY(hipMemcpyAsync(io.d_inputs, io.h_inputs, (size_t)count * sizeof(DDInput), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(io.d_cnt, 0, 16, st));  // work counter + arena head of this buffer set
+    tick(1);
     EngineParams P = P_;
     P.inputs = (const DDInput*)io.d_inputs;
     P.results = (DDResult*)io.d_results;
@@ -1012,14 +1051,18 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     static const bool lpt = [] { const char* e = std::getenv("DDO_HIP_LPT"); return !(e && std::atoi(e) == 0); }();
     if (lpt && engine_kind_ == 2 && count > nslots_) {
         // More DDs than slots: the workgroups draw them from a counter, and the launch lasts until the LAST one is done.  In input
-        // order a slot that draws a large DD late sets the length of the launch (brock400_1, 1024 root sub-problems on 512 slots:
-        // 1.58 x the mean load of a slot); drawn largest first the launch ends within one DD of the mean (1.20 x).  The number of
-        // vertices left in the residual state predicts the nodes of its DDs (correlation 0.995, tools/tail_predict.py).
-        uint32_t* order = (uint32_t*)((uint8_t*)io.d_inputs + (size_t)io.in_cap * sizeof(DDInput));
-        hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, (const DDInput*)io.d_inputs, count, (const uint8_t*)P_.pool, model_->wsT, order);
+        // order a slot that draws a large DD late sets the length of the launch; drawn largest first the launch ends within one DD
+        // of the mean load of a slot (brock400_1, 1024 root sub-problems on 512 slots, in nodes: 1.58 x the mean load -> 1.20 x;
+        // in time -8.5 %, the last DDs of a launch run faster than the first).  The number of vertices left in the residual state
+        // predicts the nodes of its DDs (correlation 0.995, tools/tail_predict.py).
+        const LptBuffers lb(io.d_inputs, io.in_cap);
+        HIP_TRY(hipMemsetAsync(lb.bins, 0, (size_t)LPT_BINS * 4, st));
+        hipLaunchKernelGGL(lpt_count_kernel, dim3((count + 255) / 256), dim3(256), 0, st, P.inputs, count, (const uint8_t*)P_.pool, model_->wsT, lb.key, lb.bins);
+        hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, count, (const uint32_t*)lb.key, (const uint32_t*)lb.bins, lb.order);
         HIP_TRY(hipGetLastError());
-        P.order = order;
+        P.order = lb.order;
     }
+    tick(2);
     P.arena_head = (unsigned long long*)(io.d_cnt + 8);
     P.arena = io.h_arena;
     if (cache && P_.tmode && cache->device == device_) {
@@ -1053,7 +1096,9 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         HIP_TRY(hipMemcpyAsync((void*)P_.pool_head, &rewind_val_, 8, hipMemcpyHostToDevice, st));
         pool_owner()->pool_head_bound_ = rewind_val_;
     }
+    tick(6);
     HIP_TRY(hipEventRecord((hipEvent_t)ev0_, st));
+    tick(7);
     if (Engine* po = pool_owner(); po->vm_base_) {
         // the kernel allocates blocks with one atomic on the pool head: back everything the launches that are not
         // fetched yet (the previous one may still run) and this one can possibly take.  The pool belongs to the owner
@@ -1066,15 +1111,19 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         P_.pool_cap = po->vm_mapped_;
         P.pool_cap = po->vm_mapped_;
     }
+    tick(3);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads_), lds_bytes_, st, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)ev1_, st));
+    tick(4);
     if (P_.phase_clocks)
         HIP_TRY(hipMemcpyAsync(io.h_results, io.d_results, (size_t)count * 2 * sizeof(DDResult), hipMemcpyDeviceToHost, st));
     else   // every record without its clocks
         HIP_TRY(hipMemcpy2DAsync(io.h_results, sizeof(DDResult), io.d_results, sizeof(DDResult), offsetof(DDResult, phase_clk), (size_t)count * 2,
                                  hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(io.h_head, io.d_cnt + 8, 8, hipMemcpyDeviceToHost, st));
+    tick(5);
+    g_launch_n += 1;
     io.count = count;
     pending_ = count;
     pending_set_ = next_set_;
@@ -1100,7 +1149,7 @@ DDInput* Engine::stage_inputs(int count) {
         io.h_results = (DDResult*)hp;
         io.h_head = (unsigned long long*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult));
         io.h_inputs = (DDInput*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult) + 64);
-        if (hipMalloc(&io.d_inputs, (size_t)cap * (sizeof(DDInput) + sizeof(uint32_t))) != hipSuccess || hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)) != hipSuccess) return nullptr;
+        if (hipMalloc(&io.d_inputs, (size_t)cap * sizeof(DDInput) + LptBuffers::bytes(cap)) != hipSuccess || hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)) != hipSuccess) return nullptr;
         io.in_cap = cap;
     }
     return io.h_inputs;

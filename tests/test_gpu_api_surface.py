@@ -215,3 +215,38 @@ def test_compile_batch_survives_a_full_output_arena(brock, oracle, monkeypatch):
     for j in range(B):
         d = diff(r, canon_from_mdd(mdds[j], comps[j], brock.ws))
         assert d is None, f"compile #{j}: {d}"
+
+
+_LPT_SCRIPT = r"""
+import json, sys
+import ddo_amd
+from ddo_amd import FixedWidth, ParallelSolver
+m = ddo_amd.Misp.read_instance(sys.argv[1])
+s = ParallelSolver(m, FixedWidth(int(sys.argv[2])), nb_threads=int(sys.argv[3]), fringe="lazy")
+c = s.maximize()
+k = s.counters()
+print(json.dumps({"best": c.best_value, "exact": c.is_exact, "explored": s.explored(), "nodes": k["nodes_expanded"], "compiles": k["compiles"],
+                  "launches": s.device_time()[1], "sol": sorted((d.variable, d.value) for d in s.best_solution())}))
+"""
+
+
+@pytest.mark.parametrize("inst,width,threads", [("brock200_4", 200, 8192), ("johnson8-4-4", 50, 4096)])
+def test_the_launch_order_changes_nothing_but_the_order(inst, width, threads, tmp_path):
+    """Engine::launch draws the DDs of a launch longest first when there are more of them than node slots (lpt_count_kernel /
+    lpt_order_kernel, `P.order`); DDO_HIP_LPT=0 keeps the input order.  Results are matched to inputs by position either way, so
+    the whole search -- optimum, explored sub-problems, nodes, compiles, launches -- must come out identical."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "lpt_run.py"
+    script.write_text(_LPT_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for lpt in ("0", "1"):
+        env = dict(os.environ, DDO_HIP_LPT=lpt, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, str(script), data_path("misp", inst + ".clq"), str(width), str(threads)], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[lpt] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["0"]["exact"] and out["0"] == out["1"], (out["0"], out["1"])
