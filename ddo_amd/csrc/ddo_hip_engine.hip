@@ -35,7 +35,8 @@ static unsigned long long g_launch_n = 0;
 
 // Launch order of a batch on the in-place engine: sub-problems by decreasing number of vertices left in their residual state -- a
 // counting sort over the popcounts, ties in no particular order.  order[k] = index of the k-th DD to be drawn.
-//   lpt_count_kernel   (n threads)       key[i] = vertices left in sub-problem i, bins[key[i]] += 1   (bins zeroed by the caller)
+//   lpt_count_kernel   (n threads)       key[i] = vertices left in sub-problem i, bins[key[i]] += 1   (bins zeroed by the caller;
+//                                         a histogram per workgroup in LDS first)
 //   lpt_order_kernel   (one workgroup)   start of every bin (the fullest states first), then order[start[key[i]]++] = i
 constexpr int LPT_BINS = 64 * MAX_WS + 1;
 struct LptBuffers {   // behind the inputs of an I/O set (Engine::launch)
@@ -50,33 +51,41 @@ struct LptBuffers {   // behind the inputs of an I/O set (Engine::launch)
     }
 };
 
-__global__ void __launch_bounds__(256) lpt_count_kernel(const DDInput* __restrict__ in, int n, const uint8_t* __restrict__ pool, int ws, uint32_t* __restrict__ key,
+__global__ void __launch_bounds__(256) lpt_count_kernel(const DDInput* __restrict__ in, int n, const uint8_t* __restrict__ pool, int ws, int nbins, uint32_t* __restrict__ key,
                                                         uint32_t* __restrict__ bins) {
+    __shared__ uint32_t mine[LPT_BINS];   // this workgroup's share of the histogram (most states of a launch fall into a few dozen bins:
+                                          // straight into HBM that is thousands of atomics on the same few addresses)
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) mine[b] = 0;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const DDInput& d = in[i];
-    int pc = 0;
-    if (d.src_off != NO_POOL_SRC) {   // a row of a cut-set block in the device pool (word-major rows)
-        const PoolBlockHeader* h = (const PoolBlockHeader*)(pool + d.src_off);
-        const uint64_t* rows = (const uint64_t*)(pool + d.src_off + h->off_states);
-        const int hw = (int)h->ws < ws ? (int)h->ws : ws;
-        const size_t stride = h->rows;
-        for (int k = 0; k < hw; ++k) pc += __popcll(rows[(size_t)k * stride + d.src_row]);
-    } else {
-        for (int k = 0; k < ws; ++k) pc += __popcll(d.state[k]);
+    if (i < n) {
+        const DDInput& d = in[i];
+        int pc = 0;
+        if (d.src_off != NO_POOL_SRC) {   // a row of a cut-set block in the device pool (word-major rows)
+            const PoolBlockHeader* h = (const PoolBlockHeader*)(pool + d.src_off);
+            const uint64_t* rows = (const uint64_t*)(pool + d.src_off + h->off_states);
+            const int hw = (int)h->ws < ws ? (int)h->ws : ws;
+            const size_t stride = h->rows;
+            for (int k = 0; k < hw; ++k) pc += __popcll(rows[(size_t)k * stride + d.src_row]);
+        } else {
+            for (int k = 0; k < ws; ++k) pc += __popcll(d.state[k]);
+        }
+        pc = pc < nbins ? pc : nbins - 1;
+        key[i] = (uint32_t)pc;
+        atomicAdd(&mine[pc], 1u);
     }
-    pc = pc < LPT_BINS ? pc : LPT_BINS - 1;
-    key[i] = (uint32_t)pc;
-    atomicAdd(&bins[pc], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x)
+        if (mine[b]) atomicAdd(&bins[b], mine[b]);
 }
 
-__global__ void __launch_bounds__(1024) lpt_order_kernel(int n, const uint32_t* __restrict__ key, const uint32_t* __restrict__ bins, uint32_t* __restrict__ order) {
+__global__ void __launch_bounds__(1024) lpt_order_kernel(int n, int nbins, const uint32_t* __restrict__ key, const uint32_t* __restrict__ bins, uint32_t* __restrict__ order) {
     __shared__ uint32_t start[LPT_BINS];
-    for (int b = threadIdx.x; b < LPT_BINS; b += blockDim.x) start[b] = bins[b];
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) start[b] = bins[b];
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t at = 0;
-        for (int b = LPT_BINS - 1; b >= 0; --b) {
+        for (int b = nbins - 1; b >= 0; --b) {
             const uint32_t cnt = start[b];
             start[b] = at;
             at += cnt;
@@ -1052,13 +1061,15 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     if (lpt && engine_kind_ == 2 && count > nslots_) {
         // More DDs than slots: the workgroups draw them from a counter, and the launch lasts until the LAST one is done.  In input
         // order a slot that draws a large DD late sets the length of the launch; drawn largest first the launch ends within one DD
-        // of the mean load of a slot (brock400_1, 1024 root sub-problems on 512 slots, in nodes: 1.58 x the mean load -> 1.20 x;
-        // in time -8.5 %, the last DDs of a launch run faster than the first).  The number of vertices left in the residual state
-        // predicts the nodes of its DDs (correlation 0.995, tools/tail_predict.py).
+        // of the mean load of a slot (brock400_1, 1024 root sub-problems on 512 slots, in nodes: 1.26 x the mean load in the host's
+        // order by ub - value, 1.58 x in cut-set order, 1.20 x here; in time -8.5 %: the last DDs of a launch run faster than the
+        // first).  The number of vertices left in the residual state predicts the nodes of its DDs (correlation 0.995,
+        // tools/tail_predict.py), and the states are on the device.
         const LptBuffers lb(io.d_inputs, io.in_cap);
-        HIP_TRY(hipMemsetAsync(lb.bins, 0, (size_t)LPT_BINS * 4, st));
-        hipLaunchKernelGGL(lpt_count_kernel, dim3((count + 255) / 256), dim3(256), 0, st, P.inputs, count, (const uint8_t*)P_.pool, model_->wsT, lb.key, lb.bins);
-        hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, count, (const uint32_t*)lb.key, (const uint32_t*)lb.bins, lb.order);
+        const int nbins = std::min(LPT_BINS, 64 * model_->wsT + 1);   // a state of wsT words has at most 64 wsT vertices left
+        HIP_TRY(hipMemsetAsync(lb.bins, 0, (size_t)nbins * 4, st));
+        hipLaunchKernelGGL(lpt_count_kernel, dim3((count + 255) / 256), dim3(256), 0, st, P.inputs, count, (const uint8_t*)P_.pool, model_->wsT, nbins, lb.key, lb.bins);
+        hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, count, nbins, (const uint32_t*)lb.key, (const uint32_t*)lb.bins, lb.order);
         HIP_TRY(hipGetLastError());
         P.order = lb.order;
     }
