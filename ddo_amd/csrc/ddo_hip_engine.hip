@@ -11,6 +11,7 @@
 // compile needs no host round trip and no inter-workgroup synchronisation.
 // =============================================================================
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <thread>
 
@@ -29,8 +30,9 @@ namespace ddo_hip {
 
 // host seconds inside launch(), by section (DDO_HIP_TIMES prints them when an engine goes away): checks + staging, inputs to the device,
 // launch order, pool growth, kernel launch, result copies
-static double g_launch_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-static unsigned long long g_launch_n = 0;
+static std::atomic<uint64_t> g_launch_ns[8];   // (engines are launched from several host threads)
+static std::atomic<uint64_t> g_launch_n{0};
+static const bool g_times_on = std::getenv("DDO_HIP_TIMES") != nullptr;
 
 
 // Launch order of a batch on the in-place engine: sub-problems by decreasing number of vertices left in their residual state -- a
@@ -651,10 +653,12 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
 }
 
 Engine::~Engine() {
-    if (g_launch_n && std::getenv("DDO_HIP_TIMES")) {
+    if (g_times_on && g_launch_n.load() > 0) {
+        auto sec = [](int k) { return (double)g_launch_ns[k].exchange(0) * 1e-9; };
+        const unsigned long long nl = g_launch_n.exchange(0);
+        const double t0 = sec(0), t1 = sec(1), t2 = sec(2), t3 = sec(3), t4 = sec(4), t5 = sec(5), t6 = sec(6), t7 = sec(7);
         std::fprintf(stderr, "[ddo times] launch() host s over %llu launches: checks %.3f, inputs %.3f, launch order %.3f, parameters + rewind %.3f, first event %.3f, pool growth %.3f, kernel %.3f, result copies %.3f\n",
-                     g_launch_n, g_launch_s[0], g_launch_s[1], g_launch_s[2], g_launch_s[6], g_launch_s[7], g_launch_s[3], g_launch_s[4], g_launch_s[5]);
-        g_launch_n = 0;
+                     nl, t0, t1, t2, t6, t7, t3, t4, t5);
     }
     if (device_ >= 0) (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize((hipStream_t)stream_);
@@ -992,8 +996,9 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     std::lock_guard<std::mutex> g(mtx_);
     auto lt0 = std::chrono::steady_clock::now();
     auto tick = [&](int k) {
+        if (!g_times_on) return;
         const auto now = std::chrono::steady_clock::now();
-        g_launch_s[k] += std::chrono::duration<double>(now - lt0).count();
+        g_launch_ns[k].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - lt0).count(), std::memory_order_relaxed);
         lt0 = now;
     };
     if (pending_ > 0) {
@@ -1134,7 +1139,7 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
                                  hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(io.h_head, io.d_cnt + 8, 8, hipMemcpyDeviceToHost, st));
     tick(5);
-    g_launch_n += 1;
+    if (g_times_on) g_launch_n.fetch_add(1, std::memory_order_relaxed);
     io.count = count;
     pending_ = count;
     pending_set_ = next_set_;
