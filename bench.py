@@ -486,6 +486,10 @@ def main():
                        "dense_tier": ("on" if os.environ.get("DDO_HIP_DENSE", "1") != "0" else "off") +
                                      " (default on: two 512-thread decision diagrams per CU; round 3, one box: on 1.703e10 nodes/s / 30.6 % of the"
                                      " roofline, off -- DDO_HIP_DENSE=0, the 1024-thread kernel, one per CU -- 1.552e10 / 27.9 %)",
+                       "launch_order": ("input order (DDO_HIP_LPT=0)" if os.environ.get("DDO_HIP_LPT", "1") == "0" else
+                                        "the decision diagrams of a launch are drawn longest first: sorted on the device by the vertices left in "
+                                        "their residual states (round 4, one box, alternating: 1.80-1.84e10 nodes/s against 1.64-1.68e10 in the "
+                                        "host's order)"),
                        "subproblems_per_step": conc, "frozen_batches": nfrozen, "prefix_steps": PREFIX_STEPS,
                        "parallelism": f"fringe-shard x{world}"},
             "subproblems_per_s": subs / elapsed,
