@@ -12,13 +12,14 @@
 // image, so the reference itself cannot be executed here (no oracle/_ref).
 // The oracle is pinned instead against the reference's own known-answer tests:
 //   * engine KATs      ddo/src/implementation/mdd/clean.rs:1153-2398
+//   * pooled DD KATs   ddo/src/implementation/mdd/pooled.rs:1024-2250 (same-named tests, same bodies as clean.rs's)
 //   * fringe KATs      ddo/src/implementation/fringe/no_duplicate.rs:412-640
 //   * solver KATs      ddo/src/implementation/solver/parallel.rs:902-1151
 //   * example optima   ddo/examples/misp/tests.rs:71-161, knapsack/tests.rs
 // (see oracle/kat_main.cpp and tests/test_oracle_*.py).
 //
-// What is NOT reproduced: the iteration order of FxHashMap (`next_l`).  This
-// restatement iterates a layer in insertion order.  For models whose
+// What is NOT reproduced: the iteration order of FxHashMap (`next_l`, Pooled's
+// `pool`).  This restatement iterates a layer / the pool in insertion order.  For models whose
 // StateRanking is a total order on states (MISP) every value the engine
 // produces is independent of that order; only tie-broken solution paths may
 // differ.
@@ -34,6 +35,7 @@
 #include <cstdint>
 #include <functional>
 #include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -1333,6 +1335,580 @@ template <class S>
 using DefaultMDDLEL = Mdd<S, LAST_EXACT_LAYER>;
 template <class S>
 using DefaultMDDFC = Mdd<S, FRONTIER>;
+
+// ---------------------------------------------------------------------------
+// Pooled<T>: the "long arc" decision diagram (implementation/mdd/pooled.rs:117-823).  Nodes wait in a pool indexed by state;
+// the layer of a variable is made of the pool nodes the variable impacts (Problem::is_impacted_by, dp.rs:68-70), the others stay
+// where they are.  Width limits, cache and dominance filters apply to those layers; the cut-set is always the frontier
+// (pooled.rs:543-564), exactness a flag the squashes clear (pooled.rs:752, :769).
+// Iteration order of the pool in this restatement = insertion order (the reference iterates an FxHashMap).
+// Pinned on pooled.rs's own unit tests (kat_main.cpp: the `Pooled` instantiations of the DD cases).
+// ---------------------------------------------------------------------------
+template <class S>
+class Pooled {
+    static constexpr size_t NONE = (size_t)-1;
+    static constexpr size_t NIL = 0;   // pooled.rs:160
+    /// pooled.rs:36-68
+    struct Node {
+        std::shared_ptr<const S> state;
+        isize value_top;
+        isize value_bot;
+        size_t best;     // Option<EdgeId>
+        size_t inbound;  // EdgesListId
+        isize rub;
+        std::optional<isize> theta;
+        NodeFlags flags;
+        size_t depth;
+    };
+    /// pooled.rs:73-84
+    struct Edge {
+        size_t from, to;
+        Decision decision;
+        isize cost;
+    };
+    /// pooled.rs:88-91 (Nil: head == NONE)
+    struct EdgesList {
+        size_t head, tail;
+    };
+
+    std::map<size_t, std::vector<size_t>> layers;   // BTreeMap<usize, Layer> (pooled.rs:123)
+    std::vector<Node> nodes;
+    std::vector<Edge> edges;
+    std::vector<EdgesList> edgelists;
+    size_t curr_l = 0;
+    std::unordered_map<std::shared_ptr<const S>, size_t, PtrHash<S>, PtrEq<S>> pool;   // pooled.rs:141
+    std::vector<size_t> pool_order;                                                     // its iteration order here
+    std::vector<Decision> path_to_root;
+    std::vector<size_t> cutset;
+    std::optional<size_t> best_node, best_exact_node;
+    bool is_exact_ = true;
+    bool has_exact_best_path_ = false;
+
+  public:
+    MddCounters counters;        // accumulated over all compile() calls
+    MddCounters last_counters;   // the latest compile() only
+
+    /// pooled.rs:230-232
+    std::optional<Completion> compile(const CompilationInput<S>& input, Reason* why = nullptr) { return _compile(input, why); }
+    /// pooled.rs:234-236
+    bool is_exact() const { return is_exact_ || has_exact_best_path_; }
+    /// pooled.rs:300-302
+    std::optional<isize> best_value() const {
+        if (best_node) return nodes[*best_node].value_top;
+        return std::nullopt;
+    }
+    /// pooled.rs:304-306
+    std::optional<Solution> best_solution() const {
+        if (best_node) return _best_path(*best_node);
+        return std::nullopt;
+    }
+    /// pooled.rs:308-310
+    std::optional<isize> best_exact_value() const {
+        if (best_exact_node) return nodes[*best_exact_node].value_top;
+        return std::nullopt;
+    }
+    /// pooled.rs:312-314
+    std::optional<Solution> best_exact_solution() const {
+        if (best_exact_node) return _best_path(*best_exact_node);
+        return std::nullopt;
+    }
+    /// pooled.rs:406-436
+    template <class F>
+    void drain_cutset(F&& func) {
+        auto bv = best_value();
+        if (bv) {
+            for (size_t id : cutset) {
+                const Node& node = nodes[id];
+                if (node.flags.is_marked()) {
+                    isize rub = sat_add(node.value_top, node.rub);
+                    isize locb = sat_add(node.value_top, node.value_bot);
+                    SubProblem<S> sp;
+                    sp.state = node.state;
+                    sp.value = node.value_top;
+                    sp.path = _best_path(id);
+                    sp.ub = std::min(std::min(rub, locb), *bv);
+                    sp.depth = node.depth;
+                    func(std::move(sp));
+                }
+            }
+            cutset.clear();
+        }
+    }
+
+    // --- introspection (not part of the reference API)
+    size_t nb_layers() const { return layers.size(); }
+    size_t nb_nodes() const { return nodes.size(); }
+    size_t nb_edges() const { return edges.size(); }
+    /// node ids of the layer stored under `depth` (empty when there is none)
+    std::vector<size_t> layer_at(size_t depth) const {
+        auto it = layers.find(depth);
+        return it == layers.end() ? std::vector<size_t>() : it->second;
+    }
+    const S& state_of(size_t id) const { return *nodes[id].state; }
+
+  private:
+    struct PoolKeysIter : StateIter<S> {
+        const std::vector<Node>& nodes;
+        const std::vector<size_t>& order;
+        size_t i = 0;
+        PoolKeysIter(const std::vector<Node>& n, const std::vector<size_t>& o) : nodes(n), order(o) {}
+        const S* next() override { return i < order.size() ? nodes[order[i++]].state.get() : nullptr; }
+    };
+    struct IdsIter : StateIter<S> {
+        const std::vector<Node>& nodes;
+        const size_t* b;
+        const size_t* e;
+        IdsIter(const std::vector<Node>& n, const size_t* b, const size_t* e) : nodes(n), b(b), e(e) {}
+        const S* next() override { return b < e ? nodes[*b++].state.get() : nullptr; }
+    };
+    struct BranchCb : DecisionCallback {
+        Pooled* self;
+        size_t node_id;
+        const Problem<S>* pb;
+        void apply(Decision d) override { self->_branch_on(node_id, d, *pb); }
+    };
+
+    /// pooled.rs:284-298
+    void _clear() {
+        layers.clear();
+        nodes.clear();
+        edges.clear();
+        edgelists.clear();
+        pool.clear();
+        pool_order.clear();
+        path_to_root.clear();
+        cutset.clear();
+        best_node.reset();
+        best_exact_node.reset();
+        is_exact_ = true;
+        has_exact_best_path_ = false;
+    }
+
+    /// pooled.rs:316-334
+    Solution _best_path(size_t id) const {
+        Solution sol = path_to_root;
+        size_t eid = nodes[id].best;
+        while (eid != NONE) {
+            const Edge& e = edges[eid];
+            sol.push_back(e.decision);
+            eid = nodes[e.from].best;
+        }
+        return sol;
+    }
+
+    /// append_edge_to! (pooled.rs:191-212): the LAST arc of maximal value is the best one
+    void append_edge_to(const Edge& edge) {
+        size_t new_eid = edges.size();
+        size_t lst_id = edgelists.size();
+        edges.push_back(edge);
+        edgelists.push_back(EdgesList{new_eid, nodes[edge.to].inbound});
+        const Node& parent = nodes[edge.from];
+        bool parent_exact = parent.flags.is_exact();
+        isize value = sat_add(parent.value_top, edge.cost);
+        Node& node = nodes[edge.to];
+        node.flags.set_exact(parent_exact & node.flags.is_exact());
+        node.inbound = lst_id;
+        if (value >= node.value_top) {
+            node.best = new_eid;
+            node.value_top = value;
+        }
+    }
+
+    /// foreach!(edge of id, ...) (pooled.rs:179-188)
+    template <class F>
+    void foreach_edge_of(size_t id, F&& action) {
+        size_t list = nodes[id].inbound;
+        while (edgelists[list].head != NONE) {
+            Edge e = edges[edgelists[list].head];
+            size_t tail = edgelists[list].tail;
+            action(e);
+            list = tail;
+        }
+    }
+
+    /// pooled.rs:336-374
+    std::optional<Completion> _compile(const CompilationInput<S>& input, Reason* why) {
+        _clear();
+        last_counters = MddCounters();
+        last_counters.compiles = 1;
+        _initialize(input);
+        for (;;) {
+            PoolKeysIter keys(nodes, pool_order);
+            auto var = input.problem->next_variable(curr_l, keys);
+            if (!var) break;
+            if (input.cutoff->must_stop()) {   // :341-343
+                if (why) *why = Reason::CutoffOccurred;
+                counters.add(last_counters);
+                return std::nullopt;
+            }
+            if (pool.empty()) break;           // :345-347
+            std::vector<size_t> to_expand = _move_to_next_layer(input, *var);
+            last_counters.layers += 1;
+            for (size_t node_id : to_expand) {   // :351-361
+                last_counters.nodes_expanded += 1;
+                std::shared_ptr<const S> state = nodes[node_id].state;
+                isize rub = input.relaxation->fast_upper_bound(*state);
+                nodes[node_id].rub = rub;
+                isize ub = sat_add(rub, nodes[node_id].value_top);
+                if (ub > input.best_lb) {
+                    BranchCb cb;
+                    cb.self = this;
+                    cb.node_id = node_id;
+                    cb.pb = input.problem;
+                    input.problem->for_each_in_domain(*var, *state, cb);
+                }
+            }
+            curr_l += 1;
+        }
+        _finalize(input);
+        counters.add(last_counters);
+        Completion c;
+        c.is_exact = is_exact();
+        c.best_value = best_value();
+        return c;
+    }
+
+    /// pooled.rs:376-399
+    void _initialize(const CompilationInput<S>& input) {
+        path_to_root = input.residual->path;
+        edgelists.push_back(EdgesList{NONE, NONE});   // Nil
+        Node root;
+        root.state = input.residual->state;
+        root.value_top = input.residual->value;
+        root.value_bot = ISIZE_MIN;
+        root.best = NONE;
+        root.inbound = NIL;
+        root.rub = ISIZE_MAX;
+        root.theta = std::nullopt;
+        root.flags = NodeFlags::new_exact();
+        root.depth = input.residual->depth;
+        nodes.push_back(root);
+        pool.emplace(root.state, 0);
+        pool_order.push_back(0);
+        edgelists.push_back(EdgesList{NONE, NONE});
+        curr_l = input.residual->depth;
+    }
+
+    /// pooled.rs:401-408
+    void _finalize(const CompilationInput<S>& input) {
+        _finalize_layers();
+        _find_best_node();
+        _finalize_exact(input);
+        _compute_frontier_cutset(input);
+        _compute_local_bounds(input);
+        _compute_thresholds(input);
+    }
+
+    /// pooled.rs:438-467
+    void _compute_local_bounds(const CompilationInput<S>& input) {
+        if (!cutset.empty() && input.comp_type == CompilationType::Relaxed) {
+            for (size_t id : layers.rbegin()->second) {   // the last layer
+                nodes[id].value_bot = 0;
+                nodes[id].flags.set_marked(true);
+            }
+            for (auto l = layers.rbegin(); l != layers.rend(); ++l) {
+                for (size_t id : l->second) {
+                    isize value = nodes[id].value_bot;
+                    if (nodes[id].flags.is_marked()) {
+                        foreach_edge_of(id, [&](const Edge& edge) {
+                            isize using_edge = sat_add(value, edge.cost);
+                            Node& parent = nodes[edge.from];
+                            parent.flags.set_marked(true);
+                            parent.value_bot = std::max(parent.value_bot, using_edge);
+                        });
+                    }
+                }
+            }
+        }
+    }
+
+    /// pooled.rs:469-528
+    void _compute_thresholds(const CompilationInput<S>& input) {
+        if (input.comp_type == CompilationType::Relaxed || is_exact_) {
+            isize best_known = input.best_lb;
+            if (best_exact_node) {
+                best_known = std::max(best_known, nodes[*best_exact_node].value_top);
+                for (size_t id : pool_order)
+                    if (nodes[id].flags.is_exact()) nodes[id].theta = best_known;
+            }
+            for (auto l = layers.rbegin(); l != layers.rend(); ++l) {
+                for (size_t id : l->second) {
+                    Node& node = nodes[id];
+                    if (node.flags.is_deleted()) continue;
+                    if (!node.flags.is_pruned_by_cache()) {   // (theta is propagated even from a node the cache pruned)
+                        isize tot_rub = sat_add(node.value_top, node.rub);
+                        if (tot_rub <= best_known) {
+                            node.theta = sat_sub(best_known, node.rub);
+                        } else if (node.flags.is_cutset()) {
+                            isize tot_locb = sat_add(node.value_top, node.value_bot);
+                            if (tot_locb <= best_known) {
+                                isize theta = node.theta.value_or(ISIZE_MAX);
+                                node.theta = std::min(theta, sat_sub(best_known, node.value_bot));
+                            } else {
+                                node.theta = node.value_top;
+                            }
+                        } else if (node.flags.is_exact() && !node.theta) {
+                            node.theta = ISIZE_MAX;
+                        }
+                        _maybe_update_cache(node, input);
+                    }
+                    if (node.theta) {
+                        isize my_theta = *node.theta;
+                        foreach_edge_of(id, [&](const Edge& edge) {
+                            Node& parent = nodes[edge.from];
+                            isize theta = parent.theta.value_or(ISIZE_MAX);
+                            parent.theta = std::min(theta, sat_sub(my_theta, edge.cost));
+                        });
+                    }
+                }
+            }
+        }
+    }
+
+    /// pooled.rs:530-541
+    static void _maybe_update_cache(const Node& node, const CompilationInput<S>& input) {
+        if (node.theta && node.flags.is_above_cutset())
+            input.cache->update_threshold(node.state, node.depth, *node.theta, !node.flags.is_cutset());
+    }
+
+    /// pooled.rs:543-566
+    void _compute_frontier_cutset(const CompilationInput<S>& input) {
+        if (input.comp_type == CompilationType::Relaxed || is_exact_) {
+            for (auto l = layers.rbegin(); l != layers.rend(); ++l) {
+                for (size_t id : l->second) {
+                    if (nodes[id].flags.is_exact()) {
+                        nodes[id].flags.set_above_cutset(true);
+                    } else {
+                        foreach_edge_of(id, [&](const Edge& edge) {
+                            Node& parent = nodes[edge.from];
+                            if (parent.flags.is_exact() && !parent.flags.is_cutset()) {
+                                if (!is_exact_) cutset.push_back(edge.from);
+                                parent.flags.set_cutset(true);
+                            }
+                        });
+                    }
+                }
+            }
+        }
+    }
+
+    /// pooled.rs:568-576: what is left in the pool is the last layer (an insert under an existing key replaces the layer)
+    void _finalize_layers() {
+        std::vector<size_t> last_l;
+        for (size_t id : pool_order) {
+            last_l.push_back(id);
+            nodes[id].depth = curr_l;
+        }
+        layers[curr_l] = std::move(last_l);
+    }
+
+    /// pooled.rs:578-590.  Iterator::max_by_key keeps the LAST maximum.
+    void _find_best_node() {
+        best_node.reset();
+        best_exact_node.reset();
+        for (size_t id : pool_order) {
+            if (!best_node || nodes[id].value_top >= nodes[*best_node].value_top) best_node = id;
+            if (nodes[id].flags.is_exact() && (!best_exact_node || nodes[id].value_top >= nodes[*best_exact_node].value_top)) best_exact_node = id;
+        }
+    }
+
+    /// pooled.rs:592-598
+    void _finalize_exact(const CompilationInput<S>& input) {
+        has_exact_best_path_ = input.comp_type == CompilationType::Relaxed && _has_exact_best_path(best_node);
+        if (has_exact_best_path_) best_exact_node = best_node;
+    }
+
+    /// pooled.rs:600-612
+    bool _has_exact_best_path(std::optional<size_t> node) const {
+        while (node) {
+            const Node& n = nodes[*node];
+            if (n.flags.is_exact()) return true;
+            if (n.flags.is_relaxed()) return false;
+            if (n.best == NONE) node.reset();
+            else node = edges[n.best].from;
+        }
+        return true;
+    }
+
+    void pool_remove(size_t id) {
+        pool.erase(nodes[id].state);
+        pool_order.erase(std::find(pool_order.begin(), pool_order.end(), id));
+    }
+
+    /// pooled.rs:614-641: the pool nodes `var` impacts leave the pool and make the layer; the others stay
+    std::vector<size_t> _move_to_next_layer(const CompilationInput<S>& input, Variable var) {
+        std::vector<size_t> layer;
+        for (size_t id : pool_order) {
+            if (input.problem->is_impacted_by(var, *nodes[id].state)) {
+                nodes[id].depth = curr_l;
+                layer.push_back(id);
+            }
+        }
+        for (size_t id : layer) pool_remove(id);
+
+        std::vector<size_t> to_expand = layer;   // the layer itself remembers the nodes the cache pruned
+        if (!layers.empty()) _filter_with_cache(input, to_expand);
+        _filter_with_dominance(input, to_expand);
+        size_t len = nodes.size();               // a squash may add the merged node
+        _squash_if_needed(input, to_expand);
+        if (nodes.size() > len) layer.push_back(len);
+        if (!layer.empty()) layers[curr_l] = layer;
+        return to_expand;
+    }
+
+    /// pooled.rs:643-660
+    void _filter_with_dominance(const CompilationInput<S>& input, std::vector<size_t>& l) {
+        std::sort(l.begin(), l.end(), [&](size_t a, size_t b) {
+            return input.dominance->cmp(*nodes[a].state, nodes[a].value_top, *nodes[b].state, nodes[b].value_top) > 0;
+        });
+        size_t w = 0;
+        for (size_t i = 0; i < l.size(); ++i) {
+            size_t id = l[i];
+            Node& node = nodes[id];
+            bool keep = true;
+            if (node.flags.is_exact()) {
+                DominanceCheckResult r = input.dominance->is_dominated_or_insert(node.state, node.depth, node.value_top);
+                if (r.dominated) {
+                    node.theta = r.threshold;
+                    keep = false;
+                }
+            }
+            if (keep) l[w++] = id;
+        }
+        l.resize(w);
+    }
+
+    /// pooled.rs:662-678
+    void _filter_with_cache(const CompilationInput<S>& input, std::vector<size_t>& l) {
+        size_t w = 0;
+        for (size_t i = 0; i < l.size(); ++i) {
+            size_t id = l[i];
+            Node& node = nodes[id];
+            auto t = input.cache->get_threshold(*node.state, node.depth);
+            bool keep = true;
+            if (t && !(node.value_top > t->value)) {
+                node.flags.set_pruned_by_cache(true);
+                node.theta = t->value;
+                keep = false;
+            }
+            if (keep) l[w++] = id;
+        }
+        l.resize(w);
+    }
+
+    /// pooled.rs:680-731
+    void _branch_on(size_t from_id, Decision decision, const Problem<S>& problem) {
+        last_counters.arcs += 1;
+        const S& state = *nodes[from_id].state;
+        auto next_state = std::make_shared<const S>(problem.transition(state, decision));
+        isize cost = problem.transition_cost(state, *next_state, decision);
+        auto it = pool.find(next_state);
+        if (it == pool.end()) {
+            const Node& parent = nodes[from_id];
+            size_t node_id = nodes.size();
+            NodeFlags flags = NodeFlags::new_exact();
+            flags.set_exact(parent.flags.is_exact());
+            Node n;
+            n.state = next_state;
+            n.value_top = sat_add(parent.value_top, cost);
+            n.value_bot = ISIZE_MIN;
+            n.best = NONE;
+            n.inbound = NIL;
+            n.rub = ISIZE_MAX;
+            n.theta = std::nullopt;
+            n.flags = flags;
+            n.depth = parent.depth + 1;   // (updated when the node is expanded)
+            nodes.push_back(std::move(n));
+            append_edge_to(Edge{from_id, node_id, decision, cost});
+            pool.emplace(next_state, node_id);
+            pool_order.push_back(node_id);
+        } else {
+            append_edge_to(Edge{from_id, it->second, decision, cost});
+        }
+    }
+
+    /// pooled.rs:734-749
+    void _squash_if_needed(const CompilationInput<S>& input, std::vector<size_t>& l) {
+        switch (input.comp_type) {
+            case CompilationType::Exact: break;
+            case CompilationType::Restricted:
+                if (l.size() > input.max_width) _restrict(input, l);
+                break;
+            case CompilationType::Relaxed:
+                if (l.size() > input.max_width && layers.size() >= 2) _relax(input, l);
+                break;
+        }
+    }
+
+    /// descending (value_top, ranking): pooled.rs:753-758, :770-775
+    void _sort_layer(const CompilationInput<S>& input, std::vector<size_t>& l) {
+        std::sort(l.begin(), l.end(), [&](size_t a, size_t b) {
+            if (nodes[a].value_top != nodes[b].value_top) return nodes[a].value_top > nodes[b].value_top;
+            return input.ranking->compare(*nodes[a].state, *nodes[b].state) > 0;
+        });
+    }
+
+    /// pooled.rs:751-766
+    void _restrict(const CompilationInput<S>& input, std::vector<size_t>& l) {
+        is_exact_ = false;
+        _sort_layer(input, l);
+        for (size_t i = input.max_width; i < l.size(); ++i) nodes[l[i]].flags.set_deleted(true);
+        l.resize(input.max_width);
+    }
+
+    /// pooled.rs:768-829
+    void _relax(const CompilationInput<S>& input, std::vector<size_t>& l) {
+        is_exact_ = false;
+        _sort_layer(input, l);
+        size_t nkeep = input.max_width - 1;
+        const size_t* merge_b = l.data() + nkeep;
+        const size_t* merge_e = l.data() + l.size();
+        IdsIter it(nodes, merge_b, merge_e);
+        auto merged = std::make_shared<const S>(input.relaxation->merge(it));
+        std::optional<size_t> recycled;
+        for (size_t i = 0; i < nkeep; ++i) {
+            if (*nodes[l[i]].state == *merged) {
+                recycled = l[i];
+                break;
+            }
+        }
+        size_t merged_id;
+        if (recycled) {
+            merged_id = *recycled;
+        } else {
+            merged_id = nodes.size();
+            Node n;
+            n.state = merged;
+            n.value_top = ISIZE_MIN;
+            n.value_bot = ISIZE_MIN;
+            n.best = NONE;
+            n.inbound = NIL;
+            n.rub = ISIZE_MAX;
+            n.theta = std::nullopt;
+            n.flags = NodeFlags::new_relaxed();
+            n.depth = nodes[*merge_b].depth;
+            nodes.push_back(std::move(n));
+        }
+        nodes[merged_id].flags.set_relaxed(true);
+        for (const size_t* p = merge_b; p < merge_e; ++p) {
+            size_t drop_id = *p;
+            nodes[drop_id].flags.set_deleted(true);
+            foreach_edge_of(drop_id, [&](const Edge& edge) {   // (the arcs appended go to merged_id's list, never drop_id's)
+                const S& src = *nodes[edge.from].state;
+                const S& dst = *nodes[edge.to].state;
+                isize rcost = input.relaxation->relax(src, dst, *merged, edge.decision, edge.cost);
+                append_edge_to(Edge{edge.from, merged_id, edge.decision, rcost});
+            });
+        }
+        if (recycled) {
+            l.resize(input.max_width);
+            nodes[l[input.max_width - 1]].flags.set_deleted(false);
+        } else {
+            l.resize(input.max_width - 1);
+            l.push_back(merged_id);
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------
 // abstraction/solver.rs:32-97

@@ -33,6 +33,18 @@ static std::string g_case;
         name();                                    \
         if (g_fail == before) std::printf("ok %s\n", #name); \
     } while (0)
+// a DD case instantiated for the default DD (clean.rs tests) and for the pooled one (the same-named tests of pooled.rs)
+#define RUN_DD(name)                                                                         \
+    do {                                                                                     \
+        g_case = #name " [Mdd, clean.rs]";                                                   \
+        int before = g_fail;                                                                 \
+        name<DefaultMDDLEL<DummyState>, DefaultMDDFC<char>>();                               \
+        if (g_fail == before) std::printf("ok %s\n", g_case.c_str());                        \
+        g_case = #name " [Pooled, pooled.rs]";                                               \
+        before = g_fail;                                                                     \
+        name<Pooled<DummyState>, Pooled<char>>();                                            \
+        if (g_fail == before) std::printf("ok %s\n", g_case.c_str());                        \
+    } while (0)
 
 // ---------------------------------------------------------------------------
 // Fixtures of clean.rs:2552-2667 (DummyProblem & co)
@@ -176,27 +188,30 @@ struct DummyEnv {
 static bool sol_eq(const Solution& s, std::initializer_list<Decision> e) { return s == Solution(e); }
 
 // clean.rs:1155-1188
-CASE(exact_completely_unrolls_the_mdd_no_matter_its_width) {
+template <class DD, class DDC>
+static void exact_completely_unrolls_the_mdd_no_matter_its_width() {
     DummyEnv e;
-    DefaultMDDLEL<DummyState> mdd;
+    DD mdd;
     CHECK(mdd.compile(e.input(CompilationType::Exact, 1, ISIZE_MIN)).has_value());
     CHECK(mdd.best_solution().has_value());
     CHECK(mdd.best_value() == std::optional<isize>(6));
     CHECK(sol_eq(*mdd.best_solution(), {{2, 2}, {1, 2}, {0, 2}}));
 }
 // clean.rs:1191-1224
-CASE(restricted_drops_the_less_interesting_nodes) {
+template <class DD, class DDC>
+static void restricted_drops_the_less_interesting_nodes() {
     DummyEnv e;
-    DefaultMDDLEL<DummyState> mdd;
+    DD mdd;
     CHECK(mdd.compile(e.input(CompilationType::Restricted, 1, ISIZE_MIN)).has_value());
     CHECK(mdd.best_value() == std::optional<isize>(6));
     CHECK(sol_eq(*mdd.best_solution(), {{2, 2}, {1, 2}, {0, 2}}));
 }
 // clean.rs:1227-1315
-CASE(completion_must_be_coherent_with_outcome) {
+template <class DD, class DDC>
+static void completion_must_be_coherent_with_outcome() {
     for (CompilationType t : {CompilationType::Exact, CompilationType::Restricted, CompilationType::Relaxed}) {
         DummyEnv e;
-        DefaultMDDLEL<DummyState> mdd;
+        DD mdd;
         auto c = mdd.compile(e.input(t, 1, ISIZE_MIN));
         CHECK(c.has_value());
         CHECK(c->is_exact == mdd.is_exact());
@@ -204,10 +219,11 @@ CASE(completion_must_be_coherent_with_outcome) {
     }
 }
 // clean.rs:1323-1403
-CASE(fails_with_cutoff_when_cutoff_occurs) {
+template <class DD, class DDC>
+static void fails_with_cutoff_when_cutoff_occurs() {
     for (CompilationType t : {CompilationType::Exact, CompilationType::Restricted, CompilationType::Relaxed}) {
         DummyEnv e;
-        DefaultMDDLEL<DummyState> mdd;
+        DD mdd;
         Reason why;
         auto c = mdd.compile(e.input(t, 1, ISIZE_MIN, false, false, true), &why);
         CHECK(!c.has_value());
@@ -215,85 +231,92 @@ CASE(fails_with_cutoff_when_cutoff_occurs) {
     }
 }
 // clean.rs:1406-1440
-CASE(relaxed_merges_the_less_interesting_nodes) {
+template <class DD, class DDC>
+static void relaxed_merges_the_less_interesting_nodes() {
     DummyEnv e;
-    DefaultMDDLEL<DummyState> mdd;
+    DD mdd;
     CHECK(mdd.compile(e.input(CompilationType::Relaxed, 1, ISIZE_MIN)).has_value());
     CHECK(mdd.best_value() == std::optional<isize>(24));
     CHECK(sol_eq(*mdd.best_solution(), {{2, 2}, {1, 0}, {0, 2}}));
 }
 // clean.rs:1443-1471
-CASE(relaxed_populates_the_cutset_and_will_not_squash_first_layer) {
+template <class DD, class DDC>
+static void relaxed_populates_the_cutset_and_will_not_squash_first_layer() {
     DummyEnv e;
-    DefaultMDDLEL<DummyState> mdd;
+    DD mdd;
     CHECK(mdd.compile(e.input(CompilationType::Relaxed, 1, ISIZE_MIN)).has_value());
     size_t n = 0;
     mdd.drain_cutset([&](SubProblem<DummyState>) { n++; });
     CHECK(n == 3);
 }
 // clean.rs:1474-1614
-CASE(exactness_flags) {
+template <class DD, class DDC>
+static void exactness_flags() {
     {   // an_exact_mdd_must_be_exact
-        DummyEnv e; DefaultMDDLEL<DummyState> mdd;
+        DummyEnv e; DD mdd;
         CHECK(mdd.compile(e.input(CompilationType::Exact, 1, ISIZE_MIN)).has_value());
         CHECK(mdd.is_exact());
     }
     {   // a_relaxed_mdd_is_exact_as_long_as_no_merge_occurs (w = 10)
-        DummyEnv e; DefaultMDDLEL<DummyState> mdd;
+        DummyEnv e; DD mdd;
         CHECK(mdd.compile(e.input(CompilationType::Relaxed, 10, ISIZE_MIN)).has_value());
         CHECK(mdd.is_exact());
     }
     {   // a_relaxed_mdd_is_not_exact_when_a_merge_occurred (w = 1)
-        DummyEnv e; DefaultMDDLEL<DummyState> mdd;
+        DummyEnv e; DD mdd;
         CHECK(mdd.compile(e.input(CompilationType::Relaxed, 1, ISIZE_MIN)).has_value());
         CHECK(!mdd.is_exact());
     }
     {   // a_restricted_mdd_is_exact_as_long_as_no_restriction_occurs (w = 10)
-        DummyEnv e; DefaultMDDLEL<DummyState> mdd;
+        DummyEnv e; DD mdd;
         CHECK(mdd.compile(e.input(CompilationType::Restricted, 10, ISIZE_MIN)).has_value());
         CHECK(mdd.is_exact());
     }
     {   // a_restricted_mdd_is_not_exact_when_a_restriction_occurred (w = 1)
-        DummyEnv e; DefaultMDDLEL<DummyState> mdd;
+        DummyEnv e; DD mdd;
         CHECK(mdd.compile(e.input(CompilationType::Restricted, 1, ISIZE_MIN)).has_value());
         CHECK(!mdd.is_exact());
     }
 }
 // clean.rs:1616-1668
-CASE(when_the_problem_is_infeasible_there_is_no_solution) {
+template <class DD, class DDC>
+static void when_the_problem_is_infeasible_there_is_no_solution() {
     DummyEnv e;
-    DefaultMDDLEL<DummyState> mdd;
+    DD mdd;
     CHECK(mdd.compile(e.input(CompilationType::Exact, 10, ISIZE_MIN, false, true)).has_value());
     CHECK(!mdd.best_solution().has_value());
     CHECK(!mdd.best_value().has_value());
 }
 // clean.rs:1670-1749
-CASE(skips_node_with_an_ub_less_than_best_known_lb) {
+template <class DD, class DDC>
+static void skips_node_with_an_ub_less_than_best_known_lb() {
     for (CompilationType t : {CompilationType::Exact, CompilationType::Restricted, CompilationType::Relaxed}) {
         DummyEnv e;
-        DefaultMDDLEL<DummyState> mdd;
+        DD mdd;
         CHECK(mdd.compile(e.input(t, (size_t)-1, 1000)).has_value());
         CHECK(!mdd.best_solution().has_value());
     }
 }
 // clean.rs:1751-1843
-CASE(skips_nodes_with_a_value_less_than_known_threshold) {
+template <class DD, class DDC>
+static void skips_nodes_with_a_value_less_than_known_threshold() {
     for (CompilationType t : {CompilationType::Exact, CompilationType::Restricted, CompilationType::Relaxed}) {
         DummyEnv e;
         e.scache.initialize(e.pb);
         for (isize v = 0; v <= 2; ++v)
             e.scache.update_threshold(std::make_shared<const DummyState>(DummyState{v, 1}), 1, v, true);
-        DefaultMDDLEL<DummyState> mdd;
+        DD mdd;
         CHECK(mdd.compile(e.input(t, (size_t)-1, ISIZE_MIN, true)).has_value());
         CHECK(!mdd.best_solution().has_value());
     }
 }
 // clean.rs:1845-1948
-CASE(computes_thresholds_when_exact) {
+template <class DD, class DDC>
+static void computes_thresholds_when_exact() {
     for (CompilationType t : {CompilationType::Restricted, CompilationType::Relaxed}) {
         DummyEnv e;
         e.scache.initialize(e.pb);
-        DefaultMDDLEL<DummyState> mdd;
+        DD mdd;
         CHECK(mdd.compile(e.input(t, 10, ISIZE_MIN, true)).has_value());
         CHECK(mdd.is_exact());
         for (size_t depth = 0; depth <= 3; ++depth)
@@ -306,11 +329,12 @@ CASE(computes_thresholds_when_exact) {
     }
 }
 // clean.rs:1951-2055
-CASE(computes_thresholds_when_all_pruned) {
+template <class DD, class DDC>
+static void computes_thresholds_when_all_pruned() {
     for (CompilationType t : {CompilationType::Restricted, CompilationType::Relaxed}) {
         DummyEnv e;
         e.scache.initialize(e.pb);
-        DefaultMDDLEL<DummyState> mdd;
+        DD mdd;
         CHECK(mdd.compile(e.input(t, 10, 15, true)).has_value());
         CHECK(mdd.is_exact());
         for (size_t depth = 0; depth <= 2; ++depth)
@@ -362,9 +386,10 @@ CASE(relaxed_computes_local_bounds_and_thresholds_1) {
     CHECK(e.none('g', 3) && e.none('h', 3) && e.none('i', 3) && e.none('t', 4));
 }
 // clean.rs:2245-2321 (FRONTIER cut-set)
-CASE(relaxed_computes_local_bounds_and_thresholds_2) {
+template <class DD, class DDC>
+static void relaxed_computes_local_bounds_and_thresholds_2() {
     LocbEnv e;
-    DefaultMDDFC<char> mdd;
+    DDC mdd;
     CHECK(mdd.compile(e.input(0)).has_value());
     CHECK(!mdd.is_exact());
     CHECK(mdd.best_value() == std::optional<isize>(16));
@@ -387,9 +412,10 @@ CASE(relaxed_computes_local_bounds_and_thresholds_2) {
     CHECK(e.none('t', 4));
 }
 // clean.rs:2324-2398 (FRONTIER cut-set, best_lb = 15)
-CASE(relaxed_computes_local_bounds_and_thresholds_with_pruning) {
+template <class DD, class DDC>
+static void relaxed_computes_local_bounds_and_thresholds_with_pruning() {
     LocbEnv e;
-    DefaultMDDFC<char> mdd;
+    DDC mdd;
     CHECK(mdd.compile(e.input(15)).has_value());
     CHECK(!mdd.is_exact());
     CHECK(mdd.best_value() == std::optional<isize>(16));
@@ -592,6 +618,11 @@ CASE(knapsack_readme_instance_220) {
     CHECK(solve_kp<SeqFcNoCache>(pb, 0, 220, {0, 1, 1}, false));
     CHECK(solve_kp<Par>(pb, 0, 220, {0, 1, 1}, true));
     CHECK(solve_kp<ParFc>(pb, 0, 220, {0, 1, 1}, true));
+    // solver/mod.rs:34-47: Seq/Par(No)CachingSolverPooled (the knapsack model impacts every state: Pooled == the default DD here)
+    CHECK((solve_kp<SequentialSolver<KnapsackState, Pooled<KnapsackState>, EmptyCache<KnapsackState>>>(pb, 0, 220, {0, 1, 1}, false)));
+    CHECK((solve_kp<SequentialSolver<KnapsackState, Pooled<KnapsackState>, SimpleCache<KnapsackState>>>(pb, 0, 220, {0, 1, 1}, false)));
+    CHECK((solve_kp<ParallelSolver<KnapsackState, Pooled<KnapsackState>, EmptyCache<KnapsackState>>>(pb, 0, 220, {0, 1, 1}, true)));
+    CHECK((solve_kp<ParallelSolver<KnapsackState, Pooled<KnapsackState>, SimpleCache<KnapsackState>>>(pb, 0, 220, {0, 1, 1}, true)));
     CHECK(solve_kp<Seq>(pb, 1, 220, {0, 1, 1}, false));
     CHECK(solve_kp<Seq>(pb, 100, 220, {0, 1, 1}, false));   // README.md:246-292 uses FixedWidth(100)
 }
@@ -642,24 +673,123 @@ CASE(bitset_ord_is_lexicographic_on_members) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Pooled on a model that implements is_impacted_by (MISP, examples/misp/main.rs:145-147): the reference has no unit test with long
+// arcs (its Dummy fixtures impact every state), so these are PROPERTIES, checked against brute force on seeded random graphs:
+// exact Pooled == the optimum == exact default DD; restricted <= optimum <= relaxed; the B&B over Pooled DDs (frontier cut-set,
+// with and without cache) proves the optimum; nodes that the variable does not impact are not copied (fewer expansions).
+// ---------------------------------------------------------------------------
+static Misp random_misp(size_t n, unsigned seed, unsigned pct_edge) {
+    Misp pb;
+    pb.nb_vars = n;
+    pb.weight.resize(n);
+    uint64_t x = seed * 2654435761u + 12345u;
+    auto rnd = [&]() { x = x * 6364136223846793005ULL + 1442695040888963407ULL; return (unsigned)(x >> 33); };
+    for (size_t i = 0; i < n; ++i) pb.weight[i] = 1 + (isize)(rnd() % 5);
+    pb.neighbors.assign(n, BitSet::full(n));          // complement rows: start from "compatible with everything"
+    for (size_t a = 0; a < n; ++a)
+        for (size_t b = a + 1; b < n; ++b)
+            if (rnd() % 100 < pct_edge) {              // an edge a-b: not compatible
+                pb.neighbors[a].remove(b);
+                pb.neighbors[b].remove(a);
+            }
+    return pb;
+}
+static isize brute_force_misp(const Misp& pb) {
+    const size_t n = pb.nb_vars;
+    isize best = 0;
+    for (uint32_t m = 0; m < (1u << n); ++m) {
+        isize v = 0;
+        bool ok = true;
+        for (size_t a = 0; a < n && ok; ++a) {
+            if (!((m >> a) & 1)) continue;
+            v += pb.weight[a];
+            for (size_t b = a + 1; b < n; ++b)
+                if (((m >> b) & 1) && !pb.neighbors[a].contains(b)) { ok = false; break; }
+        }
+        if (ok && v > best) best = v;
+    }
+    return best;
+}
+template <class SolverT>
+static std::optional<isize> solve_misp_with(const Misp& pb, size_t w) {
+    MispRelax relax(pb);
+    MispRanking rank;
+    FixedWidth<BitSet> width(w);
+    EmptyDominanceChecker<BitSet> dom;
+    NoCutoff cut;
+    MaxUB<BitSet> mx(rank);
+    SimpleFringe<BitSet> fringe(mx);
+    SolverT solver(pb, relax, rank, width, dom, cut, fringe);
+    Completion c = solver.maximize();
+    if (!c.is_exact) return std::nullopt;
+    return c.best_value;
+}
+CASE(pooled_long_arcs_on_misp) {
+    for (unsigned seed = 1; seed <= 6; ++seed) {
+        Misp pb = random_misp(12 + seed % 3, seed, 20 + 10 * (seed % 4));
+        const isize opt = brute_force_misp(pb);
+        MispRelax relax(pb);
+        MispRanking rank;
+        NoCutoff nocut;
+        EmptyCache<BitSet> cache;
+        EmptyDominanceChecker<BitSet> dom;
+        SubProblem<BitSet> root = root_of(pb.initial_state());
+        auto input = [&](CompilationType t, size_t w) {
+            return CompilationInput<BitSet>{t, &pb, &relax, &rank, &nocut, w, &root, ISIZE_MIN, &cache, &dom};
+        };
+        Pooled<BitSet> pooled;
+        DefaultMDDLEL<BitSet> plain;
+        CHECK(pooled.compile(input(CompilationType::Exact, 1)).has_value());
+        CHECK(plain.compile(input(CompilationType::Exact, 1)).has_value());
+        CHECK(pooled.is_exact() && pooled.best_value() == std::optional<isize>(opt));
+        CHECK(plain.best_value() == std::optional<isize>(opt));
+        CHECK(pooled.last_counters.nodes_expanded < plain.last_counters.nodes_expanded);   // long arcs: no copies of unaffected nodes
+        // the best path is a solution of that value
+        isize v = 0;
+        const Solution best = *pooled.best_solution();
+        for (const Decision& d : best) v += d.value == MISP_YES ? pb.weight[d.variable] : 0;
+        CHECK(v == opt);
+        for (size_t w : {2, 3, 5}) {
+            Pooled<BitSet> r, x;
+            CHECK(r.compile(input(CompilationType::Restricted, w)).has_value());
+            CHECK(x.compile(input(CompilationType::Relaxed, w)).has_value());
+            CHECK(!r.best_value() || *r.best_value() <= opt);
+            CHECK(x.best_value() && *x.best_value() >= opt);
+            if (x.is_exact()) CHECK(*x.best_value() == opt);
+            // every cut-set node is an exact node with a bound that does not exceed the relaxed DD's
+            x.drain_cutset([&](SubProblem<BitSet> n) {
+                if (n.ub > *x.best_value() || n.value > opt) g_fail++;
+            });
+            using SeqP = SequentialSolver<BitSet, Pooled<BitSet>, EmptyCache<BitSet>>;
+            using SeqPC = SequentialSolver<BitSet, Pooled<BitSet>, SimpleCache<BitSet>>;
+            using ParP = ParallelSolver<BitSet, Pooled<BitSet>, EmptyCache<BitSet>>;
+            CHECK(solve_misp_with<SeqP>(pb, w) == std::optional<isize>(opt));    // SeqNoCachingSolverPooled
+            CHECK(solve_misp_with<SeqPC>(pb, w) == std::optional<isize>(opt));   // SeqCachingSolverPooled
+            CHECK(solve_misp_with<ParP>(pb, w) == std::optional<isize>(opt));    // ParNoCachingSolverPooled
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     (void)argc;
     (void)argv;
-    RUN(exact_completely_unrolls_the_mdd_no_matter_its_width);
-    RUN(restricted_drops_the_less_interesting_nodes);
-    RUN(completion_must_be_coherent_with_outcome);
-    RUN(fails_with_cutoff_when_cutoff_occurs);
-    RUN(relaxed_merges_the_less_interesting_nodes);
-    RUN(relaxed_populates_the_cutset_and_will_not_squash_first_layer);
-    RUN(exactness_flags);
-    RUN(when_the_problem_is_infeasible_there_is_no_solution);
-    RUN(skips_node_with_an_ub_less_than_best_known_lb);
-    RUN(skips_nodes_with_a_value_less_than_known_threshold);
-    RUN(computes_thresholds_when_exact);
-    RUN(computes_thresholds_when_all_pruned);
+    RUN_DD(exact_completely_unrolls_the_mdd_no_matter_its_width);
+    RUN_DD(restricted_drops_the_less_interesting_nodes);
+    RUN_DD(completion_must_be_coherent_with_outcome);
+    RUN_DD(fails_with_cutoff_when_cutoff_occurs);
+    RUN_DD(relaxed_merges_the_less_interesting_nodes);
+    RUN_DD(relaxed_populates_the_cutset_and_will_not_squash_first_layer);
+    RUN_DD(exactness_flags);
+    RUN_DD(when_the_problem_is_infeasible_there_is_no_solution);
+    RUN_DD(skips_node_with_an_ub_less_than_best_known_lb);
+    RUN_DD(skips_nodes_with_a_value_less_than_known_threshold);
+    RUN_DD(computes_thresholds_when_exact);
+    RUN_DD(computes_thresholds_when_all_pruned);
     RUN(relaxed_computes_local_bounds_and_thresholds_1);
-    RUN(relaxed_computes_local_bounds_and_thresholds_2);
-    RUN(relaxed_computes_local_bounds_and_thresholds_with_pruning);
+    RUN_DD(relaxed_computes_local_bounds_and_thresholds_2);
+    RUN_DD(relaxed_computes_local_bounds_and_thresholds_with_pruning);
     RUN(nodup_pop_off_an_empty_fringe_is_none);
     RUN(nodup_pops_largest_ub_then_lp);
     RUN(nodup_keeps_the_copy_with_longest_path);
@@ -671,6 +801,7 @@ int main(int argc, char** argv) {
     RUN(knapsack_readme_instance_220);
     RUN(knapsack_seven_items);
     RUN(bitset_ord_is_lexicographic_on_members);
+    RUN(pooled_long_arcs_on_misp);
     std::printf("%s (%d failure%s)\n", g_fail ? "FAILED" : "ALL OK", g_fail, g_fail == 1 ? "" : "s");
     return g_fail;
 }

@@ -141,8 +141,9 @@ void oracle_misp_export(void* hh, uint64_t* rows, int64_t* weights) {
 /// Full branch-and-bound.  width == 0 -> NbUnassignedWidth (the policy of examples/misp/tests.rs);
 /// nthreads == 0 -> SequentialSolver, else ParallelSolver with that many threads;
 /// timeout_s <= 0 -> NoCutoff.  solution: (variable,value) pairs sorted by variable, capacity 2*n int64.
-int oracle_misp_solve(void* hh, uint64_t width, int nthreads, double timeout_s, oracle_solve_out* out,
-                      int64_t* solution) {
+}  // extern "C"
+template <class DD>
+static int misp_solve_with(void* hh, uint64_t width, int nthreads, double timeout_s, oracle_solve_out* out, int64_t* solution) {
     auto* h = (MispHandle*)hh;
     Misp& pb = h->pb;
     MispRelax relax(pb);
@@ -162,7 +163,7 @@ int oracle_misp_solve(void* hh, uint64_t width, int nthreads, double timeout_s, 
     std::optional<Solution> sol;
     MddCounters cnt;
     if (nthreads <= 0) {
-        SequentialSolver<BitSet> s(pb, relax, rank, w, dom, cut, fringe);
+        SequentialSolver<BitSet, DD> s(pb, relax, rank, w, dom, cut, fringe);
         c = s.maximize();
         out->best_lb = s.best_lower_bound();
         out->best_ub = s.best_upper_bound();
@@ -170,7 +171,7 @@ int oracle_misp_solve(void* hh, uint64_t width, int nthreads, double timeout_s, 
         sol = s.best_solution();
         cnt = s.counters();
     } else {
-        ParallelSolver<BitSet> s(pb, relax, rank, w, dom, cut, fringe, (size_t)nthreads);
+        ParallelSolver<BitSet, DD> s(pb, relax, rank, w, dom, cut, fringe, (size_t)nthreads);
         c = s.maximize();
         out->best_lb = s.best_lower_bound();
         out->best_ub = s.best_upper_bound();
@@ -196,6 +197,14 @@ int oracle_misp_solve(void* hh, uint64_t width, int nthreads, double timeout_s, 
         }
     }
     return 0;
+}
+extern "C" {
+int oracle_misp_solve(void* hh, uint64_t width, int nthreads, double timeout_s, oracle_solve_out* out, int64_t* solution) {
+    return misp_solve_with<DefaultMDDLEL<BitSet>>(hh, width, nthreads, timeout_s, out, solution);
+}
+/// the same search over Pooled DDs (solver/mod.rs:34, :43: Par / SeqNoCachingSolverPooled; mdd/pooled.rs)
+int oracle_misp_solve_pooled(void* hh, uint64_t width, int nthreads, double timeout_s, oracle_solve_out* out, int64_t* solution) {
+    return misp_solve_with<Pooled<BitSet>>(hh, width, nthreads, timeout_s, out, solution);
 }
 
 // ---- traced sequential solve: every compile() recorded for replay on the GPU -------------------

@@ -83,10 +83,12 @@ class MispInstance:
             s[i // 64] |= np.uint64(1) << np.uint64(i % 64)
         return s
 
-    def solve(self, width=0, nthreads=0, timeout=0.0):
+    def solve(self, width=0, nthreads=0, timeout=0.0, pooled=False):
+        """pooled=True: the same search over Pooled DDs (mdd/pooled.rs; solver/mod.rs:34-47)"""
         out = SolveOut()
         sol = np.zeros(2 * self.n + 2, dtype=np.int64)
-        self.L.oracle_misp_solve(self.h, width, nthreads, timeout, C.byref(out), sol.ctypes.data_as(C.c_void_p))
+        fn = self.L.oracle_misp_solve_pooled if pooled else self.L.oracle_misp_solve
+        fn(self.h, width, nthreads, timeout, C.byref(out), sol.ctypes.data_as(C.c_void_p))
         d = out.asdict()
         d["solution"] = [(int(sol[2 * i]), int(sol[2 * i + 1])) for i in range(out.n_solution)]
         return d
@@ -129,6 +131,7 @@ class Oracle:
         L.oracle_misp_state_words.argtypes = [C.c_void_p]
         L.oracle_misp_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_misp_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.POINTER(SolveOut), C.c_void_p]
+        L.oracle_misp_solve_pooled.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.POINTER(SolveOut), C.c_void_p]
         L.oracle_misp_trace_solve.restype = C.c_void_p
         L.oracle_misp_trace_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(SolveOut)]
         L.oracle_trace_free.argtypes = [C.c_void_p]
