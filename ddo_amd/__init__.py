@@ -9,4 +9,7 @@ works without a GPU (symbol checks), creating an ``Mdd``/solver without one rais
 from .binding import (  # noqa: F401
     CompilationType, Completion, Decision, DdoError, FixedWidth, LAST_EXACT_LAYER, FRONTIER, Mdd, DefaultMDD,
     DefaultMDDLEL, DefaultMDDFC, DefaultCachingSolver, SimpleCache, SimpleDominanceChecker, Tsptw, TsptwWidth, Misp, Knapsack, Mcp, Max2Sat, NbUnassignedWidth, NoCutoff, ParallelSolver, SequentialSolver, DefaultSolver, SubProblem, TimeBudget, lib,
-    library_path, device_count, ABI_SYMBOLS, HANDED_UP, MDD_ENGINES, Times, DivBy, width_heuristic)
+    library_path, device_count, ABI_SYMBOLS, HANDED_UP, MDD_ENGINES, Times, DivBy, width_heuristic,
+    ParNoCachingSolverLel, ParNoCachingSolverFc, ParCachingSolverLel, ParCachingSolverFc, SeqNoCachingSolverLel, SeqNoCachingSolverFc,
+    SeqCachingSolverLel, SeqCachingSolverFc, Pooled, ParNoCachingSolverPooled, ParCachingSolverPooled, SeqNoCachingSolverPooled,
+    SeqCachingSolverPooled)

@@ -817,3 +817,40 @@ class SequentialSolver(ParallelSolver):
         super().__init__(problem, width, cutoff=cutoff, nb_threads=1, device=device, fringe="nodup", sequential=True,
                          cutset_type=cutset_type, cache_entries=cache_entries, dominance_entries=dominance_entries)
   # solver/mod.rs:28
+
+
+# ---- the solver aliases of solver/mod.rs:29-47: (parallel | sequential) x (LEL | FC | Pooled) x (EmptyCache | SimpleCache)
+def _alias(parallel, cutset_type, caching, doc):
+    def make(problem, width, cutoff=None, nb_threads=256, device=0, cache_entries=1 << 22, **kw):
+        ce = cache_entries if caching else 0
+        if parallel:
+            return ParallelSolver(problem, width, cutoff, nb_threads=nb_threads, device=device, cutset_type=cutset_type, cache_entries=ce, **kw)
+        return SequentialSolver(problem, width, cutoff, device=device, cutset_type=cutset_type, cache_entries=ce, **kw)
+    make.__doc__ = doc
+    return make
+
+
+ParNoCachingSolverLel = _alias(True, LAST_EXACT_LAYER, False, "ParallelSolver<State, DefaultMDDLEL<State>, EmptyCache<State>> (solver/mod.rs:32)")
+ParNoCachingSolverFc = _alias(True, FRONTIER, False, "ParallelSolver<State, DefaultMDDFC<State>, EmptyCache<State>> (solver/mod.rs:33)")
+ParCachingSolverLel = _alias(True, LAST_EXACT_LAYER, True, "ParallelSolver<State, DefaultMDDLEL<State>, SimpleCache<State>> (solver/mod.rs:36)")
+ParCachingSolverFc = _alias(True, FRONTIER, True, "ParallelSolver<State, DefaultMDDFC<State>, SimpleCache<State>> (solver/mod.rs:37)")
+SeqNoCachingSolverLel = _alias(False, LAST_EXACT_LAYER, False, "SequentialSolver<State, DefaultMDDLEL<State>, EmptyCache<State>> (solver/mod.rs:41)")
+SeqNoCachingSolverFc = _alias(False, FRONTIER, False, "SequentialSolver<State, DefaultMDDFC<State>, EmptyCache<State>> (solver/mod.rs:42)")
+SeqCachingSolverLel = _alias(False, LAST_EXACT_LAYER, True, "SequentialSolver<State, DefaultMDDLEL<State>, SimpleCache<State>> (solver/mod.rs:45)")
+SeqCachingSolverFc = _alias(False, FRONTIER, True, "SequentialSolver<State, DefaultMDDFC<State>, SimpleCache<State>> (solver/mod.rs:46)")
+
+
+def _pooled_not_built(name, cite):
+    def make(*_a, **_k):
+        # fail loudly: there is no device variant of the long-arc DD (mdd/pooled.rs), and nothing here falls back to another DD type
+        raise DdoError(f"{name} ({cite}): Pooled decision diagrams are not built on the device (DESIGN.md section 7); "
+                       "use the Lel / Fc aliases")
+    make.__doc__ = f"`{name}` of the reference ({cite}): NOT available -- raises DdoError"
+    return make
+
+
+Pooled = _pooled_not_built("Pooled", "mdd/pooled.rs:117")
+ParNoCachingSolverPooled = _pooled_not_built("ParNoCachingSolverPooled", "solver/mod.rs:34")
+ParCachingSolverPooled = _pooled_not_built("ParCachingSolverPooled", "solver/mod.rs:38")
+SeqNoCachingSolverPooled = _pooled_not_built("SeqNoCachingSolverPooled", "solver/mod.rs:43")
+SeqCachingSolverPooled = _pooled_not_built("SeqCachingSolverPooled", "solver/mod.rs:47")

@@ -203,3 +203,16 @@ def test_width_heuristics_known_answers():
     import pytest
     with pytest.raises(ZeroDivisionError):                                       # width.rs:1073: DivBy(0, ..) panics
         DivBy(0, FixedWidth(3))
+
+
+def test_solver_aliases_of_the_reference():
+    """solver/mod.rs:29-47: fourteen aliases, (parallel | sequential) x (LEL | FC | Pooled) x (EmptyCache | SimpleCache), plus the two
+    defaults.  The ten the device has exist under the reference's names; the four Pooled ones (and `Pooled` itself) refuse loudly --
+    no silent substitution of another DD type (the pooled DD lives in the oracle only)."""
+    built = ["DefaultSolver", "DefaultCachingSolver", "ParNoCachingSolverLel", "ParNoCachingSolverFc", "ParCachingSolverLel", "ParCachingSolverFc",
+             "SeqNoCachingSolverLel", "SeqNoCachingSolverFc", "SeqCachingSolverLel", "SeqCachingSolverFc"]
+    for name in built:
+        assert callable(getattr(ddo_amd, name)), name
+    for name in ["Pooled", "ParNoCachingSolverPooled", "ParCachingSolverPooled", "SeqNoCachingSolverPooled", "SeqCachingSolverPooled"]:
+        with pytest.raises(ddo_amd.DdoError, match="not built on the device"):
+            getattr(ddo_amd, name)(None, ddo_amd.FixedWidth(10))
