@@ -483,10 +483,12 @@ void oracle_trace_get_cutset(void* t, uint64_t i, uint64_t* states, int64_t* val
 // ---- one compile() on an arbitrary residual sub-problem -----------------------------------------
 /// comp_type: 0 Exact, 1 Relaxed, 2 Restricted.  Cut-set buffers sized by the caller (cap entries).
 /// Returns the number of cut-set entries (or -1 when cap is too small).
-int64_t oracle_misp_compile(void* hh, int comp_type, uint64_t width, int64_t best_lb, const uint64_t* state,
-                            int64_t value, uint64_t depth, oracle_trace_hdr* hdr, uint64_t cap, uint64_t* cs_states,
-                            int64_t* cs_value, int64_t* cs_ub, uint64_t* cs_depth, int64_t* best_path,
-                            int64_t* n_best_path) {
+}  // extern "C"
+template <class DD>
+static int64_t misp_compile_with(void* hh, int comp_type, uint64_t width, int64_t best_lb, const uint64_t* state,
+                                 int64_t value, uint64_t depth, oracle_trace_hdr* hdr, uint64_t cap, uint64_t* cs_states,
+                                 int64_t* cs_value, int64_t* cs_ub, uint64_t* cs_depth, int64_t* best_path,
+                                 int64_t* n_best_path) {
     auto* h = (MispHandle*)hh;
     Misp& pb = h->pb;
     MispRelax relax(pb);
@@ -503,7 +505,7 @@ int64_t oracle_misp_compile(void* hh, int comp_type, uint64_t width, int64_t bes
     node.ub = ISIZE_MAX;
     CompilationInput<BitSet> in{(CompilationType)comp_type, &pb, &relax, &rank, &nocut, width, &node, best_lb,
                                 &cache, &dom};
-    DefaultMDDLEL<BitSet> mdd;
+    DD mdd;
     auto c = mdd.compile(in);
     if (!c) return -2;
     Trace tr;
@@ -543,6 +545,20 @@ int64_t oracle_misp_compile(void* hh, int comp_type, uint64_t width, int64_t bes
         std::memcpy(cs_depth, r.cs_depth.data(), r.cs_depth.size() * sizeof(uint64_t));
     }
     return (int64_t)r.cs_value.size();
+}
+extern "C" {
+int64_t oracle_misp_compile(void* hh, int comp_type, uint64_t width, int64_t best_lb, const uint64_t* state, int64_t value, uint64_t depth,
+                            oracle_trace_hdr* hdr, uint64_t cap, uint64_t* cs_states, int64_t* cs_value, int64_t* cs_ub, uint64_t* cs_depth,
+                            int64_t* best_path, int64_t* n_best_path) {
+    return misp_compile_with<DefaultMDDLEL<BitSet>>(hh, comp_type, width, best_lb, state, value, depth, hdr, cap, cs_states, cs_value, cs_ub, cs_depth,
+                                                    best_path, n_best_path);
+}
+/// the same compile as a Pooled DD (mdd/pooled.rs): its cut-set is the frontier, whatever the DD type of the caller
+int64_t oracle_misp_compile_pooled(void* hh, int comp_type, uint64_t width, int64_t best_lb, const uint64_t* state, int64_t value, uint64_t depth,
+                                   oracle_trace_hdr* hdr, uint64_t cap, uint64_t* cs_states, int64_t* cs_value, int64_t* cs_ub, uint64_t* cs_depth,
+                                   int64_t* best_path, int64_t* n_best_path) {
+    return misp_compile_with<Pooled<BitSet>>(hh, comp_type, width, best_lb, state, value, depth, hdr, cap, cs_states, cs_value, cs_ub, cs_depth,
+                                             best_path, n_best_path);
 }
 
 // ---- knapsack (config C1: plumbing, CPU only) ----------------------------------------------------

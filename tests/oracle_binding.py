@@ -99,10 +99,13 @@ class MispInstance:
         t = self.L.oracle_misp_trace_solve(self.h, width, max_compiles, C.byref(out))
         return out.asdict(), read_trace(self.L, t, self.ws)
 
-    def compile(self, comp_type, width, best_lb, state, value, depth):
-        """One compile() of an arbitrary residual sub-problem -> canonical record (+ best path)."""
+    def compile(self, comp_type, width, best_lb, state, value, depth, pooled=False):
+        """One compile() of an arbitrary residual sub-problem -> canonical record (+ best path).  pooled=True: as a Pooled DD
+        (mdd/pooled.rs; frontier cut-set, which a width does not bound)."""
         hdr = TraceHdr()
         cap = int(width) + 8 if width < (1 << 40) else 1 << 16
+        if pooled:
+            cap = 1 << 18
         st = np.ascontiguousarray(state, dtype=np.uint64)
         cs = np.zeros(cap * self.ws, dtype=np.uint64)
         cv = np.zeros(cap, dtype=np.int64)
@@ -110,7 +113,8 @@ class MispInstance:
         cd = np.zeros(cap, dtype=np.uint64)
         bp = np.zeros(2 * self.n + 2, dtype=np.int64)
         nbp = C.c_int64(0)
-        k = self.L.oracle_misp_compile(self.h, comp_type, width, best_lb, st.ctypes.data_as(C.c_void_p), value, depth,
+        fn = self.L.oracle_misp_compile_pooled if pooled else self.L.oracle_misp_compile
+        k = fn(self.h, comp_type, width, best_lb, st.ctypes.data_as(C.c_void_p), value, depth,
                                        C.byref(hdr), cap, cs.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
                                        cu.ctypes.data_as(C.c_void_p), cd.ctypes.data_as(C.c_void_p),
                                        bp.ctypes.data_as(C.c_void_p), C.byref(nbp))
@@ -139,10 +143,11 @@ class Oracle:
         L.oracle_trace_len.argtypes = [C.c_void_p]
         L.oracle_trace_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(TraceHdr), C.c_void_p]
         L.oracle_trace_get_cutset.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.oracle_misp_compile.restype = C.c_int64
-        L.oracle_misp_compile.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_int64, C.c_uint64,
-                                          C.POINTER(TraceHdr), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        for fn in (L.oracle_misp_compile, L.oracle_misp_compile_pooled):
+            fn.restype = C.c_int64
+            fn.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_int64, C.c_uint64,
+                           C.POINTER(TraceHdr), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.oracle_knapsack_solve.restype = C.c_int64
         L.oracle_knapsack_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int,
                                             C.c_void_p, C.POINTER(SolveOut)]

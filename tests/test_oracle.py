@@ -207,3 +207,28 @@ def test_tsptw_config_c5_instance(oracle):
     v, info = oracle.tsptw_file(data_path("tsptw", "Langevin", "N40ft201.dat"), 1, 4)
     assert np.float32(-v) / np.float32(10000.0) == np.float32(1109.30)
     assert info["tour_length"] == -v
+
+
+def _pooled_cases():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "misp_pooled_golden.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", _pooled_cases(), ids=lambda c: c["id"])
+def test_pooled_compiles_against_the_golden_vectors(oracle, case):
+    """single compiles as POOLED DDs (oracle Pooled<S>, pooled.rs:117-823) against tests/golden/misp_pooled_golden.json
+    (made by tests/golden/make_pooled_golden.py): the fixture a device variant of the pooled DD has to hit."""
+    import numpy as np
+    from tests.parity_util import cutset_digest
+    inst = oracle.misp(data_path("misp", case["instance"] + ".clq"))
+    state = np.array([int(x) for x in case["state"]], dtype=np.uint64)
+    r = inst.compile(case["comp_type"], case["width"], case["best_lb"], state, case["value"], case["depth"], pooled=True)
+    for k in ["is_exact", "best_value", "best_exact_value", "nodes_expanded", "arcs", "layers"]:
+        assert r[k] == case[k], (case["id"], k, r[k], case[k])
+    assert len(r["cutset"]) == case["n_cutset"] and cutset_digest(r["cutset"]) == case["cutset_digest"]
+    assert [list(p) for p in r["best_path"]] == case["best_path"]
+    # what any DD of the sub-problem must satisfy: the best path is an independent set worth best_value - value
+    if r["best_value"] is not None:
+        chosen = [v for v, x in r["best_path"] if x == 1]
+        assert int(sum(inst.weights[v] for v in chosen)) == r["best_value"] - case["value"] or not r["is_exact"]
