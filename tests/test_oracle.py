@@ -43,7 +43,9 @@ def test_misp_known_optimum(oracle, name, expected):
 
 
 # hamming8-2 is left out: the pooled relaxation of its root is weaker (134 against the default DD's exact 128 -- sound, but the
-# search that follows runs for minutes where the default DD proves the optimum at the root); brock200_2 is in the next test
+# search that follows runs for minutes where the default DD proves the optimum at the root: MISP branches on the variable the
+# fewest states contain, so a pooled layer stays below the width for a long time, nothing is merged, the pool grows -- and meets
+# the small widths NbUnassignedWidth leaves for the last layers all at once); brock200_2 is in the next test
 @pytest.mark.parametrize("name,expected", sorted((k, v) for k, v in MISP_KATS.items() if k not in ("brock200_2", "hamming8-2")))
 @pytest.mark.parametrize("nthreads", [0, 4], ids=["sequential", "4-threads"])
 def test_misp_known_optimum_over_pooled_dds(oracle, name, expected, nthreads):
