@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "ddo_model_nb_variables", "ddo_model_state_words", "ddo_model_initial_state", "ddo_model_initial_value",
     "ddo_model_compare_states", "ddo_model_export_misp", "ddo_mdd_create", "ddo_mdd_destroy", "ddo_mdd_compile",
     "ddo_mdd_compile_batch", "ddo_mdd_is_exact", "ddo_mdd_best_value", "ddo_mdd_best_exact_value",
-    "ddo_mdd_best_solution", "ddo_mdd_best_exact_solution", "ddo_mdd_drain_cutset", "ddo_mdd_last_counters",
+    "ddo_mdd_best_solution", "ddo_mdd_best_exact_solution", "ddo_mdd_drain_cutset", "ddo_mdd_last_counters", "ddo_mdd_combine_stats",
     "ddo_solver_create", "ddo_width_heuristic", "ddo_solver_destroy", "ddo_solver_maximize", "ddo_solver_best_value",
     "ddo_solver_best_solution", "ddo_solver_best_lower_bound", "ddo_solver_best_upper_bound", "ddo_solver_set_primal",
     "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_flush",
@@ -30,7 +30,7 @@ DDO_OK, DDO_CUTOFF = 0, 2
 LAST_EXACT_LAYER, FRONTIER = 1, 2
 MDD_CACHING = 0x10
 DDO_HANDED_UP = 3
-MDD_ENGINES = {"full": 0, "dense": 0x100, "tier0": 0x200, "tier1": 0x300}   # DDO_MDD_ENGINE_* (include/ddo_hip.h)
+MDD_ENGINES = {"auto": 0, "full": 0x400, "dense": 0x100, "tier0": 0x200, "tier1": 0x300}   # DDO_MDD_ENGINE_* (include/ddo_hip.h)
 
 
 class _HandedUp:
@@ -158,6 +158,7 @@ def lib():
     L.ddo_mdd_best_exact_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
     L.ddo_mdd_drain_cutset.argtypes = [C.c_void_p, _CUTSET_CB, C.c_void_p]
     L.ddo_mdd_last_counters.argtypes = [C.c_void_p, C.POINTER(_Counters)]
+    L.ddo_mdd_combine_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.ddo_solver_create.restype = C.c_void_p
     L.ddo_solver_create.argtypes = [C.c_void_p, C.POINTER(_SolverConfig)]
     L.ddo_width_heuristic.restype = C.c_size_t
@@ -533,7 +534,7 @@ class Mdd:
     """`impl DecisionDiagram for Mdd<T, CUTSET_TYPE>` (mdd.rs:75-114) on the device: LAST_EXACT_LAYER or FRONTIER cut-set;
     caching=True lets compile() take a SimpleCache."""
 
-    def __init__(self, model, max_width, device=0, cutset_type=LAST_EXACT_LAYER, caching=False, engine="full"):
+    def __init__(self, model, max_width, device=0, cutset_type=LAST_EXACT_LAYER, caching=False, engine="auto"):
         self.model = model
         self._h = lib().ddo_mdd_create(model._h, device, cutset_type | (MDD_CACHING if caching else 0) | MDD_ENGINES[engine], int(max_width))
         if not self._h:
@@ -624,6 +625,12 @@ class Mdd:
         if rc != DDO_OK:
             raise DdoError(f"ddo_mdd_drain_cutset rc={rc}: {_err()}")
         return out
+
+    def combine_stats(self):
+        """(device launches, compiles, kernel ms) that went through the combining layer of this mdd's engine (include/ddo_hip.h)"""
+        a, b, k = C.c_uint64(), C.c_uint64(), C.c_double()
+        lib().ddo_mdd_combine_stats(self._h, C.byref(a), C.byref(b), C.byref(k))
+        return a.value, b.value, k.value
 
     def counters(self):
         c = _Counters()

@@ -32,6 +32,8 @@ constexpr uint32_t IN_FRONTIER = 16u;      // CUTSET_TYPE == FRONTIER (clean.rs:
 constexpr uint32_t IN_CACHE = 32u;         // SimpleCache behind the compile: _filter_with_cache, thresholds, cache updates
 constexpr uint32_t IN_MUST_EXPLORE = 64u;  // solver pop: Cache::must_explore first (sequential.rs:341, parallel.rs:537); ST_SKIPPED when it says no
 constexpr uint32_t IN_DOMINANCE = 256u;     // SimpleDominanceChecker behind the compile: _filter_with_dominance (clean.rs:689-708)
+constexpr uint32_t IN_PATH_BITS = 512u;     // in-place engine, cut-set into the arena: paths as BIT rows (one decision bit per layer, ceil(lel / 64) words per node)
+                                             // plus the branching variables once per DD (DDResult::cs_lvar_off) instead of one u32 per decision and node
 constexpr uint32_t IN_MARK_EXPLORED = 128u; // ... and update_threshold(state, depth, value, true) when it says yes (parallel.rs:538 only)
 constexpr uint64_t NO_POOL_SRC = ~0ULL;    // DDInput.src_off: the residual state is inline (not a pool row)
 
@@ -72,6 +74,9 @@ struct DDInput {
 // DDResult.status
 constexpr int ST_OK = 0, ST_CUTOFF = 1, ST_ERR_CAPACITY = -3, ST_ERR_INTERNAL = -5, ST_NOT_RUN = 77;
 constexpr int ST_SKIPPED = 79; // IN_MUST_EXPLORE: the cache says this sub-problem need not be explored (cache.rs:32-39)
+// a DD of the layer-keeping mode outgrew its slot's pool of kept layers / of arcs (EngineParams::lpool_nodes / apool_arcs): a capacity
+// error that enlarging the output arena does not cure (DDO_HIP_LPOOL_M / DDO_HIP_APOOL_M do)
+constexpr int ST_ERR_LPOOL = ST_ERR_CAPACITY - 2100, ST_ERR_APOOL = ST_ERR_CAPACITY - 2200;
 constexpr int ST_RETRY = 78;   // capacity tier: the DD outgrew this tier's node slots (host: compile it on the next tier)
 
 /// Everything observable about one compiled DD (clean.rs:237-266).  Variable
@@ -109,6 +114,9 @@ struct DDResult {
     uint64_t cs_depth_off;         // frontier cut-set: n_cutset x i32, layer of every node below the DD's root (0: all at `lel`)
     int32_t cs_path_stride;        // u32 words per row of the cut-set paths (lel, or n_layers - 1 for a frontier cut-set)
     uint32_t cache_hits;           // nodes removed by _filter_with_cache
+    uint64_t cs_lvar_off;          // 0: cut-set paths are u32 rows (above).  Else (IN_PATH_BITS) the rows at cs_path_off are bit strings --
+                                   // (cs_path_stride + 63) / 64 u64 words per node, bit tr = decision of transition tr -- and the variables
+                                   // branched on, u32[cs_path_stride], lie at this offset
     // LAST: only downloaded when DDO_HIP_STATS asks for the clocks (the records of a launch cross PCIe: 176 instead of 432 bytes)
     uint64_t phase_clk[32];        // shader-clock ticks per phase [0..8), per code mark [8..24), thread-0 probes inside expand [24..32) (profiling aid; engine 2)
 };

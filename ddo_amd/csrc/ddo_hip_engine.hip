@@ -33,6 +33,11 @@ namespace ddo_hip {
 static std::atomic<uint64_t> g_launch_ns[8];   // (engines are launched from several host threads)
 static std::atomic<uint64_t> g_launch_n{0};
 static const bool g_times_on = std::getenv("DDO_HIP_TIMES") != nullptr;
+// combining layer (Engine::lead / combined_launch), host seconds by section: window, staging + launch, kernel wait, hand-out, idle
+// between the end of a launch and the start of the next leader's window
+static std::atomic<uint64_t> g_cq_ns[6];
+static std::atomic<int64_t> g_cq_last_end{0};
+static inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 
 // Launch order of a batch on the in-place engine: sub-problems by decreasing number of vertices left in their residual state -- a
@@ -217,6 +222,7 @@ std::shared_ptr<Engine> Engine::create_tier(Model* model, int device, Engine* ow
 
 std::shared_ptr<Engine> Engine::get_selected(Model* model, int device, long max_width, int selector) {
     std::lock_guard<std::mutex> g(model->mtx);
+    if (selector == 0) selector = DDO_MDD_ENGINE_DENSE;   // ddo_mdd_create without a selector: dense first, its owner as the fallback
     auto key = std::make_pair(device, max_width * 8 + (long)(4 + (selector >> 8)));   // (features of Engine::get stay below 4)
     auto it = model->engines.find(key);
     if (it != model->engines.end()) {
@@ -660,6 +666,12 @@ Engine::~Engine() {
         std::fprintf(stderr, "[ddo times] launch() host s over %llu launches: checks %.3f, inputs %.3f, launch order %.3f, parameters + rewind %.3f, first event %.3f, pool growth %.3f, kernel %.3f, result copies %.3f\n",
                      nl, t0, t1, t2, t6, t7, t3, t4, t5);
     }
+    if (g_times_on && cq_launches_.load() > 0) {
+        auto sec = [](int k) { return (double)g_cq_ns[k].exchange(0) * 1e-9; };
+        const double a = sec(0), b = sec(1), c = sec(2), d = sec(3), e = sec(4);
+        std::fprintf(stderr, "[ddo times] combining layer, %llu launches of %llu compiles: window %.3f s, staging + launch %.3f, kernel wait %.3f, hand-out %.3f, no leader %.3f\n",
+                     (unsigned long long)cq_launches_.load(), (unsigned long long)cq_requests_.load(), a, b, c, d, e);
+    }
     if (device_ >= 0) (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize((hipStream_t)stream_);
     for (void* p : allocs_) (void)hipFree(p);
@@ -676,7 +688,7 @@ Engine::~Engine() {
 }
 
 void Engine::set_cutoff(bool on) {
-    std::lock_guard<std::mutex> g(mtx_);
+    std::lock_guard<std::mutex> g(cut_mtx_);   // (not mtx_: wait() holds that while the driver sleeps on a long kernel -- ADVICE r04)
     int32_t v = on ? 1 : 0;
     (void)hipSetDevice(device_);
     (void)hipMemcpy((uint8_t*)d_counters_ + 16, &v, 4, hipMemcpyHostToDevice);
@@ -934,8 +946,16 @@ void Engine::decode(const DDResult& r, const uint8_t* arena, HostResult& out) co
         out.cs_value.assign(v, v + r.n_cutset);
         const int32_t* u = (const int32_t*)(base + r.cs_ub_off);
         out.cs_ub.assign(u, u + r.n_cutset);
-        const uint32_t* pth = (const uint32_t*)(base + r.cs_path_off);
-        out.cs_path.assign(pth, pth + (size_t)r.n_cutset * out.cs_path_len);
+        if (r.cs_lvar_off) {   // IN_PATH_BITS
+            out.cs_pw = (out.cs_path_len + 63) / 64;
+            const uint64_t* pb = (const uint64_t*)(base + r.cs_path_off);
+            out.cs_pbits.assign(pb, pb + (size_t)r.n_cutset * out.cs_pw);
+            const uint32_t* lv = (const uint32_t*)(base + r.cs_lvar_off);
+            out.cs_lvar.assign(lv, lv + out.cs_path_len);
+        } else {
+            const uint32_t* pth = (const uint32_t*)(base + r.cs_path_off);
+            out.cs_path.assign(pth, pth + (size_t)r.n_cutset * out.cs_path_len);
+        }
         if (r.cs_depth_off) {
             const int32_t* dp = (const int32_t*)(base + r.cs_depth_off);
             out.cs_depth.assign(dp, dp + r.n_cutset);
@@ -959,6 +979,7 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
     // parallel.rs:576-602).  The asynchronous launch()/wait()/fetch() path belongs to the lazy solver, which owns a
     // private engine.
     std::lock_guard<std::mutex> batch_guard(batch_mtx_);
+    wait_decoders(-1);   // (callers of the combining layer may still read the previous launches' buffers)
     int rc = launch(inputs, count, cache, dom);
     if (rc != DDO_OK) return rc;
     bool raised = false;
@@ -980,16 +1001,326 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
 int Engine::run_solo_growing(const DDInput& input, std::vector<HostResult>& results, const CacheTable* cache, const DominanceTable* dom) {
     auto capacity = [](const HostResult& r) { return r.hdr.status == ST_ERR_CAPACITY || r.hdr.status <= -100; };
     std::lock_guard<std::mutex> batch_guard(batch_mtx_);
+    wait_decoders(-1);
     for (;;) {
         results.assign(2, HostResult());
         int rc = launch(&input, 1, cache, dom);
         if (rc == DDO_OK) rc = collect(results);
         if (rc != DDO_OK) return rc;
         if (!(capacity(results[0]) || capacity(results[1])) || arena_cap_ >= (8ull << 30)) return DDO_OK;
-        auto pools = [](const HostResult& r) { return r.hdr.status == ST_ERR_CAPACITY - 2100 || r.hdr.status == ST_ERR_CAPACITY - 2200; };
+        auto pools = [](const HostResult& r) { return r.hdr.status == ST_ERR_LPOOL || r.hdr.status == ST_ERR_APOOL; };
         if (pools(results[0]) || pools(results[1])) return DDO_OK;   // the layer pools, not the arena: growing the arena does not help
         if ((rc = grow_arena(arena_cap_ * 4)) != DDO_OK) return rc;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Combining layer under ddo_mdd_compile (engine.hpp: compile_combined)
+// ---------------------------------------------------------------------------
+struct Engine::Waiter {   // one per compile_combined call
+    std::mutex m;
+    std::condition_variable cv;
+    int remaining = 0;    // requests of this call that are not finished
+    bool lead = false;    // "you are the leader now"
+};
+
+void Engine::wait_decoders(int set) {
+    std::unique_lock<std::mutex> lk(dec_mtx_);
+    dec_cv_.wait(lk, [&] { return set < 0 ? decoders_[0] + decoders_[1] == 0 : decoders_[set] == 0; });
+}
+void Engine::release_set(int set) {
+    std::lock_guard<std::mutex> lk(dec_mtx_);
+    if (--decoders_[set] == 0) dec_cv_.notify_all();
+}
+
+void Engine::decode_checked(const DDResult& r, const uint8_t* arena, size_t arena_used, HostResult& out) const {
+    if (r.status == ST_NOT_RUN) {
+        out.clear();
+        out.hdr = r;
+        return;
+    }
+    if (r.status == ST_OK && r.arena_off + r.arena_bytes > arena_used) {
+        out.clear();
+        out.hdr = r;
+        out.hdr.status = ST_ERR_CAPACITY;
+        out.valid = true;
+        return;
+    }
+    decode(r, arena, out);
+}
+
+void Engine::finish_req(CompileReq* r, int state) {
+    Waiter* w = r->waiter;
+    std::lock_guard<std::mutex> lk(w->m);   // (notify under the lock: the waiter lives on the caller's stack)
+    r->state = state;
+    if (--w->remaining == 0) w->cv.notify_one();
+}
+
+/// What a finished launch leaves to be handed to the callers: done AFTER the next leader has been named, so that waking a
+/// thousand threads overlaps the next launch instead of delaying it.
+struct Engine::HandOut {
+    RawBatch raw;
+    std::vector<std::pair<CompileReq*, int>> done;   // (request, its index in the launch)
+    int own = 0;                                      // requests of the leader itself among them
+};
+
+/// Hands the finished requests to their callers, who decode them out of the pinned buffers of the launch's set (in parallel; the
+/// set is not launched into again before they are done: decoders_).  The leader's own requests are decoded right here: a caller
+/// that leads never sits on undecoded results, so waiting for a set's decoders cannot wait for the leader itself.
+void Engine::hand_out(HandOut& ho, Waiter* me) {
+    for (auto& [r, i] : ho.done) {
+        const DDResult* h = ho.raw.hdr + (size_t)i * 2;
+        if (r->in.flags & IN_FUSED) decode_checked(h[1], ho.raw.arena, ho.raw.arena_used, r->out[1]);
+        if (r->waiter == me) {
+            decode_checked(h[0], ho.raw.arena, ho.raw.arena_used, r->out[0]);
+            release_set(ho.raw.set);
+            finish_req(r, 3);
+            continue;
+        }
+        r->hdr = h[0];
+        r->arena = ho.raw.arena;
+        r->arena_used = ho.raw.arena_used;
+        r->set = ho.raw.set;
+        finish_req(r, 2);
+    }
+    ho.done.clear();
+    ho.own = 0;
+}
+
+/// One launch for `batch` (compatible requests: same cache and dominance tables).  Finished requests end up in `ho` (the caller
+/// hands them out), requests that must run again (cut by another caller's flag, output arena full) come back in `again`.
+int Engine::combined_launch(std::vector<CompileReq*>& batch, std::vector<CompileReq*>& again, Waiter* me, HandOut& ho) {
+    const int n = (int)batch.size();
+    auto fail_all = [&](int rc) {
+        for (CompileReq* r : batch) {
+            r->rc = rc;
+            finish_req(r, 3);
+        }
+        return rc;
+    };
+    std::vector<DDInput> din((size_t)n);
+    for (int i = 0; i < n; ++i) din[(size_t)i] = batch[(size_t)i]->in;
+    std::unique_lock<std::mutex> bg(batch_mtx_);
+    // The compiles of a launch share the output arena.  What the previous launches wrote per compile predicts what this one
+    // needs: an arena that would overflow grows BEFORE the launch (once, to the next power of two, up to 8 GB per buffer set)
+    // instead of after a launch whose compiles then run twice.
+    if (cq_bytes_per_req_ > 0 && arena_cap_ < (8ull << 30)) {
+        const double need = (double)n * cq_bytes_per_req_ * 1.25;
+        if (need > (double)arena_cap_) {
+            size_t cap = arena_cap_;
+            while ((double)cap < need && cap < (8ull << 30)) cap *= 2;
+            wait_decoders(-1);   // both arenas are freed and allocated again at the next launches
+            (void)grow_arena(cap);
+        }
+    }
+    int set;
+    {
+        std::lock_guard<std::mutex> g(mtx_);
+        set = next_set_;
+    }
+    wait_decoders(set);   // the launch before the previous one lies in this buffer set: its callers must have decoded
+    const int64_t tq0 = g_times_on ? now_ns() : 0;
+    int rc = launch(din.data(), n, batch[0]->cache, batch[0]->dom);
+    if (rc != DDO_OK) return fail_all(rc);
+    const int64_t tq1 = g_times_on ? now_ns() : 0;
+    bool raised = false, any = false;
+    for (CompileReq* r : batch) any |= r->stop != nullptr;
+    while (any && !raised && !kernel_done()) {
+        for (int i = 0; i < n && !raised; ++i)
+            if (batch[(size_t)i]->stop && *batch[(size_t)i]->stop) raised = true;
+        if (raised) pool_owner()->set_cutoff(true);
+        else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    rc = wait();
+    if (raised) pool_owner()->set_cutoff(false);
+    if (rc != DDO_OK) return fail_all(rc);
+    const int64_t tq2 = g_times_on ? now_ns() : 0;
+    cq_last_ms_ = last_kernel_ms_;
+    RawBatch& raw = ho.raw;
+    if ((rc = fetch_raw(raw)) != DDO_OK || raw.count != n) return fail_all(rc != DDO_OK ? rc : DDO_ERR_INTERNAL);
+    cq_launches_.fetch_add(1);
+    cq_requests_.fetch_add((uint64_t)n);
+    cq_kernel_us_.fetch_add((uint64_t)(last_kernel_ms_ * 1000.0));
+    auto overflow = [&](const DDResult& r) {   // the shared output arena (not the per-slot pools of kept layers: those do not grow)
+        if (r.status == ST_OK) return r.arena_off + r.arena_bytes > raw.arena_used;
+        return r.status == ST_ERR_CAPACITY || (r.status <= -100 && r.status != ST_ERR_LPOOL && r.status != ST_ERR_APOOL);
+    };
+    bool foreign_cut = false;
+    int n_over = 0, n_ok = 0;
+    uint64_t bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        CompileReq* r = batch[(size_t)i];
+        const DDResult& h0 = raw.hdr[(size_t)i * 2];
+        const DDResult& h1 = raw.hdr[(size_t)i * 2 + 1];
+        const bool fused = (r->in.flags & IN_FUSED) != 0;
+        bytes += h0.arena_bytes + (fused && h1.status != ST_NOT_RUN ? h1.arena_bytes : 0);
+        const bool cut = h0.status == ST_CUTOFF || (fused && h1.status == ST_CUTOFF);
+        if (cut && !(r->stop && *r->stop)) {   // stopped by somebody else's flag: not this compile's business
+            foreign_cut |= !raised;
+            again.push_back(r);
+            continue;
+        }
+        if (overflow(h0) || (fused && h1.status != ST_NOT_RUN && overflow(h1))) {
+            ++n_over;
+            again.push_back(r);
+            continue;
+        }
+        ++n_ok;
+        ho.done.emplace_back(r, i);
+        ho.own += r->waiter == me;
+    }
+    cq_bytes_per_req_ = std::max(0.9 * cq_bytes_per_req_, (double)bytes / (double)n);
+    {
+        std::lock_guard<std::mutex> lk(dec_mtx_);
+        decoders_[raw.set] += (int)ho.done.size();   // (the leader's own included: it decodes them in hand_out, after the next leader may have started)
+    }
+    if (n_over) {
+        // Requests that did not fit the arena run again.  The arena grows (x2; x4 for a compile that was alone; up to 8 GB per
+        // buffer set) while launches overflow it; beyond that the launches get smaller.  (A compile that failed on the arena
+        // left nothing in the cache: misp_dd_core.hpp, thresholds follow the reservation.)
+        if (arena_cap_ < (8ull << 30)) {
+            hand_out(ho, me);
+            wait_decoders(-1);   // both arenas are freed and allocated again at the next launches
+            (void)grow_arena(std::min<size_t>(arena_cap_ * (n == 1 ? 4 : 2), 8ull << 30));
+        } else if (n > 1) {
+            cq_batch_cap_ = std::max(1, std::min(cq_batch_cap_, std::max(n_ok, n / 2)));
+        } else {   // one compile alone does not fit 8 GB: its caller gets the capacity error
+            CompileReq* r = again.back();
+            again.pop_back();
+            ho.done.emplace_back(r, 0);
+            ho.own += r->waiter == me;
+            std::lock_guard<std::mutex> lk(dec_mtx_);
+            decoders_[raw.set] += 1;
+        }
+    }
+    if (g_times_on) {
+        const int64_t tq3 = now_ns();
+        g_cq_ns[1] += (uint64_t)(tq1 - tq0), g_cq_ns[2] += (uint64_t)(tq2 - tq1), g_cq_ns[3] += (uint64_t)(tq3 - tq2);
+        g_cq_last_end.store(tq3);
+    }
+    bg.unlock();
+    if (foreign_cut) std::this_thread::sleep_for(std::chrono::microseconds(200));   // another engine's caller holds the shared flag up
+    return DDO_OK;
+}
+
+void Engine::lead(Waiter* me) {
+    for (;;) {
+        std::vector<CompileReq*> batch, again;
+        {
+            std::unique_lock<std::mutex> lk(cq_mtx_);
+            if (cq_.empty()) {
+                cq_leader_ = false;
+                return;
+            }
+            // How many requests to wait for: the callers the previous launch released are on their way back (they decode, drain
+            // their cut-set, pick their next sub-problem) and join the ones that queued up meanwhile -- cq_active_, set when that
+            // launch ended -- but never more than there are mdds on the engine, node slots to fill, or (first launch) all mdds.
+            // A launch of fewer decision diagrams than slots lasts as long as its longest one whatever their number, so waiting
+            // for the stragglers beats launching halves; the wait is bounded by a quarter of the previous launch (50 us .. 5 ms;
+            // 200 us before the first launch), and a caller that does not return (no work left) costs that once: the estimate
+            // follows what the launches really carried.
+            const int active = cq_active_ > 0 ? cq_active_ : users_.load();
+            const size_t expect = (size_t)std::max(1, std::min(std::min(users_.load(), active), std::min(nslots_, cq_batch_cap_)));
+            const int64_t tw0 = g_times_on ? now_ns() : 0;
+            if (g_times_on && g_cq_last_end.load()) g_cq_ns[4] += (uint64_t)std::max<int64_t>(0, tw0 - g_cq_last_end.exchange(0));
+            if (cq_.size() < expect) {
+                const double us = cq_last_ms_ > 0 ? std::min(5000.0, std::max(50.0, cq_last_ms_ * 250.0)) : 200.0;
+                cq_cv_.wait_for(lk, std::chrono::microseconds((long)us), [&] { return cq_.size() >= expect; });
+                if (g_times_on) g_cq_ns[0] += (uint64_t)(now_ns() - tw0);
+            }
+            const CacheTable* cache = cq_.front()->cache;
+            const DominanceTable* dom = cq_.front()->dom;
+            for (auto it = cq_.begin(); it != cq_.end() && (int)batch.size() < cq_batch_cap_;) {
+                if ((*it)->cache == cache && (*it)->dom == dom) {
+                    batch.push_back(*it);
+                    it = cq_.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
+        HandOut ho;
+        combined_launch(batch, again, me, ho);
+        bool handed_over = false;
+        {
+            std::unique_lock<std::mutex> lk(cq_mtx_);
+            for (auto it = again.rbegin(); it != again.rend(); ++it) cq_.push_front(*it);
+            cq_active_ = (int)(ho.done.size() + cq_.size());   // callers that come back + callers already waiting
+            int mine_left;
+            {
+                std::lock_guard<std::mutex> wl(me->m);
+                mine_left = me->remaining - ho.own;   // (the leader's finished requests are still to be handed out, below)
+            }
+            if (mine_left == 0) {   // the first caller in the queue leads the next launch -- named BEFORE this launch's callers are woken
+                handed_over = true;
+                if (cq_.empty()) {
+                    cq_leader_ = false;
+                } else {
+                    Waiter* w = cq_.front()->waiter;
+                    std::lock_guard<std::mutex> wl(w->m);
+                    w->lead = true;
+                    w->cv.notify_one();
+                }
+            }
+        }
+        hand_out(ho, me);
+        if (handed_over) return;   // (else one of this caller's requests runs again: it keeps leading)
+    }
+}
+
+int Engine::compile_combined(CompileReq* const* reqs, int count) {
+    if (count <= 0) return DDO_OK;
+    Waiter me;
+    me.remaining = count;
+    bool lead_now = false;
+    {
+        std::lock_guard<std::mutex> lk(cq_mtx_);
+        for (int i = 0; i < count; ++i) {
+            reqs[i]->waiter = &me;
+            reqs[i]->state = 0;
+            reqs[i]->rc = DDO_OK;
+            cq_.push_back(reqs[i]);
+        }
+        if (!cq_leader_) {
+            cq_leader_ = true;
+            lead_now = true;
+        } else {
+            cq_cv_.notify_one();   // (the leader's window re-checks the queue length)
+        }
+    }
+    for (;;) {
+        if (lead_now) {
+            lead(&me);
+            lead_now = false;
+        }
+        std::unique_lock<std::mutex> lk(me.m);
+        me.cv.wait(lk, [&] { return me.lead || me.remaining == 0; });
+        if (me.lead) {
+            me.lead = false;
+            lead_now = true;
+            lk.unlock();
+            // (requests of this call that an earlier launch finished are decoded before this caller leads: see hand_out)
+            for (int i = 0; i < count; ++i)
+                if (reqs[i]->state == 2) {
+                    decode_checked(reqs[i]->hdr, reqs[i]->arena, reqs[i]->arena_used, reqs[i]->out[0]);
+                    release_set(reqs[i]->set);
+                    reqs[i]->state = 3;
+                }
+            continue;
+        }
+        break;
+    }
+    int worst = DDO_OK;
+    for (int i = 0; i < count; ++i) {
+        CompileReq* r = reqs[i];
+        if (r->state == 2) {
+            decode_checked(r->hdr, r->arena, r->arena_used, r->out[0]);
+            release_set(r->set);
+        } else if (r->rc != DDO_OK) {
+            worst = r->rc;
+        }
+    }
+    return worst;
 }
 
 int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, const DominanceTable* dom) {
@@ -1268,6 +1599,7 @@ int Engine::fetch_raw(RawBatch& out) {
     out = RawBatch();
     if (fetch_set_ < 0) return DDO_OK;
     IoSet& io = io_[fetch_set_];
+    out.set = fetch_set_;
     fetch_set_ = -1;
     out.hdr = io.h_results;
     out.arena = io.h_arena;
@@ -1372,6 +1704,11 @@ struct ddo_mdd {
     std::shared_ptr<Engine> engine;
     int cutset_type = DDO_LAST_EXACT_LAYER;
     bool caching = false;
+    std::shared_ptr<Engine> fallback;   // engine picked by ddo_mdd_create (dense kernel): the full-width engine that takes what it hands up
+    bool registered = false;            // counted among the engine's users (Engine::add_user)
+    ~ddo_mdd() {
+        if (registered && engine) engine->add_user(-1);
+    }
     HostResult res;
     // residual of the latest compile (clean.rs:149 path_to_root, :398 depth)
     std::vector<ddo_decision> path_to_root;
@@ -1733,16 +2070,32 @@ ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, siz
     }
     Model* m = const_cast<Model*>(&model->m);
     const bool keep = caching || cutset_type == DDO_FRONTIER;   // both need every layer of the DD on the device
-    if (selector && keep) {
+    if (selector && selector != DDO_MDD_ENGINE_FULL && keep) {
         set_error("ddo_mdd_create: DDO_MDD_ENGINE_* selects a kernel of the in-place engine (DDO_LAST_EXACT_LAYER, no DDO_MDD_CACHING)");
         return nullptr;
     }
-    auto eng = selector ? Engine::get_selected(m, device, (long)max_width, selector)
-                        : Engine::get(m, device, (long)max_width, keep ? Engine::ENGINE_KEEP_LAYERS : 0);
+    // No selector: MISP decision diagrams of width 2048 and more start on the dense kernel (two decision diagrams per CU, the kernel
+    // the solver spends its time in) and what it hands up -- a layer beyond its dedup table: 0 of 6.1 million compiles of the
+    // brock400_1 search -- runs on the full-width engine; everything else on the one engine of its (model, device, width).
+    std::shared_ptr<Engine> eng, fallback;
+    if (selector == DDO_MDD_ENGINE_FULL || keep) eng = Engine::get(m, device, (long)max_width, keep ? Engine::ENGINE_KEEP_LAYERS : 0);
+    else if (selector) eng = Engine::get_selected(m, device, (long)max_width, selector);
+    else {
+        if (m->kind == MODEL_MISP && max_width >= 2048 && !std::getenv("DDO_HIP_NO_AUTO_DENSE")) {
+            const std::string keep_err = get_error();
+            eng = Engine::get_selected(m, device, (long)max_width, 0);   // (dense tier of a private full-width owner)
+            if (eng) fallback = eng->owner_shared();
+            else set_error(keep_err);   // (widths the dense tier is not built for: the plain engine below)
+        }
+        if (!eng) eng = Engine::get(m, device, (long)max_width, 0);
+    }
     if (!eng) return nullptr;
     ddo_mdd* d = new ddo_mdd();
     d->model = m;
     d->engine = eng;
+    d->fallback = fallback;
+    eng->add_user(1);
+    d->registered = true;
     d->cutset_type = cutset_type;
     d->caching = caching;
     return d;
@@ -1772,9 +2125,9 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
                           size_t count) {
     if (!mdds || !inputs || count == 0) return DDO_ERR_INVALID;
     Engine* eng = mdds[0]->engine.get();
-    std::vector<DDInput> din;
-    std::vector<size_t> active;
-    din.reserve(count);
+    std::vector<Engine::CompileReq> reqs(count);
+    std::vector<Engine::CompileReq*> active;
+    std::vector<size_t> active_i;
     const ddo_cache* cache = inputs[0].cache;
     const ddo_dominance* dom = inputs[0].dominance;
     for (size_t i = 0; i < count; ++i) {
@@ -1797,71 +2150,55 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
             if (outs) outs[i] = ddo_completion{0, 0, 0};
             continue;
         }
-        DDInput di;
-        int rc = fill_input(*mdds[i]->model, &inputs[i], di,
-                            IN_WANT_PATHS | (mdds[i]->cutset_type == DDO_FRONTIER ? IN_FRONTIER : 0u) | (cache ? IN_CACHE : 0u) | (dom ? IN_DOMINANCE : 0u));
+        Engine::CompileReq& rq = reqs[i];
+        int rc = fill_input(*mdds[i]->model, &inputs[i], rq.in,
+                            IN_WANT_PATHS | IN_PATH_BITS | (mdds[i]->cutset_type == DDO_FRONTIER ? IN_FRONTIER : 0u) | (cache ? IN_CACHE : 0u) | (dom ? IN_DOMINANCE : 0u));
         if (rc != DDO_OK) {
             set_error("ddo_mdd_compile: invalid compile input");
             return rc;
         }
-        if (inputs[i].comp_type == DDO_EXACT) di.width = (int32_t)eng->max_width();
-        if (di.width > eng->max_width() || di.width < 1) {
+        if (inputs[i].comp_type == DDO_EXACT) rq.in.width = (int32_t)eng->max_width();
+        if (rq.in.width > eng->max_width() || rq.in.width < 1) {
             set_error("ddo_mdd_compile: max_width must be in [1, width the mdd was created with]");
             return DDO_ERR_CAPACITY;
         }
-        din.push_back(di);
-        active.push_back(i);
+        rq.stop = inputs[i].cutoff;
+        rq.cache = cache ? cache->t : nullptr;
+        rq.dom = dom ? dom->t : nullptr;
+        rq.out = &mdds[i]->res;
+        active.push_back(&rq);
+        active_i.push_back(i);
     }
-    std::vector<HostResult> res;
-    std::vector<const volatile int*> stops;
-    for (size_t a : active) stops.push_back(inputs[a].cutoff);
-    int rc = eng->run_batch(din.data(), (int)din.size(), res, cache ? cache->t : nullptr, dom ? dom->t : nullptr, stops.data(), (int)stops.size());
+    // Concurrent callers -- the reference's worker threads, one mdd each (parallel.rs:576-602) -- meet in the engine's combining layer
+    // and share launches (Engine::compile_combined); so do the compiles of this batch.  Per-compile semantics are kept there: a
+    // compile cut by ANOTHER compile's cutoff flag runs again, one that found the shared output arena full runs again (the arena
+    // grows for a cut-set that does not fit it on its own).
+    int rc = eng->compile_combined(active.data(), (int)active.size());
     if (rc != DDO_OK) return rc;
-    // Cutoff::must_stop is per compile (clean.rs:352), the device flag is per launch: a raised flag of ONE caller ends every DD
-    // of the launch with ST_CUTOFF.  Compiles that were cut although their own flag is not raised (or absent) run again, among
-    // themselves, until each of them has either finished or been stopped by its own flag.
-    for (int round = 0; round < 64; ++round) {
-        std::vector<size_t> again;
-        for (size_t a = 0; a < active.size(); ++a) {
-            const volatile int* f = inputs[active[a]].cutoff;
-            if (res[2 * a].hdr.status == ST_CUTOFF && !(f && *f)) again.push_back(a);
-        }
-        if (again.empty()) break;
-        std::vector<DDInput> din2;
-        std::vector<const volatile int*> stops2;
-        for (size_t a : again) {
-            din2.push_back(din[a]);
-            stops2.push_back(inputs[active[a]].cutoff);
-        }
-        std::vector<HostResult> res2;
-        rc = eng->run_batch(din2.data(), (int)din2.size(), res2, cache ? cache->t : nullptr, dom ? dom->t : nullptr, stops2.data(), (int)stops2.size());
-        if (rc != DDO_OK) return rc;
-        for (size_t k = 0; k < again.size(); ++k) {
-            res[2 * again[k]] = std::move(res2[2 * k]);
-            res[2 * again[k] + 1] = std::move(res2[2 * k + 1]);
-        }
-    }
-    // The output arena is shared by the compiles of a launch: one that found it full is compiled again on its own, and if
-    // its cut-set alone does not fit, the arena grows -- as the solver host does (Engine::run_solo_growing; a compile that
-    // failed on the arena wrote nothing to the cache).
-    for (size_t a = 0; a < active.size(); ++a) {
-        auto capacity = [](const HostResult& r) { return r.hdr.status == ST_ERR_CAPACITY || r.hdr.status <= -100; };
-        if (!capacity(res[2 * a])) continue;
-        std::vector<HostResult> solo;
-        if (eng->run_solo_growing(din[a], solo, cache ? cache->t : nullptr, dom ? dom->t : nullptr) == DDO_OK && solo.size() >= 1)
-            res[2 * a] = std::move(solo[0]);
+    // an mdd whose engine ddo_mdd_create picked (dense kernel first): what the dense kernel hands up runs on the full-width engine
+    if (Engine* fb = mdds[0]->fallback.get()) {
+        std::vector<Engine::CompileReq*> up;
+        for (Engine::CompileReq* r : active)
+            if (r->out->hdr.status == ST_RETRY) up.push_back(r);
+        if (!up.empty() && (rc = fb->compile_combined(up.data(), (int)up.size())) != DDO_OK) return rc;
     }
     int worst = DDO_OK;
     for (size_t a = 0; a < active.size(); ++a) {
-        const size_t i = active[a];
+        const size_t i = active_i[a];
         ddo_mdd* d = mdds[i];
-        d->res = std::move(res[2 * a]);
         d->depth = inputs[i].residual.depth;
         d->path_to_root.assign(inputs[i].residual.path, inputs[i].residual.path + inputs[i].residual.path_len);
         int st = d->res.hdr.status;
         int code = st == ST_OK ? DDO_OK : (st == ST_CUTOFF ? DDO_CUTOFF : (st == ST_RETRY ? DDO_HANDED_UP : (st <= -100 ? DDO_ERR_CAPACITY : st)));
         if (statuses) statuses[i] = code;
-        if (code < 0 && worst >= 0) worst = code;
+        if (code < 0 && worst >= 0) {
+            worst = code;
+            if (st == ST_ERR_LPOOL || st == ST_ERR_APOOL)
+                set_error("device compile failed: a decision diagram outgrew the per-slot pools of kept layers / arcs "
+                          "(DDO_HIP_LPOOL_M, DDO_HIP_APOOL_M: pool sizes in millions of records)");
+            else
+                set_error("device compile failed (capacity or internal error), see per-item status");
+        }
         if (code != DDO_OK) d->res.valid = false;
         if (outs) {
             outs[i].is_exact = ddo_mdd_is_exact(d);
@@ -1869,7 +2206,6 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
             outs[i].best_value = outs[i].has_best_value ? d->res.hdr.best_value : 0;
         }
     }
-    if (worst < 0) set_error("device compile failed (capacity or internal error), see per-item status");
     return worst;
 }
 
@@ -1920,13 +2256,20 @@ int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
     mdd->drained = true;
     const HostResult& r = mdd->res;
     const int ws = mdd->model->ws;
-    std::vector<ddo_decision> path;
+    std::vector<ddo_decision> path = mdd->path_to_root;
+    const size_t root_len = path.size();
+    const bool bits = r.cs_pw > 0;
     for (int i = 0; i < r.n_cutset; ++i) {
-        path = mdd->path_to_root;
         const int plen = r.cs_depth.empty() ? r.cs_path_len : r.cs_depth[i];   // frontier cut-set: nodes of several layers
-        for (int k = 0; k < plen; ++k) {
-            uint32_t x = r.cs_path[(size_t)i * r.cs_path_len + k];
-            path.push_back(mdd->model->path_decision(x));
+        path.resize(root_len + (size_t)plen);
+        if (bits) {   // IN_PATH_BITS: node first, towards the DD's root (clean.rs:329-343)
+            const uint64_t* pb = r.cs_pbits.data() + (size_t)i * r.cs_pw;
+            for (int k = 0; k < plen; ++k) {
+                const int tr = plen - 1 - k;
+                path[root_len + (size_t)k] = mdd->model->path_decision((r.cs_lvar[(size_t)tr] << 1) | (uint32_t)((pb[tr >> 6] >> (tr & 63)) & 1ULL));
+            }
+        } else {
+            for (int k = 0; k < plen; ++k) path[root_len + (size_t)k] = mdd->model->path_decision(r.cs_path[(size_t)i * r.cs_path_len + k]);
         }
         ddo_subproblem sp;
         sp.state = r.cs_state.data() + (size_t)i * ws;
@@ -1988,6 +2331,12 @@ int ddo_cache_update_threshold(ddo_cache* cache, const uint64_t* state, size_t d
     if (!cache || !state) return DDO_ERR_INVALID;
     const int32_t tv = value >= (int64_t)TH_INF ? TH_INF : (value < INT32_MIN + 2 ? INT32_MIN + 2 : (int32_t)value);
     return cache_probe(cache->t, cache->model->wsT, state, cache->model->ws, (int)depth, 1, (long long)th_pack(tv, explored != 0), nullptr);
+}
+
+int ddo_mdd_combine_stats(const ddo_mdd* mdd, uint64_t* launches, uint64_t* requests, double* kernel_ms) {
+    if (!mdd || !mdd->engine) return DDO_ERR_INVALID;
+    mdd->engine->combine_stats(launches, requests, kernel_ms);
+    return DDO_OK;
 }
 
 int ddo_mdd_last_counters(const ddo_mdd* mdd, ddo_counters* out) {

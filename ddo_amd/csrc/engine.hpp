@@ -3,7 +3,10 @@
 // the per-(model, device, width) device engine and its batch interface.
 // =============================================================================
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -107,6 +110,11 @@ struct HostResult {
     std::vector<uint64_t> cs_state;     // n_cutset x ws (ABI words)
     std::vector<int32_t> cs_value, cs_ub;
     std::vector<uint32_t> cs_path;      // n_cutset x cs_path_len, node first
+    // IN_PATH_BITS (DDResult::cs_lvar_off): the paths as the device wrote them -- per node cs_pw words of decision bits (bit tr =
+    // decision of transition tr) and the variable of every transition once; expanded when the cut-set is drained
+    std::vector<uint64_t> cs_pbits;     // n_cutset x cs_pw
+    std::vector<uint32_t> cs_lvar;      // cs_path_len
+    int cs_pw = 0;
     std::vector<int32_t> cs_depth;      // frontier cut-set: layer of every node below the DD's root (empty: all at cs_path_len)
     uint64_t pool_off = ~0ULL;          // IN_POOL_OUT: the cut-set block stayed in the device node pool
     bool valid = false;
@@ -120,6 +128,9 @@ struct HostResult {
         cs_value.clear();
         cs_ub.clear();
         cs_path.clear();
+        cs_pbits.clear();
+        cs_lvar.clear();
+        cs_pw = 0;
         cs_depth.clear();
     }
 };
@@ -160,6 +171,47 @@ class Engine {
     /// leaves nothing in the cache (misp_dd_core.hpp: thresholds follow the reservation), so repeating it is sound.
     int run_solo_growing(const DDInput& input, std::vector<HostResult>& results, const CacheTable* cache = nullptr,
                          const DominanceTable* dom = nullptr);
+    /// ---- the combining layer under ddo_mdd_compile ------------------------------------------------------------------------------
+    /// The reference's threading contract is one DecisionDiagram per worker thread, compile() called CONCURRENTLY from all of them
+    /// (parallel.rs:576-602: `let mut mdd = D::default();` in every thread, process_one_node in a loop).  One compile is one
+    /// workgroup; a launch per caller would run the 256 CUs one workgroup at a time.  So concurrent compile() calls on the mdds of
+    /// an engine RENDEZVOUS (flat combining): a caller queues its request; if no launch is being put together it becomes the
+    /// leader, waits a short window for the other worker threads (until as many requests as there are mdds on the engine -- or
+    /// node slots -- have arrived; the window is a fraction of the previous launch's length), takes everything that is queued and
+    /// sends it out as ONE launch; callers that arrive while that launch runs queue up for the next one, whose leader is the
+    /// first of them.  Every caller decodes its own result out of the pinned output arena (in parallel, while the next launch
+    /// already runs out of the other buffer set).  Per-compile semantics stay per compile: a request cut by ANOTHER caller's
+    /// cutoff flag goes back into the queue (Cutoff::must_stop is per compile, clean.rs:352), one that found the shared output
+    /// arena full is compiled again (the arena grows when a compile does not fit it on its own).
+    struct Waiter;
+    struct CompileReq {
+        DDInput in{};
+        const volatile int* stop = nullptr;   // the caller's Cutoff flag (ddo_compile_input.cutoff)
+        const CacheTable* cache = nullptr;
+        const DominanceTable* dom = nullptr;
+        HostResult* out = nullptr;            // decoded result (two records when in.flags has IN_FUSED: out[0], out[1])
+        int rc = DDO_OK;                      // launch-level error (DDO_ERR_*): nothing was decoded
+        // filled by the combiner
+        Waiter* waiter = nullptr;
+        int state = 0;                        // 0 queued / in a launch, 2 raw result ready (decode, then release the buffer set), 3 done
+        DDResult hdr{};
+        const uint8_t* arena = nullptr;
+        size_t arena_used = 0;
+        int set = -1;
+    };
+    /// Compiles `count` requests through the combining layer; returns when all of them are finished (their `out` decoded or `rc` set).
+    int compile_combined(CompileReq* const* reqs, int count);
+    /// mdds bound to this engine (= worker threads that may call compile concurrently): what a leader waits for
+    void add_user(int d) { users_.fetch_add(d); }
+    /// launches / requests that went through the combining layer (tests, bench: mean decision diagrams per launch)
+    void combine_stats(uint64_t* launches, uint64_t* requests, double* kernel_ms) const {
+        if (launches) *launches = cq_launches_.load();
+        if (requests) *requests = cq_requests_.load();
+        if (kernel_ms) *kernel_ms = (double)cq_kernel_us_.load() * 1e-3;
+    }
+    /// decodes one result record of a fetched batch (a record whose block lies beyond `arena_used` becomes a capacity error)
+    void decode_checked(const DDResult& r, const uint8_t* arena, size_t arena_used, HostResult& out) const;
+
     /// The two halves of run_batch: launch() enqueues upload + kernel + download of the result headers and
     /// returns at once; collect() waits, fetches the arena and decodes.  One launch may be in flight.
     int launch(const DDInput* inputs, int count, const CacheTable* cache = nullptr, const DominanceTable* dom = nullptr);
@@ -178,6 +230,7 @@ class Engine {
         const uint8_t* arena = nullptr;
         int count = 0;
         size_t arena_used = 0;
+        int set = -1;   // buffer set the batch lies in
     };
     int fetch_raw(RawBatch& out);
     /// pinned staging buffer for the inputs of the next launch (`count` records): fill it in place, then launch(nullptr, count)
@@ -189,6 +242,7 @@ class Engine {
     int nslots() const { return nslots_; }
     int cap_width() const { return cap_width_; }
     bool is_tier() const { return owner_ != nullptr; }
+    std::shared_ptr<Engine> owner_shared() const { return owner_ref_; }   // get_selected: the full-width owner of this tier
     bool is_dense() const { return dense_; }
     int threads() const { return threads_; }
     int engine_kind() const { return engine_kind_; }
@@ -287,7 +341,29 @@ class Engine {
     std::mutex mtx_;
     long long rewind_ = -1;
     unsigned long long rewind_val_ = 0;
-    std::mutex batch_mtx_;   // held across launch + wait + fetch of run_batch: concurrent compile() calls on distinct mdds serialise
+    std::mutex batch_mtx_;   // held across launch + wait + fetch of run_batch / of a combined launch: one launch of this engine at a time
+    std::mutex cut_mtx_;     // set_cutoff (must not wait for mtx_, which wait() holds while the driver sleeps on a long kernel)
+    // combining layer (compile_combined)
+    std::mutex cq_mtx_;
+    std::condition_variable cq_cv_;        // the leader's window: woken when enough requests have arrived
+    std::deque<CompileReq*> cq_;
+    bool cq_leader_ = false;               // a caller is putting a launch together / has one in flight
+    int cq_batch_cap_ = 1 << 20;           // requests per launch (shrinks when the output arena, at its largest, overflows)
+    double cq_last_ms_ = 0;                // length of the previous combined launch (window = a fraction of it)
+    int cq_active_ = 0;                    // callers expected at the next launch: the ones the previous launch released + the ones already queued
+    std::atomic<int> users_{0};
+    std::atomic<uint64_t> cq_launches_{0}, cq_requests_{0}, cq_kernel_us_{0};
+    std::mutex dec_mtx_;
+    std::condition_variable dec_cv_;
+    int decoders_[2] = {0, 0};             // callers still reading results / arena of buffer set k
+    void wait_decoders(int set);           // -1: both sets
+    void release_set(int set);
+    struct HandOut;
+    double cq_bytes_per_req_ = 0;          // output-arena bytes per compile of the recent launches (sizes the arena ahead of a launch)
+    void lead(Waiter* me);
+    void hand_out(HandOut& ho, Waiter* me);
+    int combined_launch(std::vector<CompileReq*>& batch, std::vector<CompileReq*>& again, Waiter* me, HandOut& ho);
+    void finish_req(CompileReq* r, int state);
 };
 
 /// Reads a DIMACS-like .clq file the way examples/misp/main.rs:258-317 does.

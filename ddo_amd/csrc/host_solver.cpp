@@ -1438,7 +1438,7 @@ struct ddo_solver {
                 if (rc2 != DDO_OK || solo.size() < 2 || solo[0].hdr.status == ST_ERR_CAPACITY || solo[1].hdr.status == ST_ERR_CAPACITY ||
                     solo[0].hdr.status <= -100 || solo[1].hdr.status <= -100) {
                     const int st0 = solo.size() >= 2 ? std::min(solo[0].hdr.status, solo[1].hdr.status) : 0;
-                    if (st0 == ST_ERR_CAPACITY - 2100 || st0 == ST_ERR_CAPACITY - 2200)
+                    if (st0 == ST_ERR_LPOOL || st0 == ST_ERR_APOOL)
                         set_error("device compile failed: a decision diagram outgrew the per-slot pools of kept layers / arcs "
                                   "(DDO_HIP_LPOOL_M, DDO_HIP_APOOL_M: pool sizes in millions of records)");
                     else

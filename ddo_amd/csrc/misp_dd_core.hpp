@@ -1409,7 +1409,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (dynl) {   // room for this layer's nodes in the pool?
             if (node_off + (uint64_t)ntot > c.lpool) {
                 PAR_BEGIN
-                if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 21;
+                if (tid == 0) sh->status = ST_ERR_LPOOL;
                 PAR_END
                 failed = true;
                 break;
@@ -1488,7 +1488,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (dynl) {   // room for the arcs entering layer L + 1: fan per expanded node of this layer
             if (arc_off + (uint64_t)c.fan * (uint64_t)n > c.apool) {
                 PAR_BEGIN
-                if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 22;
+                if (tid == 0) sh->status = ST_ERR_APOOL;
                 PAR_END
                 failed = true;
                 break;
@@ -1863,9 +1863,10 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         if (pool_full) {
             PAR_BEGIN
-            if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 21;
+            if (tid == 0) sh->status = ST_ERR_LPOOL;
             PAR_END
             nT = 0;
+            failed = true;   // as the overflow checks inside the layer loop: no backward pass over arcs this layer never wrote
         }
         PAR_BEGIN
         if (tid == 0) {
@@ -2366,6 +2367,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         r.pool_off = NO_POOL_SRC;
         r.cs_depth_off = c.tmode ? cs_depth_off : 0;
         r.cs_path_stride = cs_path_len;
+        r.cs_lvar_off = 0;   // (IN_PATH_BITS is the in-place engine's)
         r.cache_hits = sh->cache_hits;
         *res = r;
     }

@@ -1920,9 +1920,14 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     const uint64_t cs_ub_off = off;
     off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
     const uint64_t cs_path_off = off;
-    if (!pool_out) off += ((uint64_t)ncut * cs_path_len * 4 + 7) & ~7ULL;
-    const uint64_t total = off;
     const uint32_t pw = (uint32_t)((cs_path_len + 63) / 64);
+    // IN_PATH_BITS: a cut-set node's path crosses PCIe as pw words of decision bits instead of cs_path_len u32 words (brock400_1 at
+    // width 10 000: 8 bytes instead of 160 per node -- 0.7 instead of 2.2 MB per relaxed DD, written by one store per word)
+    const bool bits_out = (in.flags & IN_PATH_BITS) != 0 && !pool_out;
+    if (!pool_out) off += bits_out ? (uint64_t)ncut * pw * 8 : (((uint64_t)ncut * cs_path_len * 4 + 7) & ~7ULL);
+    const uint64_t cs_lvar_off = off;
+    if (bits_out) off += ((uint64_t)cs_path_len * 4 + 7) & ~7ULL;
+    const uint64_t total = off;
     const uint64_t pool_bytes = (pool_out && ncut) ? pool_block_bytes((uint32_t)ncut, (uint32_t)WS, (uint32_t)cs_path_len) : 0;
 
     PAR_BEGIN
@@ -2041,6 +2046,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 o_ub[idx] = (int32_t)ub;
             }
         } else if (want_cutset && ncut) {
+            if (bits_out) {
+                uint32_t* o_lvar = (uint32_t*)(base + cs_lvar_off);
+                for (int j = tid; j < cs_path_len; j += NT) o_lvar[j] = (uint32_t)c.lvar[j];
+            }
             uint64_t* o_state = (uint64_t*)(base + cs_state_off);
             int32_t* o_value = (int32_t*)(base + cs_value_off);
             int32_t* o_ub = (int32_t*)(base + cs_ub_off);
@@ -2065,6 +2074,13 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #pragma unroll
                 for (int k = 0; k < WS; ++k) pb[k] = 0;
                 path_bits<WS>(c, c.cs_pid[i], pb);
+                if (bits_out) {
+                    uint64_t* o_bits = (uint64_t*)(base + cs_path_off);
+#pragma unroll
+                    for (int k = 0; k < WS; ++k)
+                        if ((uint32_t)k < pw) o_bits[(size_t)idx * pw + k] = pb[k];
+                    continue;
+                }
                 for (int j = 0; j < cs_path_len; ++j) {
                     const int tr = cs_path_len - 1 - j;
                     uint64_t w = 0;
@@ -2119,6 +2135,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         r.pool_off = pool_bytes ? pool_off : NO_POOL_SRC;
         r.cs_depth_off = 0;
         r.cs_path_stride = cs_path_len;
+        r.cs_lvar_off = (bits_out && arena_ok && ncut) ? cs_lvar_off : 0;
         r.cache_hits = 0;
         *res = r;
     }

@@ -54,7 +54,9 @@ extern "C" {
 #define DDO_MDD_CACHING 0x10
 /** OR into the cutset_type of ddo_mdd_create (MISP, DDO_LAST_EXACT_LAYER, no DDO_MDD_CACHING): binds the mdd to ONE of the
  *  kernels the lazy solver spreads its sub-problems over, so that each of them can be driven -- and checked against the
- *  reference's results -- compile by compile.  0 = the engine ddo_mdd_create picks itself (full width, one decision diagram
+ *  reference's results -- compile by compile.  0 = ddo_mdd_create picks: MISP at widths of 2048 and more compiles on the DENSE
+ *  kernel and, for the rare decision diagram that outgrows its dedup table, again on the FULL one (the caller sees one compile);
+ *  everything else runs on the one engine of its (model, device, width).  FULL = the full-width kernel only (one decision diagram
  *  per CU).  DENSE = misp_compile_kernel2_dense (full layer capacity, 512 threads, two decision diagrams per CU, the kernel
  *  the headline benchmark spends its time in); TIER0 / TIER1 = misp_compile_kernel2_tier with layers of at most 256 / 1024
  *  nodes (64 / 128 threads, 12 / 5 decision diagrams per CU): these never squash and answer DDO_HANDED_UP for a decision
@@ -62,7 +64,8 @@ extern "C" {
 #define DDO_MDD_ENGINE_DENSE 0x100
 #define DDO_MDD_ENGINE_TIER0 0x200
 #define DDO_MDD_ENGINE_TIER1 0x300
-#define DDO_MDD_ENGINE_MASK 0x300
+#define DDO_MDD_ENGINE_FULL 0x400
+#define DDO_MDD_ENGINE_MASK 0x700
 
 /** common.rs:58-61  struct Decision { variable: Variable, value: isize } */
 typedef struct ddo_decision {
@@ -239,6 +242,12 @@ typedef void (*ddo_cutset_cb)(const ddo_subproblem* node, void* user);
 int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user);
 /** Counters of the latest compile on this object. */
 int ddo_mdd_last_counters(const ddo_mdd* mdd, ddo_counters* out);
+/** Measurement support (no counterpart in the reference).  The reference runs one DecisionDiagram per worker thread and calls
+ *  compile() from all of them concurrently (parallel.rs:576-602); here concurrent ddo_mdd_compile calls on mdds of one (model,
+ *  device, width, engine) share device launches (one workgroup per decision diagram: see DESIGN.md, "combining layer").  Device
+ *  launches and compiles that went through that layer on this mdd's engine since it was created (requests / launches = mean
+ *  decision diagrams per launch) and the HIP-event time of those launches' kernels in milliseconds.  Any pointer may be NULL. */
+int ddo_mdd_combine_stats(const ddo_mdd* mdd, uint64_t* launches, uint64_t* requests, double* kernel_ms);
 
 /* ---- Solver (solver.rs:32-97; parallel.rs:287-641) ------------------------------------------ */
 #define DDO_WIDTH_FIXED 0         /* width.rs:166-171 FixedWidth(w)            */

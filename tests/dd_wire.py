@@ -7,7 +7,7 @@ import numpy as np
 MAX_WS = 72
 CT_EXACT, CT_RELAXED, CT_RESTRICTED = 0, 1, 2
 IN_FUSED, IN_FILTER_CUTSET, IN_WANT_PATHS = 1, 2, 4
-IN_FRONTIER, IN_CACHE, IN_MUST_EXPLORE, IN_MARK_EXPLORED, IN_DOMINANCE = 16, 32, 64, 128, 256
+IN_FRONTIER, IN_CACHE, IN_MUST_EXPLORE, IN_MARK_EXPLORED, IN_DOMINANCE, IN_PATH_BITS = 16, 32, 64, 128, 256, 512
 ST_OK, ST_CUTOFF, ST_NOT_RUN = 0, 1, 77
 
 
@@ -27,7 +27,8 @@ class DDResult(C.Structure):
                 ("arcs", C.c_uint64), ("layers", C.c_uint64), ("path_off", C.c_uint64), ("exact_off", C.c_uint64),
                 ("cs_state_off", C.c_uint64), ("cs_value_off", C.c_uint64), ("cs_ub_off", C.c_uint64),
                 ("cs_path_off", C.c_uint64), ("pool_off", C.c_uint64),
-                ("cs_depth_off", C.c_uint64), ("cs_path_stride", C.c_int32), ("cache_hits", C.c_uint32), ("phase_clk", C.c_uint64 * 32)]
+                ("cs_depth_off", C.c_uint64), ("cs_path_stride", C.c_int32), ("cache_hits", C.c_uint32), ("cs_lvar_off", C.c_uint64),
+                ("phase_clk", C.c_uint64 * 32)]
 
 
 def parse_result(res, arena_ptr, ws, depth0):
@@ -46,7 +47,16 @@ def parse_result(res, arena_ptr, ws, depth0):
     cs_states = arr(res.cs_state_off, k * ws, C.c_uint64, np.uint64)
     cs_value = arr(res.cs_value_off, k, C.c_int32, np.int32)
     cs_ub = arr(res.cs_ub_off, k, C.c_int32, np.int32)
-    cs_paths = arr(res.cs_path_off, k * lel, C.c_uint32, np.uint32).reshape(k, lel) if k else np.zeros((0, lel), np.uint32)
+    if res.cs_lvar_off and k:   # IN_PATH_BITS: bit rows + the variables once -> the u32 rows (variable << 1 | bit), node first
+        pw = (lel + 63) // 64
+        bits = arr(res.cs_path_off, k * pw, C.c_uint64, np.uint64).reshape(k, pw)
+        lvar = arr(res.cs_lvar_off, lel, C.c_uint32, np.uint32)
+        cs_paths = np.zeros((k, lel), np.uint32)
+        for j in range(lel):
+            tr = lel - 1 - j
+            cs_paths[:, j] = (lvar[tr] << np.uint32(1)) | ((bits[:, tr >> 6] >> np.uint64(tr & 63)) & np.uint64(1)).astype(np.uint32)
+    else:
+        cs_paths = arr(res.cs_path_off, k * lel, C.c_uint32, np.uint32).reshape(k, lel) if k else np.zeros((0, lel), np.uint32)
     best_path = arr(res.path_off, res.best_len, C.c_uint32, np.uint32)
     exact_path = arr(res.exact_off, res.exact_len, C.c_uint32, np.uint32)
     cut = sorted((tuple(int(x) for x in cs_states[i * ws:(i + 1) * ws]), int(cs_value[i]), int(cs_ub[i]),

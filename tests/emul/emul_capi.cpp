@@ -284,6 +284,9 @@ void emul_set_keep_layers(void* h, int on, uint64_t cache_entries) {
         const size_t ml = (size_t)e->P.max_layers;
         e->P.lpool_nodes = ml * (size_t)e->P.lstride;
         e->P.apool_arcs = ml * (size_t)(e->P.fan > 2 ? e->P.fan : 2) * (size_t)e->P.capN;
+        // tests of the overflow paths: pools SMALLER than what a DD needs (the arrays behind them keep their full size)
+        if (const char* v = std::getenv("DDO_EMUL_LPOOL_NODES")) e->P.lpool_nodes = std::min<uint64_t>(e->P.lpool_nodes, std::strtoull(v, nullptr, 10));
+        if (const char* v = std::getenv("DDO_EMUL_APOOL_ARCS")) e->P.apool_arcs = std::min<uint64_t>(e->P.apool_arcs, std::strtoull(v, nullptr, 10));
         e->lbase.assign(ml + 1, 0);
         e->abase.assign(ml + 1, 0);
         e->P.lbase = e->lbase.data();

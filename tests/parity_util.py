@@ -52,7 +52,8 @@ def is_independent_set(rows, ws, chosen):
     return True
 
 
-ENGINES = ["full", "dense", "tier0", "tier1"]   # DDO_MDD_ENGINE_*: the kernels the lazy solver (and bench.py) run
+ENGINES = ["auto", "full", "dense", "tier0", "tier1"]   # DDO_MDD_ENGINE_*: the kernels the lazy solver (and bench.py) run; "auto" = no selector
+# (ddo_mdd_create picks: at widths of 2048 and more the dense kernel with the full-width engine behind it, else the one engine of the width)
 TIER_CAP = {"tier0": 256, "tier1": 1024}
 
 
@@ -69,7 +70,7 @@ def may_hand_up(engine, rec):
     return engine in TIER_CAP and (not rec["is_exact"] or rec["nodes_expanded"] > min(TIER_CAP[engine] // 2, int(rec["width"])))
 
 
-def replay_records(model, recs, device=0, batch=64, engine="full"):
+def replay_records(model, recs, device=0, batch=64, engine="auto"):
     """Replays oracle trace records on the GPU through ddo_mdd_compile_batch; yields (i, record, canonical); canonical is
     ddo_amd.HANDED_UP when the capacity tier the mdds are bound to answered DDO_HANDED_UP."""
     maxw = engine_width(engine, max(int(r["width"]) for r in recs))

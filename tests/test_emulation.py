@@ -171,3 +171,41 @@ def test_dense_tier_emulation_matches_golden(oracle, monkeypatch, case):
     for k in ["is_exact", "best_value", "best_exact_value", "nodes_expanded", "arcs", "layers"]:
         assert g[k] == case[k], (k, g[k], case[k])
     assert len(g["cutset"]) == case["n_cutset"] and cutset_digest(g["cutset"]) == case["cutset_digest"]
+
+
+@pytest.mark.parametrize("name,width,max_compiles", [("brock200_2", 30, 80), ("brock400_1", 200, 30), ("keller4", 7, 120)])
+def test_emulation_cutset_paths_as_bit_rows(oracle, name, width, max_compiles):
+    """IN_PATH_BITS (dd_types.h; what ddo_mdd_compile asks the in-place engine for): the paths of the cut-set nodes leave the device
+    as rows of decision bits plus the branching variables once per DD.  Expanded (tests/dd_wire.py, as ddo_mdd_drain_cutset
+    does) they are the u32 rows of the plain format, node for node; and every path, replayed from the residual state, ends in
+    its node's state with its node's value (Problem::transition / transition_cost, misp/main.rs:77-93)."""
+    from tests.dd_wire import IN_PATH_BITS
+    inst = oracle.misp(data_path("misp", name + ".clq"))
+    _, recs = inst.trace_solve(width, max_compiles)
+    e = Emul(inst.n, inst.rows, inst.weights, max(r["width"] for r in recs), engine=2)
+    seen = 0
+    for i, r in enumerate(recs):
+        a = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=IN_WANT_PATHS)[0]
+        b = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=IN_WANT_PATHS | IN_PATH_BITS)[0]
+        assert diff(r, a) is None and diff(r, b) is None
+        sa, va, ua, pa = a["cutset_raw"]
+        sb, vb, ub, pb = b["cutset_raw"]
+        ka = sorted(range(len(va)), key=lambda j: tuple(int(x) for x in sa[j]))
+        kb = sorted(range(len(vb)), key=lambda j: tuple(int(x) for x in sb[j]))
+        assert len(ka) == len(kb)
+        for ja, jb in zip(ka, kb):
+            assert (sa[ja] == sb[jb]).all() and va[ja] == vb[jb] and ua[ja] == ub[jb] and (pa[ja] == pb[jb]).all(), (i, ja, jb)
+        for j in kb[:50]:   # replay: decisions root-first = the row reversed
+            st = [int(x) for x in r["state"]] + [0] * (e.ws - len(r["state"]))
+            val = r["value"]
+            for x in reversed([int(x) for x in pb[j]]):
+                v, d = x >> 1, x & 1
+                assert not d or (st[v // 64] >> (v % 64)) & 1
+                st[v // 64] &= ~(1 << (v % 64))
+                if d:
+                    for k in range(inst.ws):
+                        st[k] &= int(inst.rows[v * inst.ws + k])
+                    val += int(inst.weights[v])
+            assert st[:inst.ws] == [int(x) for x in sb[j][:inst.ws]] and val == vb[j]
+            seen += 1
+    assert seen > 20

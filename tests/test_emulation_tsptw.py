@@ -133,3 +133,53 @@ def test_tsptw_model_host_side(tmp_path):
     a, b = s.copy(), s.copy()
     b[4] = 1 << 32                                                           # deeper state ranks higher (TsptwRanking)
     assert m.compare(a, b) < 0 and m.compare(b, a) > 0 and m.compare(a, a) == 0
+
+
+def test_tsptw_layer_and_arc_pools_that_overflow(oracle, monkeypatch):
+    """kept layers and arcs as per-slot pools (run_dd: dynl) that a DD OUTGROWS: the compile must end with the named capacity status
+    (dd_types.h: ST_ERR_LPOOL / ST_ERR_APOOL) whatever layer runs out of room -- the terminal one included, where no arc of the
+    layer has been written and the backward passes must not run over them -- never with results.  The pool of the
+    second run is one record short of what the DD needs in all, so it is the LAST layer that does not fit."""
+    path = data_path("tsptw", "Langevin", "N20ft405.dat")
+    model = ddo_amd.Tsptw.read_instance(path)
+    summary, recs = oracle.trace_ex("tsptw", path, 3, 6, True, False)
+    r = next(x for x in recs if x["comp_type"] == 1)
+    fl = IN_WANT_PATHS | IN_FRONTIER
+    monkeypatch.setenv("DDO_EMUL_LPOOL", "1")
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        e = ModelEmul(model, int(r["width"]))
+        e.keep_layers(True, 0)
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=fl)[0]
+        for k in env:
+            monkeypatch.delenv(k)
+        return g
+
+    ok = run()
+    assert ok["status"] == 0 and diff(r, ok) is None
+    # the nodes all kept layers hold together: grow the pool until the compile passes; one record less then fails in the LAST layer
+    lo, hi = 1, 1 << 20
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if run(DDO_EMUL_LPOOL_NODES=mid)["status"] == 0:
+            hi = mid
+        else:
+            lo = mid + 1
+    assert run(DDO_EMUL_LPOOL_NODES=lo)["status"] == 0
+    for short in (lo - 1, lo // 2, 3):
+        g = run(DDO_EMUL_LPOOL_NODES=short)
+        assert g["status"] == -3 - 2100, (short, g["status"])
+        assert not g["cutset"] and g["best_value"] is None
+    lo, hi = 1, 1 << 22
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if run(DDO_EMUL_APOOL_ARCS=mid)["status"] == 0:
+            hi = mid
+        else:
+            lo = mid + 1
+    for short in (lo - 1, lo // 2, 3):
+        g = run(DDO_EMUL_APOOL_ARCS=short)
+        assert g["status"] in (-3 - 2200, -3 - 2100), (short, g["status"])
+        assert not g["cutset"] and g["best_value"] is None
