@@ -113,6 +113,47 @@ def cpu_baseline(instance, width, total_seconds, threads_arg):
     }
 
 
+def boundary_b1(model, args, device, threads, rounds):
+    """Throughput THROUGH THE DROP-IN BOUNDARY as the reference drives it: `threads` host threads, one
+    ddo_mdd each, every thread looping the reference's process_one_node (parallel.rs:391-437: restricted compile, then -- the
+    restricted DD being inexact -- relaxed compile + drain_cutset) through plain `ddo_mdd_compile` (tools/b1_driver.cpp).  The
+    sub-problems are the same kind of 1-in-8 sample of the root cut-set the headline freezes (exported to the HOST here: through
+    this boundary states, cut-sets and paths cross PCIe per compile, which `value` never pays -- its fringe stays in HBM).
+    Concurrent compiles share device launches (Engine::compile_combined)."""
+    import numpy as np
+
+    import ddo_amd
+    from ddo_amd import FixedWidth, ParallelSolver
+    from ddo_amd.boundary import run_b1
+
+    tmp = ParallelSolver(model, FixedWidth(args.width), nb_threads=args.concurrent, device=device, fringe="lazy")
+    tmp.step()
+    tmp.flush()
+    lb = tmp.best_lower_bound()
+    ex = tmp.export_subproblems(8 * args.concurrent)
+    del tmp
+    k = len(ex["value"])
+    pick = list(range(0, k, 8))[:args.concurrent]
+    states = np.ascontiguousarray(ex["states"][pick])
+    values = [int(ex["value"][i]) for i in pick]
+    depths = [int(ex["depth"][i]) for i in pick]
+    keep = ddo_amd.Mdd(model, args.width, device=device)   # keeps the engine of this (model, device, width) alive between the two passes
+    run_b1(model, states, values, depths, args.width, threads, len(pick), lb, device=device)             # untimed: buffers pinned, arenas sized
+    tot, r0, r1 = run_b1(model, states, values, depths, args.width, threads, rounds * len(pick), lb, device=device)
+    del keep
+    return {
+        "value": tot["nodes_expanded"] / max(tot["seconds"], 1e-9), "unit": "nodes/s", "threads": threads,
+        "what": "T host threads, one ddo_mdd each, looping process_one_node (parallel.rs:391-437) through plain ddo_mdd_compile / "
+                "ddo_mdd_drain_cutset (tools/b1_driver.cpp); concurrent compiles share device launches",
+        "sample": f"{len(pick)} sub-problems of the root cut-set (every 8th in fringe order, states on the host), {rounds} passes: "
+                  f"{tot['compiles']} compiles, {tot['nodes_expanded']} nodes in {tot['seconds']:.2f} s",
+        "launches": tot["launches"], "compiles": tot["compiles"], "decision_diagrams_per_launch": tot["requests"] / max(1, tot["launches"]),
+        "kernel_s": tot["kernel_ms"] / 1e3, "kernel_nodes_per_s": tot["nodes_expanded"] / max(tot["kernel_ms"] / 1e3, 1e-9),
+        "cutset_nodes_drained": tot["cutset_nodes"], "path_decisions_drained": tot["path_decisions"], "errors": tot["errors"],
+        "results_differing_between_passes": tot["mismatches"],
+    }
+
+
 def bench_vector(args):
     """Secondary workloads on ONE GPU, the whole branch-and-bound to the proved optimum: `max2sat` = BASELINE.json config C3,
     weighted MAX2SAT frb10-6-1 (n = 60, 667 clauses) at FixedWidth(5000); `mcp` = the ten maximum-cut instances the reference's
@@ -313,6 +354,8 @@ def main():
                          "time_to_proved_optimum_s, the second half of BASELINE.json's metric (0 = skip)")
     ap.add_argument("--prove-concurrent", type=int, default=32768,
                     help="sub-problems in flight during the proof search (8192: 93 s, 16384: 83 s, 32768: 78 s, 65536+: 79 s on one box, round 3)")
+    ap.add_argument("--b1-threads", type=int, default=2048, help="host threads of the boundary_b1 block (N = 1 only; 0 = skip): worker threads looping plain ddo_mdd_compile")
+    ap.add_argument("--b1-rounds", type=int, default=16, help="passes of the boundary_b1 block over its sub-problems")
     ap.add_argument("--freeze-stride", type=int, default=0, help="experiments only: take every k-th root cut-set node (default 8 // world)")
     ap.add_argument("--instance", default=INSTANCE)
     ap.add_argument("--width", type=int, default=WIDTH)
@@ -514,6 +557,11 @@ def main():
     # all N GPUs: every rank searches its shard of the root cut-set; incumbent, termination test and work hand-over go
     # through ddo_amd.distributed.DistributedSearch (one 40-byte MAX all-reduce per step)
     proof = None
+    if world == 1 and not args.no_cpu and args.b1_threads > 0:
+        del solver
+        solver = None
+        out["boundary_b1"] = boundary_b1(model, args, local_rank, args.b1_threads, args.b1_rounds)
+        out["boundary_b1"]["fraction_of_value"] = out["boundary_b1"]["value"] / max(out["value"], 1e-9)
     if args.prove > 0 and not args.no_cpu:   # --no-cpu = the timed steps only (profiling, A/B tools)
         from ddo_amd import TimeBudget
         from ddo_amd.distributed import DistributedSearch
