@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
 DDO_OK, DDO_CUTOFF = 0, 2
 LAST_EXACT_LAYER, FRONTIER = 1, 2
 MDD_CACHING = 0x10
+MDD_POOLED = 0x20
 DDO_HANDED_UP = 3
 MDD_ENGINES = {"auto": 0, "full": 0x400, "dense": 0x100, "tier0": 0x200, "tier1": 0x300}   # DDO_MDD_ENGINE_* (include/ddo_hip.h)
 
@@ -83,7 +84,7 @@ class _SolverConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("width_policy", C.c_int), ("width", C.c_size_t), ("nb_concurrent", C.c_int),
                 ("time_budget_s", C.c_double), ("rank", C.c_int), ("world_size", C.c_int), ("fringe", C.c_int),
                 ("sequential", C.c_int), ("cutset_type", C.c_int), ("cache_entries", C.c_size_t), ("dominance_entries", C.c_size_t),
-                ("width_times", C.c_size_t), ("width_div_by", C.c_size_t)]
+                ("width_times", C.c_size_t), ("width_div_by", C.c_size_t), ("pooled", C.c_int)]
 
 
 _CUTSET_CB = C.CFUNCTYPE(None, C.POINTER(_SubProblem), C.c_void_p)
@@ -651,7 +652,7 @@ class ParallelSolver:
     the fringe is the NoDupFringe<MaxUB>.  `nb_threads` = sub-problems compiled concurrently on the GPU."""
 
     def __init__(self, problem, width, cutoff=None, nb_threads=256, device=0, rank=0, world_size=1, fringe="nodup",
-                 sequential=False, cutset_type=LAST_EXACT_LAYER, cache_entries=0, dominance_entries=0):
+                 sequential=False, cutset_type=LAST_EXACT_LAYER, cache_entries=0, dominance_entries=0, pooled=False):
         self.problem = problem
         cfg = _SolverConfig()
         cfg.device = device
@@ -664,6 +665,7 @@ class ParallelSolver:
         cfg.cutset_type = int(cutset_type)          # the `D` of ParallelSolver<State, D, C>: DefaultMDDLEL | DefaultMDDFC
         cfg.cache_entries = int(cache_entries)      # the `C`: 0 = EmptyCache, else SimpleCache with that many entries on the device
         cfg.dominance_entries = int(dominance_entries)   # 0 = EmptyDominanceChecker, else SimpleDominanceChecker (knapsack models)
+        cfg.pooled = 1 if pooled else 0             # `D` = Pooled (mdd/pooled.rs): MISP, NoDupFringe, EmptyCache
         self._h = lib().ddo_solver_create(problem._h, C.byref(cfg))
         if not self._h:
             raise DdoError("ddo_solver_create failed: " + _err())
@@ -820,9 +822,9 @@ def DefaultCachingSolver(problem, width, cutoff=None, nb_threads=256, device=0, 
 class SequentialSolver(ParallelSolver):
     """SequentialSolver (sequential.rs:202-527): one sub-problem at a time, NoDupFringe, and its `explored` bookkeeping."""
 
-    def __init__(self, problem, width, cutoff=None, device=0, cutset_type=LAST_EXACT_LAYER, cache_entries=0, dominance_entries=0):
+    def __init__(self, problem, width, cutoff=None, device=0, cutset_type=LAST_EXACT_LAYER, cache_entries=0, dominance_entries=0, pooled=False):
         super().__init__(problem, width, cutoff=cutoff, nb_threads=1, device=device, fringe="nodup", sequential=True,
-                         cutset_type=cutset_type, cache_entries=cache_entries, dominance_entries=dominance_entries)
+                         cutset_type=cutset_type, cache_entries=cache_entries, dominance_entries=dominance_entries, pooled=pooled)
   # solver/mod.rs:28
 
 
@@ -847,17 +849,33 @@ SeqCachingSolverLel = _alias(False, LAST_EXACT_LAYER, True, "SequentialSolver<St
 SeqCachingSolverFc = _alias(False, FRONTIER, True, "SequentialSolver<State, DefaultMDDFC<State>, SimpleCache<State>> (solver/mod.rs:46)")
 
 
-def _pooled_not_built(name, cite):
+def Pooled(model, max_width, device=0):
+    """`Pooled<State>` (mdd/pooled.rs:117-823), the long-arc decision diagram, on the device: an Mdd whose layers hold the pool nodes
+    the branching variable impacts (MISP models: the reference's only model with Problem::is_impacted_by, misp/main.rs:145-147);
+    frontier cut-set, depth of a sub-problem = the layer at which its node was expanded, one decision per expanded ancestor."""
+    return Mdd(model, max_width, device=device, cutset_type=FRONTIER | MDD_POOLED)
+
+
+def _pooled_alias(parallel, doc):
+    def make(problem, width, cutoff=None, nb_threads=256, device=0, **kw):
+        if parallel:
+            return ParallelSolver(problem, width, cutoff, nb_threads=nb_threads, device=device, pooled=True, **kw)
+        return SequentialSolver(problem, width, cutoff, device=device, pooled=True, **kw)
+    make.__doc__ = doc
+    return make
+
+
+def _pooled_caching_not_built(name, cite):
     def make(*_a, **_k):
-        # fail loudly: there is no device variant of the long-arc DD (mdd/pooled.rs), and nothing here falls back to another DD type
-        raise DdoError(f"{name} ({cite}): Pooled decision diagrams are not built on the device (DESIGN.md section 7); "
-                       "use the Lel / Fc aliases")
+        # fail loudly: Pooled decision diagrams behind a SimpleCache (thresholds over long arcs, pooled.rs:469-541) have no device
+        # variant, and nothing here falls back to another DD type or to the cache-less solver
+        raise DdoError(f"{name} ({cite}): Pooled decision diagrams with a SimpleCache are not built on the device (DESIGN.md section 7); "
+                       "use the NoCaching Pooled aliases or the caching Lel / Fc ones")
     make.__doc__ = f"`{name}` of the reference ({cite}): NOT available -- raises DdoError"
     return make
 
 
-Pooled = _pooled_not_built("Pooled", "mdd/pooled.rs:117")
-ParNoCachingSolverPooled = _pooled_not_built("ParNoCachingSolverPooled", "solver/mod.rs:34")
-ParCachingSolverPooled = _pooled_not_built("ParCachingSolverPooled", "solver/mod.rs:38")
-SeqNoCachingSolverPooled = _pooled_not_built("SeqNoCachingSolverPooled", "solver/mod.rs:43")
-SeqCachingSolverPooled = _pooled_not_built("SeqCachingSolverPooled", "solver/mod.rs:47")
+ParNoCachingSolverPooled = _pooled_alias(True, "ParallelSolver<State, Pooled<State>, EmptyCache<State>> (solver/mod.rs:34)")
+SeqNoCachingSolverPooled = _pooled_alias(False, "SequentialSolver<State, Pooled<State>, EmptyCache<State>> (solver/mod.rs:43)")
+ParCachingSolverPooled = _pooled_caching_not_built("ParCachingSolverPooled", "solver/mod.rs:38")
+SeqCachingSolverPooled = _pooled_caching_not_built("SeqCachingSolverPooled", "solver/mod.rs:47")

@@ -294,7 +294,16 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     P.unit_weights = model->unit_weights ? 1 : 0;
     P.npad = (model->n + 63) / 64 * 64;
     // the terminal layer is never squashed (clean.rs:608-618): MISP ends in at most one node, a knapsack DD in up to 2W
-    const long slot_width = owner ? (long)cap_width : max_width;   // what the node slots are sized for
+    pooled_ = (features & ENGINE_POOLED) != 0;
+    if (pooled_ && (model->kind != MODEL_MISP || owner || (features & ENGINE_KEEP_LAYERS))) {
+        set_error("Pooled decision diagrams: MISP models only (Problem::is_impacted_by, misp/main.rs:145-147), no caching");
+        return DDO_ERR_UNSUPPORTED;
+    }
+    // Pooled: a slot holds a POOL -- every node that waits for a variable that impacts it -- which the width does not bound (only
+    // the layers are squashed).  It is sized for what the LDS dedup table admits: 32 768 entries at 7/8 full, 14 000 work-list entries.
+    long pool_nodes = 14000;
+    if (const char* env = std::getenv("DDO_HIP_POOLED_NODES")) pool_nodes = std::max(64L, std::min(30000L, std::atol(env)));
+    const long slot_width = pooled_ ? std::max(pool_nodes, max_width) : owner ? (long)cap_width : max_width;   // what the node slots are sized for
     P.capN = model->kind == MODEL_TSPTW ? std::max((int)slot_width, model->n) + 2      // layers are squashed to the width, the last one has one child per node
              : model->kind != MODEL_MISP ? 2 * (int)slot_width + 3 : (int)slot_width + 2;
     P.fan = model->kind == MODEL_TSPTW ? model->n : 2;
@@ -307,6 +316,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     threads_ = max_width >= 2048 ? 1024 : 256;
     dense_ = owner && (long)cap_width == max_width && tier_threads == 512;
     if (owner) threads_ = tier_threads;
+    else if (pooled_) threads_ = 512;
     else if (const char* env = std::getenv("DDO_HIP_THREADS")) {
         int t = std::atoi(env);
         if (t >= 256 && t <= 1024 && t % 64 == 0) threads_ = t;
@@ -335,7 +345,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     // build of the kernel; like every capacity tier it never squashes.
     mid_ = owner && !dense_ && tier_threads == 256 && cap_width >= 2048;
     if (mid_) P.tab2_cap = std::min(t2, 8192);
-    if (mid_ || dense_) P.capS = std::min(P.capS, (int)((long)P.tab2_cap * 7 / 8) + 16);
+    if (pooled_) P.tab2_cap = std::min(t2, 32768);   // (a pool that would fill more than 7/8 of it ends with a capacity error)
+    if (mid_ || dense_ || pooled_) P.capS = std::min(P.capS, (int)((long)P.tab2_cap * 7 / 8) + 16);
+    if (pooled_) P.hist_bins = 256;                  // 8-bit select digits: the LDS goes to the table and the bitmaps
     long long neg = 0;
     for (int i = 0; i < model->n; ++i)
         if (model->weight[i] < 0) neg += model->weight[i];
@@ -343,7 +355,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     P.phase_clocks = std::getenv("DDO_HIP_STATS") ? 1 : 0;
     P.lex_cap = 1024;
     if (const char* env = std::getenv("DDO_HIP_LEX_CAP")) P.lex_cap = std::max(1, std::min(1024, std::atoi(env)));   // tests: force the radix path
-    if (!dense_) P.lex_cap = std::max(1, std::min(P.lex_cap, P.hist_bins / 2));   // the tie-break keys (8 bytes each) share the histogram area
+    if (!dense_) P.lex_cap = std::max(1, std::min(P.lex_cap, pooled_ ? 512 : P.hist_bins / 2));   // the tie-break keys (8 bytes each) share the histogram area
     if (dense_) {
         // A dense-tier DD whose layer would hold more than 7/8 of the table's entries is handed up, so no layer ever needs more
         // node slots than that: fewer slots = smaller LDS bitmaps, and the room goes to the tie-break keys -- ties of a few
@@ -366,6 +378,10 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     if (lds2 > lds_max || model->weight_abs_sum >= (1 << 20) || P.capS >= 65535 || model->n > 2047) engine_kind_ = 1;
     if (model->kind != MODEL_MISP) engine_kind_ = 1;   // scalar-state models run on the layer-rebuilding engine
     if (features & ENGINE_KEEP_LAYERS) engine_kind_ = 1;   // frontier cut-set / thresholds / cache need every layer of the DD
+    if (pooled_ && engine_kind_ != 2) {
+        set_error("Pooled decision diagrams: the model does not fit the in-place engine (LDS, value range or variables)");
+        return DDO_ERR_UNSUPPORTED;
+    }
     P.tmode = (features & ENGINE_KEEP_LAYERS) ? 1 : 0;
     // a kept layer holds its surviving nodes AND the cache-pruned / dominated ones (their thresholds flow to the parents):
     // up to every distinct child of the layer above
@@ -636,7 +652,8 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     ev0_ = e0;
     ev1_ = e1;
 
-    kernel_fn fn = (dense_ || mid_) ? pick_kernel2_dense(model->wsT)
+    kernel_fn fn = pooled_ ? pick_kernel2_pooled(model->wsT)
+                   : (dense_ || mid_) ? pick_kernel2_dense(model->wsT)
                    : owner ? pick_kernel2_tier(model->wsT)
                    : engine_kind_ == 2 ? pick_kernel2(model->wsT, threads_)
                                        : pick_kernel(model->wsT, table_lds_);
@@ -1033,6 +1050,58 @@ void Engine::release_set(int set) {
     if (--decoders_[set] == 0) dec_cv_.notify_all();
 }
 
+void Engine::pooled_fixup(const DDInput& in, HostResult& out) const {
+    if (!out.valid || out.hdr.status != ST_OK) return;
+    const int wsT = model_->wsT;
+    const uint64_t* adj = model_->adj.data();
+    const int ws = model_->ws;
+    std::vector<uint64_t> cur((size_t)wsT);
+    auto has = [&](int v) { return (cur[(size_t)(v >> 6)] >> (v & 63)) & 1ULL; };
+    auto apply = [&](int v, bool yes) {   // Problem::transition (misp/main.rs:77-85)
+        cur[(size_t)(v >> 6)] &= ~(1ULL << (v & 63));
+        if (yes)
+            for (int k = 0; k < ws; ++k) cur[(size_t)k] &= adj[(size_t)v * ws + k];
+    };
+    // best / exact path: one (variable << 1 | bit) word per layer, terminal first -> the layers whose variable impacted the node
+    auto filter = [&](std::vector<uint32_t>& p) {
+        for (int k = 0; k < wsT; ++k) cur[(size_t)k] = in.state[k];
+        std::vector<uint32_t> kept;
+        for (size_t i = p.size(); i-- > 0;) {   // root first
+            const int v = (int)(p[i] >> 1);
+            if (!has(v)) continue;
+            kept.push_back(p[i]);
+            apply(v, (p[i] & 1u) != 0);
+        }
+        p.assign(kept.rbegin(), kept.rend());
+    };
+    filter(out.best_path);
+    filter(out.exact_path);
+    if (out.n_cutset > 0 && out.cs_pw > 0) {
+        const int stride = out.cs_path_len;
+        out.cs_path.assign((size_t)out.n_cutset * (size_t)stride, 0u);
+        out.cs_plen.assign((size_t)out.n_cutset, 0);
+        std::vector<uint32_t> kept;
+        for (int i = 0; i < out.n_cutset; ++i) {
+            for (int k = 0; k < wsT; ++k) cur[(size_t)k] = in.state[k];
+            const uint64_t* pb = out.cs_pbits.data() + (size_t)i * out.cs_pw;
+            const int depth = out.cs_depth.empty() ? stride : out.cs_depth[(size_t)i];
+            kept.clear();
+            for (int tr = 0; tr < depth; ++tr) {
+                const int v = (int)out.cs_lvar[(size_t)tr];
+                if (!has(v)) continue;
+                const bool yes = ((pb[tr >> 6] >> (tr & 63)) & 1ULL) != 0;
+                kept.push_back(((uint32_t)v << 1) | (yes ? 1u : 0u));
+                apply(v, yes);
+            }
+            out.cs_plen[(size_t)i] = (int32_t)kept.size();
+            for (size_t k = 0; k < kept.size(); ++k) out.cs_path[(size_t)i * stride + k] = kept[kept.size() - 1 - k];   // node first
+        }
+        out.cs_pbits.clear();
+        out.cs_lvar.clear();
+        out.cs_pw = 0;
+    }
+}
+
 void Engine::decode_checked(const DDResult& r, const uint8_t* arena, size_t arena_used, HostResult& out) const {
     if (r.status == ST_NOT_RUN) {
         out.clear();
@@ -1070,9 +1139,13 @@ struct Engine::HandOut {
 void Engine::hand_out(HandOut& ho, Waiter* me) {
     for (auto& [r, i] : ho.done) {
         const DDResult* h = ho.raw.hdr + (size_t)i * 2;
-        if (r->in.flags & IN_FUSED) decode_checked(h[1], ho.raw.arena, ho.raw.arena_used, r->out[1]);
+        if (r->in.flags & IN_FUSED) {
+            decode_checked(h[1], ho.raw.arena, ho.raw.arena_used, r->out[1]);
+            if (pooled_) pooled_fixup(r->in, r->out[1]);
+        }
         if (r->waiter == me) {
             decode_checked(h[0], ho.raw.arena, ho.raw.arena_used, r->out[0]);
+            if (pooled_) pooled_fixup(r->in, r->out[0]);
             release_set(ho.raw.set);
             finish_req(r, 3);
             continue;
@@ -1303,6 +1376,7 @@ int Engine::compile_combined(CompileReq* const* reqs, int count) {
             for (int i = 0; i < count; ++i)
                 if (reqs[i]->state == 2) {
                     decode_checked(reqs[i]->hdr, reqs[i]->arena, reqs[i]->arena_used, reqs[i]->out[0]);
+                    if (pooled_) pooled_fixup(reqs[i]->in, reqs[i]->out[0]);
                     release_set(reqs[i]->set);
                     reqs[i]->state = 3;
                 }
@@ -1315,6 +1389,7 @@ int Engine::compile_combined(CompileReq* const* reqs, int count) {
         CompileReq* r = reqs[i];
         if (r->state == 2) {
             decode_checked(r->hdr, r->arena, r->arena_used, r->out[0]);
+            if (pooled_) pooled_fixup(r->in, r->out[0]);
             release_set(r->set);
         } else if (r->rc != DDO_OK) {
             worst = r->rc;
@@ -1581,6 +1656,7 @@ int Engine::fetch(std::vector<HostResult>& results) {
                 continue;
             }
             decode(r, io.h_arena, out);
+            if (pooled_) pooled_fixup(io.h_inputs[i], out);
             if (r.n_cutset > 0 && r.pool_off != NO_POOL_SRC)
                 pool_owner()->pool_head_bound_ = std::max<uint64_t>(pool_owner()->pool_head_bound_,
                                                                     r.pool_off + pool_block_bytes((uint32_t)r.n_cutset, (uint32_t)model_->wsT, (uint32_t)(r.lel > 0 ? r.lel : 0)));
@@ -1706,6 +1782,7 @@ struct ddo_mdd {
     bool caching = false;
     std::shared_ptr<Engine> fallback;   // engine picked by ddo_mdd_create (dense kernel): the full-width engine that takes what it hands up
     bool registered = false;            // counted among the engine's users (Engine::add_user)
+    bool pooled = false;                // DDO_MDD_POOLED
     ~ddo_mdd() {
         if (registered && engine) engine->add_user(-1);
     }
@@ -2063,13 +2140,15 @@ ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, siz
     }
     const bool caching = (cutset_type & DDO_MDD_CACHING) != 0;
     const int selector = cutset_type & DDO_MDD_ENGINE_MASK;
-    cutset_type &= ~(DDO_MDD_CACHING | DDO_MDD_ENGINE_MASK);
+    const bool pooled = (cutset_type & DDO_MDD_POOLED) != 0;
+    cutset_type &= ~(DDO_MDD_CACHING | DDO_MDD_ENGINE_MASK | DDO_MDD_POOLED);
+    if (pooled && cutset_type == 0) cutset_type = DDO_FRONTIER;   // (a Pooled DD has one kind of cut-set: the frontier, pooled.rs:543-566)
     if (cutset_type != DDO_LAST_EXACT_LAYER && cutset_type != DDO_FRONTIER) {
         set_error("ddo_mdd_create: cutset_type must be DDO_LAST_EXACT_LAYER or DDO_FRONTIER (optionally | DDO_MDD_CACHING)");
         return nullptr;
     }
     Model* m = const_cast<Model*>(&model->m);
-    const bool keep = caching || cutset_type == DDO_FRONTIER;   // both need every layer of the DD on the device
+    const bool keep = !pooled && (caching || cutset_type == DDO_FRONTIER);   // both need every layer of the DD on the device
     if (selector && selector != DDO_MDD_ENGINE_FULL && keep) {
         set_error("ddo_mdd_create: DDO_MDD_ENGINE_* selects a kernel of the in-place engine (DDO_LAST_EXACT_LAYER, no DDO_MDD_CACHING)");
         return nullptr;
@@ -2078,7 +2157,13 @@ ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, siz
     // the solver spends its time in) and what it hands up -- a layer beyond its dedup table: 0 of 6.1 million compiles of the
     // brock400_1 search -- runs on the full-width engine; everything else on the one engine of its (model, device, width).
     std::shared_ptr<Engine> eng, fallback;
-    if (selector == DDO_MDD_ENGINE_FULL || keep) eng = Engine::get(m, device, (long)max_width, keep ? Engine::ENGINE_KEEP_LAYERS : 0);
+    if (pooled) {
+        if (caching || selector) {
+            set_error("ddo_mdd_create: DDO_MDD_POOLED takes neither DDO_MDD_CACHING (Pooled with a SimpleCache is not built) nor an engine selector");
+            return nullptr;
+        }
+        eng = Engine::get(m, device, (long)max_width, Engine::ENGINE_POOLED);
+    } else if (selector == DDO_MDD_ENGINE_FULL || keep) eng = Engine::get(m, device, (long)max_width, keep ? Engine::ENGINE_KEEP_LAYERS : 0);
     else if (selector) eng = Engine::get_selected(m, device, (long)max_width, selector);
     else {
         if (m->kind == MODEL_MISP && max_width >= 2048 && !std::getenv("DDO_HIP_NO_AUTO_DENSE")) {
@@ -2094,6 +2179,7 @@ ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, siz
     d->model = m;
     d->engine = eng;
     d->fallback = fallback;
+    d->pooled = pooled;
     eng->add_user(1);
     d->registered = true;
     d->cutset_type = cutset_type;
@@ -2152,7 +2238,7 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
         }
         Engine::CompileReq& rq = reqs[i];
         int rc = fill_input(*mdds[i]->model, &inputs[i], rq.in,
-                            IN_WANT_PATHS | IN_PATH_BITS | (mdds[i]->cutset_type == DDO_FRONTIER ? IN_FRONTIER : 0u) | (cache ? IN_CACHE : 0u) | (dom ? IN_DOMINANCE : 0u));
+                            IN_WANT_PATHS | IN_PATH_BITS | ((mdds[i]->cutset_type == DDO_FRONTIER && !mdds[i]->pooled) ? IN_FRONTIER : 0u) | (cache ? IN_CACHE : 0u) | (dom ? IN_DOMINANCE : 0u));
         if (rc != DDO_OK) {
             set_error("ddo_mdd_compile: invalid compile input");
             return rc;
@@ -2260,7 +2346,8 @@ int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
     const size_t root_len = path.size();
     const bool bits = r.cs_pw > 0;
     for (int i = 0; i < r.n_cutset; ++i) {
-        const int plen = r.cs_depth.empty() ? r.cs_path_len : r.cs_depth[i];   // frontier cut-set: nodes of several layers
+        const int ldepth = r.cs_depth.empty() ? r.cs_path_len : r.cs_depth[i];   // frontier cut-set: nodes of several layers
+        const int plen = r.cs_plen.empty() ? ldepth : r.cs_plen[i];             // Pooled: a decision per EXPANDED ancestor (pooled.rs:316-334)
         path.resize(root_len + (size_t)plen);
         if (bits) {   // IN_PATH_BITS: node first, towards the DD's root (clean.rs:329-343)
             const uint64_t* pb = r.cs_pbits.data() + (size_t)i * r.cs_pw;
@@ -2276,7 +2363,7 @@ int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
         sp.state_words = (size_t)ws;
         sp.value = r.cs_value[i];
         sp.ub = r.cs_ub[i];
-        sp.depth = mdd->depth + (size_t)plen;
+        sp.depth = mdd->depth + (size_t)ldepth;
         sp.path = path.data();
         sp.path_len = path.size();
         cb(&sp, user);

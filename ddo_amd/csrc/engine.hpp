@@ -116,6 +116,7 @@ struct HostResult {
     std::vector<uint32_t> cs_lvar;      // cs_path_len
     int cs_pw = 0;
     std::vector<int32_t> cs_depth;      // frontier cut-set: layer of every node below the DD's root (empty: all at cs_path_len)
+    std::vector<int32_t> cs_plen;       // Pooled: decisions on the path of every node (<= its depth: Engine::pooled_fixup); empty: the depth
     uint64_t pool_off = ~0ULL;          // IN_POOL_OUT: the cut-set block stayed in the device node pool
     bool valid = false;
     void clear() {
@@ -132,6 +133,7 @@ struct HostResult {
         cs_lvar.clear();
         cs_pw = 0;
         cs_depth.clear();
+        cs_plen.clear();
     }
 };
 
@@ -140,6 +142,14 @@ class Engine {
   public:
     /// features: ENGINE_KEEP_LAYERS = every layer of a DD is kept (frontier cut-set, thresholds, cache): layer-rebuilding engine
     static constexpr int ENGINE_KEEP_LAYERS = 1;
+    /// ENGINE_POOLED = the in-place engine compiles Pooled decision diagrams (mdd/pooled.rs:117-823; MISP): a slot is sized for a POOL of as
+    /// many nodes as the LDS dedup table admits (about 14 000), whatever the width the layers are squashed to
+    static constexpr int ENGINE_POOLED = 2;
+    bool is_pooled() const { return pooled_; }
+    /// Pooled results name one decision BIT per layer; the reference's paths hold a decision only where the variable impacted the
+    /// path's node (pooled.rs:316-334: one edge per EXPANDED ancestor).  Replays the paths of `out` from the residual state of `in`
+    /// and drops the other layers: best / exact path and cut-set rows become (variable << 1 | bit) lists, cs_plen their lengths.
+    void pooled_fixup(const DDInput& in, HostResult& out) const;
     static std::shared_ptr<Engine> get(Model* model, int device, long max_width, int features = 0);
     bool keeps_layers() const { return P_.tmode != 0; }
     /// an engine of its own (not shared through the model): needed by owners of the device node pool
@@ -277,6 +287,7 @@ class Engine {
     std::shared_ptr<Engine> owner_ref_;   // get_selected: the tier owns its owner
     int cap_width_ = 0;              // capacity tier: layer capacity (0 = full-width engine)
     void* kernel_ = nullptr;         // the __global__ entry picked in init(): launch() must use the very same one
+    bool pooled_ = false;            // ENGINE_POOLED
     bool dense_ = false;             // two 512-thread workgroups per CU (kernels_inplace_tier.hip: misp_compile_kernel2_dense)
     bool mid_ = false;               // wide capacity tier: four 256-thread workgroups per CU on the same kernel build
     void decode(const DDResult& r, const uint8_t* arena, HostResult& out) const;

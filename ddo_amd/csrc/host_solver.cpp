@@ -49,6 +49,7 @@ struct CutsetBlock {
     std::vector<int32_t> values;
     std::vector<uint32_t> paths;     // rows x path_len, node first (clean.rs:329-343 order)
     std::vector<int32_t> row_len;    // frontier cut-set: decisions (== layers below the parent) per row; empty: path_len for all
+    std::vector<int32_t> row_plen;   // Pooled (mdd/pooled.rs): decisions per row -- one per EXPANDED ancestor, fewer than the layers (row_len) below the parent
     const uint64_t* state(int row) const { return states.data() + (size_t)row * ws; }
 };
 
@@ -74,7 +75,7 @@ void materialize_path(const Model* model, const CutsetBlock* b, int row, std::ve
     for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
         const CutsetBlock* blk = it->first;
         const uint32_t* p = blk->paths.data() + (size_t)it->second * blk->path_len;
-        const int plen = blk->row_len.empty() ? blk->path_len : blk->row_len[(size_t)it->second];
+        const int plen = !blk->row_plen.empty() ? blk->row_plen[(size_t)it->second] : blk->row_len.empty() ? blk->path_len : blk->row_len[(size_t)it->second];
         // rows are stored node first (towards the parent): a frontier row uses the first plen entries of its stride
         for (int k = 0; k < plen; ++k) out.push_back(model->path_decision(p[k]));
     }
@@ -87,6 +88,7 @@ struct Entry {   // SubProblem (common.rs:75-87) as a handle
     int64_t value;
     int64_t ub;
     uint64_t hash;
+    int32_t plen = -1;   // decisions on the path from the problem root when that is not `depth` (Pooled decision diagrams), else -1
 };
 
 uint64_t hash_words(const uint64_t* s, int ws) {
@@ -538,7 +540,8 @@ struct ddo_solver {
         return (long)w;
     }
     /// WidthHeuristic::max_width (width.rs:168-170 / :399-401; path.len() == depth for MISP)
-    int width_of(const Entry& e) const { return (int)ddo_width_heuristic(&cfg, (size_t)model->n, (size_t)std::max(e.depth, 0)); }
+    /// (a Pooled sub-problem's path is shorter than its depth: NbUnassignedWidth counts the path, width.rs:399-401)
+    int width_of(const Entry& e) const { return (int)ddo_width_heuristic(&cfg, (size_t)model->n, (size_t)std::max(e.plen >= 0 ? e.plen : e.depth, 0)); }
     bool budget_exhausted() const {
         if (cfg.time_budget_s <= 0) return false;
         double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
@@ -590,6 +593,7 @@ struct ddo_solver {
         b->values = std::move(r.cs_value);
         b->paths = std::move(r.cs_path);
         b->row_len = std::move(r.cs_depth);
+        b->row_plen = std::move(r.cs_plen);
         block_ref(b);
         std::vector<int> order(r.n_cutset);
         for (int j = 0; j < r.n_cutset; ++j) order[j] = j;
@@ -619,6 +623,7 @@ struct ddo_solver {
             if (ub > best_lb) {                                   // :461
                 const int dj = b->row_len.empty() ? b->depth : it.depth + b->row_len[(size_t)j];
                 Entry e{b, j, dj, b->values[j], ub, hash_words(b->state(j), model->ws)};
+                if (!b->row_plen.empty()) e.plen = (it.plen >= 0 ? it.plen : it.depth) + b->row_plen[(size_t)j];
                 fringe->push(e);
                 st_push += 1;
             }
@@ -831,7 +836,9 @@ struct ddo_solver {
                     b->paths[(size_t)k] = model->path_word(d);
                 }
                 block_ref(b);
-                fringe->push(Entry{b, 0, b->depth, value[i], ub[i], hash_words(b->states.data(), ws)});
+                Entry imported{b, 0, b->depth, value[i], ub[i], hash_words(b->states.data(), ws)};
+                if (cfg.pooled) imported.plen = b->path_len;
+                fringe->push(imported);
                 block_unref(b);
             }
         }
@@ -1403,7 +1410,7 @@ struct ddo_solver {
             DDInput& in = inputs[i];
             std::memset(&in, 0, sizeof(in));
             in.comp_type = CT_RESTRICTED;
-            in.flags = IN_FUSED | IN_FILTER_CUTSET | (cfg.cutset_type == DDO_FRONTIER ? IN_FRONTIER : 0u);
+            in.flags = IN_FUSED | IN_FILTER_CUTSET | ((cfg.cutset_type == DDO_FRONTIER && !cfg.pooled) ? IN_FRONTIER : 0u);
             // DefaultCachingSolver: must_explore at the pop (sequential.rs:341 / parallel.rs:537-549; the parallel solver
             // also marks the node explored), thresholds and cache filter inside the compiles
             if (cache) in.flags |= IN_CACHE | IN_MUST_EXPLORE | (cfg.sequential ? 0u : IN_MARK_EXPLORED);
@@ -1514,7 +1521,16 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
     if (s->cfg.world_size < 1) s->cfg.world_size = 1;
     if (s->cfg.rank < 0 || s->cfg.rank >= s->cfg.world_size) s->cfg.rank = 0;
     if (s->cfg.cutset_type == 0) s->cfg.cutset_type = DDO_LAST_EXACT_LAYER;
-    const bool keep_layers = s->cfg.cutset_type == DDO_FRONTIER || s->cfg.cache_entries > 0 || s->cfg.dominance_entries > 0;
+    if (s->cfg.pooled) {
+        if (s->model->kind != MODEL_MISP || cfg->fringe != DDO_FRINGE_NODUP || s->cfg.cache_entries > 0 || s->cfg.dominance_entries > 0) {
+            set_error("ddo_solver_create: pooled = 1 (Par / SeqNoCachingSolverPooled, solver/mod.rs:34, :43) needs a MISP model, DDO_FRINGE_NODUP, "
+                      "no cache and no dominance checker (Pooled with a SimpleCache is not built)");
+            delete s;
+            return nullptr;
+        }
+        s->cfg.cutset_type = DDO_FRONTIER;   // the only cut-set a Pooled DD has (pooled.rs:543-566); computed by the pooled kernel itself
+    }
+    const bool keep_layers = !s->cfg.pooled && (s->cfg.cutset_type == DDO_FRONTIER || s->cfg.cache_entries > 0 || s->cfg.dominance_entries > 0);
     if ((s->cfg.cutset_type != DDO_LAST_EXACT_LAYER && s->cfg.cutset_type != DDO_FRONTIER) || (keep_layers && cfg->fringe == DDO_FRINGE_LAZY)) {
         set_error("ddo_solver_create: cutset_type must be LAST_EXACT_LAYER or FRONTIER; a frontier cut-set or a cache need DDO_FRINGE_NODUP");
         delete s;
@@ -1522,7 +1538,8 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
     }
     // the lazy fringe keeps its nodes in the engine's device pool and leaves launches in flight: it owns its engine
     s->engine = cfg->fringe == DDO_FRINGE_LAZY ? Engine::create_private(s->model, cfg->device, s->engine_width())
-                                               : Engine::get(s->model, cfg->device, s->engine_width(), keep_layers ? Engine::ENGINE_KEEP_LAYERS : 0);
+                                               : Engine::get(s->model, cfg->device, s->engine_width(),
+                                                             s->cfg.pooled ? Engine::ENGINE_POOLED : keep_layers ? Engine::ENGINE_KEEP_LAYERS : 0);
     if (!s->engine) {
         delete s;
         return nullptr;

@@ -21,6 +21,8 @@ kernel_fn pick_kernel2_512(int wsT);
 kernel_fn pick_kernel2_tier(int wsT);
 /// waves per SIMD the capacity-tier kernel is compiled for (its register budget): 4 x that many waves share a CU
 int tier_waves_per_simd();
+/// Pooled decision diagrams (mdd/pooled.rs) out of the in-place engine's node slots: 512 threads, one decision diagram per CU
+kernel_fn pick_kernel2_pooled(int wsT);
 /// two full-width DDs per CU: 512 threads, 4 waves per SIMD
 kernel_fn pick_kernel2_dense(int wsT);
 kernel_fn pick_kernel_lds(int wsT);

@@ -38,6 +38,8 @@ constexpr uint32_t T2_TOMB = 0xFFFFFFFEu;
 constexpr uint32_t EV_CREATED = 0x80000000u;  // flag on a YES target: the slot was created by this arc
 constexpr uint32_t EV_RAISED = 0x40000000u;   // flag on a target: the arc raised its target's key (see the event records of run_dd2)
 constexpr uint32_t EV_SLOT_MASK = 0x000FFFFFu;
+constexpr uint32_t EV_PINEX = 0x40000000u;    // POOLED, flag on the PARENT word of a record: the parent was inexact when it was expanded
+constexpr uint32_t EV_PCUT = 0x20000000u;     // POOLED, backward pass: the parent belongs to the frontier cut-set
 constexpr int KEY_POP_BITS = 11;              // key32 = (value - vbase) << 11 | popcount
 constexpr uint32_t KEY_POP_MASK = (1u << KEY_POP_BITS) - 1;
 
@@ -556,11 +558,12 @@ DDO_DEV int32_t rub2_of(const DD2Ctx<WS>& c, const uint64_t* s) {
 /// Keys may live in HBM (L2) at large widths: every sweep fetches KB keys per thread before it touches them, so the
 /// sweep costs hi / (NT * KB) dependent round trips instead of hi / NT.
 /// DEEP (workgroups of up to 512 threads: 256 VGPRs per lane) doubles the loads in flight per thread in every sweep.
-template <int WS, int DEEP = 0>
+template <int WS, int DEEP = 0, int POOLED = 0>
 DDO_DEV void select_key2(DD2Ctx<WS>& c, int K, int L) {
     constexpr int KB = DEEP ? 16 : 8;
     DD_TID_SETUP(c)
     LDS_PTR(DD2Shared) sh = c.sh;
+    LDS_PTR(uint32_t) member = POOLED ? c.fresh : c.live;   // POOLED: the layer = the pool nodes the variable impacts (marked in `fresh`)
     const int hi = DD_UNIFORM(sh->hiw);
     // Which key bits vary at all?  The AND / OR of the keys was gathered while the layer was built -- by the work-list sweep of the
     // previous transition (every node it saw) and by expand (both children of every branching node): a superset of the layer's
@@ -599,7 +602,7 @@ DDO_DEV void select_key2(DD2Ctx<WS>& c, int K, int L) {
 #pragma unroll
             for (int b = 0; b < KB; ++b) {
                 const int s = base + b * NT + tid;
-                if (s < hi && bm_test(c.live, s)) {
+                if (s < hi && bm_test(member, s)) {
                     const uint32_t k = kk[b];
                     const bool active = up >= 32 || (k >> up) == (piv >> up);
                     if (active) LDS_ADD_U32(&c.hist[(k >> shift) & dmask], 1u);
@@ -846,7 +849,17 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
 /// The squash of layer L (deleted slots, merged slot, re-added duplicate) is stored with iteration L.
 
 
-template <int WS, int DEEP = 0>
+/// POOLED = 1: the same engine compiles `Pooled` decision diagrams (mdd/pooled.rs:117-823) -- which is what its node slots are:
+/// a pool of nodes that live across layers.  What changes against clean.rs:
+///   * the layer of a variable is made of the pool nodes it IMPACTS (Problem::is_impacted_by, dp.rs:68-70; MISP: the states
+///     that contain the vertex, main.rs:145-147): width, ranking and merge apply to those only (pooled.rs:614-641, 734-829);
+///   * a node's rough upper bound is checked when the node is expanded, not in every layer it waits in (pooled.rs:351-361);
+///   * nodes_expanded counts the impacted nodes; a node's depth is the layer at which it is expanded;
+///   * the cut-set is the FRONTIER (pooled.rs:543-566): exact nodes with an inexact child, whatever their layer.  A child
+///     may turn inexact long after its parent was expanded, so the frontier is found by the backward replay of the event
+///     records (the parent's exactness travels in its record, EV_PINEX), and a cut-set node's state, value and rough upper
+///     bound are rebuilt from its best path (an exact node's state is the residual state with its path's decisions applied).
+template <int WS, int DEEP = 0, int POOLED = 0>
 DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
     constexpr int KB = DEEP ? 16 : 8;
     DD_TID_SETUP(c)
@@ -911,7 +924,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         add_bits<WS>(c.cnt, root, +1);
         c.live[0] = 1u;
         c.okb[0] = 1u;
-        c.fresh[0] = 1u;
+        c.fresh[0] = POOLED ? 0u : 1u;   // (POOLED: `fresh` marks the members of a layer that is being squashed, nothing else)
     }
     PAR_END
 
@@ -930,9 +943,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // _squash_if_needed (clean.rs:779-795) is decided up front: a layer that is NOT squashed never probes the dedup
         // table of the current layer again, so the table of the next layer is cleared here and the region that would
         // do it later disappears -- narrow layers are all barrier and round-trip latency, every region counts
-        const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
+        // (POOLED: the layer is what the variable impacts -- cnt[var] nodes, known once the variable is; decided below)
+        bool squash = !POOLED && ((restricted && nU > W) || (relaxed && nU > W && L > 1));
         PAR_BEGIN
-        if (!squash)
+        if (!squash && !POOLED)
             for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
         // Cutoff::must_stop (clean.rs:352) -- polled every 8th layer: the flag lives in host-visible memory and a
         // read is a full round trip on the critical path of the layer
@@ -957,6 +971,35 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             break;
         }
         if (L >= c.max_layers - 1 || sh->status != ST_OK) { failed = true; break; }
+        if (POOLED) {
+            // pooled.rs:734-749: the width bounds the nodes that are EXPANDED; `layers.len() >= 2` is L > 1 here (every layer so
+            // far held the nodes its variable impacts, at least one)
+            const int nimp = c.cnt[var];
+            squash = (restricted && nimp > W) || (relaxed && nimp > W && L > 1);
+            const int vw0 = var >> 6;
+            const uint64_t vbit0 = 1ULL << (var & 63);
+            PAR_BEGIN
+            if (!squash) {
+                for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
+            } else {
+                // membership of the layer (`fresh` bitmap, otherwise unused by pooled DDs) and the AND / OR of its keys for the select
+                uint32_t kb_and = 0xFFFFFFFFu, kb_or = 0;
+                const int hi = DD_UNIFORM(sh->hiw);
+                for (int s = tid; s < hi; s += NT) {
+                    if (!bm_test(c.live, s)) continue;
+                    if ((c.rec[(size_t)s * c.RW + vw0] & vbit0) == 0) continue;
+                    bm_set(c.fresh, s);
+                    const uint32_t k = K32(c, s);
+                    kb_and &= k;
+                    kb_or |= k;
+                }
+                if (kb_or != 0 || kb_and != 0xFFFFFFFFu) {
+                    LDS_AND_U32(&sh->kbits_and[L & 1], kb_and);
+                    LDS_OR_U32(&sh->kbits_or[L & 1], kb_or);
+                }
+            }
+            PAR_END
+        }
         DD2_TICK2(PH_VAR, 15)
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
         int merged_slot = -1, dup_from = -1, dup_to = -1;
@@ -973,7 +1016,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         if (squash) {
             if (lel < 0) {
                 lel = L - 1;   // _maybe_save_lel
-                if (relaxed && snapL != lel) {  // cannot happen: see the snapshot rule below
+                if (!POOLED && relaxed && snapL != lel) {  // cannot happen: see the snapshot rule below
                     PAR_BEGIN
                     if (tid == 0) sh->status = ST_ERR_INTERNAL;
                     PAR_END
@@ -982,7 +1025,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 }
             }
             const int K = restricted ? W : W - 1;
-            if (K > 0) select_key2<WS, DEEP>(c, K, L);
+            if (K > 0) select_key2<WS, DEEP, POOLED>(c, K, L);
             DD2_TICK(PH_SELECT)
             PAR_BEGIN
             if (tid == 0) {
@@ -1009,7 +1052,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 #pragma unroll
                 for (int b = 0; b < KB; ++b) {
                     const int s = base + b * NT + tid;
-                    if (s >= sh->hiw || !bm_test(c.live, s)) continue;
+                    if (s >= sh->hiw || !bm_test(POOLED ? c.fresh : c.live, s)) continue;
                     const uint32_t key = kk[b];
                     if (K > 0 && key > pivKey) continue;
                     if (K > 0 && key == pivKey) {
@@ -1245,7 +1288,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // ------------------------------------------------------------ candidate last exact layer: snapshot
         // Layer L+1 can only be squashed when n + (#YES-children) > W; only then is layer L copied, so the
         // cut-set (clean.rs:566-573) is available although layers are updated in place.
-        if (relaxed && lel < 0 && n + naff_bound > W && L >= 1) {
+        if (!POOLED && relaxed && lel < 0 && n + naff_bound > W && L >= 1) {
             PAR_BEGIN
             if (tid == 0) sh->ncut = 0;
             PAR_END
@@ -1276,6 +1319,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         if (squash) {   // the squash phases probed the table of this layer and borrowed the counters
             PAR_BEGIN
             for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;   // dedup table of the next layer (see the sweep)
+            if (POOLED)
+                for (int i = tid; i < c.nbw; i += NT) c.fresh[i] = 0;   // (the layer's membership marks)
             if (tid == 0) {
                 sh->nwl = 0;
                 sh->nwl2 = 0;
@@ -1340,7 +1385,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     if ((ww[b] & vbit) != 0) {
                         const int i = LDS_ADD_I32(&sh->nwl, 1);
                         if (i < c.capW) c.wl[i] = (uint16_t)s;
-                    } else if (bm_test(c.fresh, s)) {
+                    } else if (!POOLED && bm_test(c.fresh, s)) {
                         // unit weights: the rough upper bound is the popcount held in the key (main.rs:191-193); a fresh
                         // node that passes the check (clean.rs:362-365) is its own only child and joins the table here
                         const uint32_t key = (uint32_t)(hh[b] >> 32);
@@ -1384,10 +1429,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         const int nwl = DD_UNIFORM(sh->nwl);      // nodes containing the variable
         const int nwl2 = DD_UNIFORM(sh->nwl2);    // fresh nodes that do not
         // (n + nwl bounds the entries of the next layer's dedup table: every node of this layer and one YES-child per branching node)
-        if (nwl + nwl2 > c.capW || n > c.capW || n + nwl > c.tab_limit || sh->ev_pos + 4ull * (uint64_t)(nwl + nwl2) + 12 > c.ev_cap) {
+        // (POOLED: the pool may hold more nodes than a work list -- up to the node slots and the dedup table; only a layer is bounded)
+        if (nwl + nwl2 > c.capW || (!POOLED && n > c.capW) || n + nwl > c.tab_limit || sh->ev_pos + 4ull * (uint64_t)(nwl + nwl2) + 12 > c.ev_cap) {
             PAR_BEGIN
             if (tid == 0) {
-                sh->status = ST_ERR_CAPACITY - 100 * (nwl + nwl2 > c.capW ? 41 : (n > c.capW ? 42 : (n + nwl > c.tab_limit ? 44 : 43)));
+                sh->status = ST_ERR_CAPACITY - 100 * (nwl + nwl2 > c.capW ? 41 : ((!POOLED && n > c.capW) ? 42 : (n + nwl > c.tab_limit ? 44 : 43)));
                 sh->bestKey = ((uint64_t)(uint32_t)nwl << 32) | (uint32_t)n;   // debugging aid: reported as best_value fields
                 sh->nodes = sh->ev_pos;
                 sh->arcs = (uint64_t)L;
@@ -1493,14 +1539,14 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             ld_state_p<WS>(c, s, st, ppid);
             DD2_PROBE(0)
             const int32_t rub = c.unit_weights ? pop : rub2_of<WS>(c, st);   // main.rs:191-193
-            bm_clr(c.fresh, s);
+            if (!POOLED) bm_clr(c.fresh, s);
             if ((int64_t)rub + (int64_t)val <= best_lb) {   // clean.rs:364-365: no children
                 add_bits<WS>(c.cnt, st, -1);
                 bm_clr(c.live, s);
                 LDS_ADD_I32(&sh->nlive, -1);
                 const int r = LDS_ADD_I32(&sh->nrec, 1);
                 U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
-                *rec4 = U32x4{(uint32_t)s, NONE32, NONE32, NONE32};
+                *rec4 = U32x4{(uint32_t)s | ((POOLED && bm_test(c.inex, s)) ? EV_PINEX : 0u), NONE32, NONE32, NONE32};
                 LDS_ADD_I32(&sh->npruned, 1);
                 continue;
             }
@@ -1509,6 +1555,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             for (int k = 0; k < WS; ++k)
                 if (k == vw) hasv = (st[k] & vbit) != 0;
             if (!hasv) continue;   // fresh but unaffected: its NO-child is the node itself
+            const bool pinex = POOLED && bm_test(c.inex, s);   // (read before the table publishes the slot: a twin folds its flag into it)
             // ---- decision NO, in place (main.rs:77-85)
             uint64_t oldw = 0, neww = 0;
 #pragma unroll
@@ -1575,7 +1622,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             if (t0 != s) old0 = K32_MAX(c, t0, kno, newh);
             if (ny >= 0 && t1 != ny) old1 = K32_MAX(c, t1, kyes, yh);
             if (t0 == s) {
-                bm_set(c.fresh, s);          // it stays in the layer; its rub shrank: check it again before it is expanded
+                if (!POOLED) bm_set(c.fresh, s);   // it stays in the layer; its rub shrank: check it again before it is expanded
             } else {                         // the in-place NO-child dissolves into its twin t0
                 if (bm_test(c.inex, s)) bm_set(c.inex, t0);
                 add_bits<WS>(c.cnt, st, -1);
@@ -1586,7 +1633,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             if (ny >= 0) {
                 if (t1 == ny) {              // a new node enters the layer
                     bm_set(c.live, ny);
-                    bm_set(c.fresh, ny);
+                    if (!POOLED) bm_set(c.fresh, ny);
                     add_bits<WS>(c.cnt, y, +1);
                     LDS_ADD_I32(&sh->nlive, 1);
                     LDS_MAX_I32(&sh->hiw, ny + 1);
@@ -1600,7 +1647,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             DD2_PROBE(6)
             U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
             // parent | NO target | YES target | slot allocated for the YES-child
-            *rec4 = U32x4{(uint32_t)s, e_no, e_yes, ny >= 0 ? (uint32_t)ny : NONE32};
+            *rec4 = U32x4{(uint32_t)s | (pinex ? EV_PINEX : 0u), e_no, e_yes, ny >= 0 ? (uint32_t)ny : NONE32};
             DD2_PROBE(4)
 #if defined(DDO_HIP_PROBES)
             if (probing && i == tid) {   // thread 0's first node went the whole way: charge its chain
@@ -1636,7 +1683,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const uint32_t w = rec[1 + which];
                 if (w == NONE32 || !(w & EV_RAISED)) continue;
                 const int t = (int)(w & EV_SLOT_MASK);
-                const int x = which == 0 ? (int)rec[0] : (int)rec[3];
+                const int x = which == 0 ? (int)(rec[0] & EV_SLOT_MASK) : (int)rec[3];
                 if (K32(c, t) == K32(c, x)) {
                     // the NO arc carries the parent's path as it was when the record was written, the YES arc that plus its own node
                     const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;
@@ -1666,10 +1713,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 eo[4] = (uint32_t)(del_off >> 32);
                 eo[5] = (uint32_t)n_del;
                 sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
-                sh->nodes += (uint64_t)n;
+                sh->nodes += POOLED ? (uint64_t)nwl : (uint64_t)n;   // (POOLED: the nodes that are expanded are the impacted ones, pooled.rs:351)
                 if (n > sh->maxn) sh->maxn = n;
                 sh->nyes = nrec - sh->npruned;   // every record is a pruned node or a node with a YES-child
-                sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
+                sh->arcs += (POOLED ? (uint64_t)sh->nyes : (uint64_t)(n - sh->npruned)) + (uint64_t)sh->nyes;
                 c.cnt[var] = 0;
     #if defined(DDO_HOST_EMULATION)
                 if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
@@ -1696,7 +1743,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     const uint32_t w = rec[1 + which];
                     if (w == NONE32) continue;
                     const int t = (int)(w & EV_SLOT_MASK);
-                    const int x = which == 0 ? (int)rec[0] : (int)rec[3];
+                    const int x = which == 0 ? (int)(rec[0] & EV_SLOT_MASK) : (int)rec[3];
                     if (t == x) continue;   // the child is the holder itself
                     if (K32(c, t) == K32(c, x) && bm_test(c.okb, x) && !bm_test(c.okb, t)) {
                         const uint32_t bit = 1u << (t & 31);
@@ -1722,10 +1769,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 eo[4] = (uint32_t)(del_off >> 32);
                 eo[5] = (uint32_t)n_del;
                 sh->ev_pos = aff_off + 4ull * (uint64_t)nrec;
-                sh->nodes += (uint64_t)n;
+                sh->nodes += POOLED ? (uint64_t)nwl : (uint64_t)n;   // (POOLED: the nodes that are expanded are the impacted ones, pooled.rs:351)
                 if (n > sh->maxn) sh->maxn = n;
                 sh->nyes = nrec - sh->npruned;   // every record is a pruned node or a node with a YES-child
-                sh->arcs += (uint64_t)(n - sh->npruned) + (uint64_t)sh->nyes;
+                sh->arcs += (POOLED ? (uint64_t)sh->nyes : (uint64_t)(n - sh->npruned)) + (uint64_t)sh->nyes;
                 c.cnt[var] = 0;
     #if defined(DDO_HOST_EMULATION)
                 if (getenv("DD_TRACE")) std::printf("E2 L=%d var=%d n=%d pruned=%d yes=%d nU_next=%d squash=%d\n", L, var, n, sh->npruned, sh->nyes, sh->nlive, (int)squash);
@@ -1799,6 +1846,288 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     }
 
     DD2_TICK(PH_FINAL)
+    if (POOLED) {
+        // ============================================================ Pooled: frontier cut-set + local bounds in ONE backward replay
+        // (pooled.rs:438-467, 543-566).  ix = `inex` bitmap, replayed backwards: before transition tr is undone it tells, per slot,
+        // whether the node living there AFTER the transition ends up inexact; a parent is restored with the flag of its record.
+        const bool want_cs = relaxed && !failed && lel >= 0 && has_best;   // (exact DDs have no cut-set: pooled.rs:556; drain needs a best value: :410)
+        int32_t* vb = c.keyh ? (int32_t*)c.keyh : (int32_t*)c.key32;   // the ranking keys are dead now: reuse their storage
+        int32_t* tmp = (int32_t*)c.wl;                                   // wl + fl = capW x int32
+        const uint64_t cbase = (sh->ev_pos + 3) & ~3ULL;                 // cut list behind the event records: (record id, value_bot) pairs
+        GLB_PTR(uint32_t) cutl = c.ev + cbase;
+        const uint64_t cut_cap = c.ev_cap > cbase + 8 ? (c.ev_cap - cbase) / 2 : 0;
+        PAR_BEGIN
+        if (tid == 0) {
+            sh->ncut = 0;
+            sh->ncut2 = 0;
+        }
+        PAR_END
+        if (want_cs) {
+            PAR_BEGIN   // what is left in the pool is the last layer: value_bot = 0 and MARKED (pooled.rs:441-446)
+            for (int s = tid; s < capS; s += NT) vb[s] = (s < sh->hiw && bm_test(c.live, s)) ? 0 : VB_UNMARKED;
+            PAR_END
+            for (int tr = L - 1; tr >= 0; --tr) {
+                // (1) undo the squash of layer tr+1: arcs into a deleted node were redirected to the merged node (pooled.rs:806-819),
+                // which is inexact
+                GLB_PTR(const uint32_t) eo1 = c.evoff + (size_t)(tr + 1) * 8;
+                const int nd = (int)eo1[5];
+                const int m = c.lmerge[tr + 1];
+                if (nd > 0 && m >= 0) {
+                    const uint64_t doff = (uint64_t)eo1[3] | ((uint64_t)eo1[4] << 32);
+                    const int dfrom = c.ldup[2 * (tr + 1)], dto = c.ldup[2 * (tr + 1) + 1];
+                    PAR_BEGIN
+                    const int32_t vm = vb[m];
+                    for (int i = tid; i < nd; i += NT) {
+                        const uint32_t d = c.ev[doff + i];
+                        if (d != NONE32 && (int)d != m) {
+                            vb[d] = vm;
+                            bm_set(c.inex, (int)d);
+                        }
+                    }
+                    PAR_END
+                    if (dfrom >= 0) {
+                        PAR_BEGIN
+                        if (tid == 0) {
+                            int32_t a = vb[dfrom], b = vb[dto];
+                            vb[dfrom] = a > b ? a : b;   // X keeps its own arcs and they were also redirected (pooled.rs:821-825)
+                            bm_set(c.inex, dfrom);       // (for the arcs INTO X: they also reach the relaxed node; X's own flag is in its record)
+                        }
+                        PAR_END
+                    }
+                }
+                // (2) parents of the transition tr -> tr+1
+                GLB_PTR(const uint32_t) eo = c.evoff + (size_t)tr * 8;
+                const int na = (int)eo[2];
+                const uint64_t aoff = (uint64_t)eo[0] | ((uint64_t)eo[1] << 32);
+                const int32_t wv = c.weight[c.lvar[tr]];
+                if (na > c.capW) {   // (cannot happen: a work list holds at most capW nodes)
+                    PAR_BEGIN
+                    if (tid == 0) sh->status = ST_ERR_INTERNAL;
+                    PAR_END
+                    break;
+                }
+                PAR_BEGIN
+                for (int i = tid; i < na; i += NT) {
+                    GLB_PTR(uint32_t) rec = c.ev + aoff + 4ull * (uint64_t)i;
+                    int32_t best = VB_UNMARKED;
+                    bool cix = false;
+                    if (rec[1] != NONE32) {
+                        const int t = (int)(rec[1] & EV_SLOT_MASK);
+                        const int32_t v = vb[t];
+                        if (v != VB_UNMARKED) best = v;
+                        cix |= bm_test(c.inex, t);
+                    }
+                    if (rec[2] != NONE32) {
+                        const int t = (int)(rec[2] & EV_SLOT_MASK);
+                        const int32_t v = vb[t];
+                        if (v != VB_UNMARKED && v + wv > best) best = v + wv;
+                        cix |= bm_test(c.inex, t);
+                    }
+                    tmp[i] = best;
+                    if (cix && !(rec[0] & EV_PINEX)) rec[0] |= EV_PCUT;   // exact parent of an inexact node: frontier (pooled.rs:552-560)
+                }
+                PAR_END
+                PAR_BEGIN
+                for (int i = tid; i < na; i += NT) {
+                    GLB_PTR(const uint32_t) rec = c.ev + aoff + 4ull * (uint64_t)i;
+                    const uint32_t p0 = rec[0];
+                    const int s = (int)(p0 & EV_SLOT_MASK);
+                    vb[s] = tmp[i];
+                    bm_put(c.inex, s, (p0 & EV_PINEX) != 0);
+                    if ((p0 & EV_PCUT) && tmp[i] != VB_UNMARKED) {   // drain_cutset keeps the MARKED nodes only (pooled.rs:414)
+                        const uint64_t k = (uint64_t)LDS_ADD_I32(&sh->ncut, 1);
+                        if (k < cut_cap) {
+                            cutl[2 * k] = (uint32_t)(aoff >> 2) + (uint32_t)i;
+                            cutl[2 * k + 1] = (uint32_t)tmp[i];
+                        }
+                    }
+                }
+                PAR_END
+            }
+        }
+        const int ncut = sh->ncut;
+        const bool cut_over = (uint64_t)ncut > cut_cap;
+        const bool want_paths = (in.flags & IN_WANT_PATHS) != 0;
+        const bool emit_best = has_best && (want_paths || (int64_t)best_value > best_lb);
+        const bool emit_exact = has_best_exact && (want_paths || (int64_t)exact_value > best_lb);
+        const bool same = emit_best && emit_exact && exact_slot == best_slot;
+        const int path_len = L;   // one decision bit per transition; the host drops the layers whose variable did not impact the path's node
+        const int best_len = emit_best ? path_len : 0;
+        const int exact_len = (emit_exact && !same) ? path_len : 0;
+        const uint32_t pw = (uint32_t)((path_len + 63) / 64);
+        uint64_t off = 0;
+        const uint64_t path_off = off;
+        off += ((uint64_t)best_len * 4 + 7) & ~7ULL;
+        const uint64_t exact_off = off;
+        off += ((uint64_t)exact_len * 4 + 7) & ~7ULL;
+        const uint64_t cs_state_off = off;
+        off += (uint64_t)ncut * WS * 8;
+        const uint64_t cs_value_off = off;
+        off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
+        const uint64_t cs_ub_off = off;
+        off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
+        const uint64_t cs_depth_off = off;
+        off += ((uint64_t)ncut * 4 + 7) & ~7ULL;
+        const uint64_t cs_path_off = off;
+        off += (uint64_t)ncut * pw * 8;
+        const uint64_t cs_lvar_off = off;
+        off += ((uint64_t)path_len * 4 + 7) & ~7ULL;
+        const uint64_t total = off;
+        PAR_BEGIN
+        if (tid == 0) {
+            unsigned long long a = total ? GLB_ADD_U64(c.arena_head, (unsigned long long)total) : 0ULL;
+            sh->arena_off = a;
+            if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY - 100 * 7;
+            if (cut_over) sh->status = ST_ERR_CAPACITY - 100 * 12;   // the cut list outgrew the room behind the event records
+        }
+        PAR_END
+        const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;
+        GLB_PTR(uint8_t) base = c.arena + sh->arena_off;
+        if (arena_ok && !failed) {
+            LDS_PTR(uint64_t) bbits = (LDS_PTR(uint64_t))sh->merged;
+            LDS_PTR(uint64_t) xbits = (LDS_PTR(uint64_t))sh->xcand;   // 64 x int32 = 32 words >= WS
+            PAR_BEGIN
+            if (tid == 0 && best_len) {
+                uint64_t b[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) b[k] = 0;
+                path_bits<WS>(c, pid_ld<WS>(c, best_slot), b);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) bbits[k] = b[k];
+            }
+            if (tid == 64 % NT && exact_len) {
+                uint64_t b[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) b[k] = 0;
+                path_bits<WS>(c, pid_ld<WS>(c, exact_slot), b);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) xbits[k] = b[k];
+            }
+            PAR_END
+            PAR_BEGIN
+            if (best_len) {
+                uint32_t* out = (uint32_t*)(base + path_off);
+                for (int i = tid; i < best_len; i += NT) {
+                    const int tr = path_len - 1 - i;
+                    out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((bbits[tr >> 6] >> (tr & 63)) & 1ULL);
+                }
+            }
+            if (exact_len) {
+                uint32_t* out = (uint32_t*)(base + exact_off);
+                for (int i = tid; i < exact_len; i += NT) {
+                    const int tr = path_len - 1 - i;
+                    out[i] = ((uint32_t)c.lvar[tr] << 1) | (uint32_t)((xbits[tr >> 6] >> (tr & 63)) & 1ULL);
+                }
+            }
+            if (ncut) {
+                uint32_t* o_lvar = (uint32_t*)(base + cs_lvar_off);
+                for (int j = tid; j < path_len; j += NT) o_lvar[j] = (uint32_t)c.lvar[j];
+                uint64_t* o_state = (uint64_t*)(base + cs_state_off);
+                int32_t* o_value = (int32_t*)(base + cs_value_off);
+                int32_t* o_ub = (int32_t*)(base + cs_ub_off);
+                int32_t* o_depth = (int32_t*)(base + cs_depth_off);
+                uint64_t* o_bits = (uint64_t*)(base + cs_path_off);
+                for (int q = tid; q < ncut; q += NT) {
+                    const uint32_t eid = cutl[2 * (uint64_t)q];
+                    const int32_t locb = (int32_t)cutl[2 * (uint64_t)q + 1];
+                    const uint64_t pe = c.pt[eid];
+                    const int depth = (int)(pe >> 32);   // the layer at which the node was expanded (pooled.rs:622)
+                    uint64_t pb[WS], st[WS];
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) pb[k] = 0;
+                    path_bits<WS>(c, (uint32_t)pe, pb);
+                    // An exact node's state is the residual state with the decisions of (any of) its paths applied (main.rs:77-85),
+                    // its value the residual value plus the weights of the 1-decisions (main.rs:87-93).
+                    if (in.src_off != NO_POOL_SRC) {
+                        const PoolBlockHeader* h = (const PoolBlockHeader*)(c.pool + in.src_off);
+                        const uint64_t* rows = (const uint64_t*)(c.pool + in.src_off + h->off_states);
+#pragma unroll
+                        for (int k = 0; k < WS; ++k) st[k] = k < (int)h->ws ? rows[(size_t)k * h->rows + in.src_row] : 0;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < WS; ++k) st[k] = in.state[k];
+                    }
+                    int64_t v = in.value;
+                    for (int j = 0; j < depth; ++j) {
+                        const int x = c.lvar[j];
+                        const int xw = x >> 6;
+                        const uint64_t xb = 1ULL << (x & 63);
+                        bool has = false, yes = false;
+#pragma unroll
+                        for (int k = 0; k < WS; ++k) {
+                            if (k == xw) {
+                                has = (st[k] & xb) != 0;
+                                st[k] &= ~xb;
+                            }
+                            if (k == (j >> 6)) yes = ((pb[k] >> (j & 63)) & 1ULL) != 0;
+                        }
+                        if (has && yes) {
+#pragma unroll
+                            for (int k = 0; k < WS; ++k) st[k] &= c.adj[(size_t)x * WS + k];
+                            v += c.weight[x];
+                        }
+                    }
+                    int64_t ub = v + (int64_t)rub2_of<WS>(c, st);
+                    if (v + locb < ub) ub = v + locb;
+                    if (best_value < ub) ub = best_value;
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) o_state[(size_t)q * WS + k] = st[k];
+                    o_value[q] = (int32_t)v;
+                    o_ub[q] = (int32_t)ub;
+                    o_depth[q] = depth;
+#pragma unroll
+                    for (int k = 0; k < WS; ++k)
+                        if ((uint32_t)k < pw) o_bits[(size_t)q * pw + k] = pb[k];
+                }
+            }
+            PAR_END
+        }
+        PAR_BEGIN
+        if (tid == 0) {
+            DDResult r;
+            r.status = sh->status;
+            if (c.tier && (sh->status == ST_ERR_CAPACITY || (sh->status <= ST_ERR_CAPACITY - 100 && sh->status != ST_ERR_CAPACITY - 700 &&
+                                                             sh->status != ST_ERR_CAPACITY - 800)))
+                r.status = ST_RETRY;
+            r.comp_type = comp_type;
+            r.is_exact = is_exact ? 1 : 0;
+            r.has_exact_best_path = ebpo ? 1 : 0;
+            r.has_best = has_best ? 1 : 0;
+            r.has_best_exact = has_best_exact ? 1 : 0;
+            r.best_value = best_value;
+            r.best_exact_value = exact_value;
+            r.n_layers = n_layers;
+            r.lel = lel;
+            r.n_cutset = arena_ok ? ncut : 0;
+            r.best_len = arena_ok ? best_len : 0;
+            r.exact_len = arena_ok ? (same ? best_len : exact_len) : 0;
+            r.exact_same_as_best = same ? 1 : 0;
+            r.recycled_merges = sh->recycled_merges;
+            r.max_width_seen = (uint32_t)sh->maxn;
+            r.arena_off = sh->arena_off;
+            r.arena_bytes = total;
+            r.nodes_expanded = sh->nodes;
+            r.arcs = sh->arcs;
+            r.layers = (uint64_t)L;
+            r.path_off = path_off;
+            r.exact_off = same ? path_off : exact_off;
+            r.cs_state_off = cs_state_off;
+            r.cs_value_off = cs_value_off;
+            r.cs_ub_off = cs_ub_off;
+            r.cs_path_off = cs_path_off;
+            sh->clk[PH_FINAL] += dd_clock() - sh->clk_last;
+            for (int k = 0; k < 8; ++k) r.phase_clk[k] = sh->clk[k];
+            for (int k = 0; k < 24; ++k) r.phase_clk[8 + k] = sh->mk[k];
+            r.pool_off = NO_POOL_SRC;
+            r.cs_depth_off = (arena_ok && ncut) ? cs_depth_off : 0;
+            r.cs_path_stride = path_len;
+            r.cs_lvar_off = (arena_ok && ncut) ? cs_lvar_off : 0;
+            r.cache_hits = 0;
+            *res = r;
+        }
+        PAR_END
+        return;
+    }
     // ---------------------------------------------------------------- local bounds (clean.rs:448-475)
     const bool want_cutset = relaxed && !failed && lel >= 0 && has_best;
     int32_t* vb = c.keyh ? (int32_t*)c.keyh : (int32_t*)c.key32;   // the ranking keys are dead now: reuse their storage (LDS, or the packed words)
@@ -2145,7 +2474,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 /// restricted, then (when inexact) relaxed: the device half of process_one_node (parallel.rs:391-437).
 /// ONE call site of run_dd2 (a loop over the two compilations): the function is inlined once, not three times -- the kernel's
 /// code is a third of what it was (round 3: 48 000 lines of ISA, several times the instruction cache two CUs share).
-template <int WS, int DEEP = 0>
+template <int WS, int DEEP = 0, int POOLED = 0>
 DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
     DD_TID_SETUP(c)
     (void)NT;
@@ -2159,7 +2488,7 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
             PAR_END
             break;
         }
-        run_dd2<WS, DEEP>(c, in, fused ? (pass == 0 ? CT_RESTRICTED : CT_RELAXED) : in.comp_type, lb, &res2[pass]);
+        run_dd2<WS, DEEP, POOLED>(c, in, fused ? (pass == 0 ? CT_RESTRICTED : CT_RELAXED) : in.comp_type, lb, &res2[pass]);
         if (pass == 0 && fused) {
             PAR_BEGIN
             if (tid == 0) {

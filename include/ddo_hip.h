@@ -52,6 +52,13 @@ extern "C" {
 /** OR into the cutset_type of ddo_mdd_create: compile() may be handed a ddo_cache (every layer of the DD is then kept on the
  *  device for _compute_thresholds, clean.rs:478-545; costs memory, not needed with the EmptyCache) */
 #define DDO_MDD_CACHING 0x10
+/** OR into the cutset_type of ddo_mdd_create: the mdd is a `Pooled` decision diagram (implementation/mdd/pooled.rs:117-823; the `D` of
+ *  Par / SeqNoCachingSolverPooled, solver/mod.rs:34, :43): the layer of a variable holds the pool nodes it impacts (Problem::
+ *  is_impacted_by, dp.rs:68-70), width and ranking apply to those, the cut-set is the frontier, a sub-problem's depth is the layer at
+ *  which its node was expanded and its path holds one decision per expanded ancestor.  MISP models (the reference's only model that
+ *  implements is_impacted_by, misp/main.rs:145-147); not with DDO_MDD_CACHING.  A pool that outgrows its node slots (about 14 000
+ *  nodes) ends the compile with DDO_ERR_CAPACITY. */
+#define DDO_MDD_POOLED 0x20
 /** OR into the cutset_type of ddo_mdd_create (MISP, DDO_LAST_EXACT_LAYER, no DDO_MDD_CACHING): binds the mdd to ONE of the
  *  kernels the lazy solver spreads its sub-problems over, so that each of them can be driven -- and checked against the
  *  reference's results -- compile by compile.  0 = ddo_mdd_create picks: MISP at widths of 2048 and more compiles on the DENSE
@@ -283,6 +290,8 @@ typedef struct ddo_solver_config {
                               above.  (Times(0, inner) is the constant 1 == FixedWidth(1).)                              */
     size_t width_div_by;   /* 0: none; else DivBy(k, inner) (width.rs:875-881): max(1, inner / k); with both set the width is
                               DivBy(div_by, Times(times, inner))                                                         */
+    int pooled;            /* 1: `D` = Pooled (mdd/pooled.rs; Par / SeqNoCachingSolverPooled, solver/mod.rs:34, :43): MISP models,
+                              DDO_FRINGE_NODUP, no cache; see DDO_MDD_POOLED                                              */
 } ddo_solver_config;
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg);

@@ -1359,6 +1359,7 @@ class Pooled {
         std::optional<isize> theta;
         NodeFlags flags;
         size_t depth;
+        bool best_ok = false;   // canonical_ties: the best arc comes from a node that has an exact best path (as in Mdd)
     };
     /// pooled.rs:73-84
     struct Edge {
@@ -1383,6 +1384,8 @@ class Pooled {
     std::optional<size_t> best_node, best_exact_node;
     bool is_exact_ = true;
     bool has_exact_best_path_ = false;
+    bool canonical_ = false;   // Problem::canonical_ties() of the compile in progress (see Mdd::append_edge_to)
+    bool node_ok(const Node& n) const { return n.flags.is_exact() || (n.best_ok && !n.flags.is_relaxed()); }
 
   public:
     MddCounters counters;        // accumulated over all compile() calls
@@ -1505,12 +1508,22 @@ class Pooled {
         const Node& parent = nodes[edge.from];
         bool parent_exact = parent.flags.is_exact();
         isize value = sat_add(parent.value_top, edge.cost);
+        const bool pok = node_ok(parent);
         Node& node = nodes[edge.to];
         node.flags.set_exact(parent_exact & node.flags.is_exact());
         node.inbound = lst_id;
-        if (value >= node.value_top) {
+        if (!canonical_) {
+            if (value >= node.value_top) {
+                node.best = new_eid;
+                node.value_top = value;
+            }
+        } else if (value > node.value_top || (value == node.value_top && (pok || !node.best_ok))) {
+            // order-independent variant (Problem::canonical_ties, as in Mdd::append_edge_to): among arcs of equal value the one
+            // whose parent has an exact best path wins -- a pool node collects arcs over many layers, in an order the reference
+            // leaves to its hash map
             node.best = new_eid;
             node.value_top = value;
+            node.best_ok = pok;
         }
     }
 
@@ -1531,6 +1544,7 @@ class Pooled {
         _clear();
         last_counters = MddCounters();
         last_counters.compiles = 1;
+        canonical_ = input.problem->canonical_ties();
         _initialize(input);
         for (;;) {
             PoolKeysIter keys(nodes, pool_order);

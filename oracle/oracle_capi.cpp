@@ -207,8 +207,10 @@ int oracle_misp_solve_pooled(void* hh, uint64_t width, int nthreads, double time
     return misp_solve_with<Pooled<BitSet>>(hh, width, nthreads, timeout_s, out, solution);
 }
 
+}  // extern "C"
 // ---- traced sequential solve: every compile() recorded for replay on the GPU -------------------
-void* oracle_misp_trace_solve(void* hh, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {
+template <class DD>
+static void* misp_trace_solve_with(void* hh, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {
     auto* h = (MispHandle*)hh;
     Misp& pb = h->pb;
     MispRelax relax(pb);
@@ -228,9 +230,8 @@ void* oracle_misp_trace_solve(void* hh, uint64_t width, uint64_t max_compiles, o
     tr->ws = h->ws;
     cut.tr = tr;
     cut.max = max_compiles;
-    SequentialSolver<BitSet> s(pb, relax, rank, w, dom, cut, fringe);
-    s.on_compile = [&](const SubProblem<BitSet>& node, CompilationType t, size_t width_, isize lb,
-                       DefaultMDDLEL<BitSet>& mdd) {
+    SequentialSolver<BitSet, DD> s(pb, relax, rank, w, dom, cut, fringe);
+    s.on_compile = [&](const SubProblem<BitSet>& node, CompilationType t, size_t width_, isize lb, DD& mdd) {
         record(*tr, h->ws, node, t, width_, lb, mdd, t == CompilationType::Relaxed);
     };
     auto t0 = std::chrono::steady_clock::now();
@@ -251,6 +252,14 @@ void* oracle_misp_trace_solve(void* hh, uint64_t width, uint64_t max_compiles, o
         out->n_solution = 0;
     }
     return tr;
+}
+extern "C" {
+void* oracle_misp_trace_solve(void* hh, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {
+    return misp_trace_solve_with<DefaultMDDLEL<BitSet>>(hh, width, max_compiles, out);
+}
+/// the traced search of SeqNoCachingSolverPooled (solver/mod.rs:43): every compile a Pooled DD (mdd/pooled.rs)
+void* oracle_misp_trace_solve_pooled(void* hh, uint64_t width, uint64_t max_compiles, oracle_solve_out* out) {
+    return misp_trace_solve_with<Pooled<BitSet>>(hh, width, max_compiles, out);
 }
 }  // extern "C"
 

@@ -32,6 +32,7 @@ struct Emul {
     int nthreads = 256;
     int wsT = 0;  // template WS used
     int engine = 1;
+    bool pooled = false;
     std::vector<unsigned char> mem2;
     std::vector<unsigned char> lds2;
     std::vector<int32_t> aux[2], lddelta;   // knapsack tables, per-layer relax deltas
@@ -64,7 +65,8 @@ void run(Emul& e, const DDInput& in, DDResult* res2) {
     if (e.engine == 2) {
         DD2Ctx<WS> c2;
         dd2_bind<WS>(c2, e.P, 0, e.lds2.data(), e.nthreads);
-        run_work_item2<WS>(c2, in, res2);
+        if (e.pooled) run_work_item2<WS, 0, 1>(c2, in, res2);   // Pooled decision diagrams (mdd/pooled.rs) out of the same node slots
+        else run_work_item2<WS>(c2, in, res2);
         return;
     }
     DDCtx<WS> c;
@@ -335,6 +337,8 @@ void emul_set_dominance(void* h, uint32_t cap) {
     e->dom_stats[0] = 0;
     e->P.dom_stats = e->dom_stats;
 }
+/// engine 2 only: compile Pooled decision diagrams (run_dd2<WS, DEEP, POOLED = 1>)
+void emul_set_pooled(void* h, int on) { ((Emul*)h)->pooled = on != 0; }
 void emul_destroy(void* h) { delete (Emul*)h; }
 int emul_state_words(void* h) { return ((Emul*)h)->wsT; }
 uint64_t emul_lds_bytes(void* h) { return ((Emul*)h)->lds.size(); }

@@ -67,6 +67,11 @@ class Emul:
         self.L.emul_set_keep_layers.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         self.L.emul_set_keep_layers(self.h, 1 if on else 0, int(cache_entries))
 
+    def pooled(self, on=True):
+        """engine 2: compile Pooled decision diagrams (mdd/pooled.rs) -- run_dd2<WS, DEEP, POOLED = 1>"""
+        self.L.emul_set_pooled.argtypes = [C.c_void_p, C.c_int]
+        self.L.emul_set_pooled(self.h, 1 if on else 0)
+
     def dominance(self, cap):
         """a fresh SimpleDominanceChecker with `cap` pairs per depth (0: none); needs keep_layers(True)"""
         self.L.emul_set_dominance.argtypes = [C.c_void_p, C.c_uint32]

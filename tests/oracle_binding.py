@@ -93,10 +93,11 @@ class MispInstance:
         d["solution"] = [(int(sol[2 * i]), int(sol[2 * i + 1])) for i in range(out.n_solution)]
         return d
 
-    def trace_solve(self, width=0, max_compiles=0):
-        """Sequential B&B recording every compile(); returns (summary, [canonical records])."""
+    def trace_solve(self, width=0, max_compiles=0, pooled=False):
+        """Sequential B&B recording every compile(); returns (summary, [canonical records]).  pooled=True: SeqNoCachingSolverPooled."""
         out = SolveOut()
-        t = self.L.oracle_misp_trace_solve(self.h, width, max_compiles, C.byref(out))
+        fn = self.L.oracle_misp_trace_solve_pooled if pooled else self.L.oracle_misp_trace_solve
+        t = fn(self.h, width, max_compiles, C.byref(out))
         return out.asdict(), read_trace(self.L, t, self.ws)
 
     def compile(self, comp_type, width, best_lb, state, value, depth, pooled=False):
@@ -136,8 +137,9 @@ class Oracle:
         L.oracle_misp_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_misp_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.POINTER(SolveOut), C.c_void_p]
         L.oracle_misp_solve_pooled.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.POINTER(SolveOut), C.c_void_p]
-        L.oracle_misp_trace_solve.restype = C.c_void_p
-        L.oracle_misp_trace_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(SolveOut)]
+        for fn in (L.oracle_misp_trace_solve, L.oracle_misp_trace_solve_pooled):
+            fn.restype = C.c_void_p
+            fn.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(SolveOut)]
         L.oracle_trace_free.argtypes = [C.c_void_p]
         L.oracle_trace_len.restype = C.c_uint64
         L.oracle_trace_len.argtypes = [C.c_void_p]

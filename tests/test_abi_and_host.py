@@ -207,12 +207,14 @@ def test_width_heuristics_known_answers():
 
 def test_solver_aliases_of_the_reference():
     """solver/mod.rs:29-47: fourteen aliases, (parallel | sequential) x (LEL | FC | Pooled) x (EmptyCache | SimpleCache), plus the two
-    defaults.  The ten the device has exist under the reference's names; the four Pooled ones (and `Pooled` itself) refuse loudly --
-    no silent substitution of another DD type (the pooled DD lives in the oracle only)."""
+    defaults.  Twelve exist on the device under the reference's names (round 5: `Pooled` and the two NoCaching Pooled solvers -- their
+    GPU tests are tests/test_gpu_pooled.py); the two Pooled solvers behind a SimpleCache refuse loudly -- no silent substitution of
+    another DD type or of the cache-less solver."""
     built = ["DefaultSolver", "DefaultCachingSolver", "ParNoCachingSolverLel", "ParNoCachingSolverFc", "ParCachingSolverLel", "ParCachingSolverFc",
-             "SeqNoCachingSolverLel", "SeqNoCachingSolverFc", "SeqCachingSolverLel", "SeqCachingSolverFc"]
+             "SeqNoCachingSolverLel", "SeqNoCachingSolverFc", "SeqCachingSolverLel", "SeqCachingSolverFc", "Pooled", "ParNoCachingSolverPooled",
+             "SeqNoCachingSolverPooled"]
     for name in built:
         assert callable(getattr(ddo_amd, name)), name
-    for name in ["Pooled", "ParNoCachingSolverPooled", "ParCachingSolverPooled", "SeqNoCachingSolverPooled", "SeqCachingSolverPooled"]:
+    for name in ["ParCachingSolverPooled", "SeqCachingSolverPooled"]:
         with pytest.raises(ddo_amd.DdoError, match="not built on the device"):
             getattr(ddo_amd, name)(None, ddo_amd.FixedWidth(10))

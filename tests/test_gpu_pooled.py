@@ -1,0 +1,152 @@
+"""`Pooled` decision diagrams on the device (`-m gpu`): the reference's long-arc DD (implementation/mdd/
+pooled.rs:117-823; aliases solver/mod.rs:34, :43) compiled by the in-place engine's pooled kernel (misp_dd_inplace.hpp: run_dd2<WS,
+DEEP, POOLED = 1>, `misp_compile_kernel2_pooled`), called through the C ABI (`ddo_mdd_create(.. | DDO_MDD_POOLED ..)`,
+`ddo_solver_config.pooled`) and compared with the CPU oracle's Pooled<S>:
+
+* the 48 single compiles of tests/golden/misp_pooled_golden.json (generator beside it);
+* traced SeqNoCachingSolverPooled searches replayed compile by compile: is_exact, values, nodes / arcs / layers and the FRONTIER
+  cut-set as a multiset of (state, value, ub, depth); every cut-set node's PATH (one decision per expanded ancestor) replayed from
+  the problem root to the node's state and value;
+* the optima of examples/misp/tests.rs through Seq / ParNoCachingSolverPooled, the sequential ones with the oracle's `explored`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ddo_amd
+from ddo_amd import CompilationType, FixedWidth, NbUnassignedWidth, SubProblem
+from tests.conftest import data_path
+from tests.parity_util import canon_from_mdd, cutset_digest, diff, is_independent_set
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "misp_pooled_golden.json")
+
+
+def _cases():
+    with open(GOLDEN) as f:
+        return json.load(f)["cases"]
+
+
+_models = {}
+
+
+def _model(name):
+    if name not in _models:
+        _models[name] = ddo_amd.Misp.read_instance(data_path("misp", name + ".clq"))
+    return _models[name]
+
+
+def _replay_path(model, rows, weights, root_state, root_value, path):
+    """Problem::transition / transition_cost (misp/main.rs:77-93) along `path` (root first)"""
+    st = [int(x) for x in root_state]
+    val = int(root_value)
+    for d in path:
+        v = d.variable
+        assert (st[v // 64] >> (v % 64)) & 1, "a decision on a variable that does not impact the node (pooled.rs:316-334)"
+        st[v // 64] &= ~(1 << (v % 64))
+        if d.value == 1:
+            for k in range(model.ws):
+                st[k] &= int(rows[v * model.ws + k])
+            val += int(weights[v])
+    return st, val
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c["id"])
+def test_pooled_golden_compile(case):
+    model = _model(case["instance"])
+    mdd = ddo_amd.Pooled(model, max(case["width"], 8))
+    state = np.array([int(x) for x in case["state"]], dtype=np.uint64)
+    sub = SubProblem(state=state, value=case["value"], path=[], depth=case["depth"])
+    comp = mdd.compile(case["comp_type"], case["width"], sub, case["best_lb"])
+    got = canon_from_mdd(mdd, comp, model.ws)
+    for k in ["is_exact", "best_value", "best_exact_value", "nodes_expanded", "arcs", "layers"]:
+        assert got[k] == case[k], f"{case['id']}: {k} expected {case[k]} got {got[k]}"
+    assert len(got["cutset"]) == case["n_cutset"] and cutset_digest(got["cutset"]) == case["cutset_digest"], case["id"]
+    rows, weights = model.export()
+    # the best EXACT path (what maybe_update_best keeps, parallel.rs:446-453): decisions on impacting variables only, worth its value;
+    # (the best path of an inexact relaxed DD runs through merged nodes: no exact replay of it exists)
+    if case["best_exact_value"] is not None:
+        sol = mdd.best_exact_solution()
+        st, val = _replay_path(model, rows, weights, state, case["value"], sol[::-1])   # (terminal first, clean.rs:329-343)
+        assert val == case["best_exact_value"], case["id"]
+    for n in got["cutset_nodes"][:50]:   # cut-set paths: node first after the (empty) residual path
+        st, val = _replay_path(model, rows, weights, state, case["value"], n.path[::-1])
+        assert st[:model.ws] == [int(x) for x in n.state[:model.ws]] and val == n.value and len(n.path) <= n.depth - case["depth"]
+
+
+@pytest.mark.parametrize("name,width,max_compiles", [
+    ("johnson8-4-4", 5, 200), ("brock200_2", 5, 150), ("brock200_2", 50, 60), ("MANN_a9", 5, 200), ("keller4", 7, 200), ("p_hat300-1", 20, 60),
+    ("brock200_4", 0, 80), ("hamming8-4", 0, 60), ("brock400_1", 100, 24),
+])
+def test_pooled_replay_of_an_oracle_search(oracle, name, width, max_compiles):
+    model = _model(name)
+    inst = oracle.misp(data_path("misp", name + ".clq"))
+    _, recs = inst.trace_solve(width, max_compiles, pooled=True)
+    assert recs
+    B = 32
+    mdds = [ddo_amd.Pooled(model, max(max(int(r["width"]) for r in recs), 8)) for _ in range(min(B, len(recs)))]
+    inexact = 0
+    for base in range(0, len(recs), B):
+        chunk = recs[base:base + B]
+        subs = [SubProblem(state=np.array(r["state"], dtype=np.uint64), value=r["value"], path=[], depth=r["depth"]) for r in chunk]
+        comps = ddo_amd.Mdd.compile_batch(mdds[:len(chunk)], [r["comp_type"] for r in chunk], [r["width"] for r in chunk], subs,
+                                          [r["best_lb"] for r in chunk])
+        for j, r in enumerate(chunk):
+            d = diff(r, canon_from_mdd(mdds[j], comps[j], model.ws))
+            assert d is None, f"{name} W={width} compile #{base + j} type={r['comp_type']} depth={r['depth']}: {d}"
+            inexact += not r["is_exact"]
+    if width:
+        assert inexact > 0 or name == "p_hat300-1"
+
+
+POOLED_OPTIMA = {"brock200_3": 15, "brock200_4": 17, "c-fat200-1": 12, "c-fat200-2": 24, "c-fat200-5": 58, "c-fat500-1": 14, "c-fat500-2": 26,
+                 "hamming6-2": 32, "hamming6-4": 4, "johnson8-2-4": 4, "johnson8-4-4": 14, "keller4": 11, "MANN_a9": 16, "p_hat300-1": 8}
+
+
+@pytest.mark.parametrize("name,expected", sorted(POOLED_OPTIMA.items()))
+def test_seq_no_caching_solver_pooled_explores_what_the_oracle_explores(oracle, name, expected):
+    """SeqNoCachingSolverPooled (solver/mod.rs:43) under NbUnassignedWidth, the configuration of examples/misp/tests.rs: optimum, proof
+    and `explored` equal the oracle's sequential pooled search; the solution is an independent set of that weight"""
+    model = _model(name)
+    ref = oracle.misp(data_path("misp", name + ".clq")).solve(0, 0, pooled=True)
+    assert ref["is_exact"] and ref["best_value"] == expected
+    s = ddo_amd.SeqNoCachingSolverPooled(model, NbUnassignedWidth(model.n))
+    c = s.maximize()
+    assert c.is_exact and c.best_value == expected
+    assert s.explored() == ref["explored"], (name, s.explored(), ref["explored"])
+    k = s.counters()
+    assert (k["nodes_expanded"], k["arcs"], k["compiles"]) == (ref["nodes_expanded"], ref["arcs"], ref["compiles"]), (name, k, ref)
+    rows, weights = model.export()
+    taken = [d.variable for d in s.best_solution() if d.value == 1]
+    assert is_independent_set(rows, model.ws, taken) and int(sum(weights[v] for v in taken)) == expected
+
+
+@pytest.mark.parametrize("name", ["brock200_4", "keller4", "MANN_a9", "c-fat500-1", "johnson8-4-4"])
+def test_par_no_caching_solver_pooled_proves_the_optimum(name):
+    """ParNoCachingSolverPooled (solver/mod.rs:34), 64 sub-problems in flight, two widths"""
+    model = _model(name)
+    rows, weights = model.export()
+    for width in (NbUnassignedWidth(model.n), FixedWidth(10)):
+        s = ddo_amd.ParNoCachingSolverPooled(model, width, nb_threads=64)
+        c = s.maximize()
+        assert c.is_exact and c.best_value == POOLED_OPTIMA[name], (name, width, c)
+        taken = [d.variable for d in s.best_solution() if d.value == 1]
+        assert is_independent_set(rows, model.ws, taken) and int(sum(weights[v] for v in taken)) == c.best_value
+
+
+def test_a_pool_beyond_the_node_slots_is_a_loud_capacity_error(monkeypatch):
+    """the pool of a Pooled DD is bounded by the engine's node slots, not by the width: beyond them the compile fails with
+    DDO_ERR_CAPACITY (hamming8-2 under NbUnassignedWidth is the instance tests/test_oracle.py leaves out for the same reason)"""
+    monkeypatch.setenv("DDO_HIP_POOLED_NODES", "300")
+    model = _model("brock200_2")
+    mdd = ddo_amd.Pooled(model, 211)   # (a width no other test uses: the engine of this (model, width) is created under the small pool)
+    with pytest.raises(ddo_amd.DdoError, match="capacity|rc=-3"):
+        mdd.compile(CompilationType.Relaxed, 200, model.root(), -(1 << 40))
+
+
+def test_pooled_with_a_cache_refuses_loudly():
+    with pytest.raises(ddo_amd.DdoError, match="not built on the device"):
+        ddo_amd.SeqCachingSolverPooled(_model("johnson8-4-4"), FixedWidth(10))
+    with pytest.raises(ddo_amd.DdoError):
+        ddo_amd.Mdd(_model("johnson8-4-4"), 10, cutset_type=ddo_amd.FRONTIER | 0x20, caching=True)
