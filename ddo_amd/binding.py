@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "ddo_mdd_best_solution", "ddo_mdd_best_exact_solution", "ddo_mdd_drain_cutset", "ddo_mdd_last_counters", "ddo_mdd_combine_stats",
     "ddo_solver_create", "ddo_width_heuristic", "ddo_solver_destroy", "ddo_solver_maximize", "ddo_solver_best_value",
     "ddo_solver_best_solution", "ddo_solver_best_lower_bound", "ddo_solver_best_upper_bound", "ddo_solver_set_primal",
-    "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_flush",
+    "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_epoch", "ddo_solver_flush",
     "ddo_solver_import_lower_bound", "ddo_solver_fringe_len", "ddo_solver_fringe_best_ub", "ddo_solver_device_time", "ddo_solver_tier_count", "ddo_solver_tier_stats",
     "ddo_solver_bench_freeze", "ddo_solver_bench_step", "ddo_solver_bench_frozen",
     "ddo_solver_export_subproblems", "ddo_solver_import_subproblems",
@@ -93,7 +93,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(_HERE, "_build", "libddo_hip.so")
+    # DDO_HIP_LIBRARY: another build of the same sources (A/B runs, diagnosis builds: make BUILD=../_build_x EXTRA=-D...)
+    return os.environ.get("DDO_HIP_LIBRARY") or os.path.join(_HERE, "_build", "libddo_hip.so")
 
 
 def lib():
@@ -165,6 +166,7 @@ def lib():
     L.ddo_width_heuristic.restype = C.c_size_t
     L.ddo_width_heuristic.argtypes = [C.POINTER(_SolverConfig), C.c_size_t, C.c_size_t]
     L.ddo_solver_destroy.argtypes = [C.c_void_p]
+    L.ddo_solver_epoch.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_double]
     L.ddo_solver_maximize.argtypes = [C.c_void_p, C.POINTER(_Completion)]
     L.ddo_solver_best_value.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.ddo_solver_best_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
@@ -691,6 +693,16 @@ class ParallelSolver:
         if rc < 0:
             raise DdoError(f"ddo_solver_step rc={rc}: {_err()}")
         return rc
+
+    def epoch(self, prev, max_steps=64, min_ms=2.0):
+        """one epoch of a sharded search (include/ddo_hip.h: ddo_solver_epoch): `prev` = the reduced 7-vector of the previous epoch or None;
+        returns (rc of the last step, this rank's 7-vector for the next MAX all-reduce)"""
+        vin = (C.c_int64 * 7)(*[int(x) for x in prev]) if prev is not None else None
+        vout = (C.c_int64 * 7)()
+        rc = lib().ddo_solver_epoch(self._h, vin, vout, int(max_steps), float(min_ms))
+        if rc < 0:
+            raise DdoError(f"ddo_solver_epoch rc={rc}: {_err()}")
+        return rc, [int(x) for x in vout]
 
     def flush(self):
         rc = lib().ddo_solver_flush(self._h)

@@ -261,6 +261,8 @@ static int dev_alloc(std::vector<void*>& allocs, T*& ptr, size_t count) {
     }
     allocs.push_back(p);
     ptr = (T*)p;
+    static const bool trace = std::getenv("DDO_HIP_ALLOC_TRACE") != nullptr;   // diagnosis: which array a faulting address lies in
+    if (trace) std::fprintf(stderr, "[ddo alloc] #%zu %p .. %p (%zu bytes, %zu x %zu)\n", allocs.size() - 1, p, (void*)((uint8_t*)p + bytes), bytes, count, sizeof(T));
     return DDO_OK;
 }
 
@@ -722,7 +724,48 @@ int Engine::pool_reset() {
 
 /// maps physical chunks until `target` bytes of the reserved range are backed (or memory runs out: the pool then stays
 /// at its size and the kernel reports ST_ERR_CAPACITY when it is full, as with the fixed pool)
+/// The pool grows OFF the critical path: a mapper thread keeps two chunks mapped beyond what the launches can take (round 4 mapped
+/// them on demand inside launch(): 2.5 s of the 76 s of a brock400_1 proof, 60 ms per 2 GB chunk).  launch() still maps itself when
+/// the thread has not caught up.
+void Engine::pool_want(size_t bytes) {
+    if (!vm_base_) return;
+    bytes = std::min(bytes, vm_reserved_);
+    if (bytes <= vm_mapped_.load()) return;
+    {
+        std::lock_guard<std::mutex> g(vm_mtx_);
+        if (bytes > vm_want_) vm_want_ = bytes;
+        if (!vm_thread_.joinable()) {
+            vm_stop_ = false;
+            vm_thread_ = std::thread([this] {
+                (void)hipSetDevice(device_);
+                std::unique_lock<std::mutex> lk(vm_mtx_);
+                for (;;) {
+                    vm_cv_.wait(lk, [&] { return vm_stop_ || vm_want_ > vm_mapped_.load(); });
+                    if (vm_stop_) return;
+                    const size_t before = vm_mapped_.load();
+                    pool_grow_locked(before + vm_chunk_);   // one chunk per turn: a launch that needs the lock waits for one chunk at most
+                    if (vm_mapped_.load() == before) vm_want_ = before;   // (out of memory: stop trying)
+                    lk.unlock();
+                    lk.lock();
+                }
+            });
+        }
+    }
+    vm_cv_.notify_one();
+}
+
+void Engine::pool_expect(int count) {
+    if (!vm_base_ || count <= 0) return;
+    const size_t worst = (size_t)count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
+    pool_want(2 * worst + 2 * vm_chunk_);
+}
+
 int Engine::pool_grow(size_t target) {
+    std::lock_guard<std::mutex> g(vm_mtx_);
+    return pool_grow_locked(target);
+}
+
+int Engine::pool_grow_locked(size_t target) {
     if (!vm_base_) return DDO_OK;
     target = std::min(target, vm_reserved_);
     hipMemAllocationProp prop{};
@@ -751,6 +794,14 @@ int Engine::pool_grow(size_t target) {
     return DDO_OK;
 }
 void Engine::pool_release() {
+    if (vm_thread_.joinable()) {
+        {
+            std::lock_guard<std::mutex> g(vm_mtx_);
+            vm_stop_ = true;
+        }
+        vm_cv_.notify_one();
+        vm_thread_.join();
+    }
     if (!vm_base_) return;
     for (size_t i = 0; i < vm_handles_.size(); ++i) {
         (void)hipMemUnmap(vm_base_ + i * vm_chunk_, vm_chunk_);
@@ -1457,6 +1508,10 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         io.h_arena = (uint8_t*)hp;
         io.h_arena_cap = arena_cap_;
     }
+    if (std::getenv("DDO_HIP_ALLOC_TRACE"))
+        std::fprintf(stderr, "[ddo alloc] launch: inputs %p (+%zu) results %p (+%zu) host results %p arena %p .. %p cnt %p\n", io.d_inputs,
+                     (size_t)io.in_cap * sizeof(DDInput) + LptBuffers::bytes(io.in_cap), io.d_results, (size_t)io.in_cap * 2 * sizeof(DDResult), (void*)io.h_results,
+                     (void*)io.h_arena, (void*)(io.h_arena + arena_cap_), (void*)io.d_cnt);
     tick(0);
     if (!staged) std::memcpy(io.h_inputs, inputs, (size_t)count * sizeof(DDInput));
     HIP_TRY(hipMemcpyAsync(io.d_inputs, io.h_inputs, (size_t)count * sizeof(DDInput), hipMemcpyHostToDevice, st));
@@ -1527,7 +1582,8 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         // engine; a tier's launches are accounted there as well (fetch() takes them off again).
         const size_t worst = (size_t)count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
         const size_t need = (size_t)po->pool_head_bound_ + po->pool_unfetched_worst_ + worst;
-        if (need > po->vm_mapped_) po->pool_grow(need + 2 * po->vm_chunk_);
+        if (need > po->vm_mapped_) po->pool_grow(need + 2 * po->vm_chunk_);   // (the mapper thread fell behind)
+        po->pool_want(need + 2 * po->vm_chunk_);
         po->pool_unfetched_worst_ += worst;
         po->P_.pool_cap = po->vm_mapped_;
         P_.pool_cap = po->vm_mapped_;

@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ddo_hip.h"
@@ -266,6 +267,9 @@ class Engine {
     bool has_pool() const { return P_.pool != nullptr; }
     uint64_t pool_capacity() const { return P_.pool_cap; }
     int pool_reset();
+    /// a solver that will keep `count` sub-problems in flight: the worst case of their cut-set blocks (twice: the launch in flight and the
+    /// one being fetched) is mapped by the pool's mapper thread while the search compiles its first, small steps
+    void pool_expect(int count);
     /// bench support: the next launch() first rewinds the pool's bump allocator to `head` (on the engine stream, ahead
     /// of the kernel), so that a frozen batch can be compiled again and again without growing the pool
     void set_pool_rewind(uint64_t head) { rewind_ = (long long)head; }
@@ -339,7 +343,15 @@ class Engine {
     // are mapped as the search fills it -- creating a solver costs milliseconds instead of the seconds a 64 GB hipMalloc
     // takes, co-resident solvers only hold what they use, and one search can grow into all of the 288 GB.
     uint8_t* vm_base_ = nullptr;
-    size_t vm_reserved_ = 0, vm_mapped_ = 0, vm_chunk_ = 0;
+    size_t vm_reserved_ = 0, vm_chunk_ = 0;
+    std::atomic<size_t> vm_mapped_{0};
+    std::mutex vm_mtx_;                // mapping chunks: the mapper thread or a launch that cannot wait for it
+    std::condition_variable vm_cv_;
+    std::thread vm_thread_;
+    size_t vm_want_ = 0;
+    bool vm_stop_ = false;
+    void pool_want(size_t bytes);      // asks the mapper thread to have `bytes` of the pool mapped
+    int pool_grow_locked(size_t target);
     std::vector<void*> vm_handles_;
     uint64_t pool_head_bound_ = 0;     // upper bound of the pool head over every result fetched so far
     size_t pool_unfetched_worst_ = 0;  // worst-case growth of the launches whose results were not fetched yet

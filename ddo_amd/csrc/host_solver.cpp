@@ -1560,6 +1560,7 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
             return nullptr;
         }
         s->lazy = new LazyFringe();
+        s->engine->pool_expect(std::max(1, s->cfg.nb_concurrent));   // (mapped in the background while the first steps run)
         // capacity tiers below the full-width engine (see ddo_solver::dispatch): only where the width leaves room for them
         std::vector<std::pair<int, int>> spec;   // (layer capacity, threads per workgroup)
         if (s->cfg.width_policy == DDO_WIDTH_FIXED && s->cfg.width >= 4096) {
@@ -1718,6 +1719,34 @@ int64_t ddo_solver_fringe_best_ub(const ddo_solver* s) {
     if (s->lazy) return s->lazy->best_ub();
     const Entry* top = s->fringe->peek();
     return top ? top->ub : I64_MIN;
+}
+/// One EPOCH of a sharded search in one call (ddo_amd/distributed.py: DistributedSearch.maximize): takes the reduced vector of the
+/// previous epoch's all-reduce (`in`, may be NULL: [0] = the global incumbent), runs search steps until `min_ms` milliseconds have
+/// passed (at least one step, at most `max_steps`; a rank whose fringe is empty does none), and fills `out` with this rank's
+/// contribution to the next MAX all-reduce: [incumbent, 1 if work remains, 1 if cut off, open nodes, -open nodes, best open bound,
+/// -best open bound] (the last two INT64_MIN / 2 without open nodes).  Returns what the last step returned.
+int ddo_solver_epoch(ddo_solver* s, const int64_t* in, int64_t* out, int max_steps, double min_ms) {
+    if (!s || !out) return DDO_ERR_INVALID;
+    const int64_t LOW = -(1LL << 62);
+    if (in && in[0] > LOW) ddo_solver_import_lower_bound(s, in[0]);
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = 0;
+    for (int k = 0; k < std::max(1, max_steps); ++k) {
+        if (k > 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() >= min_ms) break;
+        rc = s->step();
+        if (rc != 1) break;
+    }
+    if (rc < 0) return rc;
+    const int64_t open = (int64_t)ddo_solver_fringe_len(s);
+    const int64_t top = open > 0 ? ddo_solver_fringe_best_ub(s) : LOW;
+    out[0] = std::max<int64_t>(s->best_lb, LOW);
+    out[1] = rc == 1 ? 1 : 0;
+    out[2] = (rc == DDO_CUTOFF || s->aborted) ? 1 : 0;
+    out[3] = open;
+    out[4] = -open;
+    out[5] = std::max<int64_t>(top, LOW);
+    out[6] = open > 0 ? -top : LOW;
+    return rc;
 }
 int ddo_solver_tier_count(const ddo_solver* s) { return s ? (int)s->tiers.size() : 0; }
 int ddo_solver_tier_stats(const ddo_solver* s, int t, ddo_tier_stats* out) {

@@ -242,10 +242,15 @@ struct DDCtx {
     // `c.field` a scratch load -- where it could live in scalar registers (72-word kernel: 2 224 -> 1 552 B/lane of scratch, C3 kernels
     // -13 %).  The narrow instantiations keep the array: with the context in registers the 16-word kernel faults on the GPU for TSPTW
     // states of four-word node sets (rbg132, n200w20.001; not reproduced by the host emulation, not understood yet).
-    Buf2<uint64_t, (WS > 16)> cstate;
-    Buf2<uint64_t, (WS > 16)> ckey;
-    Buf2<uint32_t, (WS > 16)> cpop;
-    Buf2<uint32_t, (WS > 16)> cflags;
+#if defined(DDO_BUF2_SEL_ALL)   // diagnosis build: the select-based buffers in every instantiation (the configuration that faulted in round 4)
+#define DDO_BUF2_SEL(ws) true
+#else
+#define DDO_BUF2_SEL(ws) ((ws) > 16)
+#endif
+    Buf2<uint64_t, DDO_BUF2_SEL(WS)> cstate;
+    Buf2<uint64_t, DDO_BUF2_SEL(WS)> ckey;
+    Buf2<uint32_t, DDO_BUF2_SEL(WS)> cpop;
+    Buf2<uint32_t, DDO_BUF2_SEL(WS)> cflags;
     uint32_t* ctarget;
     uint32_t* keep;
     uint32_t* posmap;

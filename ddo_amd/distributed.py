@@ -91,11 +91,12 @@ class DistributedSearch:
     order, and a rank left with unpromising nodes expands sub-problems a global best-first search would have reached much
     later, or never (search overhead).  The donor's best nodes then go round."""
 
-    def __init__(self, solver, dist, device, rebalance_every=4, donate_min=64, donate_max=32768, ub_gap=2):
+    def __init__(self, solver, dist, device, rebalance_every=4, donate_min=64, donate_max=32768, ub_gap=2, epoch_ms=2.0, max_steps=64):
         self.s, self.dist, self.device = solver, dist, device
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self.rebalance_every, self.donate_min, self.donate_max, self.ub_gap = rebalance_every, donate_min, donate_max, ub_gap
+        self.epoch_ms, self.max_steps = epoch_ms, max_steps   # an epoch: search steps for this long (at least one, at most max_steps)
         self.buf = self.work = None
         self.epochs = self.handovers = self.nodes_sent = self.nodes_received = 0
 
@@ -202,22 +203,26 @@ class DistributedSearch:
         ws = s.problem.ws
         aborted = False
         local_work = True
+        prev = None
         while True:
-            rc = s.step() if local_work or s.fringe_len() > 0 else 0
+            # one epoch = ONE native call (ddo_solver_epoch: import of the reduced incumbent, search steps for `epoch_ms` milliseconds, this
+            # rank's vector for the next reduction) and ONE asynchronous MAX all-reduce, consumed an epoch later.  Round 4 paced the loop
+            # in Python, a collective per step: small instances spent their time in it (profiles/r04/dist_overhead.jsonl).
+            if local_work or s.fringe_len() > 0:
+                rc, vec = s.epoch(prev, self.max_steps, self.epoch_ms)
+            else:
+                if prev is not None and prev[0] > I64_LOW:
+                    s.import_lower_bound(prev[0])
+                rc, vec = 0, [max(int(s.best_lower_bound()), I64_LOW), 0, 0, 0, 0, I64_LOW, I64_LOW]
             if rc == DDO_CUTOFF:
                 aborted = True
             local_work = rc == 1
             self.epochs += 1
-            open_n = int(s.fringe_len())
-            top = int(s.fringe_best_ub()) if open_n > 0 else I64_LOW
-            # (a rank without open nodes does not take part in the smallest best bound: it is a receiver anyway)
-            prev = self._post([max(int(s.best_lower_bound()), I64_LOW), 1 if local_work else 0, 1 if aborted else 0, open_n, -open_n,
-                               max(top, I64_LOW), -top if open_n > 0 else I64_LOW])
+            vec[2] = 1 if aborted else vec[2]
+            prev = self._post(vec)
             if prev is None:
                 continue
-            lb, any_work, any_abort, max_open, neg_min_open, max_top, neg_min_top = prev
-            if lb > I64_LOW:
-                s.import_lower_bound(lb)
+            lb, any_work, any_abort, max_open, neg_min_open, max_top, neg_min_top = prev   # (the incumbent is imported by the next epoch)
             if any_abort:        # a time budget ran out somewhere: everybody stops (parallel.rs:479-489 abort_search)
                 aborted = True
                 break

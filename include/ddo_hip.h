@@ -329,6 +329,11 @@ int ddo_solver_flush(ddo_solver* s);
 int ddo_solver_bench_freeze(ddo_solver* s, int nbatches, int stride);
 uint64_t ddo_solver_bench_frozen(const ddo_solver* s);
 int ddo_solver_bench_step(ddo_solver* s);
+/** One epoch of a sharded search in ONE call (one rank per GPU): `in` = the MAX-reduced vector of the previous
+ *  epoch (NULL the first time; in[0] = the global incumbent, imported before the steps), then search steps until `min_ms` ms have passed
+ *  (at least one, at most `max_steps`), then `out[7]` = this rank's contribution to the next MAX all-reduce: [incumbent, work remains,
+ *  cut off, open nodes, -open nodes, best open bound, -best open bound].  Returns the last step's return value. */
+int ddo_solver_epoch(ddo_solver* s, const int64_t* in, int64_t* out, int max_steps, double min_ms);
 /** Lower bound seen by the next step (max-reduced across ranks by the caller, parallel.rs:439-453). */
 int ddo_solver_import_lower_bound(ddo_solver* s, int64_t best_lb);
 /** Work hand-over between the solvers of a sharded search (one rank per GPU): export pops up to

@@ -104,6 +104,17 @@ class _FakeSolver:
                 self.open += [2 * u + 1, 2 * u + 2]
         return 1
 
+    def epoch(self, prev, max_steps=64, min_ms=2.0):
+        """what ddo_solver_epoch does natively (include/ddo_hip.h): import of the reduced incumbent, ONE step (the stand-in keeps the
+        epochs short so that the hand-over logic is exercised), this rank's vector for the next MAX all-reduce"""
+        low = -(1 << 62)
+        if prev is not None and prev[0] > low:
+            self.import_lower_bound(prev[0])
+        rc = self.step()
+        n = len(self.open)
+        top = max(self.open) if self.open else low
+        return rc, [max(self.lb, low), 1 if rc == 1 else 0, 0, n, -n, top, -top if n else low]
+
     def flush(self):
         return 0
 
