@@ -169,6 +169,9 @@ struct EngineParams {
     int32_t* work_counter;
     const uint32_t* order;     // in-place engine: the k-th draw of the work counter compiles inputs[order[k]] (longest first, ddo_hip_engine.hip:
                                // lpt_order_kernel); nullptr = input order
+    int32_t* done;             // in-place engine, split launches (nullptr: not split): draw k < nbatch compiles the RESTRICTED decision diagram
+                               // of sub-problem order[k] and raises done[order[k]], draw nbatch + k waits for that flag and compiles the
+                               // RELAXED one -- twice as many work items of half the size: the launch's tail is half as long
     unsigned long long* arena_head;
     uint8_t* arena;
     uint64_t arena_cap;

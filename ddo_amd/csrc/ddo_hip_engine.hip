@@ -50,11 +50,13 @@ struct LptBuffers {   // behind the inputs of an I/O set (Engine::launch)
     uint32_t* order;
     uint32_t* key;
     uint32_t* bins;
-    static size_t bytes(int cap) { return (size_t)cap * 8 + (size_t)LPT_BINS * 4; }
+    int32_t* done;    // split launches: one flag per sub-problem (EngineParams::done)
+    static size_t bytes(int cap) { return (size_t)cap * 12 + (size_t)LPT_BINS * 4; }
     LptBuffers(void* d_inputs, int cap) {
         order = (uint32_t*)((uint8_t*)d_inputs + (size_t)cap * sizeof(DDInput));
         key = order + cap;
         bins = key + cap;
+        done = (int32_t*)(bins + LPT_BINS);
     }
 };
 
@@ -1539,6 +1541,18 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         HIP_TRY(hipGetLastError());
         P.order = lb.order;
     }
+    // ... and draws the two decision diagrams of a sub-problem (restricted, then relaxed: IN_FUSED) as two work items -- all the
+    // restricted ones first, each raising a flag its relaxed twin waits for (run_work_item2).  Twice as many items of half the size:
+    // the launch ends within half a sub-problem of the mean load of a slot instead of a whole one.
+    static const bool split = [] { const char* e = std::getenv("DDO_HIP_SPLIT"); return !(e && std::atoi(e) == 0); }();
+    P.done = nullptr;
+    bool split_now = false;
+    if (split && engine_kind_ == 2 && count > nslots_) {
+        const LptBuffers lb(io.d_inputs, io.in_cap);
+        HIP_TRY(hipMemsetAsync(lb.done, 0, (size_t)count * 4, st));
+        P.done = lb.done;
+        split_now = true;
+    }
     tick(2);
     P.arena_head = (unsigned long long*)(io.d_cnt + 8);
     P.arena = io.h_arena;
@@ -1565,7 +1579,7 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
         P.dom_stats = dom->stats;
         P.dom_cap = dom->cap;
     }
-    const int grid = std::min(count, nslots_);
+    const int grid = std::min(split_now ? 2 * count : count, nslots_);
     kernel_fn fn = (kernel_fn)kernel_;
     if (rewind_ >= 0) {   // bench: the frozen batch overwrites the blocks of its previous run
         rewind_val_ = (unsigned long long)rewind_;

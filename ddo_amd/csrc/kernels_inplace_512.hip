@@ -14,15 +14,7 @@ __global__ void __launch_bounds__(MAXT) misp_compile_kernel2(EngineParams P) {
     DD2Ctx<WS>& c = *(DD2Ctx<WS>*)lds;   // the context lives in LDS (misp_dd_inplace.hpp: DD2_CTX_BYTES)
     if (threadIdx.x == 0) dd2_bind<WS>(c, P, (int)blockIdx.x, lds + DD2_CTX_BYTES, (int)blockDim.x);
     __syncthreads();
-    for (;;) {
-        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
-        __syncthreads();
-        const int drawn = c.sh->work;
-        __syncthreads();
-        if (drawn >= P.nbatch) break;
-        const int w = P.order ? (int)P.order[drawn] : drawn;   // (longest first: Engine::launch)
-        run_work_item2<WS, 1>(c, P.inputs[w], P.results + 2 * (size_t)w);   // DEEP: 256 VGPRs pay for deeper sweeps
-    }
+    dd2_work_loop<WS, 1, 0>(c, P);
 }
 
 kernel_fn pick_kernel2_512(int wsT) {

@@ -19,15 +19,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDO_TI
     DD2Ctx<WS>& c = *(DD2Ctx<WS>*)lds;   // the context lives in LDS (misp_dd_inplace.hpp: DD2_CTX_BYTES)
     if (threadIdx.x == 0) dd2_bind<WS>(c, P, (int)blockIdx.x, lds + DD2_CTX_BYTES, (int)blockDim.x);
     __syncthreads();
-    for (;;) {
-        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
-        __syncthreads();
-        const int drawn = c.sh->work;
-        __syncthreads();
-        if (drawn >= P.nbatch) break;
-        const int w = P.order ? (int)P.order[drawn] : drawn;   // (longest first: Engine::launch)
-        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
-    }
+    dd2_work_loop<WS, 0, 0>(c, P);
 }
 
 // Two decision diagrams per CU at full width: 512 threads each, 4 waves per SIMD (128 VGPRs like the 1024-thread kernel), so
@@ -39,15 +31,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     DD2Ctx<WS>& c = *(DD2Ctx<WS>*)lds;   // the context lives in LDS (misp_dd_inplace.hpp: DD2_CTX_BYTES)
     if (threadIdx.x == 0) dd2_bind<WS>(c, P, (int)blockIdx.x, lds + DD2_CTX_BYTES, (int)blockDim.x);
     __syncthreads();
-    for (;;) {
-        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
-        __syncthreads();
-        const int drawn = c.sh->work;
-        __syncthreads();
-        if (drawn >= P.nbatch) break;
-        const int w = P.order ? (int)P.order[drawn] : drawn;   // (longest first: Engine::launch)
-        run_work_item2<WS>(c, P.inputs[w], P.results + 2 * (size_t)w);
-    }
+    dd2_work_loop<WS, 0, 0>(c, P);
 }
 
 kernel_fn pick_kernel2_dense(int wsT) {

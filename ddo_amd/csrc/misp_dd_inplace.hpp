@@ -2475,16 +2475,39 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
 /// ONE call site of run_dd2 (a loop over the two compilations): the function is inlined once, not three times -- the kernel's
 /// code is a third of what it was (round 3: 48 000 lines of ISA, several times the instruction cache two CUs share).
 template <int WS, int DEEP = 0, int POOLED = 0>
-DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
+DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2, int only = -1, int32_t* done = nullptr) {
+    // `only` = -1: both compilations, one after the other (the work item of a launch that is not split).  Split launches (Engine::launch,
+    // EngineParams::done) draw the two compilations of a sub-problem as TWO work items: only = 0 compiles the restricted decision
+    // diagram (or the single compile of an item that is not fused) and raises *done; only = 1 waits for *done -- every first half
+    // is drawn before any second half, so the flag's writer is running or finished: no deadlock --, reads what the first half found
+    // (maybe_update_best) and compiles the relaxed one.
     DD_TID_SETUP(c)
     (void)NT;
     const bool fused = (in.flags & IN_FUSED) != 0;
     int64_t lb = in.best_lb;
     bool go = true;
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && !(fused && go)) {
+    if (only == 1) {
+        if (!fused) return;
+        PAR_BEGIN
+        if (tid == 0) {
+#if !defined(DDO_HOST_EMULATION)
+            while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(64);
+#endif
+            const int32_t st = LD_I32(&res2[0].status), ex = LD_I32(&res2[0].is_exact);
+            c.sh->sel_above = (st == ST_OK && !ex) ? 1 : 0;
+            c.sh->sel_bucket = LD_I32(&res2[0].has_best_exact) ? 1 : 0;
+            c.sh->sel_digit = LD_I32(&res2[0].best_exact_value);
+        }
+        PAR_END
+        go = c.sh->sel_above != 0;
+        if (c.sh->sel_bucket && (int64_t)c.sh->sel_digit > lb) lb = c.sh->sel_digit;  // maybe_update_best
+        DD_SYNC();
+        if (!go) return;   // (the first half wrote ST_NOT_RUN into the second record)
+    }
+    for (int pass = only == 1 ? 1 : 0; pass < 2; ++pass) {
+        if (pass == 1 && (only == 0 || !(fused && go))) {
             PAR_BEGIN
-            if (tid == 0) res2[1].status = ST_NOT_RUN;
+            if (tid == 0 && !(only == 0 && fused && go)) res2[1].status = ST_NOT_RUN;   // (a split item's second half writes its own record)
             PAR_END
             break;
         }
@@ -2502,6 +2525,35 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2) {
             DD_SYNC();
         }
     }
+    if (only == 0) {
+        PAR_BEGIN
+        if (tid == 0) {
+#if !defined(DDO_HOST_EMULATION)
+            __threadfence();   // the records of this half are visible before the flag is
+            __hip_atomic_store(done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        }
+        PAR_END
+    }
+}
+
+/// The body of every kernel of this engine: workgroups draw work items from the launch's counter until it runs dry.
+template <int WS, int DEEP, int POOLED>
+DDO_DEV void dd2_work_loop(DD2Ctx<WS>& c, const EngineParams& P) {
+#if !defined(DDO_HOST_EMULATION)
+    const int total = P.done ? 2 * P.nbatch : P.nbatch;
+    for (;;) {
+        if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
+        __syncthreads();
+        const int drawn = c.sh->work;
+        __syncthreads();
+        if (drawn >= total) break;
+        const int half = P.done ? (drawn >= P.nbatch ? 1 : 0) : -1;
+        const int k = half == 1 ? drawn - P.nbatch : drawn;
+        const int w = P.order ? (int)P.order[k] : k;   // (longest first: Engine::launch)
+        run_work_item2<WS, DEEP, POOLED>(c, P.inputs[w], P.results + 2 * (size_t)w, half, P.done ? P.done + w : (int32_t*)nullptr);
+    }
+#endif
 }
 
 /// LDS bytes of one in-place workgroup
