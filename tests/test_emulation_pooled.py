@@ -86,3 +86,55 @@ def test_a_pool_that_outgrows_its_slots_is_a_capacity_error(oracle):
     e.pooled(True)
     g = e.compile(1, 200, -(1 << 40), inst.root_state(), 0, 0, flags=IN_WANT_PATHS)[0]
     assert g["status"] <= -100 and not g["cutset"] and g["best_value"] is None
+
+
+def _weighted_instance(tmp_path, n=70, seed=11, p_edge=0.25):
+    rng = np.random.RandomState(seed)
+    edges = [(a, b) for a in range(n) for b in range(a + 1, n) if rng.rand() < p_edge]
+    weights = rng.randint(-4, 25, size=n)
+    p = tmp_path / "w.clq"
+    with open(p, "w") as f:
+        f.write(f"p edge {n} {len(edges)}\n")
+        for i, wv in enumerate(weights):
+            f.write(f"n {i + 1} {int(wv)}\n")
+        for a, b in edges:
+            f.write(f"e {a + 1} {b + 1}\n")
+    return str(p)
+
+
+def test_pooled_emulation_on_a_weighted_instance(oracle, tmp_path):
+    """`n` lines with negative weights (main.rs:290-297): the rough upper bound of a node is the sum of the weights of its vertices
+    (not its popcount), values fall below the residual value, and a cut-set node's value is rebuilt from the weights along its path"""
+    inst = oracle.misp(_weighted_instance(tmp_path))
+    for width in (0, 4, 16):
+        _, recs = inst.trace_solve(width, 300, pooled=True)
+        e = Emul(inst.n, inst.rows, inst.weights, 4000, engine=2)
+        e.pooled(True)
+        for i, r in enumerate(recs):
+            g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=IN_WANT_PATHS)[0]
+            assert g["status"] == 0 and diff(r, g) is None, (width, i, g["status"], diff(r, g))
+
+
+@pytest.mark.parametrize("nthreads", [64, 256, 512, 1024])
+def test_pooled_emulation_is_independent_of_the_workgroup_size(oracle, nthreads):
+    inst = oracle.misp(data_path("misp", "brock200_2.clq"))
+    _, recs = inst.trace_solve(25, 40, pooled=True)
+    e = Emul(inst.n, inst.rows, inst.weights, 4000, nthreads=nthreads, engine=2)
+    e.pooled(True)
+    for i, r in enumerate(recs):
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=IN_WANT_PATHS)[0]
+        assert g["status"] == 0 and diff(r, g) is None, (i, diff(r, g))
+
+
+def test_pooled_emulation_exact_compile_and_a_lower_bound_that_prunes_everything(oracle):
+    """CompilationType::Exact: no width, no cut-set, the optimum of the sub-problem; and a compile whose best_lb lies above every
+    rough upper bound: no node is expanded beyond the root, no best value (Completion { best_value: None })"""
+    inst = oracle.misp(data_path("misp", "hamming6-4.clq"))
+    e = Emul(inst.n, inst.rows, inst.weights, 6000, engine=2)
+    e.pooled(True)
+    root = inst.root_state()
+    for comp_type, width, lb in ((0, 6000, -(1 << 40)), (1, 5, 1000), (2, 5, 1000)):
+        ref = inst.compile(comp_type, width if comp_type else (1 << 62), lb, root, 0, 0, pooled=True)
+        g = e.compile(comp_type, width, lb, root, 0, 0, flags=IN_WANT_PATHS)[0]
+        assert g["status"] == 0 and diff(ref, g) is None, (comp_type, diff(ref, g))
+    assert inst.compile(0, 1 << 62, -(1 << 40), root, 0, 0, pooled=True)["best_value"] == 4

@@ -79,6 +79,60 @@ def test_a_raised_flag_stops_only_its_own_compile_of_a_batch():
     assert len(mdds[1].drain_cutset()) > 0
 
 
+def test_cutoffs_of_concurrent_callers_stay_their_own(oracle):
+    """The combining layer under ddo_mdd_compile (Engine::compile_combined): 24 host threads, one mdd each, loop plain compile() on
+    wide sub-problems and so share launches.  A third of them carry a Cutoff flag that goes up while they compile: THEIR compile
+    comes back as Err(CutoffOccurred) (None) -- the others, cut on the device by the same launch-wide flag, are compiled again by the
+    layer and every one of their results equals the oracle's for its input (Cutoff::must_stop is per compile, clean.rs:352)."""
+    import threading
+    import time
+
+    from tests.parity_util import canon_from_mdd, diff
+    model = ddo_amd.Misp.read_instance(data_path("misp", "brock400_1.clq"))
+    inst = oracle.misp(data_path("misp", "brock400_1.clq"))
+    W = 3000
+    _, recs = inst.trace_solve(W, 8)
+    recs = [r for r in recs if r["nodes_expanded"] > 50000][:6]
+    assert len(recs) >= 4
+    T = 24
+    errors, cut_seen, done = [], [0], [0]
+    flags = [C.c_int(0) if t % 3 == 0 else None for t in range(T)]
+    go = threading.Event()
+
+    def worker(t):
+        try:
+            mdd = ddo_amd.Mdd(model, W)
+            go.wait()
+            for rep in range(3):
+                r = recs[(t + rep) % len(recs)]
+                sub = ddo_amd.SubProblem(state=np.array(r["state"], dtype=np.uint64), value=r["value"], path=[], depth=r["depth"])
+                comp = mdd.compile(r["comp_type"], r["width"], sub, r["best_lb"], cutoff=flags[t])
+                if comp is None:
+                    assert flags[t] is not None and flags[t].value == 1, f"thread {t}: cut although its own flag is down"
+                    cut_seen[0] += 1
+                    return
+                d = diff(r, canon_from_mdd(mdd, comp, model.ws))
+                if d is not None:
+                    errors.append(f"thread {t} rep {rep}: {d}")
+                    return
+                done[0] += 1
+        except Exception as e:
+            errors.append(f"thread {t}: {e!r}")
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    go.set()
+    time.sleep(0.01)
+    for f in flags:
+        if f is not None:
+            f.value = 1
+    for th in ths:
+        th.join()
+    assert not errors, errors[:3]
+    assert done[0] >= 3 * (T - T // 3) and cut_seen[0] + done[0] >= T
+
+
 def test_best_exact_solution_of_a_relaxed_dd(brock):
     """best_exact_value / best_exact_solution (mdd.rs:96-110): the best terminal reached by an exact path"""
     mdd = ddo_amd.Mdd(brock, 50)

@@ -168,3 +168,20 @@ def test_pooled_with_a_cache_refuses_loudly():
         ddo_amd.SeqCachingSolverPooled(_model("johnson8-4-4"), FixedWidth(10))
     with pytest.raises(ddo_amd.DdoError):
         ddo_amd.Mdd(_model("johnson8-4-4"), 10, cutset_type=ddo_amd.FRONTIER | 0x20, caching=True)
+
+
+def test_pooled_on_a_weighted_instance(oracle, tmp_path):
+    """negative and non-unit weights (main.rs:290-297): rough upper bounds are weight sums, cut-set values are rebuilt from the weights
+    along the paths; replay of the oracle's pooled search, three widths"""
+    from tests.test_emulation_pooled import _weighted_instance
+    path = _weighted_instance(tmp_path)
+    model = ddo_amd.Misp.read_instance(path)
+    inst = oracle.misp(path)
+    for width in (0, 4, 16):
+        _, recs = inst.trace_solve(width, 200, pooled=True)
+        mdd = ddo_amd.Pooled(model, max(max(int(r["width"]) for r in recs), 8))
+        for i, r in enumerate(recs):
+            sub = SubProblem(state=np.array(r["state"], dtype=np.uint64), value=r["value"], path=[], depth=r["depth"])
+            comp = mdd.compile(r["comp_type"], r["width"], sub, r["best_lb"])
+            d = diff(r, canon_from_mdd(mdd, comp, model.ws))
+            assert d is None, (width, i, d)
