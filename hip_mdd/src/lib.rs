@@ -21,6 +21,7 @@ use std::sync::{Arc, RwLock};
 pub const DDO_LAST_EXACT_LAYER: c_int = 1;
 pub const DDO_FRONTIER: c_int = 2;
 pub const DDO_MDD_CACHING: c_int = 0x10;
+pub const DDO_MDD_POOLED: c_int = 0x20;             // the mdds are `Pooled` decision diagrams (mdd/pooled.rs): see install_pooled
 pub const DDO_MDD_ENGINE_DENSE: c_int = 0x100;      // test / measurement hooks: bind an mdd to one kernel of the in-place engine
 pub const DDO_MDD_ENGINE_TIER0: c_int = 0x200;
 pub const DDO_MDD_ENGINE_TIER1: c_int = 0x300;
@@ -65,6 +66,16 @@ static REGISTRY: RwLock<Option<Arc<Registry>>> = RwLock::new(None);
 /// `Misp { nb_vars, neighbors, weight }`, examples/misp/main.rs:37-51) and fixes device, cut-set type and the largest
 /// width any compile will ask for.  `cache_entries > 0` creates the device-side SimpleCache the `HipCache` below wraps.
 pub fn install(nb_vars: usize, neighbors: &[BitSet], weight: &[isize], device: i32, frontier: bool, max_width: usize, cache_entries: usize) {
+    let cutset_type = (if frontier { DDO_FRONTIER } else { DDO_LAST_EXACT_LAYER }) | (if cache_entries > 0 { DDO_MDD_CACHING } else { 0 });
+    install_with(nb_vars, neighbors, weight, device, cutset_type, max_width, cache_entries)
+}
+/// The same for `Pooled` decision diagrams (implementation/mdd/pooled.rs; `ParNoCachingSolverPooled` / `SeqNoCachingSolverPooled`,
+/// solver/mod.rs:34, :43): every `HipMdd` created afterwards compiles pooled DDs on the device -- use
+/// `ParallelSolver::<BitSet, HipMdd, EmptyCache<BitSet>>` exactly as with `install`.  (Pooled behind a SimpleCache is not built.)
+pub fn install_pooled(nb_vars: usize, neighbors: &[BitSet], weight: &[isize], device: i32, max_width: usize) {
+    install_with(nb_vars, neighbors, weight, device, DDO_FRONTIER | DDO_MDD_POOLED, max_width, 0)
+}
+fn install_with(nb_vars: usize, neighbors: &[BitSet], weight: &[isize], device: i32, cutset_type: c_int, max_width: usize, cache_entries: usize) {
     let words = (nb_vars + 63) / 64;
     let mut rows = vec![0u64; nb_vars * words];
     for (i, nb) in neighbors.iter().enumerate() { for j in nb.iter() { rows[i * words + j / 64] |= 1u64 << (j % 64); } }
@@ -72,7 +83,6 @@ pub fn install(nb_vars: usize, neighbors: &[BitSet], weight: &[isize], device: i
     let model = unsafe { ddo_model_create_misp(nb_vars as c_int, rows.as_ptr(), w.as_ptr()) };
     assert!(!model.is_null(), "ddo_model_create_misp: {:?}", unsafe { std::ffi::CStr::from_ptr(ddo_last_error()) });
     let cache = if cache_entries > 0 { unsafe { ddo_cache_create(model, device, cache_entries) } } else { std::ptr::null_mut() };
-    let cutset_type = (if frontier { DDO_FRONTIER } else { DDO_LAST_EXACT_LAYER }) | (if cache_entries > 0 { DDO_MDD_CACHING } else { 0 });
     // (MISP has no dominance relation: EmptyDominanceChecker == null; a knapsack / TSPTW shim would call ddo_dominance_create here)
     *REGISTRY.write().unwrap() = Some(Arc::new(Registry { model: model as usize, cache: cache as usize, dominance: 0, device, cutset_type,
                                                           max_width, nb_vars, words, stop: Arc::new(AtomicI32::new(0)) }));

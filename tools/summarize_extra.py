@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round-4 additions of tools/profile_round.sh -> profiles/<round>/pmc_extra.json: L2 hit rate of the dense kernel (timed launches),
 the whole search per kernel (rocprofv3 --stats of a bench run with the proof), the layer-rebuilding engine on MAX2SAT frb15-9-1
-(kernel trace + FETCH_SIZE / WRITE_SIZE / SQ passes).   python tools/summarize_extra.py gpurun_out/prof_round profiles/r04"""
+(kernel trace + FETCH_SIZE / WRITE_SIZE / SQ passes).   python tools/summarize_extra.py gpurun_out/prof_round profiles/r05"""
 import collections
 import csv
 import json
@@ -9,7 +9,7 @@ import shutil
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_round"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05"
 
 
 def agg(sub, key):
