@@ -645,6 +645,15 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         }
     }
 
+    {   // The output arena of the first buffer set -- pinned host memory the kernels write into -- is allocated here, with the rest of
+        // the workspace: pinning costs about 0.2 ms per MB, and left to the first launch it was part of every search's wall time
+        // (round 5, DDO_HIP_TIMES: 13 of the 21 ms of an MCP n = 30 search, 87 of the 239 ms of config C3).  The second set's arena
+        // is allocated when a second launch is in flight for the first time.
+        void* hp = nullptr;
+        HIP_TRY(hipHostMalloc(&hp, arena_cap_, hipHostMallocDefault));
+        io_[0].h_arena = (uint8_t*)hp;
+        io_[0].h_arena_cap = arena_cap_;
+    }
     hipStream_t st, st2;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     stream_ = st;
@@ -1547,7 +1556,10 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     static const bool split = [] { const char* e = std::getenv("DDO_HIP_SPLIT"); return !(e && std::atoi(e) == 0); }();
     P.done = nullptr;
     bool split_now = false;
-    if (split && engine_kind_ == 2 && count > nslots_) {
+    // Only where a slot sees few, large work items: a capacity tier's decision diagrams are tiny (a second draw, a flag and a
+    // re-read result record per sub-problem cost tier 0 a third of its time: 7.7 -> 10.0 s of a brock400_1 proof), and a launch
+    // of many items per slot has no tail to speak of.
+    if (split && engine_kind_ == 2 && (!owner_ || dense_) && count > nslots_ && count <= 4 * nslots_) {
         const LptBuffers lb(io.d_inputs, io.in_cap);
         HIP_TRY(hipMemsetAsync(lb.done, 0, (size_t)count * 4, st));
         P.done = lb.done;
