@@ -768,7 +768,15 @@ void Engine::pool_want(size_t bytes) {
 void Engine::pool_expect(int count) {
     if (!vm_base_ || count <= 0) return;
     const size_t worst = (size_t)count * (size_t)pool_block_bytes((uint32_t)P_.capW, (uint32_t)model_->wsT, (uint32_t)P_.max_layers);
-    pool_want(2 * worst + 2 * vm_chunk_);
+    // (bounded: 24 GB ahead, and never more than a quarter of what is free right now -- several solvers may share the device, and the
+    // engines created after this one size their slots by the memory they find)
+    size_t target = std::min<size_t>(2 * worst + 2 * vm_chunk_, (size_t)24 << 30);
+    size_t free_b = 0, total_b = 0;
+    (void)hipSetDevice(device_);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const size_t mapped = vm_mapped_.load();
+    if (target > mapped && target - mapped > free_b / 4) target = mapped + free_b / 4 / vm_chunk_ * vm_chunk_;
+    pool_want(target);
 }
 
 int Engine::pool_grow(size_t target) {

@@ -1560,7 +1560,6 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
             return nullptr;
         }
         s->lazy = new LazyFringe();
-        s->engine->pool_expect(std::max(1, s->cfg.nb_concurrent));   // (mapped in the background while the first steps run)
         // capacity tiers below the full-width engine (see ddo_solver::dispatch): only where the width leaves room for them
         std::vector<std::pair<int, int>> spec;   // (layer capacity, threads per workgroup)
         if (s->cfg.width_policy == DDO_WIDTH_FIXED && s->cfg.width >= 4096) {
@@ -1602,6 +1601,9 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
         }
     }
     s->tiers.push_back(s->engine);
+    // every engine of this solver has its workspace now: the node pool starts to map what the first large launches will reserve,
+    // in the background, while the search compiles its first (small) steps
+    if (s->lazy) s->engine->pool_expect(std::max(1, s->cfg.nb_concurrent));
     s->want_stats = std::getenv("DDO_HIP_STATS") != nullptr;
     if (const char* env = std::getenv("DDO_HIP_TIER_SKIP")) s->tier_skip_pct = std::max(1, std::min(100, std::atoi(env)));
     if (const char* env = std::getenv("DDO_HIP_HINT_SLACK")) s->hint_by_slack = std::atoi(env) != 0;   // 0: per-depth cells only (A/B)
