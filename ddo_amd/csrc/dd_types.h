@@ -222,6 +222,7 @@ struct EngineParams {
     // compiled again by the next tier.  hist_bins < 2048 shrinks the LDS area only the squash phases use.
     // TSPTW (examples/tsptw): distances [n][n], time windows, cheapest entering edge (dd_tsptw.hpp)
     const int32_t *tw_dist, *tw_early, *tw_late, *tw_cheap, *tw_order;   // tw_order: the nodes by increasing tw_cheap
+    int32_t tw_lds;            // != 0: the workgroup keeps a copy of the five tables in LDS behind its shared block (n (n + 4) words: tw_lds_words)
     // TSPTW dominance (examples/tsptw/dominance.rs:26-60): best value per (depth, position, must_visit), same table layout as the cache
     uint64_t* dkey_tab;
     uint64_t dkey_cap;

@@ -330,6 +330,14 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     table_lds_ = lds_with_table <= lds_max;
     lds_bytes_ = table_lds_ ? lds_with_table : dd_lds_bytes(0, P.npad, threads_);
     P.table_in_lds = table_lds_ ? 1 : 0;
+    P.tw_lds = 0;
+    if (model->kind == MODEL_TSPTW && !std::getenv("DDO_HIP_TW_GLOBAL")) {   // the TSPTW tables next to the shared block when LDS has the room
+        const size_t with_tw = dd_lds_bytes(table_lds_ ? P.table_cap : 0, P.npad, threads_, tw_lds_words(model->n));
+        if (with_tw <= lds_max) {
+            P.tw_lds = 1;
+            lds_bytes_ = with_tw;
+        }
+    }
     // ---- engine 2 (in-place layers) when its LDS footprint fits and values fit the packed 21-bit key
     P.capS = 2 * (int)slot_width + 8;
     P.tier = dense_ ? 2 : owner ? 1 : 0;

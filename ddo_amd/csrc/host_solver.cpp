@@ -486,6 +486,12 @@ struct ddo_solver {
                          st_host_run, st_host_post, st_host_fetch, (unsigned long long)st_push, engine ? engine->pool_capacity() / 1073741824.0 : 0.0);
             std::fprintf(stderr, "[ddo stats] dispatch s: lists + inputs %.3f, launch() %.3f, wait for a lower tier %.3f, wait for the last tier of the previous step %.3f\n",
                          st_t_fill, st_t_launch, st_t_wait, st_t_wait_last);
+            if (engine && engine->engine_kind() == 1) {   // the layer-rebuilding engine's marks (DD1_TICK in misp_dd_core.hpp)
+                const double d = 1e3 * (double)std::max<uint64_t>(1, tl);
+                std::fprintf(stderr, "[ddo stats] layer-rebuilding engine, kcycles per layer: variable + cache filter %.1f, dominance filters %.1f, select %.1f, "
+                             "classify + positions + merge %.1f, layer bookkeeping %.1f, expand + dedup %.1f, after the last layer %.1f, terminal layer %.1f\n",
+                             st_clk[7] / d, st_clk[0] / d, st_clk[1] / d, st_clk[3] / d, st_clk[5] / d, st_clk[2] / d, st_clk[4] / d, st_clk[6] / d);
+            } else
             std::fprintf(stderr, "[ddo stats] device kcycles per layer: misc(var,sweep,freelist,final,backward) %.1f select %.1f classify+tie-break %.1f victims+merge %.1f expand+dedup %.1f (unused %.1f %.1f) hand-over %.1f | total %.1f kcycles/layer, %.1f Mcycles/DD\n",
                          st_clk[0] / 1e3 / std::max<uint64_t>(1, tl), st_clk[1] / 1e3 / std::max<uint64_t>(1, tl), st_clk[2] / 1e3 / std::max<uint64_t>(1, tl),
                          st_clk[3] / 1e3 / std::max<uint64_t>(1, tl), st_clk[4] / 1e3 / std::max<uint64_t>(1, tl), st_clk[5] / 1e3 / std::max<uint64_t>(1, tl),

@@ -12,6 +12,7 @@ __global__ void __launch_bounds__(1024) misp_compile_kernel(EngineParams P) {
     DDCtx<WS> c;
     dd_bind<WS, TLDS>(c, P, (int)blockIdx.x, lds, (int)blockDim.x);
     c.tid_ = (int)threadIdx.x;
+    dd_stage_tables<WS>(c, P);
     for (;;) {
         if (threadIdx.x == 0) c.sh->work = atomicAdd(P.work_counter, 1);
         __syncthreads();

@@ -65,6 +65,7 @@ inline uint32_t emu_atomic_cas(uint32_t* p, uint32_t cmp, uint32_t v) { uint32_t
 #define LD_U32(p) (*(p))
 #define LD_I32(p) (*(p))
 #define FENCE_BLOCK()
+#define DD_WAVE_UNIFORM(x) (x)
 inline int dd_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
 inline double dd_floor(double x) { return __builtin_floor(x); }
@@ -115,6 +116,8 @@ __device__ __forceinline__ uint32_t dd_tab_cas(P p, uint32_t cmp, uint32_t v) {
 #define LD_U32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define LD_I32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define FENCE_BLOCK() __threadfence_block()
+// a value every lane of the wavefront holds: kept in a scalar register, what is computed from it runs on the scalar unit
+#define DD_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ int dd_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
 __device__ __forceinline__ double dd_floor(double x) { return __builtin_floor(x); }
@@ -364,6 +367,7 @@ DDO_DEV int32_t vec_get(const uint64_t* s, int v) {
     return r;
 }
 DDO_DEV int32_t iabs32(int32_t x) { return x < 0 ? -x : x; }
+constexpr int VEC_BATCH = 8;   // words of a signed-vector parent read ahead of the stores of its children (expand)
 /// the signed-vector models (MCP, MAX2SAT) share merge, relax, ranking and state layout; transitions and bounds differ
 DDO_DEV bool dd_is_vec(int kind) { return kind == MODEL_MCP || kind == MODEL_MAX2SAT; }
 /// States wider than 16 words only exist for the signed-vector models (MAX2SAT / MCP beyond 30 variables): in the 32- and
@@ -498,6 +502,77 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         for (int k = 0; k < WS; ++k) sh->pivLex[k] = 0;
     }
     PAR_END
+    int need = K;
+    bool done = false;
+    uint64_t pivK1 = 0;
+    // ---- NARROW layers (a few hundred candidates: MCP and knapsack at width 100, the reference's test widths): the primary keys
+    // are staged in LDS and every candidate counts the keys above its own.  The digit rounds below cost three barriers and a sweep
+    // of global memory per byte of the key whatever the layer holds (35-40 kcycles per squash of 200 candidates, a third of an MCP
+    // compile); counting is one LDS read per pair.  The LDS block is the histogram and the two scan arrays, idle during a selection.
+    const int narrow_cap = 128 + NT;
+    const bool narrow = ncl <= narrow_cap;
+    if (narrow) {
+        LDS_PTR(uint64_t) nk = (LDS_PTR(uint64_t))c.hist;   // (ds_read, not the FLAT path the engine's generic pointers take)
+        const uint64_t DEAD = ~0ULL;   // no key looks like this: the low word is a popcount or a rank
+        PAR_BEGIN
+        for (int j = tid; j < ncl; j += NT) {
+            const int cd = lin2cand(j, nprev, c.capN);
+            nk[j] = cand_live(c, cur, cd) ? k1_of(LD_U64(&key[cd]), pop[cd]) : DEAD;
+        }
+        PAR_END
+        PAR_BEGIN
+        for (int j = tid; j < ncl; j += NT) {
+            const uint64_t mine = nk[j];
+            if (mine == DEAD) continue;
+            int above = 0, equal = 0;
+#pragma unroll 8
+            for (int j2 = 0; j2 < ncl; ++j2) {   // (every lane reads the same word: an LDS broadcast; unrolled so that eight reads are in flight)
+                const uint64_t o = nk[j2];
+                above += (o != DEAD && o > mine) ? 1 : 0;
+                equal += o == mine ? 1 : 0;
+            }
+            if (above < K && K <= above + equal) {   // the K-th best key (every candidate that carries it writes the same three words)
+                sh->pivK1 = mine;
+                sh->sel_above = above;
+                sh->sel_bucket = equal;
+            }
+        }
+        PAR_END
+        pivK1 = sh->pivK1;
+        need = K - sh->sel_above;
+        const int bucket = sh->sel_bucket;
+        DD_SYNC();
+        
+#if defined(DDO_HOST_EMULATION)
+        if (getenv("DD_SELECT_TRACE")) std::fprintf(stderr, "NARROW ncl=%d K=%d need=%d bucket=%d %s\n", ncl, K, need, bucket, need == bucket ? "whole" : bucket <= 64 ? "pairs" : "radix");
+#endif
+        if (need == bucket) done = true;   // all the candidates with the pivot's key are kept: the pivot's state words stay zero
+        else if (bucket <= 64) {           // a small class of ties: each member counts the members that rank above it
+            PAR_BEGIN
+            for (int j = tid; j < ncl; j += NT) {
+                if (nk[j] != pivK1) continue;
+                const int cd = lin2cand(j, nprev, c.capN);
+                int r = 0;
+                for (int j2 = 0; j2 < ncl; ++j2) {
+                    if (j2 == j || nk[j2] != pivK1) continue;
+                    const int c2 = lin2cand(j2, nprev, c.capN);
+                    bool c2_above = false;
+                    for (int k = 0; k < WS; ++k) {
+                        const uint64_t la = lexkey(c, st[(size_t)k * capC1 + c2]), lb = lexkey(c, st[(size_t)k * capC1 + cd]);
+                        if (la != lb) {
+                            c2_above = la > lb;
+                            break;
+                        }
+                    }
+                    r += c2_above ? 1 : 0;
+                }
+                if (r == need - 1)
+                    for (int k = 0; k < WS; ++k) sh->pivLex[k] = lexkey(c, st[(size_t)k * capC1 + cd]);
+            }
+            PAR_END
+            done = true;
+        }
+    } else {
     PAR_BEGIN
     uint64_t a = ~0ULL, o = 0;
     int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
@@ -514,13 +589,11 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         LDS_OR_U64(&sh->k1or, o);
     }
     PAR_END
+    }
 
-    int need = K;
-    bool done = false;
-    const uint64_t diff = sh->k1and ^ sh->k1or;
-    uint64_t pivK1 = 0;
+    const uint64_t diff = narrow ? 0 : sh->k1and ^ sh->k1or;
     // ---- primary key: 8 bytes, most significant first (bytes that are constant over the layer cost nothing)
-    for (int b = 7; b >= 0 && !done; --b) {
+    for (int b = 7; b >= 0 && !done && !narrow; --b) {
         const int shift = 8 * b;
         if (((diff >> shift) & 0xFF) == 0) {
             pivK1 |= sh->k1and & (0xFFULL << shift);
@@ -1035,6 +1108,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             PAR_END
         }
         int ncache = (use_cache && L >= 1) ? sh->ncache : 0;
+        DD1_TICK(7)   // next_variable, cache filter
         // ------------------------------------------------------------ _filter_with_dominance (clean.rs:689-708)
         // every layer, the root's too: the exact nodes of curr_l, best (value, coordinate) first, are checked against -- and
         // added to -- the set of non-dominated states of this depth (dominance/simple.rs:67-111); a dominated node leaves
@@ -1091,7 +1165,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         }
         const int nU = sh->nU - ncache;                               // |curr_l| after the filters
 
-        DD1_TICK(0)   // next_variable, cache / dominance filters
+        DD1_TICK(0)   // dominance filters
         // ------------------------------------------------------------ _squash_if_needed (clean.rs:779-795)
         const bool squash = (restricted && nU > W) || (relaxed && nU > W && L > 1);
         if ((!squash && nU > capN) || (c.tmode && nU + ncache + 1 > LS)) {  // Exact DD wider than the workspace
@@ -1524,7 +1598,13 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         const uint64_t kpw = kp ? (uint64_t)c.kp_weight[var] : 0;
         int32_t* ac_next = c.arcc + ab_next;   // costs of the arcs entering layer L + 1
         int myarcs = 0, myuniq = 0;
-        for (int pos = tid; pos < n; pos += NT) {
+        // TSPTW: a WAVEFRONT per parent, a lane per child (decision = node to visit next, up to n of them).  What belongs to the
+        // parent -- its state, rough upper bound and domain -- is the same in all 64 lanes (one scalar computation); the children's
+        // transitions and table insertions run side by side.  (One thread per parent walked the n children one after the other:
+        // 185-290 kcycles per layer of 20-70 nodes on config C5, nine tenths of the compile.)
+        const bool twl = tw_k_of_ws(WS) != 0 && dd_kind_is<WS>(c.kind, MODEL_TSPTW);
+        const int lane = twl ? (tid & 63) : 0, lanes = twl ? 64 : 1;
+        for (int pos = twl ? DD_WAVE_UNIFORM(tid >> 6) : tid; pos < n; pos += twl ? (NT >> 6) : NT) {
             const uint32_t p = c.keep[pos];
             if (dd_is_vec_w<WS>(c.kind)) {
                 // ---- signed-vector models, STREAMED: the parent's words are read, turned into the two children's words and written
@@ -1567,9 +1647,18 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     const size_t row = (size_t)kx * c.n;
                     sum0 = c.m2_wtt[row + kx];
                     sum1 = c.m2_wff[row + kx];   // unit clauses (k) / (-k)
-#pragma unroll 2
-                    for (int k = 0; k < WS; ++k) {
-                        const uint64_t sw = src[(size_t)k * capC1];
+                    // (the parent's words arrive eight at a time: a load behind every pair of stores -- which may alias it, as far
+                    // as the compiler can tell -- left each of the 16 to 72 words waiting a full memory latency of its own)
+#pragma unroll 1
+                    for (int kb = 0; kb < WS; kb += VEC_BATCH) {
+                    uint64_t pw8[VEC_BATCH];
+#pragma unroll
+                    for (int i = 0; i < VEC_BATCH; ++i) pw8[i] = kb + i < WS ? src[(size_t)(kb + i) * capC1] : 0;
+#pragma unroll
+                    for (int i = 0; i < VEC_BATCH; ++i) {
+                        const int k = kb + i;
+                        if (k >= WS) break;
+                        const uint64_t sw = pw8[i];
                         uint64_t w0 = 0, w1 = 0;
 #pragma unroll
                         for (int hsel = 0; hsel < 2; ++hsel) {
@@ -1602,13 +1691,21 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                         h0 = hash_step(h0, w0);
                         h1 = hash_step(h1, w1);
                     }
+                    }
                 } else {
                     // mcp/model.rs:60-130 (side 0 = S, side 1 = T)
                     const int x = var;
                     const int32_t* wrow = c.vgraph + (size_t)x * c.n;
-#pragma unroll 2
-                    for (int k = 0; k < WS; ++k) {
-                        const uint64_t sw = src[(size_t)k * capC1];
+#pragma unroll 1
+                    for (int kb = 0; kb < WS; kb += VEC_BATCH) {
+                    uint64_t pw8[VEC_BATCH];
+#pragma unroll
+                    for (int i = 0; i < VEC_BATCH; ++i) pw8[i] = kb + i < WS ? src[(size_t)(kb + i) * capC1] : 0;
+#pragma unroll
+                    for (int i = 0; i < VEC_BATCH; ++i) {
+                        const int k = kb + i;
+                        if (k >= WS) break;
+                        const uint64_t sw = pw8[i];
                         uint64_t w0 = 0, w1 = 0;
 #pragma unroll
                         for (int hsel = 0; hsel < 2; ++hsel) {
@@ -1633,6 +1730,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                         if (two) dst[(size_t)k * capC1 + cd1] = w1;
                         h0 = hash_step(h0, w0);
                         h1 = hash_step(h1, w1);
+                    }
                     }
                 }
                 int32_t cost0, cost1;
@@ -1686,14 +1784,14 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
             if (c.tmode) c.lrub[lb_cur + pos] = rub;   // node.rub (clean.rs:363), read again by _compute_thresholds
             if (rub == RUB_NEG_INF || (int64_t)rub + (int64_t)val <= best_lb) {  // clean.rs:364-365: not expanded (isize::MIN + value saturates)
                 if (dd_kind_is<WS>(c.kind, MODEL_MISP)) add_bits<WS>(c.cnt, s, -1);
-                for (int d = 0; d < c.fan; ++d) c.ctarget[(size_t)d * capN + pos] = NONE32;
+                for (int d = lane; d < c.fan; d += lanes) c.ctarget[(size_t)d * capN + pos] = NONE32;
                 continue;
             }
             if (tw_k_of_ws(WS) != 0 && dd_kind_is<WS>(c.kind, MODEL_TSPTW)) {
                 // examples/tsptw/model.rs:65-139: one child per node the salesman may visit next; decision index = node
                 uint64_t dom[TWK];
                 if constexpr (tw_k_of_ws(WS) != 0) tw_domain<TWK>(c.tw, s, dom);
-                for (int j = 0; j < c.fan; ++j) {
+                for (int j = lane; j < c.fan; j += 64) {
                     const uint32_t cd = (uint32_t)((size_t)j * capN + pos);
                     uint64_t dw = dom[0];
 #pragma unroll
@@ -1814,6 +1912,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
         if (getenv("DD_TRACE")) std::printf("E1 L=%d var=%d n=%d arcs=%llu nU_next=%d squash=%d\n", L, var, n, (unsigned long long)sh->arcs, sh->nU, (int)squash);
 #endif
 
+        DD1_TICK(2)   // expand: rough upper bounds, transitions, dedup table
         cur = nxt;
         nprev = n;
         ab_cur_ = ab_next_;
@@ -2454,14 +2553,19 @@ DDO_DEV void run_work_item(DDCtx<WS>& c, const DDInput& in, DDResult* res2) {
 }
 
 /// LDS bytes needed by one workgroup.
-inline size_t dd_lds_bytes(int table_cap_lds, int npad, int nthreads) {
+inline size_t dd_lds_bytes(int table_cap_lds, int npad, int nthreads, int tw_words = 0) {
     size_t b = (size_t)table_cap_lds * 4;
     b += (size_t)npad * 4;
     b += 256 * 4;
     b += (size_t)nthreads * 4 * 2;
     b += (sizeof(DDShared) + 15) & ~(size_t)15;
+    b += (size_t)tw_words * 4;
     return (b + 15) & ~(size_t)15;
 }
+/// words of the TSPTW tables a workgroup may keep in LDS (EngineParams::tw_lds): distances, time windows, cheapest entering
+/// edges and their order.  The rough upper bound and the domain of a state walk its must-visit set one node at a time, each
+/// step a dependent table lookup: from LDS that step costs a fifth of what it costs from L2.
+inline int tw_lds_words(int n) { return n * (n + 4); }
 
 /// Binds slot `slot` of the workspace and the LDS block `lds` to a context.  TLDS: the dedup
 /// table lives in LDS (else in HBM: P.gtable, for widths whose table exceeds 160 KB of LDS).
@@ -2567,11 +2671,35 @@ DDO_DEV void dd_bind(DDCtx<WS>& c, const EngineParams& P, int slot, unsigned cha
     c.tcount2 = (int32_t*)p;
     p += (size_t)nthreads * 4;
     c.sh = (DDShared*)p;
+    p += (sizeof(DDShared) + 15) & ~(size_t)15;
+    if (P.tw_lds) {   // filled by dd_stage_tables
+        const int32_t* t = (const int32_t*)p;
+        const size_t n = (size_t)P.n;
+        c.tw = TwModel{P.n, t, t + n * n, t + n * n + n, t + n * n + 2 * n, t + n * n + 3 * n};
+    }
     c.arena = P.arena;
     c.arena_cap = P.arena_cap;
     c.arena_head = P.arena_head;
     c.cutoff_flag = P.cutoff_flag;
     c.NT = nthreads;
+}
+
+/// Once per workgroup, after dd_bind: the model tables that live in LDS (TSPTW, EngineParams::tw_lds).
+template <int WS>
+DDO_DEV void dd_stage_tables(DDCtx<WS>& c, const EngineParams& P) {
+    if (!P.tw_lds) return;
+    DD_TID_SETUP(c)
+    PAR_BEGIN
+    int32_t* t = const_cast<int32_t*>(c.tw.dist);
+    const int n = P.n, nn = n * n;
+    for (int i = tid; i < nn; i += NT) t[i] = P.tw_dist[i];
+    for (int i = tid; i < n; i += NT) {
+        t[nn + i] = P.tw_early[i];
+        t[nn + n + i] = P.tw_late[i];
+        t[nn + 2 * n + i] = P.tw_cheap[i];
+        t[nn + 3 * n + i] = P.tw_order[i];
+    }
+    PAR_END
 }
 
 }  // namespace ddo_hip

@@ -71,6 +71,7 @@ void run(Emul& e, const DDInput& in, DDResult* res2) {
     }
     DDCtx<WS> c;
     dd_bind<WS, true>(c, e.P, 0, e.lds.data(), e.nthreads);
+    dd_stage_tables<WS>(c, e.P);
     run_work_item<WS>(c, in, res2);
 }
 }  // namespace
@@ -170,7 +171,7 @@ static void* emul_finish(Emul* e, int n, int wsT, bool unit, int max_width, int 
         P.tmode = 0;
         P.lstride = (int32_t)LSm;
     }
-    e->lds.assign(dd_lds_bytes(P.table_cap, P.npad, nthreads), 0xEE);
+    e->lds.assign(dd_lds_bytes(P.table_cap, P.npad, nthreads, P.tw_lds ? tw_lds_words(n) : 0), 0xEE);
     e->arena.assign(arena_bytes, 0);
     P.arena = e->arena.data();
     P.arena_cap = arena_bytes;
@@ -262,6 +263,7 @@ void* emul_create_model(const void* model_handle, int max_width, int nthreads, u
         P.tw_late = M.tw_late.data();
         P.tw_cheap = M.tw_cheap.data();
         P.tw_order = M.tw_order.data();
+        P.tw_lds = std::getenv("EMUL_TW_GLOBAL") ? 0 : 1;   // the tables in (emulated) LDS, as Engine::init chooses when they fit
     }
     if (M.kind == MODEL_MAX2SAT) {
         P.m2_wtt = M.m2_w[0].data();

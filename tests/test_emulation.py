@@ -74,6 +74,28 @@ def test_emulation_weighted_instance(oracle, tmp_path, engine):
             assert diff(r, g) is None, (width, i, diff(r, g))
 
 
+@pytest.mark.parametrize("nthreads,width", [(256, 150), (256, 190), (1024, 500)])
+def test_emulation_narrow_layers_with_large_classes_of_ties(oracle, tmp_path, nthreads, width):
+    """Layers of at most 128 + nthreads candidates are selected by counting over keys staged in LDS (select_pivot of
+    misp_dd_core.hpp).  A graph with next to no edges makes most candidates of a layer agree on (value, popcount): classes of
+    ties of more than 64 members that the width cuts in two go on to the digit rounds over the state words, smaller ones are
+    ranked pair by pair, and a class kept whole needs neither."""
+    rng = np.random.RandomState(5)
+    n = 150
+    edges = [(a, b) for a in range(n) for b in range(a + 1, n) if rng.rand() < 0.04]
+    p = tmp_path / "sparse.clq"
+    with open(p, "w") as f:
+        f.write(f"p edge {n} {len(edges)}\n")
+        for a, b in edges:
+            f.write(f"e {a + 1} {b + 1}\n")
+    inst = oracle.misp(str(p))
+    _, recs = inst.trace_solve(width, 24)
+    e = Emul(inst.n, inst.rows, inst.weights, width, nthreads=nthreads, engine=1)
+    for i, r in enumerate(recs):
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"])[0]
+        assert diff(r, g) is None, (i, diff(r, g))
+
+
 @pytest.mark.parametrize("engine", ENGINES)
 def test_emulation_fused_restricted_then_relaxed(oracle, engine):
     """IN_FUSED == the device half of process_one_node (parallel.rs:391-437): the relaxed DD sees the lower bound

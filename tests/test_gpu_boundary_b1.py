@@ -54,7 +54,8 @@ def test_concurrent_compiles_share_launches_and_equal_the_oracle(gold, brock400,
         assert r0[i] == s["restricted"], (i, r0[i], s["restricted"])
         assert r1[i] == s["relaxed"], (i, r1[i], s["relaxed"])
     assert tot["requests"] >= tot["compiles"] and tot["launches"] > 0   # (a compile that found the shared output arena full runs again)
-    assert mean >= 0.8 * min(threads, DENSE_SLOTS), (mean, tot)
+    slots = 256 if os.environ.get("DDO_HIP_NO_AUTO_DENSE") else DENSE_SLOTS   # (diagnosis switch: the full-width engine's slots, one per CU)
+    assert mean >= 0.8 * min(threads, slots), (mean, tot)
 
 
 def test_the_cutset_checksum_is_the_drivers(gold, brock400):
