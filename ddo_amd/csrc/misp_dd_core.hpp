@@ -158,6 +158,7 @@ struct DDShared {
     int32_t cutoff;
     int32_t scan_total;
     int32_t sel_digit, sel_above, sel_bucket;
+    int32_t tie_n;               // select_pivot: candidates that carry the pivot's primary key
     int32_t nkept, merged_pos, recycled, dup_from, dup_to;
     int32_t ncut, ncut2;
     int32_t xbest;       // recycled merge: candidate re-added to the layer (clean.rs:868-872)
@@ -367,6 +368,7 @@ DDO_DEV int32_t vec_get(const uint64_t* s, int v) {
     return r;
 }
 DDO_DEV int32_t iabs32(int32_t x) { return x < 0 ? -x : x; }
+constexpr int TIE_PAIRS_MAX = 256;   // select_pivot: classes of ties up to this size are ranked pair by pair (<= the workgroup's threads: the list sits in a scan array)
 constexpr int VEC_BATCH = 8;   // words of a signed-vector parent read ahead of the stores of its children (expand)
 /// the signed-vector models (MCP, MAX2SAT) share merge, relax, ranking and state layout; transitions and bounds differ
 DDO_DEV bool dd_is_vec(int kind) { return kind == MODEL_MCP || kind == MODEL_MAX2SAT; }
@@ -479,6 +481,33 @@ DDO_DEV void block_exclusive_scan(DDCtx<WS>& c, int32_t* a, int32_t* tmp) {
     block_exclusive_scan_any(c, a, tmp, &c.sh->scan_total);
 }
 
+/// Primary keys of the candidates j0, j0 + NT, ... (SEL_BATCH of them; lanes next to each other read candidates next to each other):
+/// every load is issued before the first test, so that a sweep of the selection waits for memory once per batch, not once per
+/// candidate (an index past the layer reads candidate 0 and is not live).
+constexpr int SEL_BATCH = 4;
+template <int WS>
+DDO_DEV void sel_keys(const DDCtx<WS>& c, int cur, int j0, int NT, int ncl, int nprev, uint64_t* k1, bool* live, int* cds) {
+    uint32_t tg[SEL_BATCH], fl[SEL_BATCH], pp[SEL_BATCH];
+    uint64_t kk[SEL_BATCH];
+#pragma unroll
+    for (int u = 0; u < SEL_BATCH; ++u) {
+        const int j = j0 + u * NT;
+        cds[u] = j < ncl ? lin2cand(j, nprev, c.capN) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < SEL_BATCH; ++u) {
+        tg[u] = c.ctarget[cds[u]];
+        kk[u] = LD_U64(&c.ckey[cur][cds[u]]);
+        pp[u] = c.cpop[cur][cds[u]];
+        fl[u] = c.tmode ? c.cflags[cur][cds[u]] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < SEL_BATCH; ++u) {
+        live[u] = j0 + u * NT < ncl && tg[u] == (uint32_t)cds[u] && !(fl[u] & (NF_CACHE | NF_DOM));
+        k1[u] = k1_of(kk[u], pp[u]);
+    }
+}
+
 /// Exact K-th largest (1 <= K < nU) among the unique candidates of buffer `cur` by the total
 /// order (value_top, popcount, BitSet::cmp) -- MSD radix select, 8-bit digits, skipping the
 /// digits that are constant over the layer.  Result: sh->pivK1 / sh->pivLex with the
@@ -575,16 +604,19 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
     } else {
     PAR_BEGIN
     uint64_t a = ~0ULL, o = 0;
-    int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
-    for (int j = lo; j < hi; ++j) {
-        int cd = lin2cand(j, nprev, c.capN);
-        if (cand_live(c, cur, cd)) {
-            uint64_t k1 = k1_of(LD_U64(&key[cd]), pop[cd]);
-            a &= k1;
-            o |= k1;
-        }
+    for (int j0 = tid; j0 < ncl; j0 += SEL_BATCH * NT) {
+        uint64_t k1[SEL_BATCH];
+        bool live[SEL_BATCH];
+        int cds[SEL_BATCH];
+        sel_keys<WS>(c, cur, j0, NT, ncl, nprev, k1, live, cds);
+#pragma unroll
+        for (int u = 0; u < SEL_BATCH; ++u)
+            if (live[u]) {
+                a &= k1[u];
+                o |= k1[u];
+            }
     }
-    if (lo < hi) {
+    if (a != ~0ULL || o != 0) {
         LDS_AND_U64(&sh->k1and, a);
         LDS_OR_U64(&sh->k1or, o);
     }
@@ -603,13 +635,15 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         if (tid < 256) c.hist[tid] = 0;
         PAR_END
         PAR_BEGIN
-        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
-        for (int j = lo; j < hi; ++j) {
-            int cd = lin2cand(j, nprev, c.capN);
-            if (cand_live(c, cur, cd)) {
-                uint64_t k1 = k1_of(LD_U64(&key[cd]), pop[cd]);
-                bool active = (shift + 8 >= 64) || ((k1 >> (shift + 8)) == (pivK1 >> (shift + 8)));
-                if (active) LDS_ADD_U32(&c.hist[(k1 >> shift) & 0xFF], 1u);
+        for (int j0 = tid; j0 < ncl; j0 += SEL_BATCH * NT) {
+            uint64_t k1[SEL_BATCH];
+            bool live[SEL_BATCH];
+            int cds[SEL_BATCH];
+            sel_keys<WS>(c, cur, j0, NT, ncl, nprev, k1, live, cds);
+#pragma unroll
+            for (int u = 0; u < SEL_BATCH; ++u) {
+                const bool active = live[u] && ((shift + 8 >= 64) || ((k1[u] >> (shift + 8)) == (pivK1 >> (shift + 8))));
+                if (active) LDS_ADD_U32(&c.hist[(k1[u] >> shift) & 0xFF], 1u);
             }
         }
         PAR_END
@@ -637,20 +671,81 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
     // (Until round 3 every sweep re-compared all the words before wj: with 31- to 72-word states and a sweep or two per word,
     // the selection of a MAX2SAT layer was a quarter of its time.)
     if (!done) {
+#if defined(DDO_HOST_EMULATION)
+        if (getenv("DD_SELECT_TRACE")) std::fprintf(stderr, "TIEBREAK ncl=%d K=%d need=%d bucket=%d\n", ncl, K, need, (int)sh->sel_bucket);
+#endif
         PAR_BEGIN
-        int lo = tid * q, hi = lo + q < ncl ? lo + q : ncl;
-        for (int j = lo; j < hi; ++j) {
-            int cd = lin2cand(j, nprev, c.capN);
-            c.cls[cd] = (cand_live(c, cur, cd) && k1_of(LD_U64(&key[cd]), pop[cd]) == pivK1) ? 1 : 0;
+        if (tid == 0) sh->tie_n = 0;
+        PAR_END
+        PAR_BEGIN
+        for (int j0 = tid; j0 < ncl; j0 += SEL_BATCH * NT) {
+            uint64_t k1[SEL_BATCH];
+            bool live[SEL_BATCH];
+            int cds[SEL_BATCH];
+            sel_keys<WS>(c, cur, j0, NT, ncl, nprev, k1, live, cds);
+#pragma unroll
+            for (int u = 0; u < SEL_BATCH; ++u) {
+                if (j0 + u * NT >= ncl) continue;
+                const bool tied = live[u] && k1[u] == pivK1;
+                c.cls[cds[u]] = tied ? 1 : 0;
+                if (tied) {   // ... and listed, while the list has room (the two scan arrays, idle during a selection)
+                    const int at = LDS_ADD_I32(&sh->tie_n, 1);
+                    if (at < TIE_PAIRS_MAX) c.tcount[at] = cds[u];
+                }
+            }
         }
         PAR_END
+        // A class of at most TIE_PAIRS_MAX ties is ranked PAIR BY PAIR by the whole workgroup: b (b - 1) / 2 comparisons of state words
+        // that end at the first word that differs.  The digit rounds below narrow the class by one byte of one word per round -- three
+        // barriers and a sweep over every candidate of the layer each; the signed-vector states of MAX2SAT are small integers, most of
+        // their bytes 0x00 or 0xFF: config C3 took 15 rounds over 6 words per selection (classes of 130 ties on average), half a
+        // million cycles per squashed layer.
+        const int b = sh->tie_n;
+        if (b <= TIE_PAIRS_MAX) {
+            int32_t* tl = c.tcount;    // the tied candidates
+            int32_t* tr = c.tcount2;   // how many tied candidates rank above each
+            PAR_BEGIN
+            for (int i = tid; i < b; i += NT) tr[i] = 0;
+            PAR_END
+            PAR_BEGIN
+            for (int pi = tid; pi < b * b; pi += NT) {
+                const int ia = pi / b, ib = pi % b;
+                if (ia >= ib) continue;
+                const int ca = tl[ia], cb = tl[ib];
+                bool a_above = false;
+                for (int k = 0; k < WS; ++k) {
+                    const uint64_t la = lexkey(c, st[(size_t)k * capC1 + ca]), lb = lexkey(c, st[(size_t)k * capC1 + cb]);
+                    if (la != lb) {
+                        a_above = la > lb;
+                        break;
+                    }
+                }
+                LDS_ADD_I32(&tr[a_above ? ib : ia], 1);   // (two candidates of a layer never hold the same state)
+            }
+            PAR_END
+            PAR_BEGIN
+            for (int i = tid; i < b; i += NT)
+                if (tr[i] == need - 1)
+                    for (int k = 0; k < WS; ++k) sh->pivLex[k] = lexkey(c, st[(size_t)k * capC1 + tl[i]]);
+            PAR_END
+#if defined(DDO_HOST_EMULATION)
+            if (getenv("DD_SELECT_TRACE")) std::fprintf(stderr, "TIEPAIRS b=%d need=%d\n", b, need);
+#endif
+            done = true;
+        }
     }
     uint64_t pw = 0;
     uint64_t ldiff = 0, land = 0;   // bits of word wj in which the nodes still tied differ / agree on 1
+#if defined(DDO_HOST_EMULATION)
+    int dd_trace_words = 0, dd_trace_rounds = done ? -1 : 0;
+#endif
     for (int qd = 0; qd < 8 * WS && !done; ++qd) {
         const int wj = qd >> 3;
         const int shift = 8 * (7 - (qd & 7));
         if ((qd & 7) == 0) {
+#if defined(DDO_HOST_EMULATION)
+            ++dd_trace_words;
+#endif
             pw = 0;
             // one sweep per word: AND / OR of the word over the nodes still tied.  Bytes that are the same for all of them
             // decide nothing -- with 31-word signed-vector states most of the 248 digit rounds would be such bytes
@@ -682,6 +777,9 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
         const bool same_byte = ((ldiff >> shift) & 0xFF) == 0;   // the same byte in every tied node
         if (same_byte) pw |= land & (0xFFULL << shift);
         else {
+#if defined(DDO_HOST_EMULATION)
+        ++dd_trace_rounds;
+#endif
         PAR_BEGIN
         if (tid < 256) c.hist[tid] = 0;
         PAR_END
@@ -724,6 +822,9 @@ DDO_DEV void select_pivot(DDCtx<WS>& c, int cur, int nprev, int K) {
             PAR_END
         }
     }
+#if defined(DDO_HOST_EMULATION)
+    if (getenv("DD_SELECT_TRACE") && dd_trace_rounds >= 0) std::fprintf(stderr, "TIEEND words=%d rounds=%d\n", dd_trace_words, dd_trace_rounds);
+#endif
     PAR_BEGIN
     if (tid == 0) sh->pivK1 = pivK1;
     PAR_END

@@ -74,22 +74,22 @@ def test_emulation_weighted_instance(oracle, tmp_path, engine):
             assert diff(r, g) is None, (width, i, diff(r, g))
 
 
-@pytest.mark.parametrize("nthreads,width", [(256, 150), (256, 190), (1024, 500)])
-def test_emulation_narrow_layers_with_large_classes_of_ties(oracle, tmp_path, nthreads, width):
+@pytest.mark.parametrize("nthreads,width,n,density,seed", [(256, 150, 150, 0.04, 5), (256, 190, 150, 0.04, 5), (1024, 500, 150, 0.04, 5),
+                                                           (256, 700, 150, 0.04, 5), (256, 1500, 150, 0.04, 5), (256, 2500, 200, 0.03, 7)])
+def test_emulation_layers_with_large_classes_of_ties(oracle, tmp_path, nthreads, width, n, density, seed):
     """Layers of at most 128 + nthreads candidates are selected by counting over keys staged in LDS (select_pivot of
-    misp_dd_core.hpp).  A graph with next to no edges makes most candidates of a layer agree on (value, popcount): classes of
-    ties of more than 64 members that the width cuts in two go on to the digit rounds over the state words, smaller ones are
-    ranked pair by pair, and a class kept whole needs neither."""
-    rng = np.random.RandomState(5)
-    n = 150
-    edges = [(a, b) for a in range(n) for b in range(a + 1, n) if rng.rand() < 0.04]
+    misp_dd_core.hpp); wider layers go through the digit rounds on the primary key.  A graph with next to no edges makes most
+    candidates of a layer agree on (value, popcount): a class of ties that the width cuts in two is ranked pair by pair up to
+    256 members and by digit rounds over the state words above that (the last two cases), a class kept whole needs neither."""
+    rng = np.random.RandomState(seed)
+    edges = [(a, b) for a in range(n) for b in range(a + 1, n) if rng.rand() < density]
     p = tmp_path / "sparse.clq"
     with open(p, "w") as f:
         f.write(f"p edge {n} {len(edges)}\n")
         for a, b in edges:
             f.write(f"e {a + 1} {b + 1}\n")
     inst = oracle.misp(str(p))
-    _, recs = inst.trace_solve(width, 24)
+    _, recs = inst.trace_solve(width, 24 if width < 1000 else 12)
     e = Emul(inst.n, inst.rows, inst.weights, width, nthreads=nthreads, engine=1)
     for i, r in enumerate(recs):
         g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"])[0]
