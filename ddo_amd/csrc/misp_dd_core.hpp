@@ -66,6 +66,8 @@ inline uint32_t emu_atomic_cas(uint32_t* p, uint32_t cmp, uint32_t v) { uint32_t
 #define LD_I32(p) (*(p))
 #define FENCE_BLOCK()
 #define DD_WAVE_UNIFORM(x) (x)
+#define DD_SCALAR_PTR(T) const T*
+template <class T> inline const T* dd_scalar_ptr(const T* p) { return p; }
 inline int dd_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
 inline double dd_floor(double x) { return __builtin_floor(x); }
@@ -118,6 +120,16 @@ __device__ __forceinline__ uint32_t dd_tab_cas(P p, uint32_t cmp, uint32_t v) {
 #define FENCE_BLOCK() __threadfence_block()
 // a value every lane of the wavefront holds: kept in a scalar register, what is computed from it runs on the scalar unit
 #define DD_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// A read-only table addressed the same way by every lane (a model table indexed by the layer's variable and a loop counter): the pointer
+// in scalar registers and in the constant address space, so that the look-ups are scalar loads (s_load through the scalar cache) and
+// not 64-lane vector loads of one address -- a MAX2SAT child costs five such look-ups per remaining variable.
+#define DD_SCALAR_PTR(T) const __attribute__((address_space(4))) T*
+template <class T>
+__device__ __forceinline__ DD_SCALAR_PTR(T) dd_scalar_ptr(const T* p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (DD_SCALAR_PTR(T))(((uint64_t)hi << 32) | (uint64_t)lo);
+}
 __device__ __forceinline__ int dd_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int dd_ctz(uint64_t x) { return __builtin_ctzll(x); }
 __device__ __forceinline__ double dd_floor(double x) { return __builtin_floor(x); }
@@ -1744,10 +1756,15 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                 const bool two = !(c.kind == MODEL_MCP && depth == 0);   // MCP: the first vertex is fixed on side S (model.rs:60-63)
                 if (c.kind == MODEL_MAX2SAT) {
                     // max2sat/model.rs:270-329 (side 0 = T, side 1 = F)
-                    const int kx = var, nfree = c.n - depth - 1;
-                    const size_t row = (size_t)kx * c.n;
-                    sum0 = c.m2_wtt[row + kx];
-                    sum1 = c.m2_wff[row + kx];   // unit clauses (k) / (-k)
+                    const int kx = DD_WAVE_UNIFORM(var), nfree = c.n - depth - 1;
+                    const size_t row = (size_t)kx * DD_WAVE_UNIFORM(c.n);
+                    DD_SCALAR_PTR(int32_t) m_wtt = dd_scalar_ptr(c.m2_wtt) + row;   // the variable's rows of the four weight tables
+                    DD_SCALAR_PTR(int32_t) m_wtf = dd_scalar_ptr(c.m2_wtf) + row;
+                    DD_SCALAR_PTR(int32_t) m_wft = dd_scalar_ptr(c.m2_wft) + row;
+                    DD_SCALAR_PTR(int32_t) m_wff = dd_scalar_ptr(c.m2_wff) + row;
+                    DD_SCALAR_PTR(int32_t) m_rankpos = dd_scalar_ptr(c.m2_rankpos);
+                    sum0 = m_wtt[kx];
+                    sum1 = m_wff[kx];   // unit clauses (k) / (-k)
                     // (the parent's words arrive eight at a time: a load behind every pair of stores -- which may alias it, as far
                     // as the compiler can tell -- left each of the 16 to 72 words waiting a full memory latency of its own)
 #pragma unroll 1
@@ -1770,9 +1787,9 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                             if (v == kx) {
                                 sx = sl;
                                 a = b = 0;
-                            } else if (c.m2_rankpos[v] < nfree) {
-                                const int32_t wtt = c.m2_wtt[row + v], wtf = c.m2_wtf[row + v];
-                                const int32_t wft = c.m2_wft[row + v], wff = c.m2_wff[row + v];
+                            } else if (m_rankpos[v] < nfree) {
+                                const int32_t wtt = m_wtt[v], wtf = m_wtf[v];
+                                const int32_t wft = m_wft[v], wff = m_wff[v];
                                 const int32_t ps = sl > 0 ? sl : 0, ns = sl < 0 ? -sl : 0;
                                 const int32_t mt = ps + wft < ns + wff ? ps + wft : ns + wff;
                                 const int32_t mf = ps + wtt < ns + wtf ? ps + wtt : ns + wtf;
@@ -1795,8 +1812,8 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
                     }
                 } else {
                     // mcp/model.rs:60-130 (side 0 = S, side 1 = T)
-                    const int x = var;
-                    const int32_t* wrow = c.vgraph + (size_t)x * c.n;
+                    const int x = DD_WAVE_UNIFORM(var);
+                    DD_SCALAR_PTR(int32_t) wrow = dd_scalar_ptr(c.vgraph) + (size_t)x * DD_WAVE_UNIFORM(c.n);
 #pragma unroll 1
                     for (int kb = 0; kb < WS; kb += VEC_BATCH) {
                     uint64_t pw8[VEC_BATCH];
