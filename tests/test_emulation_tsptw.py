@@ -42,6 +42,15 @@ def test_tsptw_replay_of_oracle_search(oracle, fname, width, max_compiles, kind,
         assert inexact > 0
 
 
+@pytest.mark.parametrize("kind,frontier,cache", [("tsptw", False, False), ("tsptw+dominance", True, True)], ids=["lel", "frontier+cache+dominance"])
+def test_tsptw_tables_left_in_global_memory(oracle, monkeypatch, kind, frontier, cache):
+    """The workgroup keeps the distance / time-window tables in LDS when they fit (EngineParams::tw_lds, n <= 190 or so on the device;
+    the emulation always stages them): the same replay with the tables read where the model left them (EMUL_TW_GLOBAL; on the device the
+    instances of 201 and 233 nodes of tests/test_gpu_tsptw.py take that path, DDO_HIP_TW_GLOBAL forces it)."""
+    monkeypatch.setenv("EMUL_TW_GLOBAL", "1")
+    test_tsptw_replay_of_oracle_search(oracle, "N40ft403", 3, 80, kind, frontier, cache)
+
+
 BIG = [("AFG", "rbg067a.tw", 3, 30, 8), ("Dumas", "n80w20.001.txt", 3, 30, 8), ("AFG", "rbg125a.tw", 2, 20, 8), ("AFG", "rbg132.tw", 2, 20, 14),
        ("Dumas", "n200w20.001.txt", 2, 12, 14), ("AFG", "rbg233.tw", 2, 10, 14)]
 

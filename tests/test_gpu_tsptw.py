@@ -89,6 +89,13 @@ def test_replay_of_oracle_search(have_gpu, oracle, name, width, max_compiles, ki
             assert len(n.path) == n.depth - r["depth"] and all(0 <= dd.value < model.n for dd in n.path)
 
 
+def test_replay_with_the_tables_left_in_global_memory(have_gpu, oracle, monkeypatch):
+    """DDO_HIP_TW_GLOBAL: the engine does not stage the TSPTW tables in LDS (what it does on its own from 191 nodes or so: the 201- and
+    233-node instances below) -- the same replay must come out"""
+    monkeypatch.setenv("DDO_HIP_TW_GLOBAL", "1")
+    test_replay_of_oracle_search(have_gpu, oracle, "N40ft403", 3, 150, "tsptw+dominance", True, True)
+
+
 @pytest.mark.parametrize("name,width", [("N20ft405", 3), ("N20ft301", 2), ("N40ft403", 6), ("N40ft207", 4)])
 def test_sequential_solver_matches_the_oracle(have_gpu, oracle, name, width):
     """SeqCachingSolverFc-like configuration (frontier + cache + dominance), one sub-problem at a time: explored count and
