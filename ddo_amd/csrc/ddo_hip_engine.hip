@@ -655,12 +655,22 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
 
     {   // The output arena of the first buffer set -- pinned host memory the kernels write into -- is allocated here, with the rest of
         // the workspace: pinning costs about 0.2 ms per MB, and left to the first launch it was part of every search's wall time
-        // (round 5, DDO_HIP_TIMES: 13 of the 21 ms of an MCP n = 30 search, 87 of the 239 ms of config C3).  The second set's arena
-        // is allocated when a second launch is in flight for the first time.
-        void* hp = nullptr;
-        HIP_TRY(hipHostMalloc(&hp, arena_cap_, hipHostMallocDefault));
-        io_[0].h_arena = (uint8_t*)hp;
-        io_[0].h_arena_cap = arena_cap_;
+        // (round 5, DDO_HIP_TIMES: 13 of the 21 ms of an MCP n = 30 search, 87 of the 239 ms of config C3).
+        // The layer-rebuilding engine and the capacity tiers get the SECOND set's arena and both sets' input / result buffers here as
+        // well: launches alternate between the two sets, and what the first use of the second set allocated was still inside every
+        // search (DDO_HIP_TIMES: 45 of the 131 ms of config C3, 5-7 of the 10 ms of an MCP n = 30 search).  The full-width in-place
+        // engine keeps its second arena for the first overlapped launch: next to capacity tiers it may never see one.
+        const int eager = (engine_kind_ == 1 || owner) ? 2 : 1;
+        for (int k = 0; k < eager; ++k) {
+            void* hp = nullptr;
+            HIP_TRY(hipHostMalloc(&hp, arena_cap_, hipHostMallocDefault));
+            io_[k].h_arena = (uint8_t*)hp;
+            io_[k].h_arena_cap = arena_cap_;
+        }
+        for (int k = 0; k < 2; ++k) {
+            const int rc = io_reserve(io_[k], std::min(nslots_, 1024));
+            if (rc != DDO_OK) return rc;
+        }
     }
     hipStream_t st, st2;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -718,6 +728,7 @@ Engine::~Engine() {
         if (io_[k].d_inputs) (void)hipFree(io_[k].d_inputs);
         if (io_[k].d_results) (void)hipFree(io_[k].d_results);
         if (io_[k].h_arena) (void)hipHostFree(io_[k].h_arena);
+        if (io_[k].h_results) (void)hipHostFree(io_[k].h_results);   // (h_head and h_inputs live in the same allocation)
     }
     if (copy_stream_) (void)hipStreamDestroy((hipStream_t)copy_stream_);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
@@ -1476,6 +1487,25 @@ int Engine::compile_combined(CompileReq* const* reqs, int count) {
     return worst;
 }
 
+int Engine::io_reserve(IoSet& io, int count) {
+    if (io.d_inputs) HIP_TRY(hipFree(io.d_inputs));
+    if (io.d_results) HIP_TRY(hipFree(io.d_results));
+    if (io.h_results) HIP_TRY(hipHostFree(io.h_results));
+    io.d_inputs = io.d_results = nullptr;
+    io.h_results = nullptr;
+    io.in_cap = 0;
+    const int cap = std::max(count, 256);
+    void* hp = nullptr;
+    HIP_TRY(hipHostMalloc(&hp, (size_t)cap * 2 * sizeof(DDResult) + 64 + (size_t)cap * sizeof(DDInput), hipHostMallocDefault));
+    io.h_results = (DDResult*)hp;
+    io.h_head = (unsigned long long*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult));
+    io.h_inputs = (DDInput*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult) + 64);
+    HIP_TRY(hipMalloc(&io.d_inputs, (size_t)cap * sizeof(DDInput) + LptBuffers::bytes(cap)));   // + the launch order (lpt_order_kernel)
+    HIP_TRY(hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)));
+    io.in_cap = cap;
+    return DDO_OK;
+}
+
 int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, const DominanceTable* dom) {
     std::lock_guard<std::mutex> g(mtx_);
     auto lt0 = std::chrono::steady_clock::now();
@@ -1504,20 +1534,8 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     }
     if (staged) inputs = io.h_inputs;   // filled in place (no growth below: count <= in_cap)
     if (count > io.in_cap) {
-        if (io.d_inputs) HIP_TRY(hipFree(io.d_inputs));
-        if (io.d_results) HIP_TRY(hipFree(io.d_results));
-        if (io.h_results) HIP_TRY(hipHostFree(io.h_results));
-        io.d_inputs = io.d_results = nullptr;
-        io.h_results = nullptr;
-        int cap = std::max(count, 256);
-        void* hp = nullptr;
-        HIP_TRY(hipHostMalloc(&hp, (size_t)cap * 2 * sizeof(DDResult) + 64 + (size_t)cap * sizeof(DDInput), hipHostMallocDefault));
-        io.h_results = (DDResult*)hp;
-        io.h_head = (unsigned long long*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult));
-        io.h_inputs = (DDInput*)((uint8_t*)hp + (size_t)cap * 2 * sizeof(DDResult) + 64);
-        HIP_TRY(hipMalloc(&io.d_inputs, (size_t)cap * sizeof(DDInput) + LptBuffers::bytes(cap)));   // + the launch order (lpt_order_kernel)
-        HIP_TRY(hipMalloc(&io.d_results, (size_t)cap * 2 * sizeof(DDResult)));
-        io.in_cap = cap;
+        const int rc = io_reserve(io, count);
+        if (rc != DDO_OK) return rc;
     }
     for (int i = 0; i < count; ++i) {
         // (a capacity tier never squashes: a DD whose width is below the tier's layer capacity and that needs a squash is handed up)

@@ -334,6 +334,7 @@ class Engine {
         int count = 0;
     };
     IoSet io_[2];
+    int io_reserve(IoSet& io, int count);   // input / result buffers of a buffer set for `count` sub-problems (pinned staging + device)
     int next_set_ = 0;       // set the next launch() uses
     int pending_set_ = -1;   // set of the launch in flight
     int fetch_set_ = -1;     // set whose kernel finished (wait() done) but whose arena is not fetched yet
