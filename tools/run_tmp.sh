@@ -2,4 +2,4 @@
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -s KILL 900 python bench.py > gpurun_out/bench_stamped.json 2> gpurun_out/bench_stamped.err; tail -c 300 gpurun_out/bench_stamped.json
+timeout -s KILL 400 python tools/micro/layer_bench.py --quick > gpurun_out/micro_layers.jsonl 2> gpurun_out/micro_layers.err; wc -l gpurun_out/micro_layers.jsonl; tail -2 gpurun_out/micro_layers.err
