@@ -1,7 +1,7 @@
 #!/bin/bash
 # The host emulation of the device kernels (tests/emul/emul_capi.cpp = misp_dd_core.hpp + misp_dd_inplace.hpp built for the host)
 # under AddressSanitizer + UndefinedBehaviorSanitizer: builds the emulation library with the sanitizers in place of the regular one,
-# runs the emulation suites, restores the regular library.  CPU only; about seven minutes.
+# runs the emulation suites, restores the regular library.  CPU only; about eight minutes.
 cd "$(dirname "$0")/.." || exit 1
 LIB=tests/emul/libddo_emul.so
 python -c "from tests.emul_binding import build_emul; build_emul()" || exit 1

@@ -2,4 +2,4 @@
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -s KILL 400 python tools/micro/layer_bench.py --quick > gpurun_out/micro_layers.jsonl 2> gpurun_out/micro_layers.err; wc -l gpurun_out/micro_layers.jsonl; tail -2 gpurun_out/micro_layers.err
+timeout -s KILL 200 python -m pytest tests/test_gpu_boundary_b1.py -x -q -m gpu -p no:cacheprovider -s -k "concurrent_compiles" 2>&1 | grep -o "T=[0-9].*\|[0-9]* passed.*\|[0-9]* failed.*" > gpurun_out/boundary_b1_threads.txt; cat gpurun_out/boundary_b1_threads.txt | cut -c1-250
