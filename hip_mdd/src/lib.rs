@@ -147,7 +147,7 @@ impl HipMdd {
 /// what the C callback needs to rebuild `SubProblem<BitSet>` and hand it to the user's closure
 struct DrainCtx<'f> { func: &'f mut dyn FnMut(SubProblem<BitSet>), nb_vars: usize }
 extern "C" fn drain_trampoline(sp: *const DdoSubProblem, user: *mut c_void) {
-    let (sp, ctx) = unsafe { (&*sp, &mut *(user as *mut DrainCtx)) };
+    let (sp, ctx) = unsafe { (&*sp, &mut *(user as *mut DrainCtx<'_>)) };
     let words = unsafe { std::slice::from_raw_parts(sp.state, sp.state_words) };
     let path = if sp.path_len == 0 { vec![] } else { decisions_of(unsafe { std::slice::from_raw_parts(sp.path, sp.path_len) }) };
     (ctx.func)(SubProblem { state: Arc::new(bitset_of(words, ctx.nb_vars)), value: sp.value as isize, path,
@@ -188,7 +188,7 @@ impl DecisionDiagram for HipMdd {
     fn best_exact_solution(&self) -> Option<Solution> { self.solution(ddo_mdd_best_exact_solution) }
     fn drain_cutset<F: FnMut(SubProblem<BitSet>)>(&mut self, mut func: F) {      // mdd.rs:107-113: at most once per relaxed compile
         let mut ctx = DrainCtx { func: &mut func, nb_vars: self.r.nb_vars };
-        let rc = unsafe { ddo_mdd_drain_cutset(self.h, drain_trampoline, &mut ctx as *mut DrainCtx as *mut c_void) };
+        let rc = unsafe { ddo_mdd_drain_cutset(self.h, drain_trampoline, &mut ctx as *mut DrainCtx<'_> as *mut c_void) };
         assert!(rc == 0, "ddo_mdd_drain_cutset failed: {rc}");
     }
 }
