@@ -16,7 +16,8 @@ ABI_SYMBOLS = [
     "ddo_model_nb_variables", "ddo_model_state_words", "ddo_model_initial_state", "ddo_model_initial_value",
     "ddo_model_compare_states", "ddo_model_export_misp", "ddo_mdd_create", "ddo_mdd_destroy", "ddo_mdd_compile",
     "ddo_mdd_compile_batch", "ddo_mdd_is_exact", "ddo_mdd_best_value", "ddo_mdd_best_exact_value",
-    "ddo_mdd_best_solution", "ddo_mdd_best_exact_solution", "ddo_mdd_drain_cutset", "ddo_mdd_last_counters", "ddo_mdd_combine_stats",
+    "ddo_mdd_best_solution", "ddo_mdd_best_exact_solution", "ddo_mdd_drain_cutset", "ddo_mdd_drain_cutset_rows", "ddo_mdd_cutset_count",
+    "ddo_mdd_last_counters", "ddo_mdd_combine_stats",
     "ddo_solver_create", "ddo_width_heuristic", "ddo_solver_destroy", "ddo_solver_maximize", "ddo_solver_best_value",
     "ddo_solver_best_solution", "ddo_solver_best_lower_bound", "ddo_solver_best_upper_bound", "ddo_solver_set_primal",
     "ddo_solver_gap", "ddo_solver_explored", "ddo_solver_counters", "ddo_solver_step", "ddo_solver_epoch", "ddo_solver_flush",
@@ -59,6 +60,12 @@ class _Decision(C.Structure):
 class _SubProblem(C.Structure):
     _fields_ = [("state", C.POINTER(C.c_uint64)), ("state_words", C.c_size_t), ("value", C.c_int64), ("ub", C.c_int64),
                 ("depth", C.c_size_t), ("path", C.POINTER(_Decision)), ("path_len", C.c_size_t)]
+
+
+class _CutsetRows(C.Structure):
+    _fields_ = [("count", C.c_size_t), ("state_words", C.c_size_t), ("path_stride", C.c_size_t), ("states", C.POINTER(C.c_uint64)),
+                ("values", C.POINTER(C.c_int64)), ("ubs", C.POINTER(C.c_int64)), ("depths", C.POINTER(C.c_size_t)),
+                ("path_lens", C.POINTER(C.c_size_t)), ("paths", C.POINTER(_Decision))]
 
 
 class _CompileInput(C.Structure):
@@ -159,6 +166,9 @@ def lib():
     L.ddo_mdd_best_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
     L.ddo_mdd_best_exact_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
     L.ddo_mdd_drain_cutset.argtypes = [C.c_void_p, _CUTSET_CB, C.c_void_p]
+    L.ddo_mdd_drain_cutset_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.ddo_mdd_cutset_count.restype = C.c_size_t
+    L.ddo_mdd_cutset_count.argtypes = [C.c_void_p]
     L.ddo_mdd_last_counters.argtypes = [C.c_void_p, C.POINTER(_Counters)]
     L.ddo_mdd_combine_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.ddo_solver_create.restype = C.c_void_p
@@ -627,6 +637,25 @@ class Mdd:
         rc = lib().ddo_mdd_drain_cutset(self._h, _CUTSET_CB(cb), None)
         if rc != DDO_OK:
             raise DdoError(f"ddo_mdd_drain_cutset rc={rc}: {_err()}")
+        return out
+
+    def cutset_count(self):
+        return int(lib().ddo_mdd_cutset_count(self._h))
+
+    def drain_cutset_rows(self, ub_above=-(1 << 63), residual_path=()):
+        """ddo_mdd_drain_cutset_rows: the cut-set as flat rows (nodes with ub <= ub_above left out), rebuilt here into the
+        SubProblems drain_cutset's callbacks deliver -- the residual's own path goes in front of the DD's part."""
+        rows = _CutsetRows()
+        rc = lib().ddo_mdd_drain_cutset_rows(self._h, C.c_int64(ub_above), C.byref(rows))
+        if rc != DDO_OK:
+            raise DdoError(f"ddo_mdd_drain_cutset_rows rc={rc}: {_err()}")
+        out = []
+        ws, st = rows.state_words, rows.path_stride
+        head = list(residual_path)
+        for i in range(rows.count):
+            state = np.array([rows.states[i * ws + k] for k in range(ws)], dtype=np.uint64)
+            path = head + [Decision(rows.paths[i * st + k].variable, rows.paths[i * st + k].value) for k in range(rows.path_lens[i])]
+            out.append(SubProblem(state=state, value=rows.values[i], path=path, ub=rows.ubs[i], depth=rows.depths[i]))
         return out
 
     def combine_stats(self):

@@ -77,6 +77,10 @@ constexpr int ST_SKIPPED = 79; // IN_MUST_EXPLORE: the cache says this sub-probl
 // a DD of the layer-keeping mode outgrew its slot's pool of kept layers / of arcs (EngineParams::lpool_nodes / apool_arcs): a capacity
 // error that enlarging the output arena does not cure (DDO_HIP_LPOOL_M / DDO_HIP_APOOL_M do)
 constexpr int ST_ERR_LPOOL = ST_ERR_CAPACITY - 2100, ST_ERR_APOOL = ST_ERR_CAPACITY - 2200;
+// The SHARED OUTPUT ARENA of a launch was full: the one capacity error a re-run with a larger arena (or fewer compiles per launch)
+// cures.  Every other status <= -100 names a per-slot workspace (node slots, dedup table, work / cut lists, pools): running the
+// compile again gives the same answer, so it goes to the caller at once.
+constexpr int ST_ERR_ARENA = ST_ERR_CAPACITY - 700;
 constexpr int ST_RETRY = 78;   // capacity tier: the DD outgrew this tier's node slots (host: compile it on the next tier)
 
 /// Everything observable about one compiled DD (clean.rs:237-266).  Variable

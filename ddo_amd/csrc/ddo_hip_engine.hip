@@ -1105,7 +1105,8 @@ int Engine::run_batch(const DDInput* inputs, int count, std::vector<HostResult>&
 }
 
 int Engine::run_solo_growing(const DDInput& input, std::vector<HostResult>& results, const CacheTable* cache, const DominanceTable* dom) {
-    auto capacity = [](const HostResult& r) { return r.hdr.status == ST_ERR_CAPACITY || r.hdr.status <= -100; };
+    // only the shared output arena grows: every other capacity status names a per-slot workspace and would come back unchanged
+    auto capacity = [](const HostResult& r) { return r.hdr.status == ST_ERR_ARENA; };
     std::lock_guard<std::mutex> batch_guard(batch_mtx_);
     wait_decoders(-1);
     for (;;) {
@@ -1114,8 +1115,6 @@ int Engine::run_solo_growing(const DDInput& input, std::vector<HostResult>& resu
         if (rc == DDO_OK) rc = collect(results);
         if (rc != DDO_OK) return rc;
         if (!(capacity(results[0]) || capacity(results[1])) || arena_cap_ >= (8ull << 30)) return DDO_OK;
-        auto pools = [](const HostResult& r) { return r.hdr.status == ST_ERR_LPOOL || r.hdr.status == ST_ERR_APOOL; };
-        if (pools(results[0]) || pools(results[1])) return DDO_OK;   // the layer pools, not the arena: growing the arena does not help
         if ((rc = grow_arena(arena_cap_ * 4)) != DDO_OK) return rc;
     }
 }
@@ -1127,12 +1126,50 @@ struct Engine::Waiter {   // one per compile_combined call
     std::mutex m;
     std::condition_variable cv;
     int remaining = 0;    // requests of this call that are not finished
+    int ready = 0;        // requests of this call in state 2: raw result delivered, to be decoded by the caller (who then releases the buffer set)
     bool lead = false;    // "you are the leader now"
+    CompileReq* const* reqs = nullptr;   // the call's requests (the leader decodes its own delivered results before it waits for a buffer set)
+    int count = 0;
 };
 
-void Engine::wait_decoders(int set) {
-    std::unique_lock<std::mutex> lk(dec_mtx_);
-    dec_cv_.wait(lk, [&] { return set < 0 ? decoders_[0] + decoders_[1] == 0 : decoders_[set] == 0; });
+/// A caller holding several requests decodes each one AS SOON AS it is delivered (finish_req wakes it for every state-2 request,
+/// not only for the last): a delivered, undecoded result pins its buffer set (decoders_), and the leader waits for the sets --
+/// a caller that sat on one result while another of its requests ran again would block the launch that re-runs it.
+void Engine::decode_ready(Waiter* me) {
+    std::vector<CompileReq*> todo;
+    {
+        std::lock_guard<std::mutex> lk(me->m);
+        if (me->ready == 0) return;
+        for (int i = 0; i < me->count; ++i)
+            if (me->reqs[i]->state == 2) {
+                me->reqs[i]->state = 4;   // being decoded
+                todo.push_back(me->reqs[i]);
+            }
+        me->ready = 0;
+    }
+    for (CompileReq* r : todo) {
+        decode_checked(r->hdr, r->arena, r->arena_used, r->out[0]);
+        if (pooled_) pooled_fixup(r->in, r->out[0]);
+        r->raw_eng->release_set(r->set);
+    }
+    std::lock_guard<std::mutex> lk(me->m);
+    for (CompileReq* r : todo) r->state = 3;
+}
+
+/// `me` != nullptr: the caller is the LEADER and may itself hold delivered results (the previous leader names its successor first and
+/// hands the results out afterwards): it decodes them while it waits, so that a leader never waits for itself.
+void Engine::wait_decoders(int set, Waiter* me) {
+    auto free_now = [&] { return set < 0 ? decoders_[0] + decoders_[1] == 0 : decoders_[set] == 0; };
+    if (!me) {
+        std::unique_lock<std::mutex> lk(dec_mtx_);
+        dec_cv_.wait(lk, free_now);
+        return;
+    }
+    for (;;) {
+        decode_ready(me);
+        std::unique_lock<std::mutex> lk(dec_mtx_);
+        if (dec_cv_.wait_for(lk, std::chrono::microseconds(200), free_now)) return;
+    }
 }
 void Engine::release_set(int set) {
     std::lock_guard<std::mutex> lk(dec_mtx_);
@@ -1200,7 +1237,7 @@ void Engine::decode_checked(const DDResult& r, const uint8_t* arena, size_t aren
     if (r.status == ST_OK && r.arena_off + r.arena_bytes > arena_used) {
         out.clear();
         out.hdr = r;
-        out.hdr.status = ST_ERR_CAPACITY;
+        out.hdr.status = ST_ERR_ARENA;
         out.valid = true;
         return;
     }
@@ -1211,12 +1248,14 @@ void Engine::finish_req(CompileReq* r, int state) {
     Waiter* w = r->waiter;
     std::lock_guard<std::mutex> lk(w->m);   // (notify under the lock: the waiter lives on the caller's stack)
     r->state = state;
-    if (--w->remaining == 0) w->cv.notify_one();
+    if (state == 2) ++w->ready;
+    if (--w->remaining == 0 || state == 2) w->cv.notify_one();
 }
 
 /// What a finished launch leaves to be handed to the callers: done AFTER the next leader has been named, so that waking a
 /// thousand threads overlaps the next launch instead of delaying it.
 struct Engine::HandOut {
+    Engine* eng = nullptr;                            // the engine whose buffer set `raw` lies in (a small launch of the dense engine runs on its owner)
     RawBatch raw;
     std::vector<std::pair<CompileReq*, int>> done;   // (request, its index in the launch)
     int own = 0;                                      // requests of the leader itself among them
@@ -1235,7 +1274,7 @@ void Engine::hand_out(HandOut& ho, Waiter* me) {
         if (r->waiter == me) {
             decode_checked(h[0], ho.raw.arena, ho.raw.arena_used, r->out[0]);
             if (pooled_) pooled_fixup(r->in, r->out[0]);
-            release_set(ho.raw.set);
+            ho.eng->release_set(ho.raw.set);
             finish_req(r, 3);
             continue;
         }
@@ -1243,6 +1282,7 @@ void Engine::hand_out(HandOut& ho, Waiter* me) {
         r->arena = ho.raw.arena;
         r->arena_used = ho.raw.arena_used;
         r->set = ho.raw.set;
+        r->raw_eng = ho.eng;
         finish_req(r, 2);
     }
     ho.done.clear();
@@ -1271,8 +1311,9 @@ int Engine::combined_launch(std::vector<CompileReq*>& batch, std::vector<Compile
         if (need > (double)arena_cap_) {
             size_t cap = arena_cap_;
             while ((double)cap < need && cap < (8ull << 30)) cap *= 2;
-            wait_decoders(-1);   // both arenas are freed and allocated again at the next launches
-            (void)grow_arena(cap);
+            wait_decoders(-1, me);   // both arenas are freed and allocated again at the next launches
+            const int grc = grow_arena(cap);
+            if (grc != DDO_OK) return fail_all(grc);
         }
     }
     int set;
@@ -1280,7 +1321,7 @@ int Engine::combined_launch(std::vector<CompileReq*>& batch, std::vector<Compile
         std::lock_guard<std::mutex> g(mtx_);
         set = next_set_;
     }
-    wait_decoders(set);   // the launch before the previous one lies in this buffer set: its callers must have decoded
+    wait_decoders(set, me);   // the launch before the previous one lies in this buffer set: its callers must have decoded
     const int64_t tq0 = g_times_on ? now_ns() : 0;
     int rc = launch(din.data(), n, batch[0]->cache, batch[0]->dom);
     if (rc != DDO_OK) return fail_all(rc);
@@ -1299,16 +1340,20 @@ int Engine::combined_launch(std::vector<CompileReq*>& batch, std::vector<Compile
     const int64_t tq2 = g_times_on ? now_ns() : 0;
     cq_last_ms_ = last_kernel_ms_;
     RawBatch& raw = ho.raw;
+    ho.eng = this;
     if ((rc = fetch_raw(raw)) != DDO_OK || raw.count != n) return fail_all(rc != DDO_OK ? rc : DDO_ERR_INTERNAL);
     cq_launches_.fetch_add(1);
     cq_requests_.fetch_add((uint64_t)n);
     cq_kernel_us_.fetch_add((uint64_t)(last_kernel_ms_ * 1000.0));
-    auto overflow = [&](const DDResult& r) {   // the shared output arena (not the per-slot pools of kept layers: those do not grow)
+    // The shared output arena was full: the ONE capacity outcome a second run cures.  Every other capacity status (node slots, dedup
+    // table, work / cut lists, the pools of kept layers, a Pooled DD's pool) is the compile's own and goes to its caller at once.
+    auto overflow = [&](const DDResult& r) {
         if (r.status == ST_OK) return r.arena_off + r.arena_bytes > raw.arena_used;
-        return r.status == ST_ERR_CAPACITY || (r.status <= -100 && r.status != ST_ERR_LPOOL && r.status != ST_ERR_APOOL);
+        return r.status == ST_ERR_ARENA;
     };
     bool foreign_cut = false;
     int n_over = 0, n_ok = 0;
+    std::vector<CompileReq*> over;
     uint64_t bytes = 0;
     for (int i = 0; i < n; ++i) {
         CompileReq* r = batch[(size_t)i];
@@ -1324,7 +1369,7 @@ int Engine::combined_launch(std::vector<CompileReq*>& batch, std::vector<Compile
         }
         if (overflow(h0) || (fused && h1.status != ST_NOT_RUN && overflow(h1))) {
             ++n_over;
-            again.push_back(r);
+            over.push_back(r);
             continue;
         }
         ++n_ok;
@@ -1342,19 +1387,29 @@ int Engine::combined_launch(std::vector<CompileReq*>& batch, std::vector<Compile
         // left nothing in the cache: misp_dd_core.hpp, thresholds follow the reservation.)
         if (arena_cap_ < (8ull << 30)) {
             hand_out(ho, me);
-            wait_decoders(-1);   // both arenas are freed and allocated again at the next launches
-            (void)grow_arena(std::min<size_t>(arena_cap_ * (n == 1 ? 4 : 2), 8ull << 30));
+            wait_decoders(-1, me);   // both arenas are freed and allocated again at the next launches
+            const int grc = grow_arena(std::min<size_t>(arena_cap_ * (n == 1 ? 4 : 2), 8ull << 30));
+            if (grc != DDO_OK) {     // no larger arena to be had: the compiles that needed it fail (running them again would loop)
+                for (CompileReq* r : over) {
+                    r->rc = grc;
+                    finish_req(r, 3);
+                }
+                over.clear();
+            }
         } else if (n > 1) {
             cq_batch_cap_ = std::max(1, std::min(cq_batch_cap_, std::max(n_ok, n / 2)));
         } else {   // one compile alone does not fit 8 GB: its caller gets the capacity error
-            CompileReq* r = again.back();
-            again.pop_back();
+            CompileReq* r = over.back();
+            over.pop_back();
             ho.done.emplace_back(r, 0);
             ho.own += r->waiter == me;
             std::lock_guard<std::mutex> lk(dec_mtx_);
             decoders_[raw.set] += 1;
         }
+    } else if (cq_batch_cap_ < (1 << 20)) {
+        cq_batch_cap_ = std::min(1 << 20, cq_batch_cap_ * 2);   // clean launches win the room back that overflowing ones gave up
     }
+    again.insert(again.end(), over.begin(), over.end());
     if (g_times_on) {
         const int64_t tq3 = now_ns();
         g_cq_ns[1] += (uint64_t)(tq1 - tq0), g_cq_ns[2] += (uint64_t)(tq2 - tq1), g_cq_ns[3] += (uint64_t)(tq3 - tq2);
@@ -1402,7 +1457,22 @@ void Engine::lead(Waiter* me) {
             }
         }
         HandOut ho;
-        combined_launch(batch, again, me, ho);
+        // A launch of fewer decision diagrams than the full-width engine has node slots (one per CU) runs THERE: every DD gets a
+        // 1 024-thread workgroup and a CU of its own instead of a 512-thread one on a half-empty CU (the reference's default
+        // nb_threads is the host's core count: 64 callers are 64 decision diagrams per launch; micro grid, n = 400 / W = 10 000,
+        // batches of 16: 1.2e9 nodes/s on the full-width kernel, 0.8-0.9e9 on the dense one).  Nothing is handed up from there.
+        static const bool route_small = [] { const char* e = std::getenv("DDO_HIP_ROUTE_SMALL"); return !(e && std::atoi(e) == 0); }();
+        Engine* target = (route_small && dense_ && owner_ && !pooled_ && (int)batch.size() <= owner_->nslots_) ? owner_ : this;
+        if (target != this) {
+            uint64_t l0 = target->cq_launches_.load(), r0 = target->cq_requests_.load(), k0 = target->cq_kernel_us_.load();
+            target->combined_launch(batch, again, me, ho);
+            cq_launches_.fetch_add(target->cq_launches_.load() - l0);   // (ddo_mdd_combine_stats reads the engine the mdd is bound to)
+            cq_requests_.fetch_add(target->cq_requests_.load() - r0);
+            cq_kernel_us_.fetch_add(target->cq_kernel_us_.load() - k0);
+            cq_last_ms_ = target->cq_last_ms_;
+        } else {
+            combined_launch(batch, again, me, ho);
+        }
         bool handed_over = false;
         {
             std::unique_lock<std::mutex> lk(cq_mtx_);
@@ -1434,6 +1504,8 @@ int Engine::compile_combined(CompileReq* const* reqs, int count) {
     if (count <= 0) return DDO_OK;
     Waiter me;
     me.remaining = count;
+    me.reqs = reqs;
+    me.count = count;
     bool lead_now = false;
     {
         std::lock_guard<std::mutex> lk(cq_mtx_);
@@ -1455,35 +1527,21 @@ int Engine::compile_combined(CompileReq* const* reqs, int count) {
             lead(&me);
             lead_now = false;
         }
-        std::unique_lock<std::mutex> lk(me.m);
-        me.cv.wait(lk, [&] { return me.lead || me.remaining == 0; });
-        if (me.lead) {
+        bool all_done;
+        {
+            std::unique_lock<std::mutex> lk(me.m);
+            me.cv.wait(lk, [&] { return me.lead || me.ready > 0 || me.remaining == 0; });
+            lead_now = me.lead;
             me.lead = false;
-            lead_now = true;
-            lk.unlock();
-            // (requests of this call that an earlier launch finished are decoded before this caller leads: see hand_out)
-            for (int i = 0; i < count; ++i)
-                if (reqs[i]->state == 2) {
-                    decode_checked(reqs[i]->hdr, reqs[i]->arena, reqs[i]->arena_used, reqs[i]->out[0]);
-                    if (pooled_) pooled_fixup(reqs[i]->in, reqs[i]->out[0]);
-                    release_set(reqs[i]->set);
-                    reqs[i]->state = 3;
-                }
-            continue;
+            all_done = me.remaining == 0;
         }
-        break;
+        decode_ready(&me);   // every delivered result is decoded at once (and its buffer set released), also before this caller leads
+        if (lead_now) continue;
+        if (all_done) break;
     }
     int worst = DDO_OK;
-    for (int i = 0; i < count; ++i) {
-        CompileReq* r = reqs[i];
-        if (r->state == 2) {
-            decode_checked(r->hdr, r->arena, r->arena_used, r->out[0]);
-            if (pooled_) pooled_fixup(r->in, r->out[0]);
-            release_set(r->set);
-        } else if (r->rc != DDO_OK) {
-            worst = r->rc;
-        }
-    }
+    for (int i = 0; i < count; ++i)
+        if (reqs[i]->rc != DDO_OK) worst = reqs[i]->rc;
     return worst;
 }
 
@@ -1767,7 +1825,7 @@ int Engine::fetch(std::vector<HostResult>& results) {
             if (r.status == ST_OK && r.arena_off + r.arena_bytes > used) {
                 out.clear();
                 out.hdr = r;
-                out.hdr.status = ST_ERR_CAPACITY;
+                out.hdr.status = ST_ERR_ARENA;
                 out.valid = true;
                 continue;
             }
@@ -1907,6 +1965,11 @@ struct ddo_mdd {
     std::vector<ddo_decision> path_to_root;
     size_t depth = 0;
     bool drained = false;
+    // ddo_mdd_drain_cutset_rows: the rows handed to the caller (valid until the next compile / drain)
+    std::vector<uint64_t> rows_state;
+    std::vector<int64_t> rows_value, rows_ub;
+    std::vector<size_t> rows_depth, rows_plen;
+    std::vector<ddo_decision> rows_path;
 };
 
 extern "C" {
@@ -2452,6 +2515,66 @@ int ddo_mdd_best_exact_solution(const ddo_mdd* mdd, ddo_decision* buf, size_t* l
     if (!mdd || !mdd->res.valid || !mdd->res.hdr.has_best_exact) return 0;
     return emit_path(mdd, mdd->res.hdr.exact_same_as_best ? mdd->res.best_path : mdd->res.exact_path, buf, len);
 }
+size_t ddo_mdd_cutset_count(const ddo_mdd* mdd) {
+    if (!mdd || !mdd->res.valid || mdd->drained) return 0;
+    return (size_t)mdd->res.n_cutset;
+}
+
+int ddo_mdd_drain_cutset_rows(ddo_mdd* mdd, int64_t ub_above, ddo_cutset_rows* rows) {
+    if (!mdd || !rows) return DDO_ERR_INVALID;
+    *rows = ddo_cutset_rows{};
+    const int ws = mdd->model->ws;
+    rows->state_words = (size_t)ws;
+    if (!mdd->res.valid || mdd->drained) return DDO_OK;
+    mdd->drained = true;
+    const HostResult& r = mdd->res;
+    const bool bits = r.cs_pw > 0;
+    size_t keep = 0, stride = 0;
+    for (int i = 0; i < r.n_cutset; ++i) {
+        if ((int64_t)r.cs_ub[(size_t)i] <= ub_above) continue;
+        ++keep;
+        const int ldepth = r.cs_depth.empty() ? r.cs_path_len : r.cs_depth[(size_t)i];
+        stride = std::max(stride, (size_t)(r.cs_plen.empty() ? ldepth : r.cs_plen[(size_t)i]));
+    }
+    mdd->rows_state.resize(keep * (size_t)ws);
+    mdd->rows_value.resize(keep);
+    mdd->rows_ub.resize(keep);
+    mdd->rows_depth.resize(keep);
+    mdd->rows_plen.resize(keep);
+    mdd->rows_path.resize(keep * stride);
+    size_t o = 0;
+    for (int i = 0; i < r.n_cutset; ++i) {
+        if ((int64_t)r.cs_ub[(size_t)i] <= ub_above) continue;
+        const int ldepth = r.cs_depth.empty() ? r.cs_path_len : r.cs_depth[(size_t)i];   // frontier cut-set: nodes of several layers
+        const int plen = r.cs_plen.empty() ? ldepth : r.cs_plen[(size_t)i];             // Pooled: a decision per EXPANDED ancestor
+        std::memcpy(mdd->rows_state.data() + o * (size_t)ws, r.cs_state.data() + (size_t)i * (size_t)ws, (size_t)ws * 8);
+        mdd->rows_value[o] = r.cs_value[(size_t)i];
+        mdd->rows_ub[o] = r.cs_ub[(size_t)i];
+        mdd->rows_depth[o] = mdd->depth + (size_t)ldepth;
+        mdd->rows_plen[o] = (size_t)plen;
+        ddo_decision* out = mdd->rows_path.data() + o * stride;
+        if (bits) {   // IN_PATH_BITS: node first, towards the DD's root (clean.rs:329-343)
+            const uint64_t* pb = r.cs_pbits.data() + (size_t)i * (size_t)r.cs_pw;
+            for (int k = 0; k < plen; ++k) {
+                const int tr = plen - 1 - k;
+                out[k] = mdd->model->path_decision((r.cs_lvar[(size_t)tr] << 1) | (uint32_t)((pb[tr >> 6] >> (tr & 63)) & 1ULL));
+            }
+        } else {
+            for (int k = 0; k < plen; ++k) out[k] = mdd->model->path_decision(r.cs_path[(size_t)i * (size_t)r.cs_path_len + (size_t)k]);
+        }
+        ++o;
+    }
+    rows->count = keep;
+    rows->path_stride = stride;
+    rows->states = mdd->rows_state.data();
+    rows->values = mdd->rows_value.data();
+    rows->ubs = mdd->rows_ub.data();
+    rows->depths = mdd->rows_depth.data();
+    rows->path_lens = mdd->rows_plen.data();
+    rows->paths = mdd->rows_path.data();
+    return DDO_OK;
+}
+
 int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user) {
     if (!mdd || !cb) return DDO_ERR_INVALID;
     if (!mdd->res.valid || mdd->drained) return DDO_OK;

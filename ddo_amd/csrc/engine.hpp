@@ -209,6 +209,7 @@ class Engine {
         const uint8_t* arena = nullptr;
         size_t arena_used = 0;
         int set = -1;
+        Engine* raw_eng = nullptr;            // the engine that buffer set belongs to (release_set)
     };
     /// Compiles `count` requests through the combining layer; returns when all of them are finished (their `out` decoded or `rc` set).
     int compile_combined(CompileReq* const* reqs, int count);
@@ -380,7 +381,8 @@ class Engine {
     std::mutex dec_mtx_;
     std::condition_variable dec_cv_;
     int decoders_[2] = {0, 0};             // callers still reading results / arena of buffer set k
-    void wait_decoders(int set);           // -1: both sets
+    void wait_decoders(int set, Waiter* me = nullptr);   // -1: both sets; me: the waiting leader decodes what it is handed meanwhile
+    void decode_ready(Waiter* me);
     void release_set(int set);
     struct HandOut;
     double cq_bytes_per_req_ = 0;          // output-arena bytes per compile of the recent launches (sizes the arena ahead of a launch)

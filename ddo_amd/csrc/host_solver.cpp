@@ -1454,8 +1454,10 @@ struct ddo_solver {
                     if (st0 == ST_ERR_LPOOL || st0 == ST_ERR_APOOL)
                         set_error("device compile failed: a decision diagram outgrew the per-slot pools of kept layers / arcs "
                                   "(DDO_HIP_LPOOL_M, DDO_HIP_APOOL_M: pool sizes in millions of records)");
-                    else
+                    else if (st0 == ST_ERR_ARENA || rc2 != DDO_OK)
                         set_error("device compile failed: output arena too small for one sub-problem");
+                    else
+                        set_error("device compile failed: a decision diagram outgrew its workspace (node slots / tables; site " + std::to_string(st0) + ")");
                     err = DDO_ERR_CAPACITY;
                     break;
                 }

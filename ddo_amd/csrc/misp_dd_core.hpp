@@ -2386,7 +2386,7 @@ DDO_DEV void run_dd(DDCtx<WS>& c, const DDInput& in, int comp_type, int64_t best
     if (tid == 0) {
         unsigned long long a = total ? GLB_ADD_U64(c.arena_head, (unsigned long long)total) : 0ULL;
         sh->arena_off = a;
-        if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY;
+        if (a + total > c.arena_cap) sh->status = ST_ERR_ARENA;
     }
     PAR_END
     const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;

@@ -1977,7 +1977,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         if (tid == 0) {
             unsigned long long a = total ? GLB_ADD_U64(c.arena_head, (unsigned long long)total) : 0ULL;
             sh->arena_off = a;
-            if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY - 100 * 7;
+            if (a + total > c.arena_cap) sh->status = ST_ERR_ARENA;
             if (cut_over) sh->status = ST_ERR_CAPACITY - 100 * 12;   // the cut list outgrew the room behind the event records
         }
         PAR_END
@@ -2086,7 +2086,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         if (tid == 0) {
             DDResult r;
             r.status = sh->status;
-            if (c.tier && (sh->status == ST_ERR_CAPACITY || (sh->status <= ST_ERR_CAPACITY - 100 && sh->status != ST_ERR_CAPACITY - 700 &&
+            if (c.tier && (sh->status == ST_ERR_CAPACITY || (sh->status <= ST_ERR_CAPACITY - 100 && sh->status != ST_ERR_ARENA &&
                                                              sh->status != ST_ERR_CAPACITY - 800)))
                 r.status = ST_RETRY;
             r.comp_type = comp_type;
@@ -2263,7 +2263,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     if (tid == 0) {
         unsigned long long a = total ? GLB_ADD_U64(c.arena_head, (unsigned long long)total) : 0ULL;
         sh->arena_off = a;
-        if (a + total > c.arena_cap) sh->status = ST_ERR_CAPACITY - 100 * 7;
+        if (a + total > c.arena_cap) sh->status = ST_ERR_ARENA;
         sh->ev_pos = 0;   // reused: pool offset of this DD's cut-set block
         if (pool_bytes) {
             unsigned long long pa = GLB_ADD_U64(c.pool_head, (unsigned long long)pool_bytes);
@@ -2429,7 +2429,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         r.status = sh->status;
         // a capacity tier that ran out of node slots / work-list / event space hands the DD to the next tier (the
         // shared output arena and node pool are not the tier's: those stay errors)
-        if (c.tier && (sh->status == ST_ERR_CAPACITY || (sh->status <= ST_ERR_CAPACITY - 100 && sh->status != ST_ERR_CAPACITY - 700 &&
+        if (c.tier && (sh->status == ST_ERR_CAPACITY || (sh->status <= ST_ERR_CAPACITY - 100 && sh->status != ST_ERR_ARENA &&
                                                          sh->status != ST_ERR_CAPACITY - 800)))
             r.status = ST_RETRY;
         r.comp_type = comp_type;

@@ -18,6 +18,8 @@ use std::sync::{Arc, RwLock};
 #[repr(C)] pub struct DdoCompileInput { comp_type: c_int, max_width: usize, best_lb: i64, residual: DdoSubProblem,
                                         cutoff: *const c_int, cache: *mut c_void, dominance: *mut c_void }
 #[repr(C)] #[derive(Default)] pub struct DdoCompletion { is_exact: c_int, has_best_value: c_int, best_value: i64 }
+#[repr(C)] pub struct DdoCutsetRows { count: usize, state_words: usize, path_stride: usize, states: *const u64, values: *const i64,
+                                     ubs: *const i64, depths: *const usize, path_lens: *const usize, paths: *const DdoDecision }
 pub const DDO_LAST_EXACT_LAYER: c_int = 1;
 pub const DDO_FRONTIER: c_int = 2;
 pub const DDO_MDD_CACHING: c_int = 0x10;
@@ -44,7 +46,7 @@ extern "C" {
     fn ddo_mdd_best_exact_value(mdd: *const c_void, v: *mut i64) -> c_int;
     fn ddo_mdd_best_solution(mdd: *const c_void, buf: *mut DdoDecision, len: *mut usize) -> c_int;
     fn ddo_mdd_best_exact_solution(mdd: *const c_void, buf: *mut DdoDecision, len: *mut usize) -> c_int;
-    fn ddo_mdd_drain_cutset(mdd: *mut c_void, cb: extern "C" fn(*const DdoSubProblem, *mut c_void), user: *mut c_void) -> c_int;
+    fn ddo_mdd_drain_cutset_rows(mdd: *mut c_void, ub_above: i64, rows: *mut DdoCutsetRows) -> c_int;
 }
 
 // ---- registry: what `D::default()` (parallel.rs:580) cannot be told through its signature ------------------------
@@ -119,7 +121,10 @@ fn decisions_of(buf: &[DdoDecision]) -> Vec<Decision> {
 }
 
 // ---- `D` of ParallelSolver<'a, BitSet, HipMdd, C> ------------------------------------------------------------------
-pub struct HipMdd { h: *mut c_void, r: Arc<Registry> }
+// `ready`: the cut-set of the latest relaxed compile, ALREADY turned into SubProblems -- by compile(), in the worker's own thread.
+// The reference drains a cut-set inside the solver's critical section (parallel.rs:456-469 holds the mutex across
+// `mdd.drain_cutset(..)`): whatever drain_cutset does per node is serialised over all worker threads, so it only moves these out.
+pub struct HipMdd { h: *mut c_void, r: Arc<Registry>, ready: Vec<SubProblem<BitSet>> }
 unsafe impl Send for HipMdd {}
 
 impl Default for HipMdd {            // parallel.rs:580  `let mut mdd = D::default();` -- one per worker thread
@@ -127,7 +132,7 @@ impl Default for HipMdd {            // parallel.rs:580  `let mut mdd = D::defau
         let r = registry();
         let h = unsafe { ddo_mdd_create(r.model as *const c_void, r.device, r.cutset_type, r.max_width) };
         assert!(!h.is_null(), "ddo_mdd_create: {:?}", unsafe { std::ffi::CStr::from_ptr(ddo_last_error()) });
-        HipMdd { h, r }
+        HipMdd { h, r, ready: vec![] }
     }
 }
 impl Drop for HipMdd { fn drop(&mut self) { unsafe { ddo_mdd_destroy(self.h) } } }
@@ -144,14 +149,23 @@ impl HipMdd {
     }
 }
 
-/// what the C callback needs to rebuild `SubProblem<BitSet>` and hand it to the user's closure
-struct DrainCtx<'f> { func: &'f mut dyn FnMut(SubProblem<BitSet>), nb_vars: usize }
-extern "C" fn drain_trampoline(sp: *const DdoSubProblem, user: *mut c_void) {
-    let (sp, ctx) = unsafe { (&*sp, &mut *(user as *mut DrainCtx<'_>)) };
-    let words = unsafe { std::slice::from_raw_parts(sp.state, sp.state_words) };
-    let path = if sp.path_len == 0 { vec![] } else { decisions_of(unsafe { std::slice::from_raw_parts(sp.path, sp.path_len) }) };
-    (ctx.func)(SubProblem { state: Arc::new(bitset_of(words, ctx.nb_vars)), value: sp.value as isize, path,
-                            ub: sp.ub as isize, depth: sp.depth });
+/// One FFI call for the whole cut-set (ddo_mdd_drain_cutset_rows) instead of a callback per node: the rows become SubProblems here,
+/// outside the solver's lock.  Nodes whose bound does not exceed `best_lb` stay on the other side -- both solvers' closures drop
+/// them (`if cutset_node.ub > best_lb`, parallel.rs:461-463, sequential.rs:372-376; the bound only rises until the drain).
+fn fetch_cutset(h: *mut c_void, best_lb: isize, head: &[Decision], nb_vars: usize) -> Vec<SubProblem<BitSet>> {
+    let mut rows = DdoCutsetRows { count: 0, state_words: 0, path_stride: 0, states: std::ptr::null(), values: std::ptr::null(),
+                                   ubs: std::ptr::null(), depths: std::ptr::null(), path_lens: std::ptr::null(), paths: std::ptr::null() };
+    let rc = unsafe { ddo_mdd_drain_cutset_rows(h, best_lb as i64, &mut rows) };
+    assert!(rc == 0, "ddo_mdd_drain_cutset_rows failed: {rc}");
+    (0..rows.count).map(|i| unsafe {
+        let words = std::slice::from_raw_parts(rows.states.add(i * rows.state_words), rows.state_words);
+        let part = std::slice::from_raw_parts(rows.paths.add(i * rows.path_stride), *rows.path_lens.add(i));
+        let mut path = Vec::with_capacity(head.len() + part.len());
+        path.extend_from_slice(head);                       // the residual's own path first (clean.rs:329-343) ...
+        path.extend(part.iter().map(|d| Decision { variable: Variable(d.variable as usize), value: d.value as isize }));   // ... then the DD's part
+        SubProblem { state: Arc::new(bitset_of(words, nb_vars)), value: *rows.values.add(i) as isize, path,
+                     ub: *rows.ubs.add(i) as isize, depth: *rows.depths.add(i) }
+    }).collect()
 }
 
 impl DecisionDiagram for HipMdd {
@@ -173,9 +187,15 @@ impl DecisionDiagram for HipMdd {
             cache: r.cache as *mut c_void,        // null == EmptyCache; else the table HipCache wraps (same thresholds on both sides)
             dominance: r.dominance as *mut c_void };   // null == EmptyDominanceChecker
         let mut out = DdoCompletion::default();
+        self.ready.clear();
         match unsafe { ddo_mdd_compile(self.h, &ci, &mut out) } {
-            0 => Ok(Completion { is_exact: out.is_exact != 0,
-                                 best_value: if out.has_best_value != 0 { Some(out.best_value as isize) } else { None } }),
+            0 => {
+                if matches!(input.comp_type, CompilationType::Relaxed) && out.is_exact == 0 {
+                    self.ready = fetch_cutset(self.h, input.best_lb, &input.residual.path, r.nb_vars);
+                }
+                Ok(Completion { is_exact: out.is_exact != 0,
+                                best_value: if out.has_best_value != 0 { Some(out.best_value as isize) } else { None } })
+            }
             2 => Err(Reason::CutoffOccurred),                            // DDO_CUTOFF
             // (3 == DDO_HANDED_UP is answered only by mdds bound to a capacity tier with DDO_MDD_ENGINE_*: the shim creates none)
             e => panic!("ddo_hip error {e}: {:?}", unsafe { std::ffi::CStr::from_ptr(ddo_last_error()) }),   // the reference aborts on internal errors too
@@ -187,9 +207,7 @@ impl DecisionDiagram for HipMdd {
     fn best_solution(&self) -> Option<Solution> { self.solution(ddo_mdd_best_solution) }
     fn best_exact_solution(&self) -> Option<Solution> { self.solution(ddo_mdd_best_exact_solution) }
     fn drain_cutset<F: FnMut(SubProblem<BitSet>)>(&mut self, mut func: F) {      // mdd.rs:107-113: at most once per relaxed compile
-        let mut ctx = DrainCtx { func: &mut func, nb_vars: self.r.nb_vars };
-        let rc = unsafe { ddo_mdd_drain_cutset(self.h, drain_trampoline, &mut ctx as *mut DrainCtx<'_> as *mut c_void) };
-        assert!(rc == 0, "ddo_mdd_drain_cutset failed: {rc}");
+        for sp in self.ready.drain(..) { func(sp) }                                // (called under the solver's lock: nothing is built here)
     }
 }
 

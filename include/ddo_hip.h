@@ -247,6 +247,30 @@ int ddo_mdd_best_exact_solution(const ddo_mdd* mdd, ddo_decision* buf, size_t* l
  *  ddo_subproblem are valid during the callback only.  May be called once per compile. */
 typedef void (*ddo_cutset_cb)(const ddo_subproblem* node, void* user);
 int ddo_mdd_drain_cutset(ddo_mdd* mdd, ddo_cutset_cb cb, void* user);
+/** Bulk form of drain_cutset for hosts that keep their fringe behind ONE lock.  The reference drains a cut-set INSIDE the solver's
+ *  critical section (parallel.rs:456-469: `enqueue_cutset` holds the mutex across `mdd.drain_cutset(..)`), so whatever a shim does
+ *  per node inside that call -- building the state, the `Arc`, the `Vec<Decision>` -- is serialised over all worker threads.  This
+ *  call hands over the whole cut-set as flat rows; the shim turns them into `SubProblem`s at the END of its `compile()` -- in the
+ *  worker's own thread, before the solver takes its lock -- and its `drain_cutset` only moves them into the closure.  Rows whose
+ *  `ub <= ub_above` are left out (pass INT64_MIN for all of them): with `ub_above = input.best_lb` those are exactly the nodes both
+ *  reference solvers drop in their closures (`if cutset_node.ub > best_lb`, parallel.rs:461-463, sequential.rs:372-376; the bound
+ *  only rises between the compile and the drain).  Row order = the order of ddo_mdd_drain_cutset's callbacks.  The arrays belong
+ *  to the mdd and stay valid until its next compile / drain / destroy.  Like ddo_mdd_drain_cutset: once per compile. */
+typedef struct ddo_cutset_rows {
+    size_t count;               /* rows */
+    size_t state_words;
+    size_t path_stride;         /* decisions per row of `paths` */
+    const uint64_t* states;     /* [count][state_words] */
+    const int64_t* values;      /* [count] */
+    const int64_t* ubs;         /* [count] */
+    const size_t* depths;       /* [count] depth of the node = residual.depth + its layer in the DD */
+    const size_t* path_lens;    /* [count] decisions of row i: paths[i * path_stride .. i * path_stride + path_lens[i]) */
+    const ddo_decision* paths;  /* the DD's part of the path only, node first (clean.rs:329-343); the residual's own path
+                                   (ddo_compile_input.residual.path, which the caller holds) goes in FRONT of it */
+} ddo_cutset_rows;
+int ddo_mdd_drain_cutset_rows(ddo_mdd* mdd, int64_t ub_above, ddo_cutset_rows* rows);
+/** Nodes in the cut-set of the latest compile that have not been drained (0 after a drain, for an exact DD, or without a compile). */
+size_t ddo_mdd_cutset_count(const ddo_mdd* mdd);
 /** Counters of the latest compile on this object. */
 int ddo_mdd_last_counters(const ddo_mdd* mdd, ddo_counters* out);
 /** Measurement support (no counterpart in the reference).  The reference runs one DecisionDiagram per worker thread and calls

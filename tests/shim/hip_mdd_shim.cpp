@@ -53,6 +53,10 @@ BitSet from_words(const uint64_t* w, size_t words, size_t nb_vars) {
 /// `impl DecisionDiagram for HipMdd` (hip_mdd/src/lib.rs), in C++
 class HipMdd {
     ddo_mdd* h = nullptr;
+    /// The cut-set of the latest relaxed compile, ALREADY turned into SubProblems -- by compile(), in the worker's own thread.  The
+    /// reference drains a cut-set inside the solver's critical section (parallel.rs:456-469): what drain_cutset does per node is
+    /// serialised over all worker threads, so it only moves these into the closure.
+    std::vector<SubProblem<BitSet>> ready;
 
   public:
     MddCounters counters, last_counters;
@@ -99,6 +103,26 @@ class HipMdd {
         Completion c;
         c.is_exact = out.is_exact != 0;
         if (out.has_best_value) c.best_value = (isize)out.best_value;
+        ready.clear();
+        if (in.comp_type == CompilationType::Relaxed && !c.is_exact) {
+            // One FFI call for the whole cut-set (ddo_mdd_drain_cutset_rows) instead of a callback per node; nodes whose bound does not
+            // exceed input.best_lb are left on the other side: both solvers' closures drop them (parallel.rs:461-463, sequential.rs:372-376).
+            ddo_cutset_rows rows{};
+            if (ddo_mdd_drain_cutset_rows(h, (int64_t)in.best_lb, &rows) != DDO_OK) throw std::runtime_error(std::string("ddo_mdd_drain_cutset_rows: ") + ddo_last_error());
+            ready.resize(rows.count);
+            const auto& head = in.residual->path;
+            for (size_t i = 0; i < rows.count; ++i) {
+                SubProblem<BitSet>& n = ready[i];
+                n.state = std::make_shared<const BitSet>(from_words(rows.states + i * rows.state_words, rows.state_words, g_reg.nb_vars));
+                n.value = (isize)rows.values[i];
+                n.ub = (isize)rows.ubs[i];
+                n.depth = rows.depths[i];
+                n.path.reserve(head.size() + rows.path_lens[i]);
+                n.path.assign(head.begin(), head.end());
+                const ddo_decision* p = rows.paths + i * rows.path_stride;
+                for (size_t k = 0; k < rows.path_lens[i]; ++k) n.path.push_back(Decision{(size_t)p[k].variable, (isize)p[k].value});
+            }
+        }
         return c;
     }
     bool is_exact() const { return ddo_mdd_is_exact(h) != 0; }
@@ -121,23 +145,9 @@ class HipMdd {
     std::optional<Solution> best_solution() const { return solution_of(ddo_mdd_best_solution); }
     std::optional<Solution> best_exact_solution() const { return solution_of(ddo_mdd_best_exact_solution); }
     template <class F>
-    void drain_cutset(F&& func) {
-        struct Ctx {
-            F* f;
-        } ctx{&func};
-        ddo_mdd_drain_cutset(
-            h,
-            [](const ddo_subproblem* sp, void* user) {
-                SubProblem<BitSet> n;
-                n.state = std::make_shared<const BitSet>(from_words(sp->state, sp->state_words, g_reg.nb_vars));
-                n.value = (isize)sp->value;
-                n.ub = (isize)sp->ub;
-                n.depth = sp->depth;
-                n.path.resize(sp->path_len);
-                for (size_t i = 0; i < sp->path_len; ++i) n.path[i] = Decision{(size_t)sp->path[i].variable, (isize)sp->path[i].value};
-                (*((Ctx*)user)->f)(std::move(n));
-            },
-            &ctx);
+    void drain_cutset(F&& func) {   // mdd.rs:107-113 -- called under the solver's lock: nothing is built here
+        for (SubProblem<BitSet>& n : ready) func(std::move(n));
+        ready.clear();
     }
 };
 

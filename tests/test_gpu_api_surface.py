@@ -271,6 +271,68 @@ def test_compile_batch_survives_a_full_output_arena(brock, oracle, monkeypatch):
         assert d is None, f"compile #{j}: {d}"
 
 
+def test_two_callers_with_several_requests_each_share_overflowing_launches(brock, oracle, monkeypatch):
+    """a caller of ddo_mdd_compile_batch holds SEVERAL requests of the combining layer.  Under a 256 KB output arena
+    some of them finish while others find the arena full and run again: a caller must decode (and release the buffer set of) every
+    result the moment it is delivered, or the leader that re-runs its other requests waits for it for ever.  Two threads, 24
+    relaxed compiles each with cut-sets of some 30 KB: several rounds of overflow and growth; every result equals the oracle's."""
+    import threading
+    from tests.parity_util import canon_from_mdd, diff
+
+    monkeypatch.setenv("DDO_HIP_ARENA_KB", "256")
+    inst = oracle.misp(data_path("misp", "brock200_2.clq"))
+    W = 1503   # (a width no other test uses: its engine is created under the small arena)
+    _, recs = inst.trace_solve(W, 3)
+    relaxed = [r for r in recs if r["comp_type"] == CompilationType.Relaxed and len(r["cutset"]) > 200]
+    assert relaxed
+    B = 24
+    errors = []
+
+    def caller(t):
+        try:
+            mdds = [ddo_amd.Mdd(brock, W) for _ in range(B)]
+            for rep in range(3):
+                rs = [relaxed[(t + j + rep) % len(relaxed)] for j in range(B)]
+                subs = [ddo_amd.SubProblem(state=np.array(r["state"], dtype=np.uint64), value=r["value"], path=[], depth=r["depth"]) for r in rs]
+                comps = ddo_amd.Mdd.compile_batch(mdds, [r["comp_type"] for r in rs], [r["width"] for r in rs], subs, [r["best_lb"] for r in rs])
+                for j in range(B):
+                    d = diff(rs[j], canon_from_mdd(mdds[j], comps[j], brock.ws))
+                    if d is not None:
+                        errors.append(f"caller {t} rep {rep} compile {j}: {d}")
+                        return
+        except Exception as e:
+            errors.append(f"caller {t}: {e!r}")
+
+    ths = [threading.Thread(target=caller, args=(t,), daemon=True) for t in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=240)
+    assert not any(th.is_alive() for th in ths), "callers of compile_batch are stuck in the combining layer"
+    assert not errors, errors[:3]
+
+
+def test_a_workspace_capacity_error_is_not_mistaken_for_a_full_arena(monkeypatch):
+    """only the shared output arena is worth a second run.  A Pooled decision diagram that outgrows its pool is a normal,
+    documented outcome (status <= -100, not the arena): it must come back to its caller at once as a capacity error -- not be run
+    again and again while the pinned arenas grow to 8 GB -- and the compile next to it in the same launch must be unharmed."""
+    import time
+    monkeypatch.setenv("DDO_HIP_POOLED_NODES", "600")
+    model = ddo_amd.Misp.read_instance(data_path("misp", "brock200_2.clq"))
+    W = 77   # (a width no other test uses: the engine of this (model, width) is created under the small pool)
+    mdds = [ddo_amd.Pooled(model, W), ddo_amd.Pooled(model, W)]
+    root = model.root()
+    tiny = ddo_amd.SubProblem(state=np.array([0x3FF] + [0] * (model.ws - 1), dtype=np.uint64), value=0, path=[], depth=0)
+    t0 = time.time()
+    with pytest.raises(ddo_amd.DdoError) as ei:
+        ddo_amd.Mdd.compile_batch(mdds, [CompilationType.Relaxed] * 2, [W] * 2, [root, tiny], [-(1 << 40)] * 2)
+    assert time.time() - t0 < 20, "a per-slot capacity error was re-run as if the arena had overflowed"
+    assert "capacity" in str(ei.value).lower(), str(ei.value)
+    # the engine is still at full batch size and healthy: a compile that fits runs
+    comp = mdds[1].compile(CompilationType.Relaxed, W, tiny, -(1 << 40))
+    assert comp.is_exact
+
+
 _LPT_SCRIPT = r"""
 import json, sys
 import ddo_amd

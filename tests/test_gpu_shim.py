@@ -60,3 +60,39 @@ def test_the_reference_sequential_solver_over_pooled_hipmdd(oracle, name, width)
     assert got["is_exact"] and got["best_value"] == ref["best_value"]
     for k in ("explored", "compiles", "nodes_expanded", "arcs", "layers"):
         assert got[k] == ref[k], (name, width, k, got[k], ref[k])
+
+
+@pytest.mark.parametrize("name,width,pooled", [("brock200_2", 300, False), ("keller4", 40, False), ("keller4", 40, True)])
+def test_the_bulk_drain_hands_over_what_the_callbacks_deliver(name, width, pooled):
+    """ddo_mdd_drain_cutset_rows (the shims' one call per relaxed compile, made OUTSIDE the solver's lock) against ddo_mdd_drain_cutset:
+    same nodes in the same order -- state, value, ub, depth, and the path once the residual's own path is put in front; `ub_above`
+    leaves out exactly the nodes whose bound does not exceed it; one drain per compile, whichever of the two."""
+    import numpy as np
+    from ddo_amd import CompilationType, Decision, SubProblem
+    model = ddo_amd.Misp.read_instance(data_path("misp", name + ".clq"))
+    make = (lambda: ddo_amd.Pooled(model, width)) if pooled else (lambda: ddo_amd.Mdd(model, width))
+    a, b, c = make(), make(), make()
+    root = model.root()
+    v = model.n - 1
+    head = [Decision(v, 0)]   # the residual: the root after decision "vertex n - 1 stays out"
+    words = [int(w) for w in root.state]
+    words[v >> 6] &= ~(1 << (v & 63))
+    state = np.array(words, dtype=np.uint64)
+    sub = SubProblem(state=state, value=0, path=head, ub=1 << 40, depth=len(head))
+    for m in (a, b, c):
+        comp = m.compile(CompilationType.Relaxed, width, sub, -(1 << 40))
+        assert not comp.is_exact
+    n = a.cutset_count()
+    assert n > 10 and b.cutset_count() == n
+    ref = a.drain_cutset()
+    assert len(ref) == n and a.cutset_count() == 0 and a.drain_cutset() == []
+    rows = b.drain_cutset_rows(residual_path=head)
+    assert b.cutset_count() == 0 and b.drain_cutset() == []
+
+    def key(s):
+        return (tuple(int(w) for w in s.state), int(s.value), int(s.ub), int(s.depth), tuple((d.variable, d.value) for d in s.path))
+    assert [key(s) for s in rows] == [key(s) for s in ref]
+    ubs = sorted(int(s.ub) for s in ref)
+    cut = ubs[len(ubs) // 2]
+    some = c.drain_cutset_rows(ub_above=cut, residual_path=head)
+    assert [key(s) for s in some] == [key(s) for s in ref if int(s.ub) > cut] and len(some) < n

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # Rust struct -> C struct
 STRUCTS = {"DdoDecision": "ddo_decision", "DdoSubProblem": "ddo_subproblem", "DdoCompileInput": "ddo_compile_input",
-           "DdoCompletion": "ddo_completion"}
+           "DdoCompletion": "ddo_completion", "DdoCutsetRows": "ddo_cutset_rows"}
 # Rust type -> the C types it may stand for (pointers compare by constness only)
 SCALARS = {"c_int": {"int"}, "i64": {"int64_t"}, "u64": {"uint64_t"}, "usize": {"size_t"}, "i32": {"int32_t", "int"}, "f64": {"double"}}
 
