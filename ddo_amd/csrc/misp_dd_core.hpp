@@ -36,8 +36,22 @@
 #include <cstring>
 #include <vector>
 #define DDO_DEV inline
-#define PAR_BEGIN for (int tid = 0; tid < NT; ++tid) {
+// A PAR block is a loop over the thread ids.  DDO_EMU_ORDER picks the order the "threads" of a block run in: 0 (default) ascending,
+// 1 descending, 2 a fixed pseudo-random permutation.  A block whose threads only meet through atomics gives the same result in any
+// order; one in which a thread reads what a lower-numbered thread wrote a moment ago -- a data race on the GPU that the ascending
+// emulation cannot see -- does not (tools/diag/emu_order.sh runs the emulation suites in all three orders).
+#define PAR_BEGIN for (int tid_ = 0; tid_ < NT; ++tid_) { const int tid = ::ddo_hip_emu_tid(tid_, NT);
 #define PAR_END }
+inline int ddo_hip_emu_order() {
+    static const int mode = [] { const char* e = std::getenv("DDO_EMU_ORDER"); return e ? std::atoi(e) : 0; }();
+    return mode;
+}
+inline int ddo_hip_emu_tid(int k, int nt) {
+    const int mode = ddo_hip_emu_order();
+    if (mode == 1) return nt - 1 - k;
+    if (mode == 2) return (int)(((long long)k * 769 + 211) % nt);   // 769 is prime: a bijection for every workgroup size but its multiples
+    return k;
+}
 #define DD_SYNC()
 #define DDO_TID_DECL
 namespace ddo_hip {
@@ -83,7 +97,11 @@ inline uint64_t dd_brev(uint64_t x) {
 // ---------------------------------------------------------------- gfx950 device build
 #include <hip/hip_runtime.h>
 #define DDO_DEV __device__ __forceinline__
+#if defined(DDO_PAR_ENTRY_SYNC)   // diagnosis build (tools/diag): a barrier on ENTRY to every block as well -- separates the workgroup-uniform
+#define PAR_BEGIN { __syncthreads();   // reads of shared scalars between two blocks from the writes of the second one
+#else
 #define PAR_BEGIN {
+#endif
 #define PAR_END } __syncthreads();
 // explicit barrier: needed when workgroup-uniform code has read shared scalars that the very next phase rewrites
 #define DD_SYNC() __syncthreads()

@@ -65,7 +65,7 @@ def test_the_reference_sequential_solver_over_pooled_hipmdd(oracle, name, width)
 @pytest.mark.parametrize("name,width,pooled", [("brock200_2", 300, False), ("keller4", 40, False), ("keller4", 40, True)])
 def test_the_bulk_drain_hands_over_what_the_callbacks_deliver(name, width, pooled):
     """ddo_mdd_drain_cutset_rows (the shims' one call per relaxed compile, made OUTSIDE the solver's lock) against ddo_mdd_drain_cutset:
-    same nodes in the same order -- state, value, ub, depth, and the path once the residual's own path is put in front; `ub_above`
+    the same nodes -- state, value, ub, depth, and the path once the residual's own path is put in front; `ub_above`
     leaves out exactly the nodes whose bound does not exceed it; one drain per compile, whichever of the two."""
     import numpy as np
     from ddo_amd import CompilationType, Decision, SubProblem
@@ -90,9 +90,12 @@ def test_the_bulk_drain_hands_over_what_the_callbacks_deliver(name, width, poole
     assert b.cutset_count() == 0 and b.drain_cutset() == []
 
     def key(s):
-        return (tuple(int(w) for w in s.state), int(s.value), int(s.ub), int(s.depth), tuple((d.variable, d.value) for d in s.path))
-    assert [key(s) for s in rows] == [key(s) for s in ref]
+        # (a pooled node keeps ONE of its equal-valued paths, and which one differs between two compiles: paths are compared on the default DD)
+        return (tuple(int(w) for w in s.state), int(s.value), int(s.ub), int(s.depth), () if pooled else tuple((d.variable, d.value) for d in s.path))
+    assert all(s.path[:len(head)] == head or [(d.variable, d.value) for d in s.path[:len(head)]] == [(d.variable, d.value) for d in head] for s in rows)
+    # (two compiles of one input list their cut-set rows in different orders: the rows' positions come from device atomics)
+    assert sorted(key(s) for s in rows) == sorted(key(s) for s in ref)
     ubs = sorted(int(s.ub) for s in ref)
     cut = ubs[len(ubs) // 2]
     some = c.drain_cutset_rows(ub_above=cut, residual_path=head)
-    assert [key(s) for s in some] == [key(s) for s in ref if int(s.ub) > cut] and len(some) < n
+    assert sorted(key(s) for s in some) == sorted(key(s) for s in ref if int(s.ub) > cut) and len(some) < n
