@@ -166,9 +166,10 @@ def lib():
     L.ddo_mdd_best_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
     L.ddo_mdd_best_exact_solution.argtypes = [C.c_void_p, C.POINTER(_Decision), C.POINTER(C.c_size_t)]
     L.ddo_mdd_drain_cutset.argtypes = [C.c_void_p, _CUTSET_CB, C.c_void_p]
-    L.ddo_mdd_drain_cutset_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
-    L.ddo_mdd_cutset_count.restype = C.c_size_t
-    L.ddo_mdd_cutset_count.argtypes = [C.c_void_p]
+    if hasattr(L, "ddo_mdd_drain_cutset_rows"):   # (DDO_HIP_LIBRARY may name an older diagnosis build: tools/diag)
+        L.ddo_mdd_drain_cutset_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.ddo_mdd_cutset_count.restype = C.c_size_t
+        L.ddo_mdd_cutset_count.argtypes = [C.c_void_p]
     L.ddo_mdd_last_counters.argtypes = [C.c_void_p, C.POINTER(_Counters)]
     L.ddo_mdd_combine_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.ddo_solver_create.restype = C.c_void_p
@@ -890,33 +891,25 @@ SeqCachingSolverLel = _alias(False, LAST_EXACT_LAYER, True, "SequentialSolver<St
 SeqCachingSolverFc = _alias(False, FRONTIER, True, "SequentialSolver<State, DefaultMDDFC<State>, SimpleCache<State>> (solver/mod.rs:46)")
 
 
-def Pooled(model, max_width, device=0):
+def Pooled(model, max_width, device=0, caching=False):
     """`Pooled<State>` (mdd/pooled.rs:117-823), the long-arc decision diagram, on the device: an Mdd whose layers hold the pool nodes
     the branching variable impacts (MISP models: the reference's only model with Problem::is_impacted_by, misp/main.rs:145-147);
-    frontier cut-set, depth of a sub-problem = the layer at which its node was expanded, one decision per expanded ancestor."""
-    return Mdd(model, max_width, device=device, cutset_type=FRONTIER | MDD_POOLED)
+    frontier cut-set, depth of a sub-problem = the layer at which its node was expanded, one decision per expanded ancestor.
+    caching=True lets compile() take a SimpleCache (pooled.rs:467-535, 662-680)."""
+    return Mdd(model, max_width, device=device, cutset_type=FRONTIER | MDD_POOLED, caching=caching)
 
 
-def _pooled_alias(parallel, doc):
-    def make(problem, width, cutoff=None, nb_threads=256, device=0, **kw):
+def _pooled_alias(parallel, caching, doc):
+    def make(problem, width, cutoff=None, nb_threads=256, device=0, cache_entries=1 << 22, **kw):
+        ce = cache_entries if caching else 0
         if parallel:
-            return ParallelSolver(problem, width, cutoff, nb_threads=nb_threads, device=device, pooled=True, **kw)
-        return SequentialSolver(problem, width, cutoff, device=device, pooled=True, **kw)
+            return ParallelSolver(problem, width, cutoff, nb_threads=nb_threads, device=device, pooled=True, cache_entries=ce, **kw)
+        return SequentialSolver(problem, width, cutoff, device=device, pooled=True, cache_entries=ce, **kw)
     make.__doc__ = doc
     return make
 
 
-def _pooled_caching_not_built(name, cite):
-    def make(*_a, **_k):
-        # fail loudly: Pooled decision diagrams behind a SimpleCache (thresholds over long arcs, pooled.rs:469-541) have no device
-        # variant, and nothing here falls back to another DD type or to the cache-less solver
-        raise DdoError(f"{name} ({cite}): Pooled decision diagrams with a SimpleCache are not built on the device (DESIGN.md section 7); "
-                       "use the NoCaching Pooled aliases or the caching Lel / Fc ones")
-    make.__doc__ = f"`{name}` of the reference ({cite}): NOT available -- raises DdoError"
-    return make
-
-
-ParNoCachingSolverPooled = _pooled_alias(True, "ParallelSolver<State, Pooled<State>, EmptyCache<State>> (solver/mod.rs:34)")
-SeqNoCachingSolverPooled = _pooled_alias(False, "SequentialSolver<State, Pooled<State>, EmptyCache<State>> (solver/mod.rs:43)")
-ParCachingSolverPooled = _pooled_caching_not_built("ParCachingSolverPooled", "solver/mod.rs:38")
-SeqCachingSolverPooled = _pooled_caching_not_built("SeqCachingSolverPooled", "solver/mod.rs:47")
+ParNoCachingSolverPooled = _pooled_alias(True, False, "ParallelSolver<State, Pooled<State>, EmptyCache<State>> (solver/mod.rs:34)")
+SeqNoCachingSolverPooled = _pooled_alias(False, False, "SequentialSolver<State, Pooled<State>, EmptyCache<State>> (solver/mod.rs:43)")
+ParCachingSolverPooled = _pooled_alias(True, True, "ParallelSolver<State, Pooled<State>, SimpleCache<State>> (solver/mod.rs:38)")
+SeqCachingSolverPooled = _pooled_alias(False, True, "SequentialSolver<State, Pooled<State>, SimpleCache<State>> (solver/mod.rs:47)")

@@ -300,7 +300,7 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     // the terminal layer is never squashed (clean.rs:608-618): MISP ends in at most one node, a knapsack DD in up to 2W
     pooled_ = (features & ENGINE_POOLED) != 0;
     if (pooled_ && (model->kind != MODEL_MISP || owner || (features & ENGINE_KEEP_LAYERS))) {
-        set_error("Pooled decision diagrams: MISP models only (Problem::is_impacted_by, misp/main.rs:145-147), no caching");
+        set_error("Pooled decision diagrams: MISP models only (Problem::is_impacted_by, misp/main.rs:145-147); their cache is a ddo_cache handed to compile, not kept layers");
         return DDO_ERR_UNSUPPORTED;
     }
     // Pooled: a slot holds a POOL -- every node that waits for a variable that impacts it -- which the width does not bound (only
@@ -576,6 +576,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         if ((rc = dev_alloc(allocs_, P.s_rec, S * capS * RW))) return rc;
         P.keys_global = keys_global_ ? 1 : 0;
         if ((rc = dev_alloc(allocs_, P.s_ptree, S * (size_t)(P.ev_cap / 4)))) return rc;
+        P.s_pvr = nullptr;
+        // Pooled behind a SimpleCache (Par / SeqCachingSolverPooled): (value_top, rough upper bound) per event record for the threshold pass
+        if (pooled_ && (rc = dev_alloc(allocs_, P.s_pvr, S * (size_t)(P.ev_cap / 4)))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_hash, S * capS))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_wl, S * 2 * capW))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_ev, S * P.ev_cap))) return rc;
@@ -2337,8 +2340,8 @@ ddo_mdd* ddo_mdd_create(const ddo_model* model, int device, int cutset_type, siz
     // brock400_1 search -- runs on the full-width engine; everything else on the one engine of its (model, device, width).
     std::shared_ptr<Engine> eng, fallback;
     if (pooled) {
-        if (caching || selector) {
-            set_error("ddo_mdd_create: DDO_MDD_POOLED takes neither DDO_MDD_CACHING (Pooled with a SimpleCache is not built) nor an engine selector");
+        if (selector) {   // (DDO_MDD_CACHING: Pooled behind a SimpleCache, pooled.rs:467-535, 662-680 -- the cache of ddo_compile_input.cache)
+            set_error("ddo_mdd_create: DDO_MDD_POOLED takes no engine selector");
             return nullptr;
         }
         eng = Engine::get(m, device, (long)max_width, Engine::ENGINE_POOLED);

@@ -1530,9 +1530,9 @@ ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* c
     if (s->cfg.rank < 0 || s->cfg.rank >= s->cfg.world_size) s->cfg.rank = 0;
     if (s->cfg.cutset_type == 0) s->cfg.cutset_type = DDO_LAST_EXACT_LAYER;
     if (s->cfg.pooled) {
-        if (s->model->kind != MODEL_MISP || cfg->fringe != DDO_FRINGE_NODUP || s->cfg.cache_entries > 0 || s->cfg.dominance_entries > 0) {
-            set_error("ddo_solver_create: pooled = 1 (Par / SeqNoCachingSolverPooled, solver/mod.rs:34, :43) needs a MISP model, DDO_FRINGE_NODUP, "
-                      "no cache and no dominance checker (Pooled with a SimpleCache is not built)");
+        if (s->model->kind != MODEL_MISP || cfg->fringe != DDO_FRINGE_NODUP || s->cfg.dominance_entries > 0) {
+            set_error("ddo_solver_create: pooled = 1 (the four *SolverPooled aliases, solver/mod.rs:34, :38, :43, :47) needs a MISP model, DDO_FRINGE_NODUP "
+                      "and no dominance checker");
             delete s;
             return nullptr;
         }

@@ -245,6 +245,15 @@ struct DD2Ctx {
     int tab_limit;   // entries the dedup table may hold (a dense tier's table is smaller than 3 x the layer capacity)
     int clocks;        // per-phase shader-clock accounting (DDO_HIP_STATS): costs one barrier per phase
     int tier;          // capacity tier: no squash phases (their LDS is not there), capacity errors mean ST_RETRY
+    // Pooled decision diagrams behind a SimpleCache (pooled.rs:467-535, 662-680; dd_thresholds.hpp): the table shared by the compiles of
+    // a solver, and per event record the (value_top, rough upper bound) its node had when it was expanded (the threshold pass needs both
+    // for nodes whose state is gone by then)
+    uint64_t* cache_tab;
+    uint64_t cache_cap;
+    unsigned long long* cache_stats;
+    GLB_PTR(uint64_t) pvr;     // [ev_cap / 4]  value_top (low half) | rub (high half) per event record; nullptr without a cache
+    int cache_stride;
+    int depth0;                // depth of the residual sub-problem (node.depth = depth0 + layer)
 };
 
 template <int WS> DDO_DEV uint32_t k32_ld(const DD2Ctx<WS>& c, int i) {
@@ -859,6 +868,58 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
 ///     may turn inexact long after its parent was expanded, so the frontier is found by the backward replay of the event
 ///     records (the parent's exactness travels in its record, EV_PINEX), and a cut-set node's state, value and rough upper
 ///     bound are rebuilt from its best path (an exact node's state is the residual state with its path's decisions applied).
+/// Pooled: an exact node's state is the residual state with the decisions of (any of) its paths applied (main.rs:77-85), over the first
+/// `depth` layers; only layers whose variable the state still holds count (the others did not impact the node, pooled.rs:316-334).
+template <int WS>
+DDO_DEV void pooled_state_of(const DD2Ctx<WS>& c, const DDInput& in, uint32_t pid, int depth, uint64_t* st) {
+    uint64_t pb[WS];
+#pragma unroll
+    for (int k = 0; k < WS; ++k) pb[k] = 0;
+    path_bits<WS>(c, pid, pb);
+    if (in.src_off != NO_POOL_SRC) {
+        const PoolBlockHeader* h = (const PoolBlockHeader*)(c.pool + in.src_off);
+        const uint64_t* rows = (const uint64_t*)(c.pool + in.src_off + h->off_states);
+#pragma unroll
+        for (int k = 0; k < WS; ++k) st[k] = k < (int)h->ws ? rows[(size_t)k * h->rows + in.src_row] : 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < WS; ++k) st[k] = in.state[k];
+    }
+    for (int j = 0; j < depth; ++j) {
+        const int x = c.lvar[j];
+        const int xw = x >> 6;
+        const uint64_t xb = 1ULL << (x & 63);
+        bool has = false, yes = false;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            if (k == xw) {
+                has = (st[k] & xb) != 0;
+                st[k] &= ~xb;
+            }
+            if (k == (j >> 6)) yes = ((pb[k] >> (j & 63)) & 1ULL) != 0;
+        }
+        if (has && yes) {
+#pragma unroll
+            for (int k = 0; k < WS; ++k) st[k] &= c.adj[(size_t)x * WS + k];
+        }
+    }
+}
+
+/// A node's own threshold (pooled.rs:493-511; the corner cases of the saturating arithmetic as in misp_dd_core.hpp): `th` is what its
+/// children left it (TH_NONE: nothing), `rub` INT32_MAX for a node that was never expanded, `vbv` VB_UNMARKED for value_bot == isize::MIN.
+DDO_DEV int32_t pooled_own_theta(int32_t th, int32_t val, int32_t rub, bool is_cut, bool exact, int32_t vbv, int32_t bk, bool bk_min) {
+    if (rub != INT32_MAX && !bk_min && (int64_t)val + rub <= (int64_t)bk) return bk - rub;
+    if (is_cut) {
+        const bool locb_le = vbv == VB_UNMARKED ? (!bk_min || val <= 0) : (!bk_min && (int64_t)val + vbv <= (int64_t)bk);
+        if (!locb_le) return val;
+        const int32_t cand = vbv == VB_UNMARKED ? (bk_min ? 0 : TH_INF) : bk - vbv;
+        const int32_t old = th == TH_NONE ? TH_INF : th;
+        return cand < old ? cand : old;
+    }
+    if (exact && th == TH_NONE) return TH_INF;   // large theta for dangling nodes
+    return th;
+}
+
 template <int WS, int DEEP = 0, int POOLED = 0>
 DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t best_lb, DDResult* res) {
     constexpr int KB = DEEP ? 16 : 8;
@@ -869,6 +930,10 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     const bool relaxed = comp_type == CT_RELAXED;
     const bool restricted = comp_type == CT_RESTRICTED;
     const int32_t vbase = in.value + c.vbase_off;
+    // Pooled behind a SimpleCache (pooled.rs:467-535, 662-680): the impacted nodes of every layer but the first are looked up in the
+    // cache before the layer is squashed and expanded, and the thresholds of the finished decision diagram are written back.
+    const bool pcache = POOLED && c.cache_cap != 0 && c.pvr != nullptr && (in.flags & IN_CACHE) != 0;
+    uint32_t cache_hits = 0;
 
     // ---------------------------------------------------------------- _clear + _initialize
     PAR_BEGIN
@@ -974,10 +1039,61 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         if (POOLED) {
             // pooled.rs:734-749: the width bounds the nodes that are EXPANDED; `layers.len() >= 2` is L > 1 here (every layer so
             // far held the nodes its variable impacts, at least one)
-            const int nimp = c.cnt[var];
-            squash = (restricted && nimp > W) || (relaxed && nimp > W && L > 1);
             const int vw0 = var >> 6;
             const uint64_t vbit0 = 1ULL << (var & 63);
+            if (pcache && L >= 1) {
+                // _filter_with_cache (pooled.rs:662-680; `if !self.layers.is_empty()`, :635): an impacted node whose value does not exceed
+                // the threshold the cache holds for (state, depth) leaves the pool without being expanded -- it stays a node of the
+                // LAYER (its threshold travels upwards in _compute_thresholds), so it is listed in front of this layer's deleted
+                // nodes: (slot | exactness, threshold) pairs at cp_off, their number in evoff[L][6].
+                const uint64_t cp_off = DD_UNIFORM64(sh->ev_pos);
+                PAR_BEGIN
+                if (tid == 0) sh->ncut = 0;
+                PAR_END
+                PAR_BEGIN
+                const int hi = DD_UNIFORM(sh->hiw);
+                for (int s = tid; s < hi; s += NT) {
+                    if (!bm_test(c.live, s)) continue;
+                    if ((c.rec[(size_t)s * c.RW + vw0] & vbit0) == 0) continue;
+                    uint64_t st[WS];
+                    ld_state<WS>(c, s, st);
+                    int64_t packed = 0;
+                    if (!cache_get<WS>(c, st, c.depth0 + L, &packed)) continue;
+                    const int32_t val = vbase + (int32_t)(K32(c, s) >> KEY_POP_BITS);
+                    const int32_t tv = th_value(packed);
+                    if (val > tv) continue;   // (`node.value_top > threshold.value`: explored further)
+                    add_bits<WS>(c.cnt, st, -1);
+                    bm_clr(c.live, s);
+                    LDS_ADD_I32(&sh->nlive, -1);
+                    const uint64_t k = (uint64_t)LDS_ADD_I32(&sh->ncut, 1);
+                    if (cp_off + 2 * k + 2 <= c.ev_cap) {
+                        c.ev[cp_off + 2 * k] = (uint32_t)s | (bm_test(c.inex, s) ? EV_PINEX : 0u);
+                        c.ev[cp_off + 2 * k + 1] = (uint32_t)tv;
+                    }
+                }
+                PAR_END
+                const int n_cp = DD_UNIFORM(sh->ncut);
+                if (cp_off + 2ull * (uint64_t)n_cp + 8 > c.ev_cap) {
+                    PAR_BEGIN
+                    if (tid == 0) sh->status = ST_ERR_CAPACITY - 100 * 2;
+                    PAR_END
+                    failed = true;
+                    break;
+                }
+                PAR_BEGIN
+                if (tid == 0) {
+                    sh->ev_pos = cp_off + 2ull * (uint64_t)n_cp;
+                    c.evoff[(size_t)L * 8 + 6] = (uint32_t)n_cp;
+                }
+                PAR_END
+                cache_hits += (uint32_t)n_cp;
+            } else if (pcache) {
+                PAR_BEGIN
+                if (tid == 0) c.evoff[(size_t)L * 8 + 6] = 0;
+                PAR_END
+            }
+            const int nimp = c.cnt[var];
+            squash = (restricted && nimp > W) || (relaxed && nimp > W && L > 1);
             PAR_BEGIN
             if (!squash) {
                 for (int i = tid; i < c.tab_cap; i += NT) c.tab[i] = T2_EMPTY;
@@ -1547,6 +1663,11 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const int r = LDS_ADD_I32(&sh->nrec, 1);
                 U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
                 *rec4 = U32x4{(uint32_t)s | ((POOLED && bm_test(c.inex, s)) ? EV_PINEX : 0u), NONE32, NONE32, NONE32};
+                if (pcache) {   // the threshold pass rebuilds this node's state from its path and needs its value and bound
+                    const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;
+                    c.pt[eid] = (uint64_t)ppid | ((uint64_t)(uint32_t)L << 32);
+                    c.pvr[eid] = (uint64_t)(uint32_t)val | ((uint64_t)(uint32_t)rub << 32);
+                }
                 LDS_ADD_I32(&sh->npruned, 1);
                 continue;
             }
@@ -1582,6 +1703,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             // ---- decision YES into a free slot (main.rs:95-102)
             const int r = LDS_ADD_I32(&sh->nrec, 1);                       // this node's event record ...
             const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;   // ... is also the path-tree node of its YES arc
+            if (pcache) c.pvr[eid] = (uint64_t)(uint32_t)val | ((uint64_t)(uint32_t)rub << 32);
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
             int ny = -1;
             uint64_t y[WS];
@@ -1851,8 +1973,17 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         // (pooled.rs:438-467, 543-566).  ix = `inex` bitmap, replayed backwards: before transition tr is undone it tells, per slot,
         // whether the node living there AFTER the transition ends up inexact; a parent is restored with the flag of its record.
         const bool want_cs = relaxed && !failed && lel >= 0 && has_best;   // (exact DDs have no cut-set: pooled.rs:556; drain needs a best value: :410)
+        // _compute_thresholds (pooled.rs:467-515) rides the same replay: th[slot] = theta of the node living there after the transition
+        // that is being undone (TH_NONE: none).  `if input.comp_type == Relaxed || self.is_exact` (:469).
+        const bool want_th = pcache && !failed && sh->status == ST_OK && (relaxed || is_exact);
         int32_t* vb = c.keyh ? (int32_t*)c.keyh : (int32_t*)c.key32;   // the ranking keys are dead now: reuse their storage
+        int32_t* th = c.keyh ? vb + capS : (int32_t*)c.h32;             // (the packed key|hash words hold two int32 per slot; else the hash array)
         int32_t* tmp = (int32_t*)c.wl;                                   // wl + fl = capW x int32
+        int32_t* tmp2 = (int32_t*)c.cs_value;                            // (the snapshot arrays of the default DD are idle in a pooled one: capN >= capW int32)
+        int64_t bk64 = best_lb;
+        if (has_best_exact && (int64_t)exact_value > bk64) bk64 = exact_value;
+        const int32_t bk = bk64 < -(1 << 30) ? -(1 << 30) : (int32_t)bk64;   // best_known (:471-475); values are far above: same comparisons
+        const bool bk_min = bk64 <= -((int64_t)1 << 39);                      // no bound known: best_known == isize::MIN
         const uint64_t cbase = (sh->ev_pos + 3) & ~3ULL;                 // cut list behind the event records: (record id, value_bot) pairs
         GLB_PTR(uint32_t) cutl = c.ev + cbase;
         const uint64_t cut_cap = c.ev_cap > cbase + 8 ? (c.ev_cap - cbase) / 2 : 0;
@@ -1862,9 +1993,31 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             sh->ncut2 = 0;
         }
         PAR_END
-        if (want_cs) {
+        if (want_cs || want_th) {
+            if (want_th) {
+                PAR_BEGIN
+                for (int i = tid; i < c.nbw; i += NT) c.fresh[i] = 0;
+                PAR_END
+            }
             PAR_BEGIN   // what is left in the pool is the last layer: value_bot = 0 and MARKED (pooled.rs:441-446)
-            for (int s = tid; s < capS; s += NT) vb[s] = (s < sh->hiw && bm_test(c.live, s)) ? 0 : VB_UNMARKED;
+            for (int s = tid; s < capS; s += NT) {
+                const bool lv = s < sh->hiw && bm_test(c.live, s);
+                vb[s] = (want_cs && lv) ? 0 : VB_UNMARKED;
+                if (want_th) {
+                    // :476-482 exact pool nodes start from best_known when there is a best exact node; then their own rule (never expanded:
+                    // rub == isize::MAX, no children, not in the cut-set) and _maybe_update_cache -- depth = the layer the pool was left at (:583)
+                    int32_t t = TH_NONE;
+                    if (lv) {
+                        const bool exact = !bm_test(c.inex, s);
+                        if (exact && has_best_exact) t = bk;
+                        t = pooled_own_theta(t, 0, INT32_MAX, false, exact, VB_UNMARKED, bk, bk_min);
+                        // (its cache update waits, like every other, until the output arena is reserved: `fresh` -- idle here -- remembers
+                        // the exact nodes of the final pool, the replay below rewrites `inex`)
+                        if (exact && t != TH_NONE) bm_set(c.fresh, s);
+                    }
+                    th[s] = t;
+                }
+            }
             PAR_END
             for (int tr = L - 1; tr >= 0; --tr) {
                 // (1) undo the squash of layer tr+1: arcs into a deleted node were redirected to the merged node (pooled.rs:806-819),
@@ -1872,15 +2025,17 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 GLB_PTR(const uint32_t) eo1 = c.evoff + (size_t)(tr + 1) * 8;
                 const int nd = (int)eo1[5];
                 const int m = c.lmerge[tr + 1];
+                const uint64_t doff = (uint64_t)eo1[3] | ((uint64_t)eo1[4] << 32);
                 if (nd > 0 && m >= 0) {
-                    const uint64_t doff = (uint64_t)eo1[3] | ((uint64_t)eo1[4] << 32);
                     const int dfrom = c.ldup[2 * (tr + 1)], dto = c.ldup[2 * (tr + 1) + 1];
                     PAR_BEGIN
                     const int32_t vm = vb[m];
+                    const int32_t tm = want_th ? th[m] : TH_NONE;
                     for (int i = tid; i < nd; i += NT) {
                         const uint32_t d = c.ev[doff + i];
                         if (d != NONE32 && (int)d != m) {
                             vb[d] = vm;
+                            if (want_th) th[d] = tm;
                             bm_set(c.inex, (int)d);
                         }
                     }
@@ -1890,7 +2045,35 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                         if (tid == 0) {
                             int32_t a = vb[dfrom], b = vb[dto];
                             vb[dfrom] = a > b ? a : b;   // X keeps its own arcs and they were also redirected (pooled.rs:821-825)
+                            if (want_th) {
+                                const int32_t ta = th[dfrom], tb = th[dto];
+                                th[dfrom] = ta < tb ? ta : tb;   // (TH_NONE is the largest value: min() ignores it)
+                            }
                             bm_set(c.inex, dfrom);       // (for the arcs INTO X: they also reach the relaxed node; X's own flag is in its record)
+                        }
+                        PAR_END
+                    }
+                } else if (nd > 0 && want_th) {   // restricted: a dropped node passes nothing on (no merged node took its arcs)
+                    PAR_BEGIN
+                    for (int i = tid; i < nd; i += NT) {
+                        const uint32_t d = c.ev[doff + i];
+                        if (d != NONE32) th[d] = TH_NONE;
+                    }
+                    PAR_END
+                }
+                // (1b) the nodes of layer tr+1 the cache pruned (:662-680): back in their slots with the cached threshold as theta; they were
+                // not expanded (no children: unmarked) and only pass that theta on (pruned_by_cache: no rule of their own, no update)
+                if (pcache) {
+                    const int ncp = (int)eo1[6];
+                    if (ncp > 0) {
+                        const uint64_t cpo = doff - 2ull * (uint64_t)ncp;
+                        PAR_BEGIN
+                        for (int i = tid; i < ncp; i += NT) {
+                            const uint32_t w0 = c.ev[cpo + 2 * (uint64_t)i];
+                            const int sl = (int)(w0 & EV_SLOT_MASK);
+                            vb[sl] = VB_UNMARKED;
+                            th[sl] = want_th ? (int32_t)c.ev[cpo + 2 * (uint64_t)i + 1] : TH_NONE;
+                            bm_put(c.inex, sl, (w0 & EV_PINEX) != 0);
                         }
                         PAR_END
                     }
@@ -1910,21 +2093,41 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 for (int i = tid; i < na; i += NT) {
                     GLB_PTR(uint32_t) rec = c.ev + aoff + 4ull * (uint64_t)i;
                     int32_t best = VB_UNMARKED;
+                    int32_t tch = TH_NONE;   // what the children pass up: min over the arcs of theta(child) - cost (:519-525)
                     bool cix = false;
                     if (rec[1] != NONE32) {
                         const int t = (int)(rec[1] & EV_SLOT_MASK);
                         const int32_t v = vb[t];
                         if (v != VB_UNMARKED) best = v;
                         cix |= bm_test(c.inex, t);
+                        if (want_th && th[t] != TH_NONE) tch = th[t];
                     }
                     if (rec[2] != NONE32) {
                         const int t = (int)(rec[2] & EV_SLOT_MASK);
                         const int32_t v = vb[t];
                         if (v != VB_UNMARKED && v + wv > best) best = v + wv;
                         cix |= bm_test(c.inex, t);
+                        if (want_th && th[t] != TH_NONE) {
+                            const int32_t u = th_sub(th[t], wv);
+                            if (u < tch) tch = u;
+                        }
                     }
                     tmp[i] = best;
                     if (cix && !(rec[0] & EV_PINEX)) rec[0] |= EV_PCUT;   // exact parent of an inexact node: frontier (pooled.rs:552-560)
+                    if (want_th) {
+                        const uint32_t p0 = rec[0];
+                        const bool exact = !(p0 & EV_PINEX);
+                        const bool is_cut = (p0 & EV_PCUT) != 0;
+                        const uint32_t eid = (uint32_t)(aoff >> 2) + (uint32_t)i;
+                        const uint64_t vr = c.pvr[eid];
+                        const int32_t val = (int32_t)(uint32_t)vr, rub = (int32_t)(uint32_t)(vr >> 32);
+                        const int32_t t = pooled_own_theta(tch, val, rub, is_cut, exact, want_cs ? best : VB_UNMARKED, bk, bk_min);
+                        tmp2[i] = t;
+                        // _maybe_update_cache (:527-535): above the cut-set == exact (:548-550), explored unless in the cut-set.  The update
+                        // itself waits until the output arena is reserved (a compile that finds the arena full runs again and must not meet
+                        // its own thresholds): the record keeps theta | update << 32 | explored << 33 in place of (value, rub)
+                        c.pvr[eid] = (uint64_t)(uint32_t)t | ((exact && t != TH_NONE) ? (1ULL << 32) : 0ULL) | (!is_cut ? (1ULL << 33) : 0ULL);
+                    }
                 }
                 PAR_END
                 PAR_BEGIN
@@ -1933,8 +2136,9 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     const uint32_t p0 = rec[0];
                     const int s = (int)(p0 & EV_SLOT_MASK);
                     vb[s] = tmp[i];
+                    if (want_th) th[s] = tmp2[i];
                     bm_put(c.inex, s, (p0 & EV_PINEX) != 0);
-                    if ((p0 & EV_PCUT) && tmp[i] != VB_UNMARKED) {   // drain_cutset keeps the MARKED nodes only (pooled.rs:414)
+                    if (want_cs && (p0 & EV_PCUT) && tmp[i] != VB_UNMARKED) {   // drain_cutset keeps the MARKED nodes only (pooled.rs:414)
                         const uint64_t k = (uint64_t)LDS_ADD_I32(&sh->ncut, 1);
                         if (k < cut_cap) {
                             cutl[2 * k] = (uint32_t)(aoff >> 2) + (uint32_t)i;
@@ -1983,6 +2187,34 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         PAR_END
         const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;
         GLB_PTR(uint8_t) base = c.arena + sh->arena_off;
+        if (want_th && sh->status == ST_OK) {
+            // ---- _maybe_update_cache for every node the replay flagged: an exact node's state is rebuilt from its path
+            for (int tr = 0; tr < L; ++tr) {
+                GLB_PTR(const uint32_t) eo = c.evoff + (size_t)tr * 8;
+                const int na = (int)eo[2];
+                const uint64_t aoff = (uint64_t)eo[0] | ((uint64_t)eo[1] << 32);
+                PAR_BEGIN
+                for (int i = tid; i < na; i += NT) {
+                    const uint32_t eid = (uint32_t)(aoff >> 2) + (uint32_t)i;
+                    const uint64_t w = c.pvr[eid];
+                    if (!(w & (1ULL << 32))) continue;
+                    uint64_t st[WS];
+                    pooled_state_of<WS>(c, in, (uint32_t)c.pt[eid], tr, st);
+                    cache_update<WS>(c, st, c.depth0 + tr, th_pack((int32_t)(uint32_t)w, (w & (1ULL << 33)) != 0));
+                }
+                PAR_END
+            }
+            PAR_BEGIN
+            for (int s = tid; s < capS; s += NT) {
+                if (!bm_test(c.fresh, s)) continue;
+                int32_t t = has_best_exact ? bk : TH_NONE;
+                t = pooled_own_theta(t, 0, INT32_MAX, false, true, VB_UNMARKED, bk, bk_min);
+                uint64_t st[WS];
+                ld_state<WS>(c, s, st);
+                cache_update<WS>(c, st, c.depth0 + L, th_pack(t, true));
+            }
+            PAR_END
+        }
         if (arena_ok && !failed) {
             LDS_PTR(uint64_t) bbits = (LDS_PTR(uint64_t))sh->merged;
             LDS_PTR(uint64_t) xbits = (LDS_PTR(uint64_t))sh->xcand;   // 64 x int32 = 32 words >= WS
@@ -2122,7 +2354,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             r.cs_depth_off = (arena_ok && ncut) ? cs_depth_off : 0;
             r.cs_path_stride = path_len;
             r.cs_lvar_off = (arena_ok && ncut) ? cs_lvar_off : 0;
-            r.cache_hits = 0;
+            r.cache_hits = cache_hits;
             *res = r;
         }
         PAR_END
@@ -2486,6 +2718,40 @@ DDO_DEV void run_work_item2(DD2Ctx<WS>& c, const DDInput& in, DDResult* res2, in
     const bool fused = (in.flags & IN_FUSED) != 0;
     int64_t lb = in.best_lb;
     bool go = true;
+    if (POOLED) {
+        PAR_BEGIN
+        if (tid == 0) c.depth0 = in.depth;
+        PAR_END
+        if ((in.flags & IN_MUST_EXPLORE) && (in.flags & IN_CACHE) && c.cache_cap && c.pvr != nullptr && in.src_off == NO_POOL_SRC) {
+            // the solver's pop (parallel.rs:537-549, sequential.rs:341): Cache::must_explore (cache.rs:32-39), then update_threshold(.., explored)
+            PAR_BEGIN
+            if (tid == 0) {
+                uint64_t rs[WS];
+#pragma unroll
+                for (int k = 0; k < WS; ++k) rs[k] = in.state[k];
+                int64_t packed = 0;
+                bool explore = true;
+                if (cache_get<WS>(c, rs, in.depth, &packed)) {
+                    const int32_t tv = th_value(packed);
+                    explore = tv != TH_INF && (in.value > tv || (in.value == tv && !th_explored(packed)));
+                }
+                if (explore && (in.flags & IN_MARK_EXPLORED)) cache_update<WS>(c, rs, in.depth, th_pack(in.value, true));
+                c.sh->sel_above = explore ? 1 : 0;
+            }
+            PAR_END
+            const bool explore = c.sh->sel_above != 0;
+            DD_SYNC();
+            if (!explore) {
+                PAR_BEGIN
+                if (tid == 0) {
+                    res2[0].status = ST_SKIPPED;
+                    res2[1].status = ST_NOT_RUN;
+                }
+                PAR_END
+                return;
+            }
+        }
+    }
     if (only == 1) {
         if (!fused) return;
         PAR_BEGIN
@@ -2670,6 +2936,12 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.tab_limit = P.tab2_cap >= 3 * P.capW ? 0x7FFFFFFF : (int)((long)P.tab2_cap * 7 / 8);
     c.tier = P.tier;
     c.NT = nthreads;
+    c.cache_tab = P.cache_tab;
+    c.cache_cap = P.s_pvr ? P.cache_cap : 0;   // (only engines that keep the per-record values can serve a cache)
+    c.cache_stats = P.cache_stats;
+    c.cache_stride = P.cache_stride;
+    c.pvr = P.s_pvr ? (GLB_PTR(uint64_t))(P.s_pvr + s * (P.ev_cap / 4)) : (GLB_PTR(uint64_t))nullptr;
+    c.depth0 = 0;
 }
 
 }  // namespace ddo_hip

@@ -71,11 +71,13 @@ pub fn install(nb_vars: usize, neighbors: &[BitSet], weight: &[isize], device: i
     let cutset_type = (if frontier { DDO_FRONTIER } else { DDO_LAST_EXACT_LAYER }) | (if cache_entries > 0 { DDO_MDD_CACHING } else { 0 });
     install_with(nb_vars, neighbors, weight, device, cutset_type, max_width, cache_entries)
 }
-/// The same for `Pooled` decision diagrams (implementation/mdd/pooled.rs; `ParNoCachingSolverPooled` / `SeqNoCachingSolverPooled`,
-/// solver/mod.rs:34, :43): every `HipMdd` created afterwards compiles pooled DDs on the device -- use
-/// `ParallelSolver::<BitSet, HipMdd, EmptyCache<BitSet>>` exactly as with `install`.  (Pooled behind a SimpleCache is not built.)
-pub fn install_pooled(nb_vars: usize, neighbors: &[BitSet], weight: &[isize], device: i32, max_width: usize) {
-    install_with(nb_vars, neighbors, weight, device, DDO_FRONTIER | DDO_MDD_POOLED, max_width, 0)
+/// The same for `Pooled` decision diagrams (implementation/mdd/pooled.rs; the four `*SolverPooled` aliases, solver/mod.rs:34, :38, :43,
+/// :47): every `HipMdd` created afterwards compiles pooled DDs on the device -- use `ParallelSolver::<BitSet, HipMdd, EmptyCache<BitSet>>`
+/// exactly as with `install`, or, with `cache_entries > 0`, `ParallelSolver::<BitSet, HipMdd, HipCache>` (Pooled behind the device-side
+/// SimpleCache: `_filter_with_cache` / `_compute_thresholds` over the long arcs, pooled.rs:467-535, 662-680).
+pub fn install_pooled(nb_vars: usize, neighbors: &[BitSet], weight: &[isize], device: i32, max_width: usize, cache_entries: usize) {
+    let cutset_type = DDO_FRONTIER | DDO_MDD_POOLED | (if cache_entries > 0 { DDO_MDD_CACHING } else { 0 });
+    install_with(nb_vars, neighbors, weight, device, cutset_type, max_width, cache_entries)
 }
 fn install_with(nb_vars: usize, neighbors: &[BitSet], weight: &[isize], device: i32, cutset_type: c_int, max_width: usize, cache_entries: usize) {
     let words = (nb_vars + 63) / 64;

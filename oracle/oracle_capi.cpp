@@ -377,6 +377,14 @@ void* oracle_trace_solve_ex(const char* kind, const char* path, uint64_t width, 
             MispRanking rank;
             return traced_solve_any<BitSet>(pb, relax, rank, pb.nb_vars, (pb.nb_vars + 63) / 64, width, max_compiles, frontier, cache, out);
         }
+        if (k == "misp+pooled") {   // Pooled<T> (mdd/pooled.rs) with EmptyCache / SimpleCache: Seq{No,}CachingSolverPooled (solver/mod.rs:43, :47)
+            Misp pb = read_misp_instance(path);
+            MispRelax relax(pb);
+            MispRanking rank;
+            const size_t ws = (pb.nb_vars + 63) / 64;
+            if (cache) return traced_solve_dc<BitSet, Pooled<BitSet>, SimpleCache<BitSet>>(pb, relax, rank, pb.nb_vars, ws, width, max_compiles, out);
+            return traced_solve_dc<BitSet, Pooled<BitSet>, EmptyCache<BitSet>>(pb, relax, rank, pb.nb_vars, ws, width, max_compiles, out);
+        }
         if (k == "knapsack" || k == "knapsack+dominance") {   // "+dominance": SimpleDominanceChecker(KPDominance), knapsack/main.rs:325
             Knapsack pb = read_knapsack_instance(path);
             KPRelax relax(pb);

@@ -39,6 +39,7 @@ struct Emul {
     std::vector<unsigned char> mem3;         // kept layers (frontier cut-set / thresholds / cache)
     std::vector<uint64_t> lbase, abase;      // DDO_EMUL_LPOOL: kept layers and arcs as pools (run_dd: dynl)
     std::vector<uint64_t> cache_tab;
+    std::vector<uint64_t> pvr;       // pooled engine behind a cache: (value, rub) per event record (EngineParams::s_pvr)
     std::vector<uint64_t> dom_coord;
     std::vector<int32_t> dom_value;
     std::vector<uint32_t> dom_count, dom_lock;
@@ -341,6 +342,24 @@ void emul_set_dominance(void* h, uint32_t cap) {
 }
 /// engine 2 only: compile Pooled decision diagrams (run_dd2<WS, DEEP, POOLED = 1>)
 void emul_set_pooled(void* h, int on) { ((Emul*)h)->pooled = on != 0; }
+/// Pooled decision diagrams behind a fresh, empty SimpleCache of at least `entries` entries (0: EmptyCache again)
+void emul_set_pooled_cache(void* h, uint64_t entries) {
+    Emul* e = (Emul*)h;
+    e->P.cache_cap = 0;
+    e->P.cache_tab = nullptr;
+    e->P.s_pvr = nullptr;
+    if (!entries) return;
+    uint64_t cap = 1024;
+    while (cap < entries) cap <<= 1;
+    e->P.cache_stride = 3 + e->wsT;
+    e->cache_tab.assign(cap * (size_t)e->P.cache_stride, 0);
+    e->P.cache_tab = e->cache_tab.data();
+    e->P.cache_cap = cap;
+    e->cache_stats[0] = e->cache_stats[1] = 0;
+    e->P.cache_stats = e->cache_stats;
+    e->pvr.assign((size_t)(e->P.ev_cap / 4 + 1), 0);
+    e->P.s_pvr = e->pvr.data();
+}
 void emul_destroy(void* h) { delete (Emul*)h; }
 int emul_state_words(void* h) { return ((Emul*)h)->wsT; }
 uint64_t emul_lds_bytes(void* h) { return ((Emul*)h)->lds.size(); }

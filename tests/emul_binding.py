@@ -72,6 +72,11 @@ class Emul:
         self.L.emul_set_pooled.argtypes = [C.c_void_p, C.c_int]
         self.L.emul_set_pooled(self.h, 1 if on else 0)
 
+    def pooled_cache(self, entries):
+        """Pooled behind a fresh, empty SimpleCache (pooled.rs:467-535, 662-680); 0: EmptyCache"""
+        self.L.emul_set_pooled_cache.argtypes = [C.c_void_p, C.c_uint64]
+        self.L.emul_set_pooled_cache(self.h, int(entries))
+
     def dominance(self, cap):
         """a fresh SimpleDominanceChecker with `cap` pairs per depth (0: none); needs keep_layers(True)"""
         self.L.emul_set_dominance.argtypes = [C.c_void_p, C.c_uint32]

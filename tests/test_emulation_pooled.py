@@ -138,3 +138,31 @@ def test_pooled_emulation_exact_compile_and_a_lower_bound_that_prunes_everything
         g = e.compile(comp_type, width, lb, root, 0, 0, flags=IN_WANT_PATHS)[0]
         assert g["status"] == 0 and diff(ref, g) is None, (comp_type, diff(ref, g))
     assert inst.compile(0, 1 << 62, -(1 << 40), root, 0, 0, pooled=True)["best_value"] == 4
+
+
+@pytest.mark.parametrize("name,width,max_compiles", [("johnson8-4-4", 4, 300), ("johnson8-4-4", 0, 200), ("keller4", 7, 200), ("brock200_2", 10, 100),
+                                                     ("MANN_a9", 3, 300), ("hamming6-4", 5, 150), ("p_hat300-1", 20, 60), ("brock200_4", 0, 40)])
+def test_pooled_emulation_replays_a_search_behind_a_simple_cache(oracle, name, width, max_compiles):
+    """SeqCachingSolverPooled (solver/mod.rs:47): Pooled decision diagrams behind a SimpleCache -- _filter_with_cache on the impacted nodes
+    of every layer but the first (pooled.rs:635, 662-680), _compute_thresholds + _maybe_update_cache over the long arcs (:467-535).  The
+    replay is stateful like the default DD's (tests/test_emulation_cache.py): a threshold written by compile k decides what compile
+    k + 1 prunes, so every record only matches when the device-side table holds what the reference's holds after each compile."""
+    from tests.dd_wire import IN_CACHE, IN_MUST_EXPLORE
+    path = data_path("misp", name + ".clq")
+    inst = oracle.misp(path)
+    plain, _ = oracle.trace_ex("misp+pooled", path, width, max_compiles, False, False)
+    summary, recs = oracle.trace_ex("misp+pooled", path, width, max_compiles, False, True)
+    assert recs
+    e = Emul(inst.n, inst.rows, inst.weights, POOL, engine=2)
+    e.pooled(True)
+    e.pooled_cache(1 << 16)
+    hits = 0
+    for i, r in enumerate(recs):
+        fl = IN_WANT_PATHS | IN_CACHE | (IN_MUST_EXPLORE if r["comp_type"] == 2 else 0)
+        g = e.compile(r["comp_type"], r["width"], r["best_lb"], r["state"], r["value"], r["depth"], flags=fl)[0]
+        assert g is not None and g["status"] == 0, (i, None if g is None else g["status"])
+        d = diff(r, g)
+        assert d is None, f"{name} W={width} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+        hits += g["cache_hits"]
+    assert e.cache_used() > 0
+    print(name, width, "compiles", len(recs), "cache hits", hits, "explored", summary["explored"], "vs", plain["explored"])

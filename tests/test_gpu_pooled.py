@@ -163,11 +163,47 @@ def test_a_pool_beyond_the_node_slots_is_a_loud_capacity_error(monkeypatch):
         mdd.compile(CompilationType.Relaxed, 200, model.root(), -(1 << 40))
 
 
-def test_pooled_with_a_cache_refuses_loudly():
-    with pytest.raises(ddo_amd.DdoError, match="not built on the device"):
-        ddo_amd.SeqCachingSolverPooled(_model("johnson8-4-4"), FixedWidth(10))
-    with pytest.raises(ddo_amd.DdoError):
-        ddo_amd.Mdd(_model("johnson8-4-4"), 10, cutset_type=ddo_amd.FRONTIER | 0x20, caching=True)
+@pytest.mark.parametrize("name,width,max_compiles", [("johnson8-4-4", 4, 300), ("keller4", 7, 200), ("brock200_2", 10, 100), ("MANN_a9", 3, 300),
+                                                     ("hamming6-4", 5, 150), ("p_hat300-1", 20, 60), ("brock200_4", 0, 40)])
+def test_pooled_behind_a_simple_cache_replays_the_oracle_search(oracle, name, width, max_compiles):
+    """SeqCachingSolverPooled (solver/mod.rs:47) compile by compile: Pooled decision diagrams with ONE device cache over the whole replay --
+    _filter_with_cache on the impacted nodes of every layer but the first (pooled.rs:635, 662-680), _compute_thresholds and
+    _maybe_update_cache over the long arcs (:467-535).  Stateful: a threshold written by compile k decides what compile k + 1 prunes, so
+    the records (values, counters, frontier cut-set) only match when the device table holds what the reference's holds after each compile."""
+    path = data_path("misp", name + ".clq")
+    model = _model(name)
+    plain, _ = oracle.trace_ex("misp+pooled", path, width, max_compiles, False, False)
+    summary, recs = oracle.trace_ex("misp+pooled", path, width, max_compiles, False, True)
+    assert recs
+    cache = ddo_amd.SimpleCache(model, 1 << 16)
+    mdd = ddo_amd.Pooled(model, max(max(int(r["width"]) for r in recs), 8), caching=True)
+    for i, r in enumerate(recs):
+        sub = SubProblem(state=np.array(r["state"], dtype=np.uint64), value=r["value"], path=[], depth=r["depth"])
+        comp = mdd.compile(r["comp_type"], r["width"], sub, r["best_lb"], cache=cache)
+        d = diff(r, canon_from_mdd(mdd, comp, model.ws))
+        assert d is None, f"{name} W={width} compile #{i} type={r['comp_type']} depth={r['depth']}: {d}"
+    st = cache.stats()
+    assert st["used"] > 0 and st["dropped"] == 0
+    assert summary["explored"] <= plain["explored"] + max_compiles   # (a bounded trace: the two searches stop at the same number of compiles)
+
+
+@pytest.mark.parametrize("name,width,expected", [("johnson8-4-4", 0, 14), ("hamming6-4", 0, 4), ("MANN_a9", 0, 16), ("keller4", 0, 11), ("c-fat200-1", 0, 12),
+                                                 ("hamming6-2", 0, 32), ("hamming6-4", 5, 4)])
+def test_seq_caching_solver_pooled_explores_what_the_oracle_explores(oracle, name, width, expected):
+    """SeqCachingSolverPooled on the device against the oracle's (width 0: NbUnassignedWidth, the reference's test configuration): optimum,
+    proof and `explored` (MANN_a9: 330 sub-problems against 360 without the cache, keller4: 5 625 against 6 670); ParCachingSolverPooled
+    proves the same optimum"""
+    path = data_path("misp", name + ".clq")
+    model = _model(name)
+    ref, _ = oracle.trace_ex("misp+pooled", path, width, 0, False, True)
+    wh = FixedWidth(width) if width else NbUnassignedWidth(model.n)
+    s = ddo_amd.SeqCachingSolverPooled(model, wh)
+    c = s.maximize()
+    assert c.is_exact and c.best_value == expected == ref["best_value"]
+    assert s.explored() == ref["explored"], (name, s.explored(), ref["explored"])
+    p = ddo_amd.ParCachingSolverPooled(model, wh, nb_threads=16)
+    cp = p.maximize()
+    assert cp.is_exact and cp.best_value == expected
 
 
 def test_pooled_on_a_weighted_instance(oracle, tmp_path):
