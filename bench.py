@@ -77,6 +77,26 @@ def kernel_source_fingerprint():
     return h.hexdigest()[:16]
 
 
+def committed_traffic(key):
+    """HBM bytes per expanded node of a secondary workload from the newest committed rocprofv3 --pmc passes (profiles/<round>/
+    pmc_extra.json: FETCH_SIZE x calibrated factor + WRITE_SIZE over the nodes expanded under the counters -- tools/profile_round.sh,
+    tools/summarize_extra.py), or (None, reason).  Counters of another build of the kernels say nothing about this run."""
+    fp = kernel_source_fingerprint()
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted((d for d in os.listdir(pdir) if d.startswith("r")), reverse=True) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, rnd, "pmc_extra.json")
+        if not os.path.exists(f):
+            continue
+        e = json.load(open(f)).get("secondary", {}).get(key)
+        if not e or "hbm_bytes_per_node" not in e:
+            return None, f"null: profiles/{rnd}/pmc_extra.json holds no counter pass of {key}"
+        if e.get("kernel_sources") != fp:
+            return None, f"null: profiles/{rnd}/pmc_extra.json ({key}) was collected on kernel sources {e.get('kernel_sources')}, this build is {fp}"
+        return e["hbm_bytes_per_node"], (f"profiles/{rnd}/pmc_extra.json: {key} (FETCH_SIZE x {e.get('fetch_factor')} [calibrated] + WRITE_SIZE over the "
+                                         f"{e.get('nodes'):.0f} nodes expanded under the counters, kernel sources {fp}) x nodes per launch")
+    return None, "null: no profiles/<round>/pmc_extra.json"
+
+
 def cpu_baseline(instance, width, total_seconds, threads_arg):
     """The CPU oracle (C++ restatement of ddo, kind = "port") on the same instance / width, built -O3 -march=native for
     the host this runs on, swept over thread counts inside a bounded time budget; the best configuration is reported."""
@@ -181,6 +201,7 @@ def bench_vector(args):
         load, label = ddo_amd.Mcp.read_instance, "MCP mcp_n30_p0.1_000..009.mcp"
     models = [load(p) for p, _ in cases]
     tot = None
+    nodes_all = 0            # nodes expanded by BOTH passes: what a profiler wrapped around this process has counted
     for rep in range(2):     # first pass = warm-up (engine creation, first launches)
         tot = {"dt": 0.0, "nodes": 0, "kms": 0.0, "launches": 0, "explored": 0, "compiles": 0, "values": [], "proved": True}
         for model in models:
@@ -194,6 +215,7 @@ def bench_vector(args):
             cnt = s.counters()
             tot["dt"] += dt
             tot["nodes"] += cnt["nodes_expanded"]
+            nodes_all += cnt["nodes_expanded"]
             tot["kms"] += k1 - k0
             tot["launches"] += l1 - l0
             tot["explored"] += s.explored()
@@ -207,6 +229,8 @@ def bench_vector(args):
     S = 4 * n + 4
     bpn = (S + 8) + 2 * (S + 16)
     ach = tot["nodes"] * bpn / max(tot["kms"] / 1e3, 1e-12) / 1e9
+    tkey = ("max2sat_" + name.replace("-", "_")) if args.workload == "max2sat" else "mcp_n30"
+    tpn, tsrc = committed_traffic(tkey)
     out = {
         "metric": f"MDD nodes expanded/sec, {label} w={width} (whole search to the proved optimum)",
         "value": tot["nodes"] / tot["dt"], "unit": "nodes/s", "n_gpus": 1, "steps": int(tot["launches"]), "warmup": 1,
@@ -217,8 +241,10 @@ def bench_vector(args):
         "proved": tot["proved"], "best_values": tot["values"], "time_to_proved_optimum_s": tot["dt"] if tot["proved"] else None,
         "bounds_lb_ub_gap": tot.get("bounds"), "time_budget_s": budget.seconds if budget else None,
         "subproblems": tot["explored"], "compiles": tot["compiles"],
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "traffic_source": "null: no rocprofv3 --pmc pass of this workload is committed",
+        "profile_key": tkey, "kernel_sources": kernel_source_fingerprint(), "nodes_all_passes": nodes_all,
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": None if tpn is None else tpn * tot["nodes"] / max(1, tot["launches"]), "traffic_unit": "bytes per launch",
+                     "traffic_source": tsrc,
                      "kernel": "ddo_hip::misp_compile_kernel<WS, table in LDS> (layer-rebuilding engine, signed-vector states: "
                                f"{(n + 1) // 2 + 1} words)",
                      "kernel_ms_avg": tot["kms"] / max(1, tot["launches"]), "kernel_s": tot["kms"] / 1e3, "wall_s": tot["dt"],
@@ -269,6 +295,7 @@ def bench_tsptw(args):
         width, wlabel, label = FixedWidth(20000), "FixedWidth(20000)", "TSPTW Langevin N40ft201/207/403/410 (config C5)"
     models = [ddo_amd.Tsptw.read_instance(p) for p in cases]
     tot = None
+    nodes_all = 0            # nodes expanded by BOTH passes: what a profiler wrapped around this process has counted
     for rep in range(2):     # first pass = warm-up (engine creation, first launches)
         tot = {"dt": 0.0, "nodes": 0, "arcs": 0, "kms": 0.0, "launches": 0, "explored": 0, "compiles": 0, "values": [], "proved": True}
         for model in models:
@@ -282,6 +309,7 @@ def bench_tsptw(args):
             cnt = s.counters()
             tot["dt"] += dt
             tot["nodes"] += cnt["nodes_expanded"]
+            nodes_all += cnt["nodes_expanded"]
             tot["arcs"] += cnt["arcs"]
             tot["kms"] += k1 - k0
             tot["launches"] += l1 - l0
@@ -292,6 +320,8 @@ def bench_tsptw(args):
             del s
     assert tot["kms"] / 1e3 <= tot["dt"] * 1.001, "kernel time must fit inside the wall time of the searches it belongs to"
     S = 8 * models[0].ws
+    tkey = "tsptw_c5" if args.instance == INSTANCE else "tsptw_" + os.path.basename(args.instance).split(".")[0]
+    tpn, tsrc = committed_traffic(tkey)
     fan = tot["arcs"] / max(1, tot["nodes"])
     bpn = (S + 8) + fan * (S + 16)
     ach = tot["nodes"] * bpn / max(tot["kms"] / 1e3, 1e-12) / 1e9
@@ -304,8 +334,10 @@ def bench_tsptw(args):
                                f"{args.concurrent} sub-problems in flight", "parallelism": "1 GPU"},
         "proved": tot["proved"], "best_values": tot["values"], "time_to_proved_optimum_s": tot["dt"] if tot["proved"] else None,
         "subproblems": tot["explored"], "compiles": tot["compiles"], "arcs_per_node": fan,
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "traffic_source": "null: no rocprofv3 --pmc pass of this workload is committed",
+        "profile_key": tkey, "kernel_sources": kernel_source_fingerprint(), "nodes_all_passes": nodes_all,
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": None if tpn is None else tpn * tot["nodes"] / max(1, tot["launches"]), "traffic_unit": "bytes per launch",
+                     "traffic_source": tsrc,
                      "kernel": f"ddo_hip::misp_compile_kernel<WS, table in LDS / HBM> (layer-rebuilding engine, {models[0].ws}-word TSPTW states, "
                                f"{models[0].n} children per node)",
                      "kernel_ms_avg": tot["kms"] / max(1, tot["launches"]), "kernel_s": tot["kms"] / 1e3, "wall_s": tot["dt"],
@@ -337,9 +369,62 @@ def bench_tsptw(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_pooled(args):
+    """Secondary line on ONE GPU: the reference's second decision-diagram type, `Pooled` (mdd/pooled.rs), beside the
+    default one on the same instances -- whole searches under the reference's own MISP configuration (NbUnassignedWidth, NoDupFringe, MaxUB,
+    examples/misp/main.rs) and a time budget: brock200_4 and the headline instance brock400_1; `--instance NAME` runs one other DIMACS graph
+    of data/misp.  Per (instance, DD type): nodes expanded per second, sub-problems explored, compiles, the bounds reached.  `value` = the
+    pooled search's rate on the first instance; the pooled kernel is the in-place engine with POOLED = 1, one 512-thread workgroup per CU."""
+    import ddo_amd
+    from ddo_amd import NbUnassignedWidth, ParallelSolver
+
+    names = [args.instance] if args.instance != INSTANCE else ["brock200_4", "brock400_1"]
+    budget_s = min(args.prove, 30.0) if args.prove > 0 else 20.0
+    rows = []
+    for name in names:
+        model = ddo_amd.Misp.read_instance(os.path.join(ROOT, "data", "misp", name + ".clq"))
+        for dd in ("default", "pooled", "pooled+cache"):
+            for rep in range(2):   # first pass = warm-up (engine creation), 2 s
+                s = ParallelSolver(model, NbUnassignedWidth(model.n), ddo_amd.TimeBudget(budget_s if rep else 2.0), nb_threads=args.concurrent, fringe="nodup",
+                                   pooled=dd != "default", cache_entries=(1 << 22) if dd == "pooled+cache" else 0)
+                k0, l0 = s.device_time()
+                t0 = time.perf_counter()
+                c = s.maximize()
+                dt = time.perf_counter() - t0
+                k1, l1 = s.device_time()
+                cnt = s.counters()
+                row = {"instance": name, "dd": dd, "proved": bool(c.is_exact), "best_value": c.best_value, "best_lb": s.best_lower_bound(),
+                       "best_ub": s.best_upper_bound(), "wall_s": dt, "subproblems": s.explored(), "compiles": cnt["compiles"],
+                       "nodes_expanded": cnt["nodes_expanded"], "arcs": cnt["arcs"], "nodes_per_s": cnt["nodes_expanded"] / max(dt, 1e-9),
+                       "kernel_s": (k1 - k0) / 1e3, "launches": int(l1 - l0),
+                       "kernel_nodes_per_s": cnt["nodes_expanded"] / max((k1 - k0) / 1e3, 1e-9)}
+                del s
+            rows.append(row)
+    first = next(r for r in rows if r["dd"] == "pooled")
+    base = next(r for r in rows if r["dd"] == "default" and r["instance"] == first["instance"])
+    n = ddo_amd.Misp.read_instance(os.path.join(ROOT, "data", "misp", first["instance"] + ".clq")).n
+    S = 8 * ((n + 63) // 64)
+    cmean = first["arcs"] / max(1, first["nodes_expanded"])
+    bpn = (S + 8) + cmean * (S + 16)
+    ach = first["nodes_expanded"] * bpn / max(first["kernel_s"], 1e-12) / 1e9
+    print(json.dumps({
+        "metric": f"MDD nodes expanded/sec, MISP {first['instance']} Pooled decision diagrams, NbUnassignedWidth (search under a time budget)",
+        "value": first["nodes_per_s"], "unit": "nodes/s", "n_gpus": 1, "steps": first["launches"], "warmup": 1,
+        "ms_per_step": 1e3 * first["wall_s"] / max(1, first["launches"]), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+        "data": "real instances (DIMACS graphs shipped with the reference)",
+        "config": {"workload": f"MISP {', '.join(names)}: ParallelSolver over Pooled / Pooled + SimpleCache / default decision diagrams, NbUnassignedWidth, "
+                               f"NoDupFringe(MaxUB), {args.concurrent} sub-problems per launch, TimeBudget {budget_s:.0f} s", "parallelism": "1 GPU"},
+        "time_budget_s": budget_s, "searches": rows, "pooled_vs_default_nodes_per_s": first["nodes_per_s"] / max(base["nodes_per_s"], 1e-9),
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "traffic_source": "null: no rocprofv3 --pmc pass of this workload is committed",
+                     "kernel": "ddo_hip::misp_compile_kernel2_pooled<WS> (in-place engine, POOLED = 1, 512 threads, one decision diagram per CU)",
+                     "kernel_s": first["kernel_s"], "launches": first["launches"], "bytes_per_node": bpn, "kernel_nodes_per_s": first["kernel_nodes_per_s"]},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="misp", choices=["misp", "max2sat", "mcp", "tsptw"],
+    ap.add_argument("--workload", default="misp", choices=["misp", "max2sat", "mcp", "tsptw", "misp-pooled"],
                     help="misp: the headline metric (default); max2sat: BASELINE config C3 on one GPU (secondary line); tsptw: config C5 on one GPU")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -376,6 +461,10 @@ def main():
         if args.concurrent == 1024:
             args.concurrent = 64
         return bench_tsptw(args)
+    if args.workload == "misp-pooled":
+        if args.concurrent == 1024:
+            args.concurrent = 256
+        return bench_pooled(args)
     # test hook (single-GPU boxes): DDO_BENCH_ONE_GPU=1 puts every rank on cuda:0 and rendezvous over gloo, so the
     # multi-process path (sharded root cut-set, incumbent all-reduce, max-over-ranks timing) can be exercised there
     one_gpu = os.environ.get("DDO_BENCH_ONE_GPU") == "1"

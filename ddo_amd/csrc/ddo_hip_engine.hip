@@ -263,6 +263,13 @@ static int dev_alloc(std::vector<void*>& allocs, T*& ptr, size_t count) {
     }
     allocs.push_back(p);
     ptr = (T*)p;
+    // diagnosis (tools/diag): hipMalloc does not clear; DDO_HIP_ALLOC_FILL=<byte> fills every workspace array with that byte, so that a
+    // kernel that reads memory it never wrote behaves the same whatever the allocator handed out (and differently from byte to byte)
+    static const char* fill = std::getenv("DDO_HIP_ALLOC_FILL");
+    if (fill && hipMemset(p, (int)std::strtol(fill, nullptr, 0) & 0xFF, bytes) != hipSuccess) {
+        set_error("hipMemset (DDO_HIP_ALLOC_FILL) failed");
+        return DDO_ERR_NO_DEVICE;
+    }
     static const bool trace = std::getenv("DDO_HIP_ALLOC_TRACE") != nullptr;   // diagnosis: which array a faulting address lies in
     if (trace) std::fprintf(stderr, "[ddo alloc] #%zu %p .. %p (%zu bytes, %zu x %zu)\n", allocs.size() - 1, p, (void*)((uint8_t*)p + bytes), bytes, count, sizeof(T));
     return DDO_OK;
@@ -1663,7 +1670,7 @@ int Engine::launch(const DDInput* inputs, int count, const CacheTable* cache, co
     tick(2);
     P.arena_head = (unsigned long long*)(io.d_cnt + 8);
     P.arena = io.h_arena;
-    if (cache && P_.tmode && cache->device == device_) {
+    if (cache && (P_.tmode || pooled_) && cache->device == device_) {   // (kept layers of the layer-rebuilding engine, or a Pooled DD's event replay)
         P.cache_tab = cache->tab;
         P.cache_cap = cache->cap;
         P.cache_stride = cache->stride;

@@ -1928,6 +1928,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             c.ldup[2 * L] = -1;
             c.ldup[2 * L + 1] = -1;
             c.evoff[(size_t)L * 8 + 5] = 0;
+            c.evoff[(size_t)L * 8 + 6] = 0;   // (no node of a layer that was never built was pruned by the cache: the replay reads the entry)
         }
     }
     PAR_END

@@ -53,11 +53,13 @@ extern "C" {
  *  device for _compute_thresholds, clean.rs:478-545; costs memory, not needed with the EmptyCache) */
 #define DDO_MDD_CACHING 0x10
 /** OR into the cutset_type of ddo_mdd_create: the mdd is a `Pooled` decision diagram (implementation/mdd/pooled.rs:117-823; the `D` of
- *  Par / SeqNoCachingSolverPooled, solver/mod.rs:34, :43): the layer of a variable holds the pool nodes it impacts (Problem::
+ *  four *SolverPooled aliases, solver/mod.rs:34, :38, :43, :47): the layer of a variable holds the pool nodes it impacts (Problem::
  *  is_impacted_by, dp.rs:68-70), width and ranking apply to those, the cut-set is the frontier, a sub-problem's depth is the layer at
  *  which its node was expanded and its path holds one decision per expanded ancestor.  MISP models (the reference's only model that
- *  implements is_impacted_by, misp/main.rs:145-147); not with DDO_MDD_CACHING.  A pool that outgrows its node slots (about 14 000
- *  nodes) ends the compile with DDO_ERR_CAPACITY. */
+ *  implements is_impacted_by, misp/main.rs:145-147).  With DDO_MDD_CACHING compile() may be handed a ddo_cache: the impacted nodes of
+ *  every layer but the first are filtered by it (_filter_with_cache, pooled.rs:635, 662-680) and the thresholds of the finished
+ *  decision diagram are written back over its long arcs (_compute_thresholds, _maybe_update_cache, :467-535).  A pool that outgrows
+ *  its node slots (about 14 000 nodes) ends the compile with DDO_ERR_CAPACITY. */
 #define DDO_MDD_POOLED 0x20
 /** OR into the cutset_type of ddo_mdd_create (MISP, DDO_LAST_EXACT_LAYER, no DDO_MDD_CACHING): binds the mdd to ONE of the
  *  kernels the lazy solver spreads its sub-problems over, so that each of them can be driven -- and checked against the
@@ -314,8 +316,9 @@ typedef struct ddo_solver_config {
                               above.  (Times(0, inner) is the constant 1 == FixedWidth(1).)                              */
     size_t width_div_by;   /* 0: none; else DivBy(k, inner) (width.rs:875-881): max(1, inner / k); with both set the width is
                               DivBy(div_by, Times(times, inner))                                                         */
-    int pooled;            /* 1: `D` = Pooled (mdd/pooled.rs; Par / SeqNoCachingSolverPooled, solver/mod.rs:34, :43): MISP models,
-                              DDO_FRINGE_NODUP, no cache; see DDO_MDD_POOLED                                              */
+    int pooled;            /* 1: `D` = Pooled (mdd/pooled.rs; Par / SeqNoCachingSolverPooled, solver/mod.rs:34, :43, and with
+                              cache_entries > 0 Par / SeqCachingSolverPooled, :38, :47): MISP models, DDO_FRINGE_NODUP; see
+                              DDO_MDD_POOLED                                                                             */
 } ddo_solver_config;
 
 ddo_solver* ddo_solver_create(const ddo_model* model, const ddo_solver_config* cfg);

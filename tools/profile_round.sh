@@ -26,3 +26,17 @@ timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/m2_fetch -
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/m2_write -o r --output-format csv -- $M > $OUT/m2_write.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d $OUT/m2_sq -o r --output-format csv -- $M > $OUT/m2_sq.log 2>&1
 find $OUT -name "*stats*.csv" | head; du -sh $OUT
+# ---- round 6: FETCH_SIZE / WRITE_SIZE passes of the secondary workloads (bench.py --workload ...: roofline.traffic of those lines;
+# tools/summarize_extra.py -> pmc_extra.json "secondary").  Every pass prints its own bench line: the nodes expanded under the counters.
+sec() {   # sec <key> <bench.py arguments...>
+  key=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    sub=${key}_$(echo $c | tr A-Z a-z | cut -d_ -f1)
+    timeout -s KILL 300 rocprofv3 --pmc $c --kernel-trace -d $OUT/$sub -o r --output-format csv -- python bench.py "$@" --no-cpu > $OUT/$sub.log 2>&1
+  done
+}
+sec max2sat_frb10_6_1 --workload max2sat
+sec max2sat_frb15_9_1 --workload max2sat --instance frb15-9-1 --prove 10
+sec mcp_n30 --workload mcp
+sec tsptw_c5 --workload tsptw
+du -sh $OUT

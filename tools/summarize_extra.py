@@ -56,5 +56,39 @@ bm = [json.loads(l) for l in open(f"{src}/m2_trace.log") if l.startswith("{")]
 if bm:
     b = bm[-1]
     out["max2sat_frb15_9_1"]["bench_under_trace"] = {"value": b["value"], "roofline": {k: b["roofline"][k] for k in ("achieved", "frac", "kernel_s", "bytes_per_node", "kernel_nodes_per_s")}}
+# ---- round 6: the secondary workloads' HBM traffic per expanded node (bench.py: committed_traffic).  Each counter pass printed its
+# own bench line; `nodes_all_passes` = the nodes expanded by the process the counters were wrapped around (warm-up pass included).
+import os
+
+cal = None
+for cand in (f"{dst}/counter_calibration.json", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r05", "counter_calibration.json"),
+             os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r04", "counter_calibration.json")):
+    if os.path.exists(cand):
+        cal = json.load(open(cand))["patterns"]
+        break
+ff = 0.5 * (cal["read_line64_slot"]["fetch_factor_lines"] + cal["read_word8_slot"]["fetch_factor_lines"]) if cal else 2.0
+sec = {}
+for key in ("max2sat_frb10_6_1", "max2sat_frb15_9_1", "mcp_n30", "tsptw_c5"):
+    ent = {}
+    try:
+        for cname, sub in (("FETCH_SIZE", key + "_fetch"), ("WRITE_SIZE", key + "_write")):
+            a = agg(sub, "misp_compile_kernel")
+            d = durs(sub, "misp_compile_kernel")
+            line = [json.loads(l) for l in open(f"{src}/{sub}.log") if l.startswith("{")][-1]
+            kb = sum(v[cname] for v in a.values())
+            ent[cname] = {"kb": kb, "launches": len(a), "kernel_s": sum(d.values()) / 1e9, "nodes": line["nodes_all_passes"],
+                          "bytes_per_node_raw": kb * 1024.0 / line["nodes_all_passes"]}
+            ent["kernel_sources"] = line["kernel_sources"]
+            ent["algorithmic_bytes_per_node"] = line["roofline"]["bytes_per_node"]
+            ent["roofline_frac_under_counters"] = line["roofline"]["frac"]
+        ent["fetch_factor"] = ff
+        ent["nodes"] = ent["FETCH_SIZE"]["nodes"]
+        ent["hbm_bytes_per_node"] = ff * ent["FETCH_SIZE"]["bytes_per_node_raw"] + ent["WRITE_SIZE"]["bytes_per_node_raw"]
+        ent["ratio_to_algorithmic"] = ent["hbm_bytes_per_node"] / ent["algorithmic_bytes_per_node"]
+        sec[key] = ent
+    except (OSError, IndexError, KeyError, ZeroDivisionError) as e:
+        sec[key] = {"error": repr(e)}
+out["secondary"] = sec
 json.dump(out, open(f"{dst}/pmc_extra.json", "w"), indent=1)
+print(json.dumps({k: {q: v.get(q) for q in ("hbm_bytes_per_node", "ratio_to_algorithmic", "error")} for k, v in sec.items()}))
 print(json.dumps(out["dense_kernel_l2"]), out["whole_search_kernels"][:2])
