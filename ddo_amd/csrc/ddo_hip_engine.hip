@@ -364,6 +364,15 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     // build of the kernel; like every capacity tier it never squashes.
     mid_ = owner && !dense_ && tier_threads == 256 && cap_width >= 2048;
     if (mid_) P.tab2_cap = std::min(t2, 8192);
+    // A 128-thread capacity tier (layers of up to 1 024 nodes) is held to five workgroups per CU by its LDS -- 29.8 KB, more than half of
+    // it the 4 096-entry dedup table -- where its registers admit six (3 waves per SIMD).  A narrow decision diagram is all latency: what
+    // a CU delivers follows the number it overlaps.  With 2 048 entries (a layer whose nodes and YES-children would fill more than 7/8
+    // of them hands the DD up, as in the dense tier: about n > 1 500 at the usual share of branching nodes, i.e. never below the layer
+    // capacity) a workgroup takes 21.6 KB.  DDO_HIP_TIER1_TABLE=4096 restores the full table.
+    if (owner && !dense_ && !mid_ && tier_threads == 128) {
+        const char* env = std::getenv("DDO_HIP_TIER1_TABLE");
+        P.tab2_cap = std::min(t2, env ? std::max(1024, std::atoi(env)) : 2048);
+    }
     if (pooled_) P.tab2_cap = std::min(t2, 32768);   // (a pool that would fill more than 7/8 of it ends with a capacity error)
     if (mid_ || dense_ || pooled_) P.capS = std::min(P.capS, (int)((long)P.tab2_cap * 7 / 8) + 16);
     if (pooled_) P.hist_bins = 256;                  // 8-bit select digits: the LDS goes to the table and the bitmaps
@@ -1472,7 +1481,9 @@ void Engine::lead(Waiter* me) {
         // nb_threads is the host's core count: 64 callers are 64 decision diagrams per launch; micro grid, n = 400 / W = 10 000,
         // batches of 16: 1.2e9 nodes/s on the full-width kernel, 0.8-0.9e9 on the dense one).  Nothing is handed up from there.
         static const bool route_small = [] { const char* e = std::getenv("DDO_HIP_ROUTE_SMALL"); return !(e && std::atoi(e) == 0); }();
-        Engine* target = (route_small && dense_ && owner_ && !pooled_ && (int)batch.size() <= owner_->nslots_) ? owner_ : this;
+        bool route_ok = route_small && dense_ && owner_ && !pooled_ && (int)batch.size() <= owner_->nslots_;
+        for (CompileReq* r : batch) route_ok = route_ok && r->route_ok;   // (an mdd bound to THIS kernel by DDO_MDD_ENGINE_DENSE stays on it)
+        Engine* target = route_ok ? owner_ : this;
         if (target != this) {
             uint64_t l0 = target->cq_launches_.load(), r0 = target->cq_requests_.load(), k0 = target->cq_kernel_us_.load();
             target->combined_launch(batch, again, me, ho);
@@ -2438,6 +2449,7 @@ int ddo_mdd_compile_batch(ddo_mdd* const* mdds, const ddo_compile_input* inputs,
             return DDO_ERR_CAPACITY;
         }
         rq.stop = inputs[i].cutoff;
+        rq.route_ok = mdds[i]->fallback != nullptr;
         rq.cache = cache ? cache->t : nullptr;
         rq.dom = dom ? dom->t : nullptr;
         rq.out = &mdds[i]->res;

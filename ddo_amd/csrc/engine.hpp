@@ -200,6 +200,8 @@ class Engine {
         const volatile int* stop = nullptr;   // the caller's Cutoff flag (ddo_compile_input.cutoff)
         const CacheTable* cache = nullptr;
         const DominanceTable* dom = nullptr;
+        bool route_ok = false;                // the mdd left the choice of the kernel to ddo_mdd_create (no DDO_MDD_ENGINE_* selector): a small
+                                              // launch of the dense engine may run on its owner, the full-width engine
         HostResult* out = nullptr;            // decoded result (two records when in.flags has IN_FUSED: out[0], out[1])
         int rc = DDO_OK;                      // launch-level error (DDO_ERR_*): nothing was decoded
         // filled by the combiner
