@@ -16,7 +16,11 @@ namespace ddo_hip {
 constexpr int32_t TH_NONE = INT32_MAX;        // theta: None
 constexpr int32_t TH_INF = INT32_MAX - 1;     // theta: isize::MAX and everything derived from it by saturating arithmetic
 constexpr int64_t TH_INF64 = (int64_t)1 << 40;
-constexpr uint64_t CACHE_MAX_PROBES = 4096;     // an entry lives at most this many slots from its home slot (update and get agree)
+// An entry lives at most this many slots from its home slot (update and get agree).  Round 6: 256 (was 4 096) -- a search that fills the
+// table (Pooled DDs cache every exact node they expand: hundreds of millions of (state, depth) pairs on brock200_4) made every look-up
+// and every refused insertion walk the whole budget, a dependent global load per step: seconds per decision diagram.  At the load
+// factors a table is sized for a chain of 256 does not occur; in a full one the look-up is bounded and the insertion refused (counted).
+constexpr uint64_t CACHE_MAX_PROBES = 256;
 constexpr uint64_t CT_EMPTY = 0ULL, CT_LOCKED = 2ULL;   // tag word: 0 empty, 2 being written, (hash | 1) ready
 
 DD_HD inline int64_t th_pack(int32_t theta, bool explored) {
@@ -106,12 +110,20 @@ DDO_DEV void cache_update(const Ctx& c, const uint64_t* s, int depth, int64_t pa
     const uint64_t tag = h | 1ULL;
     const uint64_t mask = c.cache_cap - 1;
     uint64_t slot = (h >> 1) & mask;
+    // a table that is HALF full takes no new entries (thresholds of states it already holds still rise): sound -- less pruning -- and the
+    // look-ups keep their short chains (linear probing: 2.5 probes per miss at one half, 32 at seven eighths -- each a dependent global
+    // load; brock200_4 under ParCachingSolverPooled, 4 M entries: 18.6 s of kernels with a 7/8 limit, 0.93 s with a table that never fills)
+    const bool full = CT_LD(&c.cache_stats[0]) >= (unsigned long long)(c.cache_cap >> 1);
     for (uint64_t probes = 0; probes <= mask && probes < CACHE_MAX_PROBES; ++probes) {
         uint64_t* e = c.cache_tab + slot * (uint64_t)c.cache_stride;
         bool done = false, next = false;
         while (!done && !next) {   // the winner of the claim finishes inside one iteration: lanes of a wave cannot starve each other
             uint64_t t = CT_LD(&e[0]);
             if (t == CT_EMPTY) {
+                if (full) {
+                    CT_ADD(&c.cache_stats[1], 1ULL);
+                    return;
+                }
                 if (CT_CAS(&e[0], CT_EMPTY, CT_LOCKED) == CT_EMPTY) {
                     CT_ST(&e[1], (uint64_t)INT64_MIN);
                     CT_ST(&e[2], (uint64_t)depth);

@@ -210,6 +210,8 @@ struct EngineParams {
     uint64_t* s_rec;           // [slot][capS][RW]  node records: the state words, RW = 8*ceil((ws+1)/8) words (whole 64-byte lines)
     uint64_t* s_ptree;         // [slot][ev_cap/4]  path tree: per event record, parent path id | layer << 32 (misp_dd_inplace.hpp: PID_NONE)
     uint64_t* s_pvr;           // [slot][ev_cap/4]  pooled engine with a cache: value_top | rub << 32 of the node of every event record (nullptr otherwise)
+    uint64_t* s_pst;           // [slot][pst_cap][ws]  ... and the state it had then (the cache update of an exact node needs it); nullptr otherwise
+    uint32_t pst_cap;          // event records per slot whose states are kept (a decision diagram with more of them ends with a capacity error)
     uint64_t* s_hash;          // [slot][capS]      keys_global: key32 << 32 | h32 per node; else the h32 values as a u32 array (streamed by the
                                //                   select sweeps and the per-layer table rebuild)
     uint16_t* s_wl;            // [slot][2*capW]    work list + free list

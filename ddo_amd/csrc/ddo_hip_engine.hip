@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/ddo_hip.h"
 #include "engine.hpp"
@@ -369,6 +370,9 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
     // a CU delivers follows the number it overlaps.  With 2 048 entries (a layer whose nodes and YES-children would fill more than 7/8
     // of them hands the DD up, as in the dense tier: about n > 1 500 at the usual share of branching nodes, i.e. never below the layer
     // capacity) a workgroup takes 21.6 KB.  DDO_HIP_TIER1_TABLE=4096 restores the full table.
+    if (owner && !dense_ && !mid_ && tier_threads == 64) {   // experiment knob: the one-wave tier's table (default: 3 x its layer capacity)
+        if (const char* env = std::getenv("DDO_HIP_TIER0_TABLE")) P.tab2_cap = std::min(t2, std::max(512, std::atoi(env)));
+    }
     if (owner && !dense_ && !mid_ && tier_threads == 128) {
         const char* env = std::getenv("DDO_HIP_TIER1_TABLE");
         P.tab2_cap = std::min(t2, env ? std::max(1024, std::atoi(env)) : 2048);
@@ -595,6 +599,14 @@ int Engine::init(Model* model, int device, long max_width, bool want_pool, Engin
         P.s_pvr = nullptr;
         // Pooled behind a SimpleCache (Par / SeqCachingSolverPooled): (value_top, rough upper bound) per event record for the threshold pass
         if (pooled_ && (rc = dev_alloc(allocs_, P.s_pvr, S * (size_t)(P.ev_cap / 4)))) return rc;
+        P.s_pst = nullptr;
+        P.pst_cap = 0;
+        if (pooled_) {   // the states of the first pst_cap event records of a DD (1 M by default: far beyond what a pool of 28 000 nodes expands)
+            long m = 1;
+            if (const char* env = std::getenv("DDO_HIP_POOLED_STATES_M")) m = std::max(1L, std::min(64L, std::atol(env)));
+            P.pst_cap = (uint32_t)std::min<uint64_t>(P.ev_cap / 4, (uint64_t)m << 20);
+            if ((rc = dev_alloc(allocs_, P.s_pst, S * (size_t)P.pst_cap * wsT))) return rc;
+        }
         if ((rc = dev_alloc(allocs_, P.s_hash, S * capS))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_wl, S * 2 * capW))) return rc;
         if ((rc = dev_alloc(allocs_, P.s_ev, S * P.ev_cap))) return rc;
@@ -986,7 +998,7 @@ CacheTable* CacheTable::create(const Model* model, int device, size_t capacity_e
         return nullptr;
     }
     size_t cap = 1024;
-    while (cap < capacity_entries) cap <<= 1;
+    while (cap < 2 * capacity_entries) cap <<= 1;   // (the table takes new entries up to HALF its slots: dd_thresholds.hpp, cache_update)
     CacheTable* t = new CacheTable();
     t->device = device;
     t->cap = cap;
@@ -1244,6 +1256,34 @@ void Engine::pooled_fixup(const DDInput& in, HostResult& out) const {
         out.cs_pbits.clear();
         out.cs_lvar.clear();
         out.cs_pw = 0;
+        // The device lists its cut-set rows in the order its threads won an atomic counter: different from run to run.  The hosts keep
+        // the FIRST of two equal-ranked sub-problems (NoDupFringe, heap ties by insertion), so the rows leave in a fixed order: by the
+        // layer of expansion, then by state (a state occurs once per layer).
+        std::vector<int> ord((size_t)out.n_cutset);
+        for (int i = 0; i < out.n_cutset; ++i) ord[(size_t)i] = i;
+        const size_t w = (size_t)ws;
+        std::sort(ord.begin(), ord.end(), [&](int x, int y) {
+            const int dx = out.cs_depth.empty() ? 0 : out.cs_depth[(size_t)x], dy = out.cs_depth.empty() ? 0 : out.cs_depth[(size_t)y];
+            if (dx != dy) return dx < dy;
+            for (size_t k = 0; k < w; ++k) {
+                const uint64_t a2 = out.cs_state[(size_t)x * w + k], b2 = out.cs_state[(size_t)y * w + k];
+                if (a2 != b2) return a2 < b2;
+            }
+            return x < y;
+        });
+        auto permute = [&](auto& v, size_t per) {
+            if (v.empty()) return;
+            std::remove_reference_t<decltype(v)> t(v.size());
+            for (size_t i = 0; i < ord.size(); ++i)
+                for (size_t k = 0; k < per; ++k) t[i * per + k] = v[(size_t)ord[i] * per + k];
+            v.swap(t);
+        };
+        permute(out.cs_state, w);
+        permute(out.cs_value, 1);
+        permute(out.cs_ub, 1);
+        permute(out.cs_depth, 1);
+        permute(out.cs_plen, 1);
+        permute(out.cs_path, (size_t)stride);
     }
 }
 

@@ -252,6 +252,8 @@ struct DD2Ctx {
     uint64_t cache_cap;
     unsigned long long* cache_stats;
     GLB_PTR(uint64_t) pvr;     // [ev_cap / 4]  value_top (low half) | rub (high half) per event record; nullptr without a cache
+    GLB_PTR(uint64_t) pst;     // [pst_cap][WS] the state every expanded node had WHEN it was expanded (its slot is rewritten in place): what
+    uint32_t pst_cap;          //              _maybe_update_cache writes for the exact ones; records beyond pst_cap end the compile (capacity)
     int cache_stride;
     int depth0;                // depth of the residual sub-problem (node.depth = depth0 + layer)
 };
@@ -868,43 +870,6 @@ DDO_DEV bool lex_split2(DD2Ctx<WS>& c, uint16_t* tie, int m, int need) {
 ///     may turn inexact long after its parent was expanded, so the frontier is found by the backward replay of the event
 ///     records (the parent's exactness travels in its record, EV_PINEX), and a cut-set node's state, value and rough upper
 ///     bound are rebuilt from its best path (an exact node's state is the residual state with its path's decisions applied).
-/// Pooled: an exact node's state is the residual state with the decisions of (any of) its paths applied (main.rs:77-85), over the first
-/// `depth` layers; only layers whose variable the state still holds count (the others did not impact the node, pooled.rs:316-334).
-template <int WS>
-DDO_DEV void pooled_state_of(const DD2Ctx<WS>& c, const DDInput& in, uint32_t pid, int depth, uint64_t* st) {
-    uint64_t pb[WS];
-#pragma unroll
-    for (int k = 0; k < WS; ++k) pb[k] = 0;
-    path_bits<WS>(c, pid, pb);
-    if (in.src_off != NO_POOL_SRC) {
-        const PoolBlockHeader* h = (const PoolBlockHeader*)(c.pool + in.src_off);
-        const uint64_t* rows = (const uint64_t*)(c.pool + in.src_off + h->off_states);
-#pragma unroll
-        for (int k = 0; k < WS; ++k) st[k] = k < (int)h->ws ? rows[(size_t)k * h->rows + in.src_row] : 0;
-    } else {
-#pragma unroll
-        for (int k = 0; k < WS; ++k) st[k] = in.state[k];
-    }
-    for (int j = 0; j < depth; ++j) {
-        const int x = c.lvar[j];
-        const int xw = x >> 6;
-        const uint64_t xb = 1ULL << (x & 63);
-        bool has = false, yes = false;
-#pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            if (k == xw) {
-                has = (st[k] & xb) != 0;
-                st[k] &= ~xb;
-            }
-            if (k == (j >> 6)) yes = ((pb[k] >> (j & 63)) & 1ULL) != 0;
-        }
-        if (has && yes) {
-#pragma unroll
-            for (int k = 0; k < WS; ++k) st[k] &= c.adj[(size_t)x * WS + k];
-        }
-    }
-}
-
 /// A node's own threshold (pooled.rs:493-511; the corner cases of the saturating arithmetic as in misp_dd_core.hpp): `th` is what its
 /// children left it (TH_NONE: nothing), `rub` INT32_MAX for a node that was never expanded, `vbv` VB_UNMARKED for value_bot == isize::MIN.
 DDO_DEV int32_t pooled_own_theta(int32_t th, int32_t val, int32_t rub, bool is_cut, bool exact, int32_t vbv, int32_t bk, bool bk_min) {
@@ -932,7 +897,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
     const int32_t vbase = in.value + c.vbase_off;
     // Pooled behind a SimpleCache (pooled.rs:467-535, 662-680): the impacted nodes of every layer but the first are looked up in the
     // cache before the layer is squashed and expanded, and the thresholds of the finished decision diagram are written back.
-    const bool pcache = POOLED && c.cache_cap != 0 && c.pvr != nullptr && (in.flags & IN_CACHE) != 0;
+    const bool pcache = POOLED && c.cache_cap != 0 && c.pvr != nullptr && c.pst != nullptr && (in.flags & IN_CACHE) != 0;
     uint32_t cache_hits = 0;
 
     // ---------------------------------------------------------------- _clear + _initialize
@@ -1667,6 +1632,12 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;
                     c.pt[eid] = (uint64_t)ppid | ((uint64_t)(uint32_t)L << 32);
                     c.pvr[eid] = (uint64_t)(uint32_t)val | ((uint64_t)(uint32_t)rub << 32);
+                    if (eid < c.pst_cap) {
+#pragma unroll
+                        for (int k = 0; k < WS; ++k) c.pst[(size_t)eid * WS + k] = st[k];
+                    } else {
+                        sh->status = ST_ERR_CAPACITY - 100 * 13;
+                    }
                 }
                 LDS_ADD_I32(&sh->npruned, 1);
                 continue;
@@ -1703,7 +1674,15 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
             // ---- decision YES into a free slot (main.rs:95-102)
             const int r = LDS_ADD_I32(&sh->nrec, 1);                       // this node's event record ...
             const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;   // ... is also the path-tree node of its YES arc
-            if (pcache) c.pvr[eid] = (uint64_t)(uint32_t)val | ((uint64_t)(uint32_t)rub << 32);
+            if (pcache) {
+                c.pvr[eid] = (uint64_t)(uint32_t)val | ((uint64_t)(uint32_t)rub << 32);
+                if (eid < c.pst_cap) {   // the node as it was expanded (st holds its NO-child by now: word vw back to what it was)
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) c.pst[(size_t)eid * WS + k] = k == vw ? oldw : st[k];
+                } else {
+                    sh->status = ST_ERR_CAPACITY - 100 * 13;
+                }
+            }
             const int fi = LDS_ADD_I32(&sh->nnew, 1);
             int ny = -1;
             uint64_t y[WS];
@@ -2200,7 +2179,8 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                     const uint64_t w = c.pvr[eid];
                     if (!(w & (1ULL << 32))) continue;
                     uint64_t st[WS];
-                    pooled_state_of<WS>(c, in, (uint32_t)c.pt[eid], tr, st);
+#pragma unroll
+                    for (int k = 0; k < WS; ++k) st[k] = c.pst[(size_t)eid * WS + k];
                     cache_update<WS>(c, st, c.depth0 + tr, th_pack((int32_t)(uint32_t)w, (w & (1ULL << 33)) != 0));
                 }
                 PAR_END
@@ -2942,6 +2922,8 @@ DDO_DEV void dd2_bind(DD2Ctx<WS>& c, const EngineParams& P, int slot, unsigned c
     c.cache_stats = P.cache_stats;
     c.cache_stride = P.cache_stride;
     c.pvr = P.s_pvr ? (GLB_PTR(uint64_t))(P.s_pvr + s * (P.ev_cap / 4)) : (GLB_PTR(uint64_t))nullptr;
+    c.pst = P.s_pst ? (GLB_PTR(uint64_t))(P.s_pst + s * (size_t)P.pst_cap * (size_t)WS) : (GLB_PTR(uint64_t))nullptr;
+    c.pst_cap = P.s_pst ? P.pst_cap : 0u;
     c.depth0 = 0;
 }
 

@@ -40,6 +40,7 @@ struct Emul {
     std::vector<uint64_t> lbase, abase;      // DDO_EMUL_LPOOL: kept layers and arcs as pools (run_dd: dynl)
     std::vector<uint64_t> cache_tab;
     std::vector<uint64_t> pvr;       // pooled engine behind a cache: (value, rub) per event record (EngineParams::s_pvr)
+    std::vector<uint64_t> pst;       // ... and the state it was expanded with (EngineParams::s_pst)
     std::vector<uint64_t> dom_coord;
     std::vector<int32_t> dom_value;
     std::vector<uint32_t> dom_count, dom_lock;
@@ -307,7 +308,7 @@ void emul_set_keep_layers(void* h, int on, uint64_t cache_entries) {
     e->P.cache_tab = nullptr;
     if (on && cache_entries) {
         uint64_t cap = 1024;
-        while (cap < cache_entries) cap <<= 1;
+        while (cap < 2 * cache_entries) cap <<= 1;   // (new entries up to half the slots: CacheTable::create does the same)
         e->P.cache_stride = 3 + e->wsT;
         e->cache_tab.assign(cap * (size_t)e->P.cache_stride, 0);
         e->P.cache_tab = e->cache_tab.data();
@@ -354,9 +355,11 @@ void emul_set_pooled_cache(void* h, uint64_t entries) {
     e->P.cache_cap = 0;
     e->P.cache_tab = nullptr;
     e->P.s_pvr = nullptr;
+    e->P.s_pst = nullptr;
+    e->P.pst_cap = 0;
     if (!entries) return;
     uint64_t cap = 1024;
-    while (cap < entries) cap <<= 1;
+    while (cap < 2 * entries) cap <<= 1;
     e->P.cache_stride = 3 + e->wsT;
     e->cache_tab.assign(cap * (size_t)e->P.cache_stride, 0);
     e->P.cache_tab = e->cache_tab.data();
@@ -365,6 +368,9 @@ void emul_set_pooled_cache(void* h, uint64_t entries) {
     e->P.cache_stats = e->cache_stats;
     e->pvr.assign((size_t)(e->P.ev_cap / 4 + 1), 0x0101010101010101ULL * emu_poison());
     e->P.s_pvr = e->pvr.data();
+    e->P.pst_cap = (uint32_t)std::min<uint64_t>(e->P.ev_cap / 4 + 1, 1u << 18);
+    e->pst.assign((size_t)e->P.pst_cap * (size_t)e->wsT, 0x0101010101010101ULL * emu_poison());
+    e->P.s_pst = e->pst.data();
 }
 void emul_destroy(void* h) { delete (Emul*)h; }
 int emul_state_words(void* h) { return ((Emul*)h)->wsT; }
