@@ -1,3 +1,6 @@
+"""Diagnosis: what a SimpleCache that fills up costs a pooled search: ParCachingSolverPooled on brock200_4 under
+NbUnassignedWidth without a cache, with the default 4 M entries, and with a table that never fills -- proved?, explored, compiles, wall and
+kernel seconds, launches.   gpurun -- python tools/diag/pooled_cache_probe.py"""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import ddo_amd
