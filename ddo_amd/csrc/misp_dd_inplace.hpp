@@ -1628,7 +1628,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
                 const int r = LDS_ADD_I32(&sh->nrec, 1);
                 U32x4* rec4 = (U32x4*)(c.ev + aff_off + 4ull * (uint64_t)r);
                 *rec4 = U32x4{(uint32_t)s | ((POOLED && bm_test(c.inex, s)) ? EV_PINEX : 0u), NONE32, NONE32, NONE32};
-                if (pcache) {   // the threshold pass rebuilds this node's state from its path and needs its value and bound
+                if (pcache) {   // the threshold pass needs what this node was when it was pruned: value, bound, state (its slot is free from here on)
                     const uint32_t eid = (uint32_t)(aff_off >> 2) + (uint32_t)r;
                     c.pt[eid] = (uint64_t)ppid | ((uint64_t)(uint32_t)L << 32);
                     c.pvr[eid] = (uint64_t)(uint32_t)val | ((uint64_t)(uint32_t)rub << 32);
@@ -2168,7 +2168,7 @@ DDO_DEV void run_dd2(DD2Ctx<WS>& c, const DDInput& in, int comp_type, int64_t be
         const bool arena_ok = sh->status == ST_OK || sh->status == ST_CUTOFF;
         GLB_PTR(uint8_t) base = c.arena + sh->arena_off;
         if (want_th && sh->status == ST_OK) {
-            // ---- _maybe_update_cache for every node the replay flagged: an exact node's state is rebuilt from its path
+            // ---- _maybe_update_cache for every node the replay flagged, with the state logged when the node was expanded (c.pst)
             for (int tr = 0; tr < L; ++tr) {
                 GLB_PTR(const uint32_t) eo = c.evoff + (size_t)tr * 8;
                 const int na = (int)eo[2];
