@@ -274,15 +274,14 @@ struct DDCtx {
     // the two candidate buffers (current / next layer).  In the wide instantiations (signed-vector models, WS > 16) they are picked
     // by SELECTS, not by indexing an array member: an array indexed at run time pins the whole context in scratch memory -- every
     // `c.field` a scratch load -- where it could live in scalar registers (72-word kernel: 2 224 -> 1 552 B/lane of scratch, C3 kernels
-    // -13 %).  The narrow instantiations keep the array: with the context in registers the 16-word kernel faulted on the GPU for TSPTW
-    // states of four-word node sets (rbg132, n200w20.001).  Round 5 traced it (tools/diag/tsptw_fault.py): the
-    // first wild access is c.ckey / c.cstate[cur][i] with i in [2^32 - 512, 2^32) -- yet with every index of ckey / cpop / cflags and
-    // every keep[] entry checked on the device no check ever fires, the fault MOVES when a check clamps an index, VANISHES when a
-    // printf is added at the check sites, and vanishes when the same source is built without -amdgpu-atomic-optimizer-strategy=DPP
-    // (all twenty compiles then equal the oracle's).  Same source, same data, different code generation: the DPP atomic optimizer
-    // miscompiles this instantiation when the context lives in registers.  The SHIPPED layout with the same bounds checks passes the
-    // TSPTW / vector / knapsack / cache suites (296 tests) without a check firing.
-#if defined(DDO_BUF2_SEL_ALL)   // diagnosis build: the select-based buffers in every instantiation (the configuration that faulted in round 4)
+    // -13 %).  The narrow instantiations keep the array.  History: with select buffers the 16-word kernel of rounds 4 / 5 faulted on the
+    // GPU for TSPTW states of four-word node sets (rbg132, n200w20.001), and round 5 blamed the DPP atomic optimizer (the fault moved or
+    // vanished with unrelated code changes, no bounds check ever fired).  Round 6 (tools/diag, profiles/r06/diag):
+    // it was a read of memory the compile never wrote -- DDO_HIP_ALLOC_FILL=0x55 moves the faulting address to ckey + 8 x 0x55555555 in
+    // that tree -- in the one-thread-per-parent TSPTW expansion that round 5 later replaced; an entry barrier on every block does not
+    // remove it (no race on shared scalars), and today's tree passes the engine-1 GPU suites under 0x55 / 0xFF fills in BOTH layouts.
+    // With the fault gone the two layouts were measured again: within a few percent on every secondary workload, so the split stays.
+#if defined(DDO_BUF2_SEL_ALL)   // diagnosis / A-B build: the select-based buffers in every instantiation
 #define DDO_BUF2_SEL(ws) true
 #else
 #define DDO_BUF2_SEL(ws) ((ws) > 16)
