@@ -15,7 +15,7 @@ use std::sync::Mutex;
 
 use bit_set::BitSet;
 use ddo::*;
-use hip_mdd::{install, HipMdd};
+use hip_mdd::{install, install_pooled, HipCache, HipMdd};
 
 struct Misp { nb_vars: usize, compatible: Vec<BitSet>, weight: Vec<isize> }   // compatible[i]: the vertices NOT adjacent to i
 
@@ -118,3 +118,32 @@ optimum! {
     johnson8_2_4: "johnson8-2-4.clq" => 4, johnson8_4_4: "johnson8-4-4.clq" => 14,
     keller4: "keller4.clq" => 11,         mann_a9: "MANN_a9.clq" => 16,         p_hat300_1: "p_hat300-1.clq" => 8,
 }
+
+/// The same searches over `Pooled` decision diagrams on the device (implementation/mdd/pooled.rs; hip_mdd::install_pooled): the
+/// reference's `ParNoCachingSolverPooled` / `ParCachingSolverPooled` (solver/mod.rs:34, :38) with `HipMdd` as their `D` and, behind
+/// the cache, `HipCache` -- the SimpleCache living in device memory -- as their `C`.
+fn solve_pooled_on_the_gpu(id: &str, cache_entries: usize) -> isize {
+    let _guard = ONE_AT_A_TIME.lock().unwrap_or_else(|e| e.into_inner());
+    let dir = std::env::var("DDO_RESOURCES").map(PathBuf::from)
+        .unwrap_or_else(|_| PathBuf::from(env!("CARGO_MANIFEST_DIR")).join("..").join("data"));
+    let problem = read_dimacs(&dir.join("misp").join(id));
+    let relaxation = MispRelax(&problem);
+    let ranking = MispRanking;
+    let width = NbUnassignedWidth(problem.nb_variables());
+    let dominance = EmptyDominanceChecker::default();
+    let cutoff = NoCutoff;
+    let mut fringe = NoDupFringe::new(MaxUB::new(&ranking));
+    install_pooled(problem.nb_vars, &problem.compatible, &problem.weight, 0, problem.nb_vars, cache_entries);
+    let Completion { is_exact, best_value } = if cache_entries > 0 {
+        ParallelSolver::<BitSet, HipMdd, HipCache>::custom(&problem, &relaxation, &ranking, &width, &dominance, &cutoff, &mut fringe, 8).maximize()
+    } else {
+        ParallelSolver::<BitSet, HipMdd, EmptyCache<BitSet>>::custom(&problem, &relaxation, &ranking, &width, &dominance, &cutoff, &mut fringe, 8).maximize()
+    };
+    assert!(is_exact);
+    best_value.unwrap_or(-1)
+}
+#[test] fn pooled_johnson8_4_4() { assert_eq!(solve_pooled_on_the_gpu("johnson8-4-4.clq", 0), 14); }
+#[test] fn pooled_mann_a9() { assert_eq!(solve_pooled_on_the_gpu("MANN_a9.clq", 0), 16); }
+#[test] fn pooled_keller4() { assert_eq!(solve_pooled_on_the_gpu("keller4.clq", 0), 11); }
+#[test] fn pooled_cached_mann_a9() { assert_eq!(solve_pooled_on_the_gpu("MANN_a9.clq", 1 << 20), 16); }
+#[test] fn pooled_cached_keller4() { assert_eq!(solve_pooled_on_the_gpu("keller4.clq", 1 << 20), 11); }
