@@ -38,6 +38,7 @@ struct Registry {
     size_t max_width = 0;
     size_t words = 0;
     size_t nb_vars = 0;
+    ddo_cache* cache = nullptr;   // the device-side SimpleCache `HipCache` wraps (hip_mdd::install(.., cache_entries)); nullptr == EmptyCache
 };
 Registry g_reg;
 
@@ -89,6 +90,7 @@ class HipMdd {
         ci.residual.path = path.empty() ? nullptr : path.data();
         ci.residual.path_len = path.size();
         ci.cutoff = &stop;
+        ci.cache = g_reg.cache;   // null == EmptyCache; else the table HipCache wraps (same thresholds on both sides)
         ddo_completion out{};
         const int rc = ddo_mdd_compile(h, &ci, &out);
         if (rc == DDO_CUTOFF) {
@@ -151,6 +153,32 @@ class HipMdd {
     }
 };
 
+/// `impl Cache for HipCache` (hip_mdd/src/lib.rs), in C++: the solver's own calls (must_explore at the pop, update_threshold in the
+/// parallel solver, clear) reach the device table through the ABI's host views; the compiles read and write it on the device.
+class HipCache : public Cache<BitSet> {
+  public:
+    void initialize(const Problem<BitSet>&) override {}   // created by install()
+    std::optional<Threshold> get_threshold(const BitSet& state, size_t depth) const override {
+        if (!g_reg.cache) return std::nullopt;
+        std::vector<uint64_t> st(g_reg.words);
+        to_words(state, g_reg.words, st.data());
+        int64_t v = 0;
+        int e = 0;
+        if (ddo_cache_get_threshold(g_reg.cache, st.data(), depth, &v, &e) != 1) return std::nullopt;
+        return Threshold{(isize)v, e != 0};
+    }
+    void update_threshold(std::shared_ptr<const BitSet> state, size_t depth, isize value, bool explored) override {
+        if (!g_reg.cache) return;
+        std::vector<uint64_t> st(g_reg.words);
+        to_words(*state, g_reg.words, st.data());
+        ddo_cache_update_threshold(g_reg.cache, st.data(), depth, (int64_t)value, explored ? 1 : 0);
+    }
+    void clear_layer(size_t) override {}   // memory management only in the reference (parallel.rs:506-511)
+    void clear() override {
+        if (g_reg.cache) ddo_cache_clear(g_reg.cache);
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -167,7 +195,15 @@ struct shim_out {
 /// The reference's solver over the device: width 0 = NbUnassignedWidth, nthreads 0 = SequentialSolver, else ParallelSolver with that
 /// many worker threads (each with its own HipMdd); pooled: the mdds are Pooled decision diagrams (hip_mdd::install_pooled).
 /// solution: (variable, value) pairs, capacity 2 * n.  Returns 0, or -1 with the message on stderr.
+int shim_misp_solve_ex(const char* path, uint64_t width, int nthreads, int device, double timeout_s, int pooled, uint64_t cache_entries,
+                       shim_out* out, int64_t* solution);
 int shim_misp_solve(const char* path, uint64_t width, int nthreads, int device, double timeout_s, int pooled, shim_out* out, int64_t* solution) {
+    return shim_misp_solve_ex(path, width, nthreads, device, timeout_s, pooled, 0, out, solution);
+}
+/// cache_entries > 0: hip_mdd::install(.., cache_entries) -- the mdds take the device-side SimpleCache, the solver's `C` is HipCache
+/// (the reference's Seq / ParCachingSolverLel, and with pooled = 1 Seq / ParCachingSolverPooled, solver/mod.rs:36, :38, :45, :47)
+int shim_misp_solve_ex(const char* path, uint64_t width, int nthreads, int device, double timeout_s, int pooled, uint64_t cache_entries,
+                       shim_out* out, int64_t* solution) {
     try {
         Misp pb = read_misp_instance(path);
         MispRelax relax(pb);
@@ -182,7 +218,13 @@ int shim_misp_solve(const char* path, uint64_t width, int nthreads, int device, 
         }
         ddo_model* model = ddo_model_create_misp((int)pb.nb_vars, rows.data(), w.data());
         if (!model) throw std::runtime_error(std::string("ddo_model_create_misp: ") + ddo_last_error());
-        g_reg = Registry{model, device, pooled ? (DDO_FRONTIER | DDO_MDD_POOLED) : DDO_LAST_EXACT_LAYER, width ? (size_t)width : pb.nb_vars, words, pb.nb_vars};
+        ddo_cache* cache = nullptr;
+        if (cache_entries) {
+            cache = ddo_cache_create(model, device, (size_t)cache_entries);
+            if (!cache) throw std::runtime_error(std::string("ddo_cache_create: ") + ddo_last_error());
+        }
+        g_reg = Registry{model, device, (pooled ? (DDO_FRONTIER | DDO_MDD_POOLED) : DDO_LAST_EXACT_LAYER) | (cache ? DDO_MDD_CACHING : 0),
+                         width ? (size_t)width : pb.nb_vars, words, pb.nb_vars, cache};
         FixedWidth<BitSet> fixed(width);
         NbUnassignedWidth<BitSet> unassigned(pb.nb_vars);
         const WidthHeuristic<BitSet>& wh = width ? (const WidthHeuristic<BitSet>&)fixed : unassigned;
@@ -201,22 +243,26 @@ int shim_misp_solve(const char* path, uint64_t width, int nthreads, int device, 
             Completion c;
             std::optional<Solution> sol;
             MddCounters cnt;
-            if (nthreads <= 0) {
-                SequentialSolver<BitSet, HipMdd> s(pb, relax, rank, wh, dom, cut, fringe);
+            auto run = [&](auto& s) {
                 c = s.maximize();
                 out->best_lb = s.best_lower_bound();
                 out->best_ub = s.best_upper_bound();
                 out->explored = s.explored();
                 sol = s.best_solution();
                 cnt = s.counters();
+            };
+            if (nthreads <= 0 && cache) {
+                SequentialSolver<BitSet, HipMdd, HipCache> s(pb, relax, rank, wh, dom, cut, fringe);
+                run(s);
+            } else if (nthreads <= 0) {
+                SequentialSolver<BitSet, HipMdd> s(pb, relax, rank, wh, dom, cut, fringe);
+                run(s);
+            } else if (cache) {
+                ParallelSolver<BitSet, HipMdd, HipCache> s(pb, relax, rank, wh, dom, cut, fringe, (size_t)nthreads);
+                run(s);
             } else {
                 ParallelSolver<BitSet, HipMdd> s(pb, relax, rank, wh, dom, cut, fringe, (size_t)nthreads);
-                c = s.maximize();
-                out->best_lb = s.best_lower_bound();
-                out->best_ub = s.best_upper_bound();
-                out->explored = s.explored();
-                sol = s.best_solution();
-                cnt = s.counters();
+                run(s);
             }
             out->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             ddo_mdd_combine_stats(ph, &l1, &r1, nullptr);
@@ -237,6 +283,7 @@ int shim_misp_solve(const char* path, uint64_t width, int nthreads, int device, 
                     out->n_solution++;
                 }
         }
+        if (cache) ddo_cache_destroy(cache);
         ddo_model_destroy(model);
         g_reg = Registry{};
         return 0;

@@ -33,16 +33,17 @@ def build_shim():
 _L = None
 
 
-def shim_misp_solve(path, width=0, nthreads=0, device=0, timeout_s=0.0, pooled=False):
-    """the reference's solver (oracle restatement) over HipMdd; returns a dict like tests.oracle_binding.MispInstance.solve"""
+def shim_misp_solve(path, width=0, nthreads=0, device=0, timeout_s=0.0, pooled=False, cache_entries=0):
+    """the reference's solver (oracle restatement) over HipMdd -- with cache_entries > 0 behind HipCache, the device-side SimpleCache;
+    returns a dict like tests.oracle_binding.MispInstance.solve"""
     global _L
     if _L is None:
         _L = C.CDLL(build_shim())
-        _L.shim_misp_solve.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(ShimOut), C.c_void_p]
+        _L.shim_misp_solve_ex.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.POINTER(ShimOut), C.c_void_p]
     out = ShimOut()
     sol = np.zeros(4096, dtype=np.int64)
-    rc = _L.shim_misp_solve(path.encode(), int(width), int(nthreads), int(device), float(timeout_s), 1 if pooled else 0, C.byref(out),
-                            sol.ctypes.data_as(C.c_void_p))
+    rc = _L.shim_misp_solve_ex(path.encode(), int(width), int(nthreads), int(device), float(timeout_s), 1 if pooled else 0, int(cache_entries),
+                               C.byref(out), sol.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise RuntimeError("shim_misp_solve failed (message on stderr)")
     d = {k: getattr(out, k) for k, _ in ShimOut._fields_}

@@ -99,3 +99,29 @@ def test_the_bulk_drain_hands_over_what_the_callbacks_deliver(name, width, poole
     cut = ubs[len(ubs) // 2]
     some = c.drain_cutset_rows(ub_above=cut, residual_path=head)
     assert sorted(key(s) for s in some) == sorted(key(s) for s in ref if int(s.ub) > cut) and len(some) < n
+
+
+@pytest.mark.parametrize("name,width,pooled", [("johnson8-4-4", 4, False), ("MANN_a9", 3, False), ("hamming6-4", 6, False), ("brock200_2", 100, False),
+                                               ("MANN_a9", 0, True), ("hamming6-4", 5, True), ("keller4", 0, True)])
+def test_the_reference_sequential_solver_over_hipmdd_and_hipcache_is_the_same_search(oracle, name, width, pooled):
+    """`SequentialSolver<BitSet, HipMdd, HipCache>`: the mdds take the device-side SimpleCache (DDO_MDD_CACHING, ddo_compile_input.cache) and the
+    solver's own Cache calls -- must_explore at the pop, clear -- reach the same table through the ABI's host views (`impl Cache for
+    HipCache`, hip_mdd/src/lib.rs; here its C++ twin).  The search is the oracle's cached search: SeqCachingSolverLel (solver/mod.rs:45) and,
+    over Pooled decision diagrams, SeqCachingSolverPooled (:47) -- same explored sub-problems, same optimum, proof."""
+    path = data_path("misp", name + ".clq")
+    ref, _ = oracle.trace_ex("misp+pooled" if pooled else "misp", path, width, 0, False, True)
+    plain, _ = oracle.trace_ex("misp+pooled" if pooled else "misp", path, width, 0, False, False)
+    # (a table large enough never to refuse an entry: a pooled search caches every exact node it expands -- keller4 fills 2^18 entries,
+    # explores 6 666 sub-problems instead of 5 625 and is still right: a refused threshold is less pruning)
+    got = shim_misp_solve(path, width, 0, pooled=pooled, cache_entries=1 << 22)
+    assert got["is_exact"] and got["best_value"] == ref["best_value"] == plain["best_value"]
+    assert got["explored"] == ref["explored"], (name, width, pooled, got["explored"], ref["explored"], plain["explored"])
+    assert _feasible(name, got["solution"], ref["best_value"])
+
+
+@pytest.mark.parametrize("name,width,threads,pooled,expected", [("keller4", 0, 16, False, 11), ("brock200_2", 100, 32, False, 12), ("MANN_a9", 0, 16, True, 16)])
+def test_the_reference_parallel_solver_over_hipmdd_and_hipcache(name, width, threads, pooled, expected):
+    path = data_path("misp", name + ".clq")
+    got = shim_misp_solve(path, width, threads, pooled=pooled, cache_entries=1 << 18)
+    assert got["is_exact"] and got["best_value"] == expected and got["best_lb"] == got["best_ub"] == expected
+    assert _feasible(name, got["solution"], expected)
